@@ -115,11 +115,13 @@ def forward(params, x):
 
 def cbce_loss(output, label, size_average=True, batch_average=True):
     """osvos_layers.py:19-48, same operation order."""
-    labels = (label >= 0.5).to(output.dtype)
+    # NB: the reference casts both masks with .float(), so the class weights n_neg/n_tot and
+    # n_pos/n_tot are float32 quotients even when the logits are float64 (osvos_layers.py:28-34,41)
+    labels = (label >= 0.5).float()
     n_pos = labels.sum()
     n_neg = (1.0 - labels).sum()
     n_tot = n_pos + n_neg
-    g = (output >= 0).to(output.dtype)
+    g = (output >= 0).float()
     val = output * (labels - g) - torch.log(1 + torch.exp(output - 2 * output * g))
     l_pos = (-(labels * val)).sum()
     l_neg = (-((1.0 - labels) * val)).sum()
