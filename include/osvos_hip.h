@@ -1,0 +1,157 @@
+/* osvos_hip.h -- C ABI of libosvos_hip.so: the MI355X (gfx950) OSVOS forward/backward hot path.
+ *
+ * The reference (kmaninis/OSVOS-PyTorch) has no FFI boundary of its own: its "operator API" is
+ * torch.nn.Module + autograd and every arithmetic op is delegated to ATen.  This header is the
+ * boundary a maintainer binds instead (INTEGRATION.md shows the ctypes stub).  Each entry point
+ * cites the reference call site whose ATen op(s) it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless it says "host"; the caller (PyTorch) owns all
+ *     memory, including workspaces; the library never allocates, frees or synchronises
+ *   - every function enqueues on `stream` (a hipStream_t passed as void*) and returns
+ *     0 on success, >0 a hipError_t, <0 an argument error; osvos_last_error() has the text
+ *   - activations are NHWC ("channels last") float32 (dtype 0) or bfloat16 (dtype 1) unless
+ *     a parameter says nchw; parameters arrive in the reference's state_dict layout (OIHW fp32)
+ *   - re-entrant: no mutable global state except the per-thread error string
+ */
+#ifndef OSVOS_HIP_H
+#define OSVOS_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OSVOS_ABI_VERSION 1
+#define OSVOS_F32 0
+#define OSVOS_BF16 1
+#define OSVOS_NPARAMS 52 /* tensors of OSVOS.state_dict(), reference order */
+
+int osvos_version(void);
+const char* osvos_last_error(void);
+
+/* ---- layout helpers -------------------------------------------------------------------- */
+/* NCHW fp32 [N,C,H,W] -> NHWC with `cpad` channels (zero filled), replaces the implicit layout
+ * of the tensor handed to OSVOS.forward (vgg_osvos.py:59). */
+int osvos_nchw_to_nhwc(const float* src, void* dst, int N, int C, int H, int W, int cpad, int dtype, void* stream);
+/* NHWC (channel stride cs) -> NCHW fp32 [N,C,H,W] */
+int osvos_nhwc_to_nchw(const void* src, float* dst, int N, int C, int H, int W, int cs, int dtype, void* stream);
+
+/* OIHW fp32 [Cout,Cin,3,3] -> forward pack [9][CinP/G][CoutP][G] (G = 4 fp32 / 8 bf16 channels per
+ * 16-byte group; CinP = Cin rounded up to 2G, CoutP = Cout rounded up to 32; zero filled). */
+size_t osvos_wpack_bytes(int Cout, int Cin, int dtype);
+int osvos_pack_conv3x3_fwd(const float* w_oihw, void* wpk, int Cout, int Cin, int dtype, void* stream);
+/* same weights packed for the data-gradient: a 3x3 conv of dY with the 180-degree rotated,
+ * channel-transposed filter; pack is [9][CoutP'/G][CinP'][G] with roles swapped. */
+size_t osvos_wpack_dgrad_bytes(int Cout, int Cin, int dtype);
+int osvos_pack_conv3x3_dgrad(const float* w_oihw, void* wpk, int Cout, int Cin, int dtype, void* stream);
+
+/* ---- 3x3 convolution (replaces aten::convolution for nn.Conv2d(k=3,p=1): vgg_osvos.py:41,142
+ *      and, with the dgrad pack, the input-gradient half of aten::convolution_backward) ------
+ * y[n,h,w,co] = epi( bias[co] + sum_{r,s,ci} x[n,h+r-1,w+s-1,ci] * W[co,ci,r,s] )
+ *   x: NHWC, channel stride Cin (multiple of 2G);  y: NHWC, channel stride y_cs, Cout written
+ *   bias: fp32 [Cout] or NULL;  relu != 0: epi = max(.,0)  (vgg_osvos.py:143)
+ *   mask: NHWC like y or NULL: epi zeroes the result where mask <= 0 (ReLU backward of the
+ *         producer layer fused into this layer's data-gradient: aten::threshold_backward)
+ *   tile: -1 = automatic, otherwise a tile-config index (tuning / tests) */
+int osvos_conv3x3(const void* x, const void* wpk, const float* bias, const void* mask, void* y,
+                  int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int dtype, int tile, void* stream);
+int osvos_conv3x3_num_tiles(void);
+
+/* ---- 3x3 weight gradient (weight/bias half of aten::convolution_backward) -----------------
+ * dW[co,ci,r,s] = sum_{n,h,w} dY[n,h,w,co] * x[n,h+r-1,w+s-1,ci];  db[co] = sum dY
+ *   x: NHWC stride Cin_s (only ci < Cin used); dy: NHWC stride Cout_s (already ReLU-masked)
+ *   ws: workspace of osvos_wgrad_ws_bytes(); dw: fp32 OIHW [Cout,Cin,3,3]; db: fp32 [Cout] or NULL
+ *   accumulate != 0: dw/db += result (gradient accumulation) else overwritten */
+size_t osvos_wgrad_ws_bytes(int N, int H, int W, int Cin, int Cout, int dtype);
+int osvos_conv3x3_wgrad(const void* x, const void* dy, void* ws, float* dw, float* db,
+                        int N, int H, int W, int Cin, int Cin_s, int Cout, int Cout_s,
+                        int accumulate, int dtype, void* stream);
+
+/* ---- 2x2/2 max-pool, ceil_mode (aten::max_pool2d_with_indices, vgg_osvos.py:140) ---------- */
+int osvos_maxpool2x2(const void* x, void* y, int N, int H, int W, int C, int dtype, void* stream);
+/* fused backward: dx = relu_mask(x) * ( route(dy, first max of the window in scan order) + dside )
+ * x is the (post-ReLU) pool input, dside (NULL ok) the gradient from the side branch. */
+int osvos_maxpool2x2_bwd(const void* x, const void* dy, const void* dside, void* dx,
+                         int N, int H, int W, int C, int dtype, void* stream);
+
+/* ---- side-output / fuse head (vgg_osvos.py:68-72: score_dsn 1x1, upscale_/upscale transposed
+ *      convs, center_crop (osvos_layers.py:51-56), torch.cat, fuse 1x1) ----------------------
+ * Commuted form: valid when upscale[i].weight is diagonal with one shared
+ * k x k filter; the caller checks that with osvos_deconv_diag_check and must refuse otherwise.
+ *   prep:   NHWC [N,h,w,16] output of side_prep[i]
+ *   wd/bd:  score_dsn[i] weight[16] / bias[1];  wf: fuse.weight[16*i .. 16*i+15]
+ *   score, fpart: fp32 [N,h,w] low-resolution maps */
+int osvos_head_lowres(const void* prep, const float* wd, const float* bd, const float* wf,
+                      float* score, float* fpart, int N, int h, int w, int dtype, void* stream);
+/* outs[0..3] = crop(upscale_[i](score_i)), outs[4] = fuse.bias + sum_i crop(up_i(fpart_i)); all
+ * fp32 NCHW [N,1,H,W].  score/fpart/f1/f16: host arrays of 4 device pointers (filters k x k,
+ * k = 4,8,16,32; f1 = upscale_[i].weight[0,0], f16 = upscale[i].weight[0,0]); hs/ws: host int[4]. */
+int osvos_head_upsample(const float* const* score, const float* const* fpart,
+                        const float* const* f1, const float* const* f16, const float* fuse_bias,
+                        float* const* outs, int N, int H, int W, const int* hs, const int* ws, void* stream);
+/* backward of both, per scale: dprep[N,h,w,16] (NHWC, dtype) = wf*up^T(dfused) + wd*up_^T(dside);
+ * accumulates into acc (double[34]: dwf[16], dwd[16], dbd, spare) the weight/bias gradients.
+ * dside / dfused: fp32 NCHW [N,1,H,W] or NULL (treated as zero). */
+int osvos_head_bwd(const void* prep, const float* dside, const float* dfused,
+                   const float* f1, const float* f16, const float* wd, const float* wf,
+                   void* dprep, double* acc, int N, int H, int W, int h, int w, int scale_idx,
+                   int dtype, void* stream);
+/* max |off-diagonal| and max |w[c,c]-w[0,0]| of a [16,16,k,k] deconv weight -> out[2] (device) */
+int osvos_deconv_diag_check(const float* w, int C, int k, float* out2, void* stream);
+
+/* ---- class-balanced BCE with logits (osvos_layers.py:19-48) ------------------------------
+ * out/label fp32, `count` elements over N images.  mode 0: size_average, 1: batch_average,
+ * 2: neither.  loss: fp32[1]; grad: fp32[count] = dLoss/dOut (upstream 1) or NULL;
+ * scratch: 32 bytes, zeroed by this call. */
+int osvos_cbce(const float* out, const float* label, float* loss, float* grad, void* scratch,
+               long count, int N, int mode, void* stream);
+/* y[i] = x[i] * (*scalar)   (loss.backward() chain rule with a device-resident upstream grad) */
+int osvos_scale(const float* x, const float* scalar, float* y, long count, void* stream);
+
+/* ---- whole network ------------------------------------------------------------------------
+ * One call = OSVOS.forward (vgg_osvos.py:59-74) / its autograd backward.
+ *   params: host array of 52 device pointers, state_dict order, fp32, contiguous
+ *   wbuf:   persistent buffer of osvos_net_wbuf_bytes(): packed weights (refresh with
+ *           osvos_net_pack whenever a parameter changed, e.g. after optimizer.step())
+ *   ws:     per-call workspace of osvos_net_ws_bytes(); forward leaves the activations the
+ *           backward needs in it
+ *   outs:   host array of 5 device pointers, fp32 [N,1,H,W] */
+size_t osvos_net_wbuf_bytes(int dtype);
+size_t osvos_net_ws_bytes(int N, int H, int W, int dtype);
+int osvos_net_pack(const float* const* params, void* wbuf, int dtype, int with_dgrad, void* stream);
+int osvos_net_forward(const float* x_nchw, const void* wbuf, void* ws, float* const* outs,
+                      int N, int H, int W, int dtype, void* stream);
+/* douts: host array of 5 device pointers (NULL = no gradient for that head).
+ * grads: host array of 52 device pointers (NULL entries are skipped; deconv weights are frozen in
+ *        both reference scripts -- train_online.py:84-85 -- and are never written).
+ * dx_nchw: fp32 [N,3,H,W] or NULL.  accumulate != 0: grads += instead of overwrite. */
+int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, float* const* grads,
+                       float* dx_nchw, int N, int H, int W, int dtype, int accumulate, void* stream);
+/* byte offset / element count of a saved activation inside ws (tests): which = 0..12 trunk conv
+ * outputs, 13..16 pooled inputs of stages 1-4, 17..20 side_prep outputs, 21 NHWC input */
+int osvos_net_ws_query(int N, int H, int W, int dtype, int which, size_t* offset, size_t* elems, int* channels, int* h, int* w);
+
+/* ---- fused SGD (torch.optim.SGD semantics, train_online.py:79-88,147) ----------------------
+ * for each i: d = g + wd*p; buf = first ? d : momentum*buf + d; p -= lr*buf      (flat tensors) */
+int osvos_sgd_step(float* p, const float* g, float* buf, long count, float lr, float momentum,
+                   float weight_decay, int first, void* stream);
+
+/* ---- opt-in launch profiler (bench.py only): hipEvent pairs around every kernel family that
+ * osvos_net_forward/backward launches, recorded on the caller's stream.  Families: 0 conv3x3
+ * forward, 1 conv3x3 data-gradient, 2 weight-gradient (+ slab reduce), 3 spare.
+ * osvos_prof_stop fills ms[4] (sum of launch durations), flops[4] (algorithmic FLOPs of those
+ * launches: 2*N*H*W*Cout*9*Cin) and count[4]; synchronise the stream before calling it. */
+int osvos_prof_start(int max_records);
+int osvos_prof_stop(double* ms, double* flops, long* count);
+
+/* ---- debug references (plain one-thread-per-output kernels, used only by tests) ----------- */
+int osvos_debug_conv3x3_naive(const float* x, const float* w_oihw, const float* bias, float* y,
+                              int N, int H, int W, int Cin, int Cin_s, int Cout, int relu, void* stream);
+int osvos_debug_mfma_layout(float* out /* 4*64*16 floats */, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,109 @@
+"""ctypes binding of libosvos_hip.so (C ABI: include/osvos_hip.h).  Fails loudly: there is no
+CPU or PyTorch fallback for any compute entry point."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import shutil
+import subprocess
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libosvos_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+_lock = threading.Lock()
+_lib = None
+
+F32, BF16 = 0, 1
+NPARAMS = 52
+
+_vp, _i, _l, _sz, _f = C.c_void_p, C.c_int, C.c_long, C.c_size_t, C.c_float
+
+# name -> (restype, argtypes); every symbol declared in include/osvos_hip.h
+PROTOTYPES = {
+    "osvos_version": (_i, []),
+    "osvos_last_error": (C.c_char_p, []),
+    "osvos_nchw_to_nhwc": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "osvos_nhwc_to_nchw": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "osvos_wpack_bytes": (_sz, [_i, _i, _i]),
+    "osvos_pack_conv3x3_fwd": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "osvos_wpack_dgrad_bytes": (_sz, [_i, _i, _i]),
+    "osvos_pack_conv3x3_dgrad": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "osvos_conv3x3": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "osvos_conv3x3_num_tiles": (_i, []),
+    "osvos_wgrad_ws_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
+    "osvos_conv3x3_wgrad": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "osvos_maxpool2x2": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "osvos_maxpool2x2_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "osvos_head_lowres": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "osvos_head_upsample": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "osvos_head_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "osvos_deconv_diag_check": (_i, [_vp, _i, _i, _vp, _vp]),
+    "osvos_cbce": (_i, [_vp, _vp, _vp, _vp, _vp, _l, _i, _i, _vp]),
+    "osvos_scale": (_i, [_vp, _vp, _vp, _l, _vp]),
+    "osvos_net_wbuf_bytes": (_sz, [_i]),
+    "osvos_net_ws_bytes": (_sz, [_i, _i, _i, _i]),
+    "osvos_net_pack": (_i, [_vp, _vp, _i, _i, _vp]),
+    "osvos_net_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "osvos_net_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "osvos_net_ws_query": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "osvos_sgd_step": (_i, [_vp, _vp, _vp, _l, _f, _f, _f, _i, _vp]),
+    "osvos_prof_start": (_i, [_i]),
+    "osvos_prof_stop": (_i, [_vp, _vp, _vp]),
+    "osvos_debug_conv3x3_naive": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "osvos_debug_mfma_layout": (_i, [_vp, _vp]),
+}
+
+
+def build(force: bool = False) -> str:
+    """Compile csrc/ for gfx950 with hipcc (cross-compiles without a GPU)."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        raise RuntimeError("libosvos_hip.so is not built and hipcc was not found; run `make -C %s`" % CSRC)
+    cmd = ["make", "-C", CSRC, "-j8", "-s", "HIPCC=" + hipcc]
+    if force:
+        subprocess.check_call(cmd + ["clean"])
+    subprocess.check_call(cmd)
+    return SO_PATH
+
+
+def _stale() -> bool:
+    if not os.path.exists(SO_PATH):
+        return True
+    t = os.path.getmtime(SO_PATH)
+    for f in os.listdir(CSRC):
+        if f.endswith((".hip", ".cpp", ".h")) and os.path.getmtime(os.path.join(CSRC, f)) > t:
+            return True
+    return os.path.getmtime(os.path.join(_HERE, "..", "include", "osvos_hip.h")) > t
+
+
+def lib() -> C.CDLL:
+    """The loaded library.  Builds it first when it is missing or older than its sources and a
+    compiler is available; raises RuntimeError otherwise (never falls back to another path)."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if _stale():
+                build()
+            try:
+                l = C.CDLL(SO_PATH)
+            except OSError as e:  # pragma: no cover
+                raise RuntimeError("cannot load %s: %s" % (SO_PATH, e))
+            for name, (res, args) in PROTOTYPES.items():
+                fn = getattr(l, name)          # AttributeError = ABI mismatch: fail loudly
+                fn.restype = res
+                fn.argtypes = args
+            _lib = l
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().osvos_last_error().decode(errors="replace")
+        raise RuntimeError("libosvos_hip %s failed (rc=%d): %s" % (what, rc, msg))
+
+
+def ptr_array(ptrs):
+    """Host array of device pointers (ints or None)."""
+    arr = (C.c_void_p * len(ptrs))(*[C.c_void_p(p) if p else None for p in ptrs])
+    return arr

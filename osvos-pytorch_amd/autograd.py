@@ -1,0 +1,151 @@
+"""autograd glue: one Function for the whole network (forward = osvos_net_forward, backward =
+osvos_net_backward) and one for the loss.  PyTorch is plumbing here: it owns device memory,
+streams and the autograd tape; every FLOP runs in libosvos_hip.so."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from ._lib import F32, NPARAMS, check, lib, ptr_array
+
+# indices (state_dict order) of the frozen transposed-conv weights: lr 0 in both reference
+# scripts (train_online.py:84-85, train_parent.py:99-100); their gradients are never formed
+_FROZEN = set(range(8))
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class NetRuntime:
+    """Packed-parameter cache of one OSVOS module (wbuf of include/osvos_hip.h).  Re-packs when
+    any parameter's (storage, version) changed, e.g. after optimizer.step()."""
+
+    def __init__(self):
+        self.wbuf = None
+        self.key = None
+        self.deconv_key = None
+        self.dtype = F32
+
+    def ensure_packed(self, params):
+        dev = params[0].device
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        if self.wbuf is not None and key == self.key and self.wbuf.device == dev:
+            return
+        l = lib()
+        if self.wbuf is None or self.wbuf.device != dev:
+            self.wbuf = torch.empty(l.osvos_net_wbuf_bytes(self.dtype), device=dev, dtype=torch.uint8)
+            self.deconv_key = None
+        dkey = key[:4]
+        if dkey != self.deconv_key:
+            self._check_deconv(params[:4])
+            self.deconv_key = dkey
+        check(l.osvos_net_pack(ptr_array([p.data_ptr() for p in params]), C.c_void_p(self.wbuf.data_ptr()),
+                               self.dtype, 1, _stream()), "net_pack")
+        self.key = key
+
+    @staticmethod
+    def _check_deconv(ups):
+        """The fused head is exact only for diagonal, shared-filter upscale weights (what
+        interp_surgery produces, osvos_layers.py:72-85).  Anything else is refused."""
+        l = lib()
+        res = torch.empty((4, 2), device=ups[0].device, dtype=torch.float32)
+        for i, w in enumerate(ups):
+            check(l.osvos_deconv_diag_check(C.c_void_p(w.data_ptr()), w.shape[0], w.shape[2],
+                                            C.c_void_p(res[i].data_ptr()), _stream()), "deconv_diag_check")
+        vals = res.cpu()
+        if float(vals.max()) != 0.0:
+            raise NotImplementedError(
+                "upscale[i].weight is not diagonal with one shared filter (max off-diagonal %g, max "
+                "channel deviation %g): the MI355X head uses the commuted upsample/fuse form and "
+                "refuses non-diagonal transposed-conv weights" % (float(vals[:, 0].max()), float(vals[:, 1].max())))
+
+
+class OSVOSNetFunction(torch.autograd.Function):
+    """(x [N,3,H,W], 52 parameters) -> 5 logit maps [N,1,H,W]   (vgg_osvos.py:59-74)."""
+
+    @staticmethod
+    def forward(ctx, rt, x, *params):
+        if not x.is_cuda:
+            raise RuntimeError("OSVOS (osvos_pytorch_amd) runs on the GPU only: move the module and the input to "
+                               "'cuda'; there is no CPU fallback")
+        if len(params) != NPARAMS:
+            raise RuntimeError("expected %d parameters, got %d" % (NPARAMS, len(params)))
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise RuntimeError("expected input of shape [N,3,H,W], got %s" % (tuple(x.shape),))
+        l = lib()
+        xin = x.detach().contiguous().float()
+        ps = [p.detach().contiguous() for p in params]
+        for p in ps:
+            if p.dtype != torch.float32 or p.device != xin.device:
+                raise RuntimeError("parameters must be float32 on the input's device")
+        rt.ensure_packed(ps)
+        n, _, h, w = xin.shape
+        ws = torch.empty(l.osvos_net_ws_bytes(n, h, w, rt.dtype), device=xin.device, dtype=torch.uint8)
+        outs = [torch.empty((n, 1, h, w), device=xin.device, dtype=torch.float32) for _ in range(5)]
+        check(l.osvos_net_forward(C.c_void_p(xin.data_ptr()), C.c_void_p(rt.wbuf.data_ptr()), C.c_void_p(ws.data_ptr()),
+                                  ptr_array([o.data_ptr() for o in outs]), n, h, w, rt.dtype, _stream()), "net_forward")
+        ctx.rt, ctx.ws, ctx.shape = rt, ws, (n, h, w)
+        ctx.param_meta = [(tuple(p.shape), p.device) for p in ps]
+        ctx.pack_key = rt.key
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        rt, ws = ctx.rt, ctx.ws
+        n, h, w = ctx.shape
+        if rt.key != ctx.pack_key:
+            raise RuntimeError("parameters changed between forward and backward of the same graph")
+        l = lib()
+        dev = ws.device
+        d = [None if g is None else g.contiguous().float() for g in douts]
+        grads = []
+        for i, (shape, _) in enumerate(ctx.param_meta):
+            need = ctx.needs_input_grad[2 + i] and i not in _FROZEN
+            if need and 42 <= i < 50 and all(g is None for g in d[:4]):
+                need = False       # score_dsn gets no gradient when only the fused head is used
+            grads.append(torch.empty(shape, device=dev, dtype=torch.float32) if need else None)
+        dx = torch.empty((n, 3, h, w), device=dev, dtype=torch.float32) if ctx.needs_input_grad[1] else None
+        check(l.osvos_net_backward(C.c_void_p(rt.wbuf.data_ptr()), C.c_void_p(ws.data_ptr()),
+                                   ptr_array([None if g is None else g.data_ptr() for g in d]),
+                                   ptr_array([None if g is None else g.data_ptr() for g in grads]),
+                                   C.c_void_p(dx.data_ptr()) if dx is not None else None,
+                                   n, h, w, rt.dtype, 0, _stream()), "net_backward")
+        ctx.ws = None
+        return (None, dx) + tuple(grads)
+
+
+class CBCELossFunction(torch.autograd.Function):
+    """class_balanced_cross_entropy_loss (osvos_layers.py:19-48); loss and dLoss/dOutput come out
+    of the same kernel pass, the backward only scales by the (device-resident) upstream gradient."""
+
+    @staticmethod
+    def forward(ctx, output, label, mode):
+        if not output.is_cuda:
+            raise RuntimeError("class_balanced_cross_entropy_loss (osvos_pytorch_amd) needs CUDA tensors; no CPU fallback")
+        l = lib()
+        out = output.detach().contiguous().float()
+        lab = label.detach().to(device=out.device, dtype=torch.float32).contiguous()
+        if lab.numel() != out.numel():
+            raise RuntimeError("output and label must have the same number of elements")
+        loss = torch.empty((), device=out.device, dtype=torch.float32)
+        need = ctx.needs_input_grad[0]
+        grad = torch.empty_like(out) if need else None
+        scratch = torch.empty(4, device=out.device, dtype=torch.float64)
+        check(l.osvos_cbce(C.c_void_p(out.data_ptr()), C.c_void_p(lab.data_ptr()), C.c_void_p(loss.data_ptr()),
+                           C.c_void_p(grad.data_ptr()) if need else None, C.c_void_p(scratch.data_ptr()),
+                           out.numel(), out.shape[0], int(mode), _stream()), "cbce")
+        ctx.grad = grad
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        grad = ctx.grad
+        if grad is None:
+            return None, None, None
+        g = g.detach().to(torch.float32).contiguous()
+        gx = torch.empty_like(grad)
+        check(lib().osvos_scale(C.c_void_p(grad.data_ptr()), C.c_void_p(g.data_ptr()), C.c_void_p(gx.data_ptr()),
+                                grad.numel(), _stream()), "scale")
+        return gx, None, None

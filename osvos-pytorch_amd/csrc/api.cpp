@@ -1,0 +1,77 @@
+// extern "C" surface of libosvos_hip.so: argument checks + dtype dispatch for the per-op entry
+// points declared in include/osvos_hip.h.  (The whole-network calls live in net.cpp.)
+#include "kernels.h"
+
+#define NEED_F32(dtype, what)                                                                     \
+  OSVOS_ARG_CHECK((dtype) == OSVOS_F32, "%s: dtype %d not built (this build ships the fp32 path)", what, (int)(dtype))
+
+extern "C" {
+
+int osvos_nchw_to_nhwc(const float* src, void* dst, int N, int C, int H, int W, int cpad, int dtype, void* stream) {
+  NEED_F32(dtype, "nchw_to_nhwc");
+  return osvos_nchw_to_nhwc_f32(src, (float*)dst, N, C, H, W, cpad, (hipStream_t)stream);
+}
+int osvos_nhwc_to_nchw(const void* src, float* dst, int N, int C, int H, int W, int cs, int dtype, void* stream) {
+  NEED_F32(dtype, "nhwc_to_nchw");
+  return osvos_nhwc_to_nchw_f32((const float*)src, dst, N, C, H, W, cs, (hipStream_t)stream);
+}
+
+size_t osvos_wpack_bytes(int Cout, int Cin, int dtype) {
+  return (size_t)9 * osvos_cin_pad(Cin, dtype) * osvos_cout_pad(Cout) * osvos_elem(dtype);
+}
+size_t osvos_wpack_dgrad_bytes(int Cout, int Cin, int dtype) {
+  return (size_t)9 * osvos_cin_pad(Cout, dtype) * osvos_cout_pad(Cin) * osvos_elem(dtype);
+}
+int osvos_pack_conv3x3_fwd(const float* w, void* wpk, int Cout, int Cin, int dtype, void* stream) {
+  NEED_F32(dtype, "pack_conv3x3_fwd");
+  return osvos_pack_fwd_f32(w, (float*)wpk, Cout, Cin, (hipStream_t)stream);
+}
+int osvos_pack_conv3x3_dgrad(const float* w, void* wpk, int Cout, int Cin, int dtype, void* stream) {
+  NEED_F32(dtype, "pack_conv3x3_dgrad");
+  return osvos_pack_dgrad_f32(w, (float*)wpk, Cout, Cin, (hipStream_t)stream);
+}
+
+int osvos_conv3x3(const void* x, const void* wpk, const float* bias, const void* mask, void* y,
+                  int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int dtype, int tile, void* stream) {
+  NEED_F32(dtype, "conv3x3");
+  return osvos_conv3x3_f32((const float*)x, (const float*)wpk, bias, (const float*)mask, (float*)y,
+                           N, H, W, Cin, Cout, y_cs, relu, tile, (hipStream_t)stream);
+}
+
+size_t osvos_wgrad_ws_bytes(int N, int H, int W, int Cin, int Cout, int dtype) {
+  (void)dtype;
+  return osvos_wgrad_ws_bytes_f32(N, H, W, Cin, Cout);
+}
+int osvos_conv3x3_wgrad(const void* x, const void* dy, void* ws, float* dw, float* db,
+                        int N, int H, int W, int Cin, int Cin_s, int Cout, int Cout_s,
+                        int accumulate, int dtype, void* stream) {
+  NEED_F32(dtype, "conv3x3_wgrad");
+  return osvos_conv3x3_wgrad_f32((const float*)x, (const float*)dy, ws, dw, db, N, H, W, Cin, Cin_s, Cout, Cout_s,
+                                 accumulate, (hipStream_t)stream);
+}
+
+int osvos_maxpool2x2(const void* x, void* y, int N, int H, int W, int C, int dtype, void* stream) {
+  NEED_F32(dtype, "maxpool2x2");
+  return osvos_maxpool2x2_f32((const float*)x, (float*)y, N, H, W, C, (hipStream_t)stream);
+}
+int osvos_maxpool2x2_bwd(const void* x, const void* dy, const void* dside, void* dx,
+                         int N, int H, int W, int C, int dtype, void* stream) {
+  NEED_F32(dtype, "maxpool2x2_bwd");
+  return osvos_maxpool2x2_bwd_f32((const float*)x, (const float*)dy, (const float*)dside, (float*)dx, N, H, W, C, (hipStream_t)stream);
+}
+
+int osvos_head_lowres(const void* prep, const float* wd, const float* bd, const float* wf,
+                      float* score, float* fpart, int N, int h, int w, int dtype, void* stream) {
+  NEED_F32(dtype, "head_lowres");
+  return osvos_head_lowres_f32((const float*)prep, wd, bd, wf, score, fpart, N, h, w, (hipStream_t)stream);
+}
+int osvos_head_bwd(const void* prep, const float* dside, const float* dfused,
+                   const float* f1, const float* f16, const float* wd, const float* wf,
+                   void* dprep, double* acc, int N, int H, int W, int h, int w, int scale_idx,
+                   int dtype, void* stream) {
+  NEED_F32(dtype, "head_bwd");
+  return osvos_head_bwd_f32((const float*)prep, dside, dfused, f1, f16, wd, wf, (float*)dprep, acc, N, H, W, h, w,
+                            scale_idx, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,307 @@
+// 3x3 stride-1 pad-1 convolution, NHWC fp32, implicit GEMM on v_mfma_f32_32x32x2_f32 (gfx950).
+//
+// Replaces aten::convolution for nn.Conv2d(k=3, padding=1) (reference vgg_osvos.py:41,142-143)
+// and, fed with the rotated/transposed weight pack, the data-gradient half of
+// aten::convolution_backward.  Exact fp32: the MFMA is bitwise a k-ordered fmaf chain.
+//
+// GEMM view: M = output pixels, N = Cout, K = 9 * Cin.
+//   * a workgroup (4 waves) owns a TW x TH spatial patch x BN output channels
+//   * per 8-channel K chunk the (TH+2) x (TW+2) input halo is staged ONCE into LDS as two
+//     planes of 16-byte channel quads ([quad][row][col] float4) and reused by all 9 taps:
+//     a tap is just an LDS address offset (r*PITCH + s), so the 9x im2col blow-up never
+//     touches L2/HBM
+//   * MFMA row block = 32 pixels laid out RBW wide x 32/RBW tall; lane l (pixel l&31, half l>>5)
+//     reads ONE ds_read_b128 = channels 4*(l>>5)..+3 of its pixel and feeds 4 MFMAs
+//     (k = l>>5 selects the quad) -> conflict-free 16-B slots, 1 LDS instr per 4 MFMAs
+//   * weights are pre-packed [tap][Cin/4][CoutP][4] so the B operand is the same one-b128 pattern
+//   * global->LDS staging is register double-buffered: loads of chunk k+1 are issued before the
+//     MFMAs of chunk k and written to the other LDS buffer after them (one barrier per chunk)
+//   * blockIdx -> tile mapping puts the Cout tile in the low bits so that each XCD (block b runs
+//     on XCD b % 8) keeps re-using the same weight slice from its private L2
+#include "common.h"
+
+namespace {
+
+struct ConvArgs {
+  const float* x;
+  const float* wpk;
+  const float* bias;
+  const float* mask;
+  float* y;
+  int N, H, W, Cin, Cout, CoutP, y_cs;
+  int tiles_x, tiles_y, nct;
+  int relu;
+};
+
+constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
+constexpr int pitch_for(int rbw, int hw) {
+  // RBW 32: any pitch is conflict free; RBW 16: pitch % 16 == 0; RBW 8: pitch % 16 == 8
+  return rbw == 32 ? hw : (rbw == 16 ? cdiv(hw, 16) * 16 : cdiv(hw - 8, 16) * 16 + 8);
+}
+
+template <int RBW_, int TBX_, int TBY_, int NB_, int WGM_, int WGN_>
+struct Cfg {
+  static constexpr int RBW = RBW_, TBX = TBX_, TBY = TBY_, NB = NB_, WGM = WGM_, WGN = WGN_;
+  static constexpr int RBH = 32 / RBW;
+  static constexpr int TW = TBX * RBW, TH = TBY * RBH;
+  static constexpr int HWD = TW + 2, HHT = TH + 2;
+  static constexpr int PITCH = pitch_for(RBW, HWD);
+  static constexpr int PLANE = HHT * PITCH;
+  static constexpr int BN = NB * 32;
+  static constexpr int A_F4 = 2 * PLANE;
+  static constexpr int B_F4 = 9 * 2 * BN;
+  static constexpr int BUF_F4 = A_F4 + B_F4;
+  static constexpr int A_LOAD = HHT * HWD * 2;
+  static constexpr int NA = cdiv(A_LOAD, 256);
+  static constexpr int NBL = cdiv(B_F4, 256);
+  static constexpr int MB = TBX * TBY;
+  static constexpr int WM = MB / WGM, WN = NB / WGN;
+  static constexpr size_t LDS_BYTES = (size_t)2 * BUF_F4 * 16;
+  static_assert(WGM * WGN == 4, "4 waves per workgroup");
+  static_assert(MB % WGM == 0 && NB % WGN == 0, "wave grid must divide the tile");
+};
+
+template <class C>
+__global__ __launch_bounds__(256) void conv3x3_f32_kernel(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  f32x4* lds = reinterpret_cast<f32x4*>(smem);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm = wave / C::WGN, wn = wave % C::WGN;
+
+  int sp = blockIdx.x / a.nct;
+  const int ct = blockIdx.x % a.nct;
+  const int tx = sp % a.tiles_x;
+  sp /= a.tiles_x;
+  const int ty = sp % a.tiles_y;
+  const int n = sp / a.tiles_y;
+  const int x0 = tx * C::TW, y0 = ty * C::TH, co0 = ct * C::BN;
+  const int CQ = a.Cin >> 2;
+
+  const float* ximg = a.x + (size_t)n * a.H * a.W * a.Cin;
+
+  // ---- per-thread staging descriptors (invariant over K chunks) --------------------------
+  int a_src[C::NA];   // element offset inside the image, -1 = zero fill, -2 = no element
+  int a_dst[C::NA];
+#pragma unroll
+  for (int i = 0; i < C::NA; ++i) {
+    const int e = tid + i * 256;
+    a_src[i] = -2;
+    a_dst[i] = 0;
+    if (e < C::A_LOAD) {
+      const int h = e & 1, pix = e >> 1;
+      const int hy = pix / C::HWD, hx = pix % C::HWD;
+      const int gy = y0 + hy - 1, gx = x0 + hx - 1;
+      a_dst[i] = h * C::PLANE + hy * C::PITCH + hx;
+      a_src[i] = (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? ((gy * a.W + gx) * a.Cin + 4 * h) : -1;
+    }
+  }
+  int b_src[C::NBL];  // float4 index into wpk for chunk 0, -2 = none
+#pragma unroll
+  for (int i = 0; i < C::NBL; ++i) {
+    const int e = tid + i * 256;
+    b_src[i] = -2;
+    if (e < C::B_F4) {
+      const int tap = e / (2 * C::BN), rem = e % (2 * C::BN);
+      const int h = rem / C::BN, nn = rem % C::BN;
+      b_src[i] = (co0 + nn < a.CoutP) ? (tap * CQ + h) * a.CoutP + co0 + nn : -1;
+    }
+  }
+
+  f32x4 ra[C::NA], rb[C::NBL];
+  auto load_chunk = [&](int kc) {
+    const int c0 = kc * 8;
+#pragma unroll
+    for (int i = 0; i < C::NA; ++i) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (a_src[i] >= 0) v = *reinterpret_cast<const f32x4*>(ximg + a_src[i] + c0);
+      ra[i] = v;
+    }
+    const f32x4* wq = reinterpret_cast<const f32x4*>(a.wpk) + (size_t)(c0 >> 2) * a.CoutP;
+#pragma unroll
+    for (int i = 0; i < C::NBL; ++i) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (b_src[i] >= 0) v = wq[b_src[i]];
+      rb[i] = v;
+    }
+  };
+  auto store_chunk = [&](int buf) {
+    f32x4* As = lds + buf * C::BUF_F4;
+    f32x4* Bs = As + C::A_F4;
+#pragma unroll
+    for (int i = 0; i < C::NA; ++i)
+      if (a_src[i] != -2) As[a_dst[i]] = ra[i];
+#pragma unroll
+    for (int i = 0; i < C::NBL; ++i)
+      if (b_src[i] != -2) Bs[tid + i * 256] = rb[i];
+  };
+
+  // ---- per-lane fragment addresses ---------------------------------------------------------
+  int a_idx[C::WM];
+#pragma unroll
+  for (int mi = 0; mi < C::WM; ++mi) {
+    const int mb = wm * C::WM + mi;
+    const int mbx = mb % C::TBX, mby = mb / C::TBX;
+    const int dy = li / C::RBW, dx = li % C::RBW;
+    a_idx[mi] = lh * C::PLANE + (mby * C::RBH + dy) * C::PITCH + mbx * C::RBW + dx;
+  }
+  const int b_idx = lh * C::BN + wn * C::WN * 32 + li;
+
+  f32x16 acc[C::WM][C::WN];
+#pragma unroll
+  for (int mi = 0; mi < C::WM; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < C::WN; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  const int nchunks = a.Cin >> 3;
+  load_chunk(0);
+  store_chunk(0);
+  __syncthreads();
+  for (int kc = 0; kc < nchunks; ++kc) {
+    const bool more = kc + 1 < nchunks;
+    if (more) load_chunk(kc + 1);
+    const f32x4* As = lds + (kc & 1) * C::BUF_F4;
+    const f32x4* Bs = As + C::A_F4;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int r = tap / 3, s = tap % 3;
+      f32x4 fa[C::WM], fb[C::WN];
+#pragma unroll
+      for (int mi = 0; mi < C::WM; ++mi) fa[mi] = As[a_idx[mi] + r * C::PITCH + s];
+#pragma unroll
+      for (int ni = 0; ni < C::WN; ++ni) fb[ni] = Bs[b_idx + tap * 2 * C::BN + ni * 32];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mi = 0; mi < C::WM; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < C::WN; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mi][j], fb[ni][j], acc[mi][ni], 0, 0, 0);
+    }
+    if (more) store_chunk((kc + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: D[row = pixel][col = cout]; lane holds col li, rows (r&3) + 8*(r>>2) + 4*lh ---
+#pragma unroll
+  for (int ni = 0; ni < C::WN; ++ni) {
+    const int co = co0 + (wn * C::WN + ni) * 32 + li;
+    const bool co_ok = co < a.Cout;
+    const float bv = (a.bias != nullptr && co_ok) ? a.bias[co] : 0.f;
+#pragma unroll
+    for (int mi = 0; mi < C::WM; ++mi) {
+      const int mb = wm * C::WM + mi;
+      const int mbx = mb % C::TBX, mby = mb / C::TBX;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int prow = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int oy = y0 + mby * C::RBH + prow / C::RBW;
+        const int ox = x0 + mbx * C::RBW + prow % C::RBW;
+        if (co_ok && oy < a.H && ox < a.W) {
+          const size_t o = ((size_t)(n * a.H + oy) * a.W + ox) * a.y_cs + co;
+          float v = acc[mi][ni][r] + bv;
+          if (a.relu) v = v > 0.f ? v : 0.f;
+          if (a.mask != nullptr) v = a.mask[o] > 0.f ? v : 0.f;
+          a.y[o] = v;
+        }
+      }
+    }
+  }
+}
+
+template <class C>
+int launch_cfg(const ConvArgs& a0, hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    OSVOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f32_kernel<C>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
+    attr_set = true;
+  }
+  ConvArgs a = a0;
+  a.tiles_x = ceil_div(a.W, C::TW);
+  a.tiles_y = ceil_div(a.H, C::TH);
+  a.nct = ceil_div(a.CoutP, C::BN);
+  const long blocks = (long)a.nct * a.tiles_x * a.tiles_y * a.N;
+  OSVOS_ARG_CHECK(blocks > 0 && blocks < (1L << 31), "conv3x3: grid of %ld blocks", blocks);
+  hipLaunchKernelGGL(conv3x3_f32_kernel<C>, dim3((unsigned)blocks), dim3(256), C::LDS_BYTES, stream, a);
+  OSVOS_LAUNCH_CHECK();
+  return 0;
+}
+
+struct TileInfo {
+  int tw, th, bn, wm, wn;
+  size_t lds;
+};
+
+//                RBW TBX TBY NB WGM WGN
+using T0 = Cfg<32, 1, 8, 4, 2, 2>;   // 256 px x 128 co
+using T1 = Cfg<32, 1, 8, 2, 4, 1>;   // 256 px x  64 co
+using T2 = Cfg<32, 1, 4, 2, 2, 2>;   // 128 px x  64 co
+using T3 = Cfg<32, 1, 8, 1, 4, 1>;   // 256 px x  32 co
+using T4 = Cfg<16, 1, 4, 2, 2, 2>;   // 16x8 px x 64 co
+using T5 = Cfg<8, 1, 2, 2, 2, 2>;    //  8x8 px x 64 co
+using T6 = Cfg<16, 1, 2, 2, 2, 2>;   // 16x4 px x 64 co
+using T7 = Cfg<32, 1, 2, 2, 2, 2>;   // 32x2 px x 64 co
+using T8 = Cfg<32, 1, 4, 4, 2, 2>;   // 128 px x 128 co
+using T9 = Cfg<16, 1, 4, 1, 4, 1>;   // 16x8 px x 32 co
+constexpr int kNumTiles = 10;
+
+template <class C>
+constexpr TileInfo info() { return TileInfo{C::TW, C::TH, C::BN, C::WM, C::WN, C::LDS_BYTES}; }
+const TileInfo kTiles[kNumTiles] = {info<T0>(), info<T1>(), info<T2>(), info<T3>(), info<T4>(),
+                                    info<T5>(), info<T6>(), info<T7>(), info<T8>(), info<T9>()};
+
+int pick_tile(int N, int H, int W, int Cin, int CoutP) {
+  // crude model: MFMA-issue-bound blocks, `bpc` workgroups co-resident per CU (LDS limited)
+  double best = 1e300;
+  int best_i = 0;
+  for (int i = 0; i < kNumTiles; ++i) {
+    const TileInfo& t = kTiles[i];
+    if (t.bn > CoutP && t.bn != 32) continue;
+    const long tiles = (long)N * ceil_div(H, t.th) * ceil_div(W, t.tw) * ceil_div(CoutP, t.bn);
+    int bpc = (int)(160 * 1024 / t.lds);
+    if (bpc > 4) bpc = 4;
+    if (bpc < 1) bpc = 1;
+    const double per_chunk = t.wm * t.wn * 9.0 * 4.0 * 64.0 + 700.0;
+    const double rounds = (double)((tiles + 256L * bpc - 1) / (256L * bpc));
+    const double cost = rounds * bpc * per_chunk * (Cin / 8);
+    if (cost < best) { best = cost; best_i = i; }
+  }
+  return best_i;
+}
+
+}  // namespace
+
+extern "C" int osvos_conv3x3_num_tiles(void) { return kNumTiles; }
+
+int osvos_conv3x3_f32(const float* x, const float* wpk, const float* bias, const float* mask, float* y,
+                      int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int tile, hipStream_t stream) {
+  OSVOS_ARG_CHECK(x && wpk && y, "conv3x3: null pointer");
+  OSVOS_ARG_CHECK(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv3x3: bad shape");
+  OSVOS_ARG_CHECK(Cin % 8 == 0, "conv3x3 f32: Cin (%d) must be a multiple of 8 (pad the input)", Cin);
+  OSVOS_ARG_CHECK(y_cs >= Cout, "conv3x3: y channel stride %d < Cout %d", y_cs, Cout);
+  OSVOS_ARG_CHECK((long)H * W * Cin < (1L << 31), "conv3x3: image too large for 32-bit offsets");
+  ConvArgs a;
+  a.x = x; a.wpk = wpk; a.bias = bias; a.mask = mask; a.y = y;
+  a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.CoutP = osvos_cout_pad(Cout); a.y_cs = y_cs;
+  a.relu = relu;
+  if (tile < 0) {
+    const char* env = getenv("OSVOS_CONV_TILE");
+    tile = env ? atoi(env) : pick_tile(N, H, W, Cin, a.CoutP);
+  }
+  switch (tile) {
+    case 0: return launch_cfg<T0>(a, stream);
+    case 1: return launch_cfg<T1>(a, stream);
+    case 2: return launch_cfg<T2>(a, stream);
+    case 3: return launch_cfg<T3>(a, stream);
+    case 4: return launch_cfg<T4>(a, stream);
+    case 5: return launch_cfg<T5>(a, stream);
+    case 6: return launch_cfg<T6>(a, stream);
+    case 7: return launch_cfg<T7>(a, stream);
+    case 8: return launch_cfg<T8>(a, stream);
+    case 9: return launch_cfg<T9>(a, stream);
+    default: osvos_set_error("conv3x3: unknown tile config %d", tile); return -1;
+  }
+}

@@ -1,0 +1,65 @@
+// Debug references used only by tests: a one-thread-per-output direct convolution (to separate
+// MFMA-tiling bugs from plumbing bugs in GPU test logs) and an MFMA fragment-layout probe.
+#include "common.h"
+
+namespace {
+
+__global__ void conv3x3_naive_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                     float* __restrict__ y, int N, int H, int W, int Cin, int Cin_s, int Cout, int relu) {
+  const long total = (long)N * H * W * Cout;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int co = (int)(i % Cout);
+    long t = i / Cout;
+    const int ox = (int)(t % W);
+    t /= W;
+    const int oy = (int)(t % H);
+    const long n = t / H;
+    float acc = bias ? bias[co] : 0.f;
+    for (int r = 0; r < 3; ++r) {
+      const int iy = oy + r - 1;
+      if (iy < 0 || iy >= H) continue;
+      for (int s = 0; s < 3; ++s) {
+        const int ix = ox + s - 1;
+        if (ix < 0 || ix >= W) continue;
+        const float* xp = x + ((n * H + iy) * W + ix) * Cin_s;
+        for (int ci = 0; ci < Cin; ++ci) acc = fmaf(xp[ci], w[((long)co * Cin + ci) * 9 + r * 3 + s], acc);
+      }
+    }
+    y[i] = (relu && acc < 0.f) ? 0.f : acc;
+  }
+}
+
+// out[v][lane][r], v = 0: only k=0 operands non-zero, v = 1: only k=1, v = 2: both, v = 3: lane/reg echo
+__global__ void mfma_layout_kernel(float* out) {
+  const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
+  for (int v = 0; v < 3; ++v) {
+    const bool on = (v == 2) || (lh == v);
+    const float av = on ? (float)(li + 1) * (lh ? 3.f : 1.f) : 0.f;          // A[i][k] = (i+1) * (k ? 3 : 1)
+    const float bv = on ? (float)(li + 1) * 100.f * (lh ? 7.f : 1.f) : 0.f;  // B[k][j] = 100 (j+1) * (k ? 7 : 1)
+    f32x16 c;
+    for (int r = 0; r < 16; ++r) c[r] = 0.f;
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, c, 0, 0, 0);
+    for (int r = 0; r < 16; ++r) out[(v * 64 + lane) * 16 + r] = c[r];
+  }
+  for (int r = 0; r < 16; ++r) out[(3 * 64 + lane) * 16 + r] = (float)(lane * 16 + r);
+}
+
+}  // namespace
+
+extern "C" int osvos_debug_conv3x3_naive(const float* x, const float* w_oihw, const float* bias, float* y,
+                                         int N, int H, int W, int Cin, int Cin_s, int Cout, int relu, void* stream) {
+  OSVOS_ARG_CHECK(x && w_oihw && y, "debug conv: null pointer");
+  const long total = (long)N * H * W * Cout;
+  long b = (total + 255) / 256;
+  if (b > 65535) b = 65535;
+  hipLaunchKernelGGL(conv3x3_naive_kernel, dim3((unsigned)b), dim3(256), 0, (hipStream_t)stream, x, w_oihw, bias, y, N, H, W, Cin, Cin_s, Cout, relu);
+  OSVOS_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int osvos_debug_mfma_layout(float* out, void* stream) {
+  OSVOS_ARG_CHECK(out, "debug mfma: null pointer");
+  hipLaunchKernelGGL(mfma_layout_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out);
+  OSVOS_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,275 @@
+// Side-output / fuse head of OSVOS.forward (reference vgg_osvos.py:68-72) in its commuted form.
+//
+// Reference, per scale i (s = 2^(i+1), k = 2s):   P = side_prep[i](x)            [N,16,h,w]
+//   side_out[i] = center_crop(upscale_[i](score_dsn[i](P)))                       1 channel
+//   side[i]     = center_crop(upscale[i](P))                                      16 channels
+//   fused       = fuse(cat(side))                                                 64 -> 1
+// upscale[i].weight is diagonal with ONE shared k x k filter f (interp_surgery,
+// osvos_layers.py:72-85; frozen by lr 0 in both training scripts), and upsample, crop and the
+// 1x1 fuse are all linear, so     fused = b + sum_i crop(up_f( sum_c wfuse[16i+c] * P[c] )).
+// The 64-channel full-resolution concat (105 MB fp32 per 854x480 frame) and the eight negative-pad
+// copies (osvos_layers.py:56) never exist here: two dot-16 per low-res pixel, then one gather of
+// <= 2x2 taps per scale per output pixel.  The caller verifies the diagonal/shared-filter
+// precondition with osvos_deconv_diag_check and refuses to run otherwise.
+#include "common.h"
+
+namespace {
+
+// score = bd + wd . P[pix], fpart = wf . P[pix]
+__global__ void head_lowres_f32_kernel(const f32x4* __restrict__ prep, const float* __restrict__ wd,
+                                       const float* __restrict__ bd, const float* __restrict__ wf,
+                                       float* __restrict__ score, float* __restrict__ fpart, long npix) {
+  float w1[16], w2[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) { w1[c] = wd[c]; w2[c] = wf[c]; }
+  const float b = bd[0];
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (long)gridDim.x * blockDim.x) {
+    float s = b, f = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 v = prep[i * 4 + q];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { s += w1[q * 4 + e] * v[e]; f += w2[q * 4 + e] * v[e]; }
+    }
+    score[i] = s;
+    fpart[i] = f;
+  }
+}
+
+struct UpArgs {
+  const float* score[4];
+  const float* fpart[4];
+  const float* f1[4];
+  const float* f16[4];
+  const float* fuse_bias;
+  float* outs[5];
+  int N, H, W;
+  int hs[4], ws[4];
+};
+
+// transposed conv (k = 2s, stride s, no padding) + center crop, gathered per output pixel:
+// out[Y,X] = sum_{y,x} in[y,x] * f[Yp - y*s][Xp - x*s],  Yp = Y + top, top = floor((Ho - H)/2)
+__global__ void head_upsample_kernel(UpArgs a) {
+  const long hw = (long)a.H * a.W;
+  const long total = (long)a.N * hw;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int X = (int)(idx % a.W);
+    const int Y = (int)((idx / a.W) % a.H);
+    const long n = idx / hw;
+    float fused = a.fuse_bias[0];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int s = 2 << i, k = 2 * s;
+      const int h = a.hs[i], w = a.ws[i];
+      const int top = ((h + 1) * s - a.H) / 2, left = ((w + 1) * s - a.W) / 2;
+      const int Yp = Y + top, Xp = X + left;
+      const int yh = Yp / s, xh = Xp / s;
+      float side = 0.f, fu = 0.f;
+#pragma unroll
+      for (int ddy = 0; ddy < 2; ++ddy) {
+        const int y = yh - 1 + ddy;
+        if (y < 0 || y >= h) continue;
+        const int ky = Yp - y * s;
+#pragma unroll
+        for (int ddx = 0; ddx < 2; ++ddx) {
+          const int x = xh - 1 + ddx;
+          if (x < 0 || x >= w) continue;
+          const int kx = Xp - x * s;
+          const long li = (n * h + y) * w + x;
+          side += a.score[i][li] * a.f1[i][ky * k + kx];
+          fu += a.fpart[i][li] * a.f16[i][ky * k + kx];
+        }
+      }
+      a.outs[i][idx] = side;
+      fused += fu;
+    }
+    a.outs[4][idx] = fused;
+  }
+}
+
+struct HbArgs {
+  const f32x4* prep;
+  const float* dside;
+  const float* dfused;
+  const float* f1;
+  const float* f16;
+  const float* wd;
+  const float* wf;
+  f32x4* dprep;
+  double* acc;   // [0..15] dwf, [16..31] dwd, [32] dbd, [33] spare
+  int N, H, W, h, w, s;
+};
+
+// One group of TPP lanes per low-resolution pixel: the k*k taps of the transposed-conv adjoint
+// (a stride-s gather over the full-resolution upstream gradients) are split across the group and
+// reduced with wave shuffles; lane 0 of the group then forms dprep and the parameter-gradient
+// partials, which are wave-reduced and pushed with one double atomic per wave per value.
+template <int TPP>
+__global__ __launch_bounds__(256) void head_bwd_f32_kernel(HbArgs a) {
+  const int k = 2 * a.s, kk = k * k;
+  const int top = ((a.h + 1) * a.s - a.H) / 2, left = ((a.w + 1) * a.s - a.W) / 2;
+  const int sub = threadIdx.x % TPP;
+  const long npix = (long)a.N * a.h * a.w;
+  const int groups_per_block = 256 / TPP;
+  float pwf[16], pwd[16], pbd = 0.f;
+#pragma unroll
+  for (int c = 0; c < 16; ++c) { pwf[c] = 0.f; pwd[c] = 0.f; }
+  const long ngroups_total = (long)gridDim.x * groups_per_block;
+  const long iters = (npix + ngroups_total - 1) / ngroups_total;
+  for (long it = 0; it < iters; ++it) {
+    const long pix = it * ngroups_total + (long)blockIdx.x * groups_per_block + threadIdx.x / TPP;
+    const bool live = pix < npix;      // whole groups go dead together; shuffles stay wave-uniform
+    float df = 0.f, ds = 0.f;
+    int x = 0, y = 0;
+    long n = 0;
+    if (live) {
+      x = (int)(pix % a.w);
+      y = (int)((pix / a.w) % a.h);
+      n = pix / ((long)a.w * a.h);
+      for (int t = sub; t < kk; t += TPP) {
+        const int ky = t / k, kx = t % k;
+        const int Y = y * a.s + ky - top, X = x * a.s + kx - left;
+        if (Y >= 0 && Y < a.H && X >= 0 && X < a.W) {
+          const long o = (n * a.H + Y) * a.W + X;
+          if (a.dfused != nullptr) df += a.f16[t] * a.dfused[o];
+          if (a.dside != nullptr) ds += a.f1[t] * a.dside[o];
+        }
+      }
+    }
+#pragma unroll
+    for (int o = TPP / 2; o > 0; o >>= 1) {
+      df += __shfl_xor(df, o, 64);
+      ds += __shfl_xor(ds, o, 64);
+    }
+    if (live && sub == 0) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 p = a.prep[pix * 4 + q];
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int c = q * 4 + e;
+          o[e] = a.wf[c] * df + a.wd[c] * ds;
+          pwf[c] += p[e] * df;
+          pwd[c] += p[e] * ds;
+        }
+        a.dprep[pix * 4 + q] = o;
+      }
+      pbd += ds;
+    }
+  }
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    const double s1 = wave_sum((double)pwf[c]);
+    const double s2 = wave_sum((double)pwd[c]);
+    if (lane == 0) {
+      atomicAdd(&a.acc[c], s1);
+      atomicAdd(&a.acc[16 + c], s2);
+    }
+  }
+  const double s3 = wave_sum((double)pbd);
+  if (lane == 0) atomicAdd(&a.acc[32], s3);
+}
+
+__global__ void sum_to_double_kernel(const float* __restrict__ x, long count, double* acc) {
+  double s = 0.0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) s += (double)x[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) atomicAdd(acc, s);
+}
+
+// out[0] = max |w[ci][co]| over ci != co, out[1] = max |w[c][c] - w[0][0]|   (w: [C][C][k][k])
+__global__ void deconv_diag_check_kernel(const float* __restrict__ w, int C, int kk, float* out) {
+  float off = 0.f, dev = 0.f;
+  const long total = (long)C * C * kk;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int t = (int)(i % kk);
+    const int co = (int)((i / kk) % C);
+    const int ci = (int)(i / ((long)kk * C));
+    const float v = w[i];
+    if (ci != co) off = fmaxf(off, fabsf(v));
+    else dev = fmaxf(dev, fabsf(v - w[t]));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    off = fmaxf(off, __shfl_xor(off, o, 64));
+    dev = fmaxf(dev, __shfl_xor(dev, o, 64));
+  }
+  if ((threadIdx.x & 63) == 0) {   // values are >= 0: integer max on the bit pattern is order preserving
+    atomicMax(reinterpret_cast<unsigned int*>(out), __float_as_uint(off));
+    atomicMax(reinterpret_cast<unsigned int*>(out) + 1, __float_as_uint(dev));
+  }
+}
+
+inline int grid_for(long total, int cap) {
+  long b = (total + 255) / 256;
+  return (int)(b > cap ? cap : (b < 1 ? 1 : b));
+}
+
+}  // namespace
+
+int osvos_head_lowres_f32(const float* prep, const float* wd, const float* bd, const float* wf,
+                          float* score, float* fpart, int N, int h, int w, hipStream_t stream) {
+  OSVOS_ARG_CHECK(prep && wd && bd && wf && score && fpart && N > 0 && h > 0 && w > 0, "head_lowres: bad arguments");
+  const long npix = (long)N * h * w;
+  hipLaunchKernelGGL(head_lowres_f32_kernel, dim3(grid_for(npix, 2048)), dim3(256), 0, stream,
+                     reinterpret_cast<const f32x4*>(prep), wd, bd, wf, score, fpart, npix);
+  OSVOS_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int osvos_head_upsample(const float* const* score, const float* const* fpart,
+                                   const float* const* f1, const float* const* f16, const float* fuse_bias,
+                                   float* const* outs, int N, int H, int W, const int* hs, const int* ws, void* stream) {
+  OSVOS_ARG_CHECK(score && fpart && f1 && f16 && fuse_bias && outs && hs && ws && N > 0 && H > 0 && W > 0, "head_upsample: bad arguments");
+  UpArgs a;
+  for (int i = 0; i < 4; ++i) {
+    a.score[i] = score[i]; a.fpart[i] = fpart[i]; a.f1[i] = f1[i]; a.f16[i] = f16[i];
+    a.hs[i] = hs[i]; a.ws[i] = ws[i];
+    const int s = 2 << i;
+    OSVOS_ARG_CHECK((hs[i] + 1) * s >= H && (ws[i] + 1) * s >= W, "head_upsample: scale %d output smaller than crop", i);
+  }
+  for (int i = 0; i < 5; ++i) a.outs[i] = outs[i];
+  a.fuse_bias = fuse_bias;
+  a.N = N; a.H = H; a.W = W;
+  hipLaunchKernelGGL(head_upsample_kernel, dim3(grid_for((long)N * H * W, 4096)), dim3(256), 0, (hipStream_t)stream, a);
+  OSVOS_LAUNCH_CHECK();
+  return 0;
+}
+
+int osvos_head_bwd_f32(const float* prep, const float* dside, const float* dfused, const float* f1, const float* f16,
+                       const float* wd, const float* wf, float* dprep, double* acc, int N, int H, int W, int h, int w,
+                       int scale_idx, hipStream_t stream) {
+  OSVOS_ARG_CHECK(prep && f1 && f16 && wd && wf && dprep && acc, "head_bwd: null pointer");
+  OSVOS_ARG_CHECK(scale_idx >= 0 && scale_idx < 4 && N > 0 && H > 0 && W > 0 && h > 0 && w > 0, "head_bwd: bad shape");
+  HbArgs a;
+  a.prep = reinterpret_cast<const f32x4*>(prep);
+  a.dside = dside; a.dfused = dfused; a.f1 = f1; a.f16 = f16; a.wd = wd; a.wf = wf;
+  a.dprep = reinterpret_cast<f32x4*>(dprep);
+  a.acc = acc;
+  a.N = N; a.H = H; a.W = W; a.h = h; a.w = w; a.s = 2 << scale_idx;
+  const long npix = (long)N * h * w;
+  switch (scale_idx) {
+    case 0: hipLaunchKernelGGL(head_bwd_f32_kernel<1>, dim3(grid_for(npix, 512)), dim3(256), 0, stream, a); break;
+    case 1: hipLaunchKernelGGL(head_bwd_f32_kernel<4>, dim3(grid_for(npix * 4, 512)), dim3(256), 0, stream, a); break;
+    case 2: hipLaunchKernelGGL(head_bwd_f32_kernel<16>, dim3(grid_for(npix * 16, 512)), dim3(256), 0, stream, a); break;
+    default: hipLaunchKernelGGL(head_bwd_f32_kernel<64>, dim3(grid_for(npix * 64, 512)), dim3(256), 0, stream, a); break;
+  }
+  OSVOS_LAUNCH_CHECK();
+  return 0;
+}
+
+int osvos_sum_to_double(const float* x, long count, double* acc, hipStream_t stream) {
+  hipLaunchKernelGGL(sum_to_double_kernel, dim3(grid_for(count, 256)), dim3(256), 0, stream, x, count, acc);
+  OSVOS_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int osvos_deconv_diag_check(const float* w, int C, int k, float* out2, void* stream) {
+  OSVOS_ARG_CHECK(w && out2 && C > 0 && k > 0, "deconv_diag_check: bad arguments");
+  OSVOS_HIP_CHECK(hipMemsetAsync(out2, 0, 2 * sizeof(float), (hipStream_t)stream));
+  hipLaunchKernelGGL(deconv_diag_check_kernel, dim3(grid_for((long)C * C * k * k, 256)), dim3(256), 0, (hipStream_t)stream, w, C, k * k, out2);
+  OSVOS_LAUNCH_CHECK();
+  return 0;
+}

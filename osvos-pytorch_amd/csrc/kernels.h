@@ -1,0 +1,23 @@
+// Internal (non-ABI) launchers implemented by the .hip translation units.
+#pragma once
+#include "common.h"
+
+int osvos_conv3x3_f32(const float* x, const float* wpk, const float* bias, const float* mask, float* y,
+                      int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int tile, hipStream_t stream);
+size_t osvos_wgrad_ws_bytes_f32(int N, int H, int W, int Cin_s, int Cout);
+int osvos_conv3x3_wgrad_f32(const float* x, const float* dy, void* ws, float* dw, float* db,
+                            int N, int H, int W, int Cin, int Cin_s, int Cout, int Cout_s,
+                            int accumulate, hipStream_t stream);
+int osvos_nchw_to_nhwc_f32(const float* src, float* dst, int N, int C, int H, int W, int cpad, hipStream_t stream);
+int osvos_nhwc_to_nchw_f32(const float* src, float* dst, int N, int C, int H, int W, int cs, hipStream_t stream);
+int osvos_pack_fwd_f32(const float* w, float* wpk, int Cout, int Cin, hipStream_t stream);
+int osvos_pack_dgrad_f32(const float* w, float* wpk, int Cout, int Cin, hipStream_t stream);
+int osvos_maxpool2x2_f32(const float* x, float* y, int N, int H, int W, int C, hipStream_t stream);
+int osvos_maxpool2x2_bwd_f32(const float* x, const float* dy, const float* dside, float* dx,
+                             int N, int H, int W, int C, hipStream_t stream);
+int osvos_head_lowres_f32(const float* prep, const float* wd, const float* bd, const float* wf,
+                          float* score, float* fpart, int N, int h, int w, hipStream_t stream);
+int osvos_head_bwd_f32(const float* prep, const float* dside, const float* dfused, const float* f1, const float* f16,
+                       const float* wd, const float* wf, float* dprep, double* acc, int N, int H, int W, int h, int w,
+                       int scale_idx, hipStream_t stream);
+int osvos_sum_to_double(const float* x, long count, double* acc, hipStream_t stream);

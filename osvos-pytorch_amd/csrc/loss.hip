@@ -1,0 +1,114 @@
+// Class-balanced binary cross-entropy with logits, forward + gradient in one pass over the map
+// (reference layers/osvos_layers.py:19-48; called train_online.py:127, train_parent.py:145).
+//
+//   y = label >= 0.5;  n_pos = sum y;  w_pos = n_neg/n_tot, w_neg = n_pos/n_tot  (float32 quotients,
+//   as in the reference where both masks are .float());
+//   val = x*(y - [x>=0]) - log(1 + exp(x - 2x[x>=0]))          (== y*x - softplus(x), stable form)
+//   loss = (w_pos * sum(-y*val) + w_neg * sum(-(1-y)*val)) / div,   dLoss/dx = w(y) (sigmoid(x) - y) / div
+// HBM-bound: two sweeps of the logit map (count, then loss+grad); wavefront shuffles + one double
+// atomic per wave; everything stays on the device (no .item() needed to form the loss).
+#include "common.h"
+
+namespace {
+
+struct Scratch {            // 32 bytes, zeroed per call
+  unsigned long long npos;
+  double lpos, lneg;
+  double spare;
+};
+
+__global__ void cbce_count_kernel(const float* __restrict__ label, long count, Scratch* sc) {
+  unsigned int c = 0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x)
+    c += label[i] >= 0.5f ? 1u : 0u;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(&sc->npos, (unsigned long long)c);
+}
+
+__global__ void cbce_main_kernel(const float* __restrict__ out, const float* __restrict__ label,
+                                 float* __restrict__ grad, long count, float inv_div, Scratch* sc) {
+  const float ntot = (float)count;
+  const float npos = (float)sc->npos;
+  const float wpos = (ntot - npos) / ntot, wneg = npos / ntot;
+  double lpos = 0.0, lneg = 0.0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
+    const float x = out[i];
+    const float y = label[i] >= 0.5f ? 1.f : 0.f;
+    const float g = x >= 0.f ? 1.f : 0.f;
+    const float val = x * (y - g) - logf(1.f + expf(x - 2.f * x * g));
+    lpos += (double)(-y * val);
+    lneg += (double)(-(1.f - y) * val);
+    if (grad != nullptr) {
+      const float sg = 1.f / (1.f + expf(-x));
+      grad[i] = (y > 0.5f ? wpos : wneg) * (sg - y) * inv_div;
+    }
+  }
+  lpos = wave_sum(lpos);
+  lneg = wave_sum(lneg);
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&sc->lpos, lpos);
+    atomicAdd(&sc->lneg, lneg);
+  }
+}
+
+__global__ void cbce_final_kernel(const Scratch* sc, long count, float inv_div, float* loss) {
+  const float ntot = (float)count;
+  const float npos = (float)sc->npos;
+  const float wpos = (ntot - npos) / ntot, wneg = npos / ntot;
+  loss[0] = (float)(((double)wpos * sc->lpos + (double)wneg * sc->lneg) * (double)inv_div);
+}
+
+__global__ void scale_kernel(const float* __restrict__ x, const float* __restrict__ scalar, float* __restrict__ y, long count) {
+  const float s = scalar[0];
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) y[i] = x[i] * s;
+}
+
+__global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, long count,
+                           float lr, float momentum, float wd, int first) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
+    const float pv = p[i];
+    float d = g[i] + wd * pv;
+    const float b = first ? d : momentum * buf[i] + d;
+    buf[i] = b;
+    p[i] = pv - lr * b;
+  }
+}
+
+inline int grid_for(long total, int cap) {
+  long b = (total + 255) / 256;
+  return (int)(b > cap ? cap : (b < 1 ? 1 : b));
+}
+
+}  // namespace
+
+extern "C" int osvos_cbce(const float* out, const float* label, float* loss, float* grad, void* scratch,
+                          long count, int N, int mode, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  OSVOS_ARG_CHECK(out && label && loss && scratch && count > 0 && N > 0, "cbce: bad arguments");
+  OSVOS_ARG_CHECK(mode >= 0 && mode <= 2, "cbce: mode %d", mode);
+  const float inv_div = mode == 0 ? 1.f / (float)count : (mode == 1 ? 1.f / (float)N : 1.f);
+  Scratch* sc = reinterpret_cast<Scratch*>(scratch);
+  OSVOS_HIP_CHECK(hipMemsetAsync(sc, 0, sizeof(Scratch), stream));
+  const int g = grid_for(count, 1024);
+  hipLaunchKernelGGL(cbce_count_kernel, dim3(g), dim3(256), 0, stream, label, count, sc);
+  hipLaunchKernelGGL(cbce_main_kernel, dim3(g), dim3(256), 0, stream, out, label, grad, count, inv_div, sc);
+  hipLaunchKernelGGL(cbce_final_kernel, dim3(1), dim3(1), 0, stream, sc, count, inv_div, loss);
+  OSVOS_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int osvos_scale(const float* x, const float* scalar, float* y, long count, void* stream) {
+  OSVOS_ARG_CHECK(x && scalar && y && count > 0, "scale: bad arguments");
+  hipLaunchKernelGGL(scale_kernel, dim3(grid_for(count, 2048)), dim3(256), 0, (hipStream_t)stream, x, scalar, y, count);
+  OSVOS_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int osvos_sgd_step(float* p, const float* g, float* buf, long count, float lr, float momentum,
+                              float weight_decay, int first, void* stream) {
+  OSVOS_ARG_CHECK(p && g && buf && count > 0, "sgd_step: bad arguments");
+  hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(count, 4096)), dim3(256), 0, (hipStream_t)stream, p, g, buf, count, lr, momentum, weight_decay, first);
+  OSVOS_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,337 @@
+// Whole-network orchestration: OSVOS.forward (reference vgg_osvos.py:59-74) and its backward as
+// two C calls that only enqueue kernels on the caller's stream (no allocation, no sync, so both
+// are hipGraph-capturable).  The caller owns `wbuf` (packed parameters) and `ws` (activations +
+// gradient scratch); their layouts are defined here and nowhere else.
+#include <string.h>
+
+#include "kernels.h"
+#include "prof.h"
+
+namespace {
+
+constexpr int kStageN[5] = {2, 2, 3, 3, 3};
+constexpr int kStageC[5] = {64, 128, 256, 512, 512};
+constexpr int kNumTrunk = 13;
+constexpr int kNumConv = 17;          // 13 trunk + 4 side_prep
+constexpr int kInPad = 8;             // conv1_1 input channels padded 3 -> 8 (one K chunk)
+
+struct ConvDesc {
+  int stage, cin, cin_s, cout, w_param, b_param;
+};
+
+void conv_table(ConvDesc* d) {
+  int l = 0, cin = 3;
+  for (int si = 0; si < 5; ++si)
+    for (int j = 0; j < kStageN[si]; ++j) {
+      d[l] = ConvDesc{si, cin, cin == 3 ? kInPad : cin, kStageC[si], 8 + 2 * l, 9 + 2 * l};
+      cin = kStageC[si];
+      ++l;
+    }
+  for (int i = 0; i < 4; ++i) d[kNumTrunk + i] = ConvDesc{i + 1, kStageC[i + 1], kStageC[i + 1], 16, 34 + 2 * i, 35 + 2 * i};
+}
+
+int last_of_stage(int si) {
+  int l = -1;
+  for (int s = 0; s <= si; ++s) l += kStageN[s];
+  return l;
+}
+
+struct WbufLayout {
+  size_t fwd[kNumConv], dgrad[kNumConv], bias[kNumConv];
+  size_t wd[4], bd[4], wf, bf, f1[4], f16[4];
+  size_t total;
+};
+
+WbufLayout wbuf_layout(int dtype) {
+  WbufLayout L;
+  ConvDesc d[kNumConv];
+  conv_table(d);
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+  for (int l = 0; l < kNumConv; ++l) {
+    L.fwd[l] = take(osvos_wpack_bytes(d[l].cout, d[l].cin_s, dtype));
+    L.dgrad[l] = take(osvos_wpack_dgrad_bytes(d[l].cout, d[l].cin, dtype));
+    L.bias[l] = take(sizeof(float) * d[l].cout);
+  }
+  for (int i = 0; i < 4; ++i) { L.wd[i] = take(16 * sizeof(float)); L.bd[i] = take(sizeof(float)); }
+  L.wf = take(64 * sizeof(float));
+  L.bf = take(sizeof(float));
+  for (int i = 0; i < 4; ++i) { const int k = 4 << i; L.f1[i] = take(sizeof(float) * k * k); L.f16[i] = take(sizeof(float) * k * k); }
+  L.total = off;
+  return L;
+}
+
+struct WsLayout {
+  int hs[5], ws[5];
+  size_t xin, act[kNumTrunk], pooled[5], prep[4], score[4], fpart[4];
+  size_t gA, gB, dside[4], dprep[4], wgrad, acc, dxin;
+  size_t total;
+};
+
+WsLayout ws_layout(int N, int H, int W, int dtype) {
+  WsLayout L;
+  memset(&L, 0, sizeof(L));
+  const size_t es = osvos_elem(dtype);
+  L.hs[0] = H; L.ws[0] = W;
+  for (int i = 1; i < 5; ++i) { L.hs[i] = (L.hs[i - 1] + 1) / 2; L.ws[i] = (L.ws[i - 1] + 1) / 2; }
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+  ConvDesc d[kNumConv];
+  conv_table(d);
+  L.xin = take(es * N * H * W * kInPad);
+  size_t max_act = 0, max_wg = 0;
+  for (int l = 0; l < kNumTrunk; ++l) {
+    const int si = d[l].stage;
+    const size_t b = es * N * L.hs[si] * L.ws[si] * d[l].cout;
+    L.act[l] = take(b);
+    if (b > max_act) max_act = b;
+  }
+  for (int si = 1; si < 5; ++si) L.pooled[si] = take(es * N * L.hs[si] * L.ws[si] * kStageC[si - 1]);
+  for (int i = 0; i < 4; ++i) {
+    const size_t npix = (size_t)N * L.hs[i + 1] * L.ws[i + 1];
+    L.prep[i] = take(es * npix * 16);
+    L.score[i] = take(sizeof(float) * npix);
+    L.fpart[i] = take(sizeof(float) * npix);
+    L.dprep[i] = take(es * npix * 16);
+    L.dside[i] = take(es * npix * kStageC[i + 1]);
+  }
+  L.gA = take(max_act);
+  L.gB = take(max_act);
+  for (int l = 0; l < kNumConv; ++l) {
+    const int si = d[l].stage;
+    const size_t b = osvos_wgrad_ws_bytes(N, L.hs[si], L.ws[si], d[l].cin_s, d[l].cout, dtype);
+    if (b > max_wg) max_wg = b;
+  }
+  L.wgrad = take(max_wg);
+  L.acc = take(sizeof(double) * (4 * 34 + 2));
+  L.dxin = take(es * N * H * W * 4);
+  L.total = off;
+  return L;
+}
+
+inline double conv_flops(int N, int h, int w, int cin, int cout) { return 2.0 * N * h * w * (double)cout * 9.0 * cin; }
+
+__attribute__((unused)) inline char* at(void* base, size_t off) { return reinterpret_cast<char*>(base) + off; }
+inline const char* at(const void* base, size_t off) { return reinterpret_cast<const char*>(base) + off; }
+
+}  // namespace
+
+// device-side helpers implemented in net_kernels.hip
+int osvos_gather_small(const float* const* srcs, const size_t* dst_off, const int* counts, int n, void* wbuf, hipStream_t stream);
+int osvos_head_grads_finalize(const double* acc, float* const* grads, int accumulate, int have_side, hipStream_t stream);
+
+extern "C" {
+
+size_t osvos_net_wbuf_bytes(int dtype) { return wbuf_layout(dtype).total; }
+size_t osvos_net_ws_bytes(int N, int H, int W, int dtype) { return ws_layout(N, H, W, dtype).total; }
+
+int osvos_net_ws_query(int N, int H, int W, int dtype, int which, size_t* offset, size_t* elems, int* channels, int* h, int* w) {
+  OSVOS_ARG_CHECK(which >= 0 && which <= 21 && offset && elems && channels && h && w, "ws_query: bad arguments");
+  WsLayout L = ws_layout(N, H, W, dtype);
+  ConvDesc d[kNumConv];
+  conv_table(d);
+  int si, c;
+  size_t off;
+  if (which < 13) { si = d[which].stage; c = d[which].cout; off = L.act[which]; }
+  else if (which < 17) { si = which - 12; c = kStageC[si - 1]; off = L.pooled[si]; }
+  else if (which < 21) { si = which - 16; c = 16; off = L.prep[which - 17]; }
+  else { si = 0; c = kInPad; off = L.xin; }
+  *offset = off; *channels = c; *h = L.hs[si]; *w = L.ws[si];
+  *elems = (size_t)N * L.hs[si] * L.ws[si] * c;
+  return 0;
+}
+
+int osvos_net_pack(const float* const* params, void* wbuf, int dtype, int with_dgrad, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  OSVOS_ARG_CHECK(params && wbuf, "net_pack: null pointer");
+  OSVOS_ARG_CHECK(dtype == OSVOS_F32, "net_pack: dtype %d not built", dtype);
+  for (int i = 0; i < OSVOS_NPARAMS; ++i) OSVOS_ARG_CHECK(params[i] != nullptr, "net_pack: params[%d] is null", i);
+  WbufLayout L = wbuf_layout(dtype);
+  ConvDesc d[kNumConv];
+  conv_table(d);
+  const float* srcs[64];
+  size_t dsts[64];
+  int counts[64];
+  int ns = 0;
+  for (int l = 0; l < kNumConv; ++l) {
+    int rc = osvos_pack_conv3x3_fwd(params[d[l].w_param], at(wbuf, L.fwd[l]), d[l].cout, d[l].cin, dtype, stream);
+    if (rc) return rc;
+    if (with_dgrad) {
+      rc = osvos_pack_conv3x3_dgrad(params[d[l].w_param], at(wbuf, L.dgrad[l]), d[l].cout, d[l].cin, dtype, stream);
+      if (rc) return rc;
+    }
+    srcs[ns] = params[d[l].b_param]; dsts[ns] = L.bias[l]; counts[ns] = d[l].cout; ++ns;
+  }
+  for (int i = 0; i < 4; ++i) {
+    const int k = 4 << i;
+    srcs[ns] = params[42 + 2 * i]; dsts[ns] = L.wd[i]; counts[ns] = 16; ++ns;
+    srcs[ns] = params[43 + 2 * i]; dsts[ns] = L.bd[i]; counts[ns] = 1; ++ns;
+    srcs[ns] = params[4 + i]; dsts[ns] = L.f1[i]; counts[ns] = k * k; ++ns;     // upscale_[i].weight[0,0]
+    srcs[ns] = params[i]; dsts[ns] = L.f16[i]; counts[ns] = k * k; ++ns;         // upscale[i].weight[0,0]
+  }
+  srcs[ns] = params[50]; dsts[ns] = L.wf; counts[ns] = 64; ++ns;
+  srcs[ns] = params[51]; dsts[ns] = L.bf; counts[ns] = 1; ++ns;
+  return osvos_gather_small(srcs, dsts, counts, ns, wbuf, stream);
+}
+
+int osvos_net_forward(const float* x_nchw, const void* wbuf, void* ws, float* const* outs,
+                      int N, int H, int W, int dtype, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  OSVOS_ARG_CHECK(x_nchw && wbuf && ws && outs, "net_forward: null pointer");
+  OSVOS_ARG_CHECK(dtype == OSVOS_F32, "net_forward: dtype %d not built", dtype);
+  OSVOS_ARG_CHECK(N > 0 && H > 0 && W > 0, "net_forward: bad shape %dx%dx%d", N, H, W);
+  for (int i = 0; i < 5; ++i) OSVOS_ARG_CHECK(outs[i] != nullptr, "net_forward: outs[%d] is null", i);
+  const WbufLayout P = wbuf_layout(dtype);
+  const WsLayout L = ws_layout(N, H, W, dtype);
+  ConvDesc d[kNumConv];
+  conv_table(d);
+  int rc = osvos_nchw_to_nhwc(x_nchw, at(ws, L.xin), N, 3, H, W, kInPad, dtype, stream);
+  if (rc) return rc;
+  const void* cur = at(ws, L.xin);
+  int l = 0;
+  const float* score[4]; const float* fpart[4]; const float* f1[4]; const float* f16[4];
+  for (int si = 0; si < 5; ++si) {
+    const int h = L.hs[si], w = L.ws[si];
+    if (si > 0) {
+      rc = osvos_maxpool2x2(cur, at(ws, L.pooled[si]), N, L.hs[si - 1], L.ws[si - 1], kStageC[si - 1], dtype, stream);
+      if (rc) return rc;
+      cur = at(ws, L.pooled[si]);
+    }
+    for (int j = 0; j < kStageN[si]; ++j, ++l) {
+      {
+        ProfScope ps(OSVOS_PROF_CONV_FWD, conv_flops(N, h, w, d[l].cin, d[l].cout), stream);
+        rc = osvos_conv3x3(cur, at(wbuf, P.fwd[l]), reinterpret_cast<const float*>(at(wbuf, P.bias[l])), nullptr,
+                           at(ws, L.act[l]), N, h, w, d[l].cin_s, d[l].cout, d[l].cout, 1, dtype, -1, stream);
+      }
+      if (rc) return rc;
+      cur = at(ws, L.act[l]);
+    }
+    if (si > 0) {
+      const int i = si - 1, sl = kNumTrunk + i;
+      {
+        ProfScope ps(OSVOS_PROF_CONV_FWD, conv_flops(N, h, w, d[sl].cin, 16), stream);
+        rc = osvos_conv3x3(cur, at(wbuf, P.fwd[sl]), reinterpret_cast<const float*>(at(wbuf, P.bias[sl])), nullptr,
+                           at(ws, L.prep[i]), N, h, w, d[sl].cin_s, 16, 16, 0, dtype, -1, stream);
+      }
+      if (rc) return rc;
+      float* sc = reinterpret_cast<float*>(at(ws, L.score[i]));
+      float* fp = reinterpret_cast<float*>(at(ws, L.fpart[i]));
+      rc = osvos_head_lowres(at(ws, L.prep[i]), reinterpret_cast<const float*>(at(wbuf, P.wd[i])),
+                             reinterpret_cast<const float*>(at(wbuf, P.bd[i])),
+                             reinterpret_cast<const float*>(at(wbuf, P.wf)) + 16 * i, sc, fp, N, h, w, dtype, stream);
+      if (rc) return rc;
+      score[i] = sc; fpart[i] = fp;
+      f1[i] = reinterpret_cast<const float*>(at(wbuf, P.f1[i]));
+      f16[i] = reinterpret_cast<const float*>(at(wbuf, P.f16[i]));
+    }
+  }
+  return osvos_head_upsample(score, fpart, f1, f16, reinterpret_cast<const float*>(at(wbuf, P.bf)), outs, N, H, W,
+                             &L.hs[1], &L.ws[1], stream);
+}
+
+int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, float* const* grads,
+                       float* dx_nchw, int N, int H, int W, int dtype, int accumulate, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  OSVOS_ARG_CHECK(wbuf && ws && douts && grads, "net_backward: null pointer");
+  OSVOS_ARG_CHECK(dtype == OSVOS_F32, "net_backward: dtype %d not built", dtype);
+  const WbufLayout P = wbuf_layout(dtype);
+  const WsLayout L = ws_layout(N, H, W, dtype);
+  ConvDesc d[kNumConv];
+  conv_table(d);
+  int rc;
+  double* acc = reinterpret_cast<double*>(at(ws, L.acc));
+  OSVOS_HIP_CHECK(hipMemsetAsync(acc, 0, sizeof(double) * (4 * 34 + 2), stream));
+  bool have_side = false;
+  for (int i = 0; i < 4; ++i) have_side = have_side || douts[i] != nullptr;
+  const float* dfused = douts[4];
+
+  // ---- head: upstream full-resolution gradients -> dprep[i] (+ score_dsn / fuse gradients) ----
+  for (int i = 0; i < 4; ++i) {
+    const int si = i + 1;
+    rc = osvos_head_bwd(at(ws, L.prep[i]), douts[i], dfused, reinterpret_cast<const float*>(at(wbuf, P.f1[i])),
+                        reinterpret_cast<const float*>(at(wbuf, P.f16[i])), reinterpret_cast<const float*>(at(wbuf, P.wd[i])),
+                        reinterpret_cast<const float*>(at(wbuf, P.wf)) + 16 * i, at(ws, L.dprep[i]), acc + 34 * i,
+                        N, H, W, L.hs[si], L.ws[si], i, dtype, stream);
+    if (rc) return rc;
+  }
+  if (dfused != nullptr) {
+    rc = osvos_sum_to_double(dfused, (long)N * H * W, acc + 4 * 34, stream);
+    if (rc) return rc;
+  }
+  rc = osvos_head_grads_finalize(acc, grads, accumulate, have_side ? 1 : 0, stream);
+  if (rc) return rc;
+
+  // ---- side_prep convs: weight gradients + data gradients into the stage outputs --------------
+  for (int i = 0; i < 4; ++i) {
+    const int si = i + 1, sl = kNumTrunk + i, h = L.hs[si], w = L.ws[si];
+    const int lx = last_of_stage(si);
+    if (grads[d[sl].w_param] != nullptr) {
+      {
+        ProfScope ps(OSVOS_PROF_WGRAD, conv_flops(N, h, w, d[sl].cin, 16), stream);
+        rc = osvos_conv3x3_wgrad(at(ws, L.act[lx]), at(ws, L.dprep[i]), at(ws, L.wgrad), grads[d[sl].w_param], grads[d[sl].b_param],
+                                 N, h, w, d[sl].cin, d[sl].cin_s, 16, 16, accumulate, dtype, stream);
+      }
+      if (rc) return rc;
+    }
+    // stage 4 has no pool after it: its ReLU mask is applied right here and the result is the
+    // upstream gradient of conv5_3; stages 1-3 are merged in maxpool2x2_bwd below
+    void* dst = (i == 3) ? at(ws, L.gA) : at(ws, L.dside[i]);
+    {
+      ProfScope ps(OSVOS_PROF_CONV_DGRAD, conv_flops(N, h, w, d[sl].cin, 16), stream);
+      rc = osvos_conv3x3(at(ws, L.dprep[i]), at(wbuf, P.dgrad[sl]), nullptr, (i == 3) ? at(ws, L.act[lx]) : nullptr, dst,
+                         N, h, w, 16, d[sl].cin, d[sl].cin, 0, dtype, -1, stream);
+    }
+    if (rc) return rc;
+  }
+
+  // ---- trunk, deepest layer first; g = dLoss/d(conv output), ReLU mask already applied -------
+  void* g = at(ws, L.gA);
+  void* other = at(ws, L.gB);
+  for (int l = kNumTrunk - 1; l >= 0; --l) {
+    const int si = d[l].stage, h = L.hs[si], w = L.ws[si];
+    const bool first_of_stage = (l == 0) || d[l - 1].stage != si;
+    const void* xin = first_of_stage ? (si == 0 ? at(ws, L.xin) : at(ws, L.pooled[si])) : at(ws, L.act[l - 1]);
+    if (grads[d[l].w_param] != nullptr) {
+      {
+        ProfScope ps(OSVOS_PROF_WGRAD, conv_flops(N, h, w, d[l].cin, d[l].cout), stream);
+        rc = osvos_conv3x3_wgrad(xin, g, at(ws, L.wgrad), grads[d[l].w_param], grads[d[l].b_param],
+                                 N, h, w, d[l].cin, d[l].cin_s, d[l].cout, d[l].cout, accumulate, dtype, stream);
+      }
+      if (rc) return rc;
+    }
+    if (l == 0) {
+      if (dx_nchw != nullptr) {
+        {
+          ProfScope ps(OSVOS_PROF_CONV_DGRAD, conv_flops(N, h, w, 3, d[0].cout), stream);
+          rc = osvos_conv3x3(g, at(wbuf, P.dgrad[0]), nullptr, nullptr, at(ws, L.dxin), N, h, w, d[0].cout, 3, 4, 0, dtype, -1, stream);
+        }
+        if (rc) return rc;
+        rc = osvos_nhwc_to_nchw(at(ws, L.dxin), dx_nchw, N, 3, H, W, 4, dtype, stream);
+        if (rc) return rc;
+      }
+      break;
+    }
+    if (first_of_stage) {
+      // through the pool into the previous stage's output (+ that stage's side branch, + ReLU mask)
+      {
+        ProfScope ps(OSVOS_PROF_CONV_DGRAD, conv_flops(N, h, w, d[l].cin, d[l].cout), stream);
+        rc = osvos_conv3x3(g, at(wbuf, P.dgrad[l]), nullptr, nullptr, other, N, h, w, d[l].cout, d[l].cin, d[l].cin, 0, dtype, -1, stream);
+      }
+      if (rc) return rc;
+      const int ps = si - 1;
+      const void* dside = ps >= 1 ? at(ws, L.dside[ps - 1]) : nullptr;
+      rc = osvos_maxpool2x2_bwd(at(ws, L.act[l - 1]), other, dside, g, N, L.hs[ps], L.ws[ps], kStageC[ps], dtype, stream);
+      if (rc) return rc;
+    } else {
+      {
+        ProfScope ps(OSVOS_PROF_CONV_DGRAD, conv_flops(N, h, w, d[l].cin, d[l].cout), stream);
+        rc = osvos_conv3x3(g, at(wbuf, P.dgrad[l]), nullptr, at(ws, L.act[l - 1]), other, N, h, w, d[l].cout, d[l].cin, d[l].cin, 0, dtype, -1, stream);
+      }
+      if (rc) return rc;
+      void* t = g; g = other; other = t;
+    }
+  }
+  return 0;
+}
+
+}  // extern "C"

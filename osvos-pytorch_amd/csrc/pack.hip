@@ -1,0 +1,102 @@
+// Layout conversions and weight packing (fp32 flavour; bf16 variants live next to their kernels).
+//   NCHW <-> NHWC ................ boundary of OSVOS.forward (reference vgg_osvos.py:59, NCHW fp32)
+//   OIHW -> MFMA operand packs ... nn.Conv2d.weight [Cout,Cin,3,3] (reference vgg_osvos.py:41,142)
+#include "common.h"
+
+namespace {
+
+__global__ void nchw_to_nhwc_f32_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                        int N, int C, int H, int W, int cpad) {
+  const long total = (long)N * H * W * cpad;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cpad);
+    const long pix = i / cpad;
+    const long hw = (long)H * W;
+    const long n = pix / hw, p = pix % hw;
+    dst[i] = c < C ? src[(n * C + c) * hw + p] : 0.f;
+  }
+}
+
+__global__ void nhwc_to_nchw_f32_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                        int N, int C, int H, int W, int cs) {
+  const long hw = (long)H * W;
+  const long total = (long)N * C * hw;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long p = i % hw;
+    const long nc = i / hw;
+    const long n = nc / C, c = nc % C;
+    dst[i] = src[(n * hw + p) * cs + c];
+  }
+}
+
+// wpk[((tap*CQ + cq)*CoutP + co)*4 + e] = W[co][4cq+e][tap]   (zero padded)
+__global__ void pack_fwd_f32_kernel(const float* __restrict__ w, float* __restrict__ wpk,
+                                    int Cout, int Cin, int CinP, int CoutP) {
+  const int CQ = CinP / 4;
+  const long total = 9L * CQ * CoutP * 4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int e = (int)(i & 3);
+    long t = i >> 2;
+    const int co = (int)(t % CoutP);
+    t /= CoutP;
+    const int cq = (int)(t % CQ);
+    const int tap = (int)(t / CQ);
+    const int ci = cq * 4 + e;
+    wpk[i] = (co < Cout && ci < Cin) ? w[((long)co * Cin + ci) * 9 + tap] : 0.f;
+  }
+}
+
+// data-gradient pack: dX = conv3x3(dY, Wd), Wd[ci][co][r'][s'] = W[co][ci][2-r'][2-s']
+// wpk[((tap'*CQo + coq)*CinP + ci)*4 + e] = W[4coq+e][ci][8 - tap']
+__global__ void pack_dgrad_f32_kernel(const float* __restrict__ w, float* __restrict__ wpk,
+                                      int Cout, int Cin, int CoutK, int CinP) {
+  const int CQ = CoutK / 4;
+  const long total = 9L * CQ * CinP * 4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int e = (int)(i & 3);
+    long t = i >> 2;
+    const int ci = (int)(t % CinP);
+    t /= CinP;
+    const int coq = (int)(t % CQ);
+    const int tap = (int)(t / CQ);
+    const int co = coq * 4 + e;
+    wpk[i] = (co < Cout && ci < Cin) ? w[((long)co * Cin + ci) * 9 + (8 - tap)] : 0.f;
+  }
+}
+
+inline int grid_for(long total) {
+  long b = (total + 255) / 256;
+  return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
+}
+
+}  // namespace
+
+int osvos_nchw_to_nhwc_f32(const float* src, float* dst, int N, int C, int H, int W, int cpad, hipStream_t stream) {
+  OSVOS_ARG_CHECK(src && dst && N > 0 && C > 0 && H > 0 && W > 0 && cpad >= C, "nchw_to_nhwc: bad arguments");
+  hipLaunchKernelGGL(nchw_to_nhwc_f32_kernel, dim3(grid_for((long)N * H * W * cpad)), dim3(256), 0, stream, src, dst, N, C, H, W, cpad);
+  OSVOS_LAUNCH_CHECK();
+  return 0;
+}
+
+int osvos_nhwc_to_nchw_f32(const float* src, float* dst, int N, int C, int H, int W, int cs, hipStream_t stream) {
+  OSVOS_ARG_CHECK(src && dst && N > 0 && C > 0 && H > 0 && W > 0 && cs >= C, "nhwc_to_nchw: bad arguments");
+  hipLaunchKernelGGL(nhwc_to_nchw_f32_kernel, dim3(grid_for((long)N * H * W * C)), dim3(256), 0, stream, src, dst, N, C, H, W, cs);
+  OSVOS_LAUNCH_CHECK();
+  return 0;
+}
+
+int osvos_pack_fwd_f32(const float* w, float* wpk, int Cout, int Cin, hipStream_t stream) {
+  OSVOS_ARG_CHECK(w && wpk && Cout > 0 && Cin > 0, "pack_fwd: bad arguments");
+  const int CinP = osvos_cin_pad(Cin, OSVOS_F32), CoutP = osvos_cout_pad(Cout);
+  hipLaunchKernelGGL(pack_fwd_f32_kernel, dim3(grid_for(9L * CinP * CoutP)), dim3(256), 0, stream, w, wpk, Cout, Cin, CinP, CoutP);
+  OSVOS_LAUNCH_CHECK();
+  return 0;
+}
+
+int osvos_pack_dgrad_f32(const float* w, float* wpk, int Cout, int Cin, hipStream_t stream) {
+  OSVOS_ARG_CHECK(w && wpk && Cout > 0 && Cin > 0, "pack_dgrad: bad arguments");
+  const int CoutK = osvos_cin_pad(Cout, OSVOS_F32), CinP = osvos_cout_pad(Cin);
+  hipLaunchKernelGGL(pack_dgrad_f32_kernel, dim3(grid_for(9L * CoutK * CinP)), dim3(256), 0, stream, w, wpk, Cout, Cin, CoutK, CinP);
+  OSVOS_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,104 @@
+// 2x2 stride-2 max-pool with ceil_mode=True, NHWC fp32 (reference vgg_osvos.py:140,
+// nn.MaxPool2d(kernel_size=2, stride=2, ceil_mode=True) -> aten::max_pool2d_with_indices) and its
+// backward fused with the ReLU backward of the producing conv and the side-branch gradient add.
+// HBM-bound glue: one thread per (window, 4-channel quad), 16-byte accesses, no indices stored --
+// the backward recomputes the argmax from the saved (post-ReLU) pool input.
+#include "common.h"
+
+namespace {
+
+__global__ void maxpool_f32_kernel(const f32x4* __restrict__ x, f32x4* __restrict__ y,
+                                   int N, int H, int W, int C4) {
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  const long total = (long)N * Ho * Wo * C4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4);
+    long t = i / C4;
+    const int ox = (int)(t % Wo);
+    t /= Wo;
+    const int oy = (int)(t % Ho);
+    const long n = t / Ho;
+    const int iy = 2 * oy, ix = 2 * ox;
+    const bool vx = ix + 1 < W, vy = iy + 1 < H;   // clipped (never padded) partial windows
+    const f32x4* p = x + ((n * H + iy) * W + ix) * C4 + c;
+    f32x4 m = p[0];
+    if (vx) { f32x4 v = p[C4]; for (int k = 0; k < 4; ++k) m[k] = v[k] > m[k] ? v[k] : m[k]; }
+    if (vy) {
+      f32x4 v = p[(long)W * C4];
+      for (int k = 0; k < 4; ++k) m[k] = v[k] > m[k] ? v[k] : m[k];
+      if (vx) { f32x4 u = p[(long)W * C4 + C4]; for (int k = 0; k < 4; ++k) m[k] = u[k] > m[k] ? u[k] : m[k]; }
+    }
+    y[i] = m;
+  }
+}
+
+// dx[pos] = (x[pos] > 0) * ( (pos == first argmax of the window) * dy + dside[pos] )
+__global__ void maxpool_bwd_f32_kernel(const f32x4* __restrict__ x, const f32x4* __restrict__ dy,
+                                       const f32x4* __restrict__ dside, f32x4* __restrict__ dx,
+                                       int N, int H, int W, int C4) {
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  const long total = (long)N * Ho * Wo * C4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4);
+    long t = i / C4;
+    const int ox = (int)(t % Wo);
+    t /= Wo;
+    const int oy = (int)(t % Ho);
+    const long n = t / Ho;
+    const int iy = 2 * oy, ix = 2 * ox;
+    const bool vx = ix + 1 < W, vy = iy + 1 < H;
+    const long o00 = ((n * H + iy) * W + ix) * C4 + c;
+    const long off[4] = {o00, o00 + C4, o00 + (long)W * C4, o00 + (long)W * C4 + C4};
+    const bool valid[4] = {true, vx, vy, vx && vy};
+    f32x4 v[4], s[4];
+    for (int q = 0; q < 4; ++q) {
+      v[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+      s[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (valid[q]) {
+        v[q] = x[off[q]];
+        if (dside != nullptr) s[q] = dside[off[q]];
+      }
+    }
+    const f32x4 g = dy[i];
+    f32x4 out[4];
+    for (int k = 0; k < 4; ++k) {
+      int bi = 0;
+      float best = v[0][k];
+      for (int q = 1; q < 4; ++q)          // scan order (0,0) (0,1) (1,0) (1,1); strict > keeps the first max
+        if (valid[q] && v[q][k] > best) { best = v[q][k]; bi = q; }
+      for (int q = 0; q < 4; ++q) {
+        const float gq = (q == bi ? g[k] : 0.f) + s[q][k];
+        out[q][k] = v[q][k] > 0.f ? gq : 0.f;
+      }
+    }
+    for (int q = 0; q < 4; ++q)
+      if (valid[q]) dx[off[q]] = out[q];
+  }
+}
+
+inline int grid_for(long total) {
+  long b = (total + 255) / 256;
+  return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
+}
+
+}  // namespace
+
+int osvos_maxpool2x2_f32(const float* x, float* y, int N, int H, int W, int C, hipStream_t stream) {
+  OSVOS_ARG_CHECK(x && y && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "maxpool: bad arguments (C=%d)", C);
+  const long total = (long)N * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4);
+  hipLaunchKernelGGL(maxpool_f32_kernel, dim3(grid_for(total)), dim3(256), 0, stream,
+                     reinterpret_cast<const f32x4*>(x), reinterpret_cast<f32x4*>(y), N, H, W, C / 4);
+  OSVOS_LAUNCH_CHECK();
+  return 0;
+}
+
+int osvos_maxpool2x2_bwd_f32(const float* x, const float* dy, const float* dside, float* dx,
+                             int N, int H, int W, int C, hipStream_t stream) {
+  OSVOS_ARG_CHECK(x && dy && dx && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "maxpool_bwd: bad arguments (C=%d)", C);
+  const long total = (long)N * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4);
+  hipLaunchKernelGGL(maxpool_bwd_f32_kernel, dim3(grid_for(total)), dim3(256), 0, stream,
+                     reinterpret_cast<const f32x4*>(x), reinterpret_cast<const f32x4*>(dy),
+                     reinterpret_cast<const f32x4*>(dside), reinterpret_cast<f32x4*>(dx), N, H, W, C / 4);
+  OSVOS_LAUNCH_CHECK();
+  return 0;
+}

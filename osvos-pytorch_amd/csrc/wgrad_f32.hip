@@ -1,0 +1,262 @@
+// 3x3 convolution weight + bias gradient, NHWC fp32, on v_mfma_f32_32x32x2_f32 (gfx950).
+//
+// Replaces the weight/bias half of aten::convolution_backward for nn.Conv2d(k=3, padding=1)
+// (reference vgg_osvos.py:41,142; invoked by loss.backward(), train_online.py:141).
+//
+// GEMM view: D[co][ci] (per tap) = sum over pixels dY[p][co] * X[p + tap][ci]; the reduction
+// dimension is the PIXEL axis (up to 409,920 at 854x480) and the output is tiny, so
+//   * a workgroup owns a (CB*32 couts) x (IB*32 cins) x 9 taps output tile (one 32x32 MFMA
+//     block pair per wave, 9 tap accumulators = 144 accumulator registers) and walks a range of
+//     32x2-pixel patches ("split"); per patch the dY tile and the X halo tile are staged once in
+//     LDS in their natural [pixel][channel] order -- the MFMA A operand (dY^T) and B operand
+//     (X shifted by the tap) are then plain conflict-free ds_read_b32 rows, and the 9 taps
+//     re-use the same X tile through an LDS address offset
+//   * splits write fp32 partial slabs; a second deterministic pass sums them, fuses the
+//     transposition to the reference's OIHW layout and (optionally) the gradient accumulation
+//   * the bias gradient (column sums of dY) rides along in the workgroups of the first Cin tile
+#include "common.h"
+
+namespace {
+
+constexpr int PW = 32, PH = 2;                 // pixel patch
+constexpr int PPIX = PW * PH;                  // 64 output pixels per patch
+constexpr int XW = PW + 2, XH = PH + 2;        // halo
+constexpr int XPIX = XW * XH;                  // 136
+
+struct WgArgs {
+  const float* x;
+  const float* dy;
+  float* slab;
+  float* bslab;
+  int N, H, W, Cin_s, Cout, Cout_s;
+  int npx, npy, npatches, nsplit, per_split;
+  int nco_t, nci_t;
+};
+
+template <int CB, int IB>
+__global__ __launch_bounds__(256) void wgrad_f32_kernel(WgArgs a) {
+  constexpr int BCO = CB * 32, BCI = IB * 32;
+  constexpr int DY_F4 = PPIX * BCO / 4, X_F4 = XPIX * BCI / 4;
+  constexpr int BUF_F4 = DY_F4 + X_F4;
+  constexpr int NDY = (DY_F4 + 255) / 256, NX = (X_F4 + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  f32x4* lds4 = reinterpret_cast<f32x4*>(smem);
+  const float* lds = reinterpret_cast<const float*>(smem);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int cb = wave / IB, ib = wave % IB;
+
+  int id = blockIdx.x;
+  const int cit = id % a.nci_t;
+  id /= a.nci_t;
+  const int cot = id % a.nco_t;
+  const int split = id / a.nco_t;
+  const int co0 = cot * BCO, ci0 = cit * BCI;
+  const int p_begin = split * a.per_split;
+  const int p_end = min(p_begin + a.per_split, a.npatches);
+
+  f32x4 rdy[NDY], rx[NX];
+  auto load_patch = [&](int p) {
+    const int px = p % a.npx;
+    int t = p / a.npx;
+    const int py = t % a.npy;
+    const int n = t / a.npy;
+    const int x0 = px * PW, y0 = py * PH;
+#pragma unroll
+    for (int i = 0; i < NDY; ++i) {
+      const int e = tid + i * 256;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (e < DY_F4) {
+        const int pix = e / (BCO / 4), q = e % (BCO / 4);
+        const int gy = y0 + pix / PW, gx = x0 + pix % PW, co = co0 + 4 * q;
+        if (gy < a.H && gx < a.W && co < a.Cout)
+          v = *reinterpret_cast<const f32x4*>(a.dy + ((size_t)(n * a.H + gy) * a.W + gx) * a.Cout_s + co);
+      }
+      rdy[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int e = tid + i * 256;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (e < X_F4) {
+        const int pix = e / (BCI / 4), q = e % (BCI / 4);
+        const int gy = y0 + pix / XW - 1, gx = x0 + pix % XW - 1, ci = ci0 + 4 * q;
+        if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && ci < a.Cin_s)
+          v = *reinterpret_cast<const f32x4*>(a.x + ((size_t)(n * a.H + gy) * a.W + gx) * a.Cin_s + ci);
+      }
+      rx[i] = v;
+    }
+  };
+  auto store_patch = [&](int buf) {
+    f32x4* d = lds4 + buf * BUF_F4;
+#pragma unroll
+    for (int i = 0; i < NDY; ++i) {
+      const int e = tid + i * 256;
+      if (e < DY_F4) d[e] = rdy[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int e = tid + i * 256;
+      if (e < X_F4) d[DY_F4 + e] = rx[i];
+    }
+  };
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  float bsum = 0.f;
+  const bool do_bias = (a.bslab != nullptr) && (cit == 0);
+  constexpr int BG = 256 / BCO;            // pixel groups for the bias column sums
+  const int bco = tid % BCO, bgrp = tid / BCO;
+
+  if (p_begin < p_end) {
+    load_patch(p_begin);
+    store_patch(0);
+  }
+  __syncthreads();
+  int buf = 0;
+  for (int p = p_begin; p < p_end; ++p) {
+    const bool more = p + 1 < p_end;
+    if (more) load_patch(p + 1);
+    const float* dYs = lds + (size_t)buf * BUF_F4 * 4;
+    const float* Xs = dYs + DY_F4 * 4;
+#pragma unroll 2
+    for (int pp = 0; pp < PPIX / 2; ++pp) {
+      const int dy = pp / (PW / 2), dx = (pp % (PW / 2)) * 2 + lh;
+      const float av = dYs[(dy * PW + dx) * BCO + cb * 32 + li];
+      const float* xb = Xs + (dy * XW + dx) * BCI + ib * 32 + li;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const float bv = xb[((t / 3) * XW + (t % 3)) * BCI];
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+      }
+    }
+    if (do_bias) {
+#pragma unroll 4
+      for (int pix = bgrp; pix < PPIX; pix += BG) bsum += dYs[pix * BCO + bco];
+    }
+    if (more) store_patch(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  // ---- write the partial slab: D row = cout (r&3)+8*(r>>2)+4*lh, col = cin li ----------------
+  const int ci = ci0 + ib * 32 + li;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (co < a.Cout && ci < a.Cin_s)
+        a.slab[((size_t)(split * 9 + t) * a.Cout + co) * a.Cin_s + ci] = acc[t][r];
+    }
+  }
+  if (do_bias) {
+    float* red = reinterpret_cast<float*>(smem);   // all LDS reads are behind the last barrier
+    red[tid] = bsum;
+    __syncthreads();
+    if (tid < BCO) {
+      float s = 0.f;
+#pragma unroll
+      for (int g = 0; g < BG; ++g) s += red[g * BCO + tid];
+      if (co0 + tid < a.Cout) a.bslab[(size_t)split * a.Cout + co0 + tid] = s;
+    }
+  }
+}
+
+// dw[co][ci][tap] (OIHW, Cin real) (+)= sum_split slab[split][tap][co][ci]
+__global__ void wgrad_reduce_kernel(const float* slab, const float* bslab, float* dw, float* db,
+                                    int nsplit, int Cout, int Cin, int Cin_s, int accumulate) {
+  const int total = Cout * Cin_s * 9;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < total) {
+    const int ci = idx % Cin_s;
+    const int co = (idx / Cin_s) % Cout;
+    const int t = idx / (Cin_s * Cout);
+    if (ci < Cin) {
+      float s = 0.f;
+      for (int sp = 0; sp < nsplit; ++sp) s += slab[(size_t)sp * total + idx];
+      float* o = dw + ((size_t)co * Cin + ci) * 9 + t;
+      *o = accumulate ? (*o + s) : s;
+    }
+  }
+  if (db != nullptr && idx < Cout) {
+    float s = 0.f;
+    for (int sp = 0; sp < nsplit; ++sp) s += bslab[(size_t)sp * Cout + idx];
+    db[idx] = accumulate ? (db[idx] + s) : s;
+  }
+}
+
+struct WgPlan {
+  int cb, ib, nco_t, nci_t, npx, npy, npatches, nsplit, per_split;
+  size_t slab_floats, bslab_floats;
+};
+
+WgPlan make_plan(int N, int H, int W, int Cin_s, int Cout) {
+  WgPlan p;
+  if (Cout <= 32) { p.cb = 1; p.ib = 4; } else { p.cb = 2; p.ib = 2; }
+  p.nco_t = ceil_div(Cout, p.cb * 32);
+  p.nci_t = ceil_div(Cin_s, p.ib * 32);
+  p.npx = ceil_div(W, PW);
+  p.npy = ceil_div(H, PH);
+  p.npatches = N * p.npx * p.npy;
+  int want = ceil_div(512, p.nco_t * p.nci_t);
+  int max_split = p.npatches / 4 > 0 ? p.npatches / 4 : 1;
+  p.nsplit = want < max_split ? want : max_split;
+  if (p.nsplit > 256) p.nsplit = 256;
+  if (p.nsplit < 1) p.nsplit = 1;
+  p.per_split = ceil_div(p.npatches, p.nsplit);
+  p.nsplit = ceil_div(p.npatches, p.per_split);
+  p.slab_floats = (size_t)p.nsplit * 9 * Cout * Cin_s;
+  p.bslab_floats = (size_t)p.nsplit * Cout;
+  return p;
+}
+
+template <int CB, int IB>
+int launch_wgrad(const WgArgs& a, long blocks, hipStream_t stream) {
+  constexpr size_t lds = (size_t)2 * (PPIX * CB * 32 + XPIX * IB * 32) * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    OSVOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_f32_kernel<CB, IB>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((wgrad_f32_kernel<CB, IB>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
+  OSVOS_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace
+
+size_t osvos_wgrad_ws_bytes_f32(int N, int H, int W, int Cin_s, int Cout) {
+  WgPlan p = make_plan(N, H, W, Cin_s, Cout);
+  return align_up((p.slab_floats + p.bslab_floats) * sizeof(float), 256);
+}
+
+int osvos_conv3x3_wgrad_f32(const float* x, const float* dy, void* ws, float* dw, float* db,
+                            int N, int H, int W, int Cin, int Cin_s, int Cout, int Cout_s,
+                            int accumulate, hipStream_t stream) {
+  OSVOS_ARG_CHECK(x && dy && ws && dw, "wgrad: null pointer");
+  OSVOS_ARG_CHECK(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "wgrad: bad shape");
+  OSVOS_ARG_CHECK(Cin_s % 4 == 0 && Cout_s % 4 == 0 && Cout % 4 == 0 && Cin <= Cin_s && Cout <= Cout_s,
+                  "wgrad f32: channel strides must be multiples of 4 (Cin %d/%d Cout %d/%d)", Cin, Cin_s, Cout, Cout_s);
+  WgPlan p = make_plan(N, H, W, Cin_s, Cout);
+  WgArgs a;
+  a.x = x; a.dy = dy;
+  a.slab = reinterpret_cast<float*>(ws);
+  a.bslab = db ? a.slab + p.slab_floats : nullptr;
+  a.N = N; a.H = H; a.W = W; a.Cin_s = Cin_s; a.Cout = Cout; a.Cout_s = Cout_s;
+  a.npx = p.npx; a.npy = p.npy; a.npatches = p.npatches; a.nsplit = p.nsplit; a.per_split = p.per_split;
+  a.nco_t = p.nco_t; a.nci_t = p.nci_t;
+  const long blocks = (long)p.nsplit * p.nco_t * p.nci_t;
+  int rc = (p.cb == 1) ? launch_wgrad<1, 4>(a, blocks, stream) : launch_wgrad<2, 2>(a, blocks, stream);
+  if (rc) return rc;
+  const int total = Cout * Cin_s * 9;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, stream,
+                     a.slab, a.bslab, dw, db, p.nsplit, Cout, Cin, Cin_s, accumulate);
+  OSVOS_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,138 @@
+"""Per-op wrappers over the C ABI, taking torch CUDA tensors.  These are thin (pointer + shape
+marshalling only) and exist for the parity tests and for users who want single ops; the network
+itself runs through the two whole-network calls in ``autograd.py``.
+
+Tensors are NHWC ("channels last" memory, shape [N,H,W,C]) unless a name says nchw."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import F32, check, lib, ptr_array
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("osvos_pytorch_amd ops need CUDA (ROCm) tensors; there is no CPU fallback")
+
+
+def nchw_to_nhwc(x, cpad):
+    _need_cuda(x)
+    x = x.contiguous().float()
+    n, c, h, w = x.shape
+    y = torch.empty((n, h, w, cpad), device=x.device, dtype=torch.float32)
+    check(lib().osvos_nchw_to_nhwc(_p(x), _p(y), n, c, h, w, cpad, F32, _stream()), "nchw_to_nhwc")
+    return y
+
+
+def nhwc_to_nchw(x, c):
+    _need_cuda(x)
+    n, h, w, cs = x.shape
+    y = torch.empty((n, c, h, w), device=x.device, dtype=torch.float32)
+    check(lib().osvos_nhwc_to_nchw(_p(x), _p(y), n, c, h, w, cs, F32, _stream()), "nhwc_to_nchw")
+    return y
+
+
+def pack_fwd(w_oihw):
+    _need_cuda(w_oihw)
+    w = w_oihw.contiguous().float()
+    cout, cin = w.shape[:2]
+    buf = torch.empty(lib().osvos_wpack_bytes(cout, cin, F32) // 4, device=w.device, dtype=torch.float32)
+    check(lib().osvos_pack_conv3x3_fwd(_p(w), _p(buf), cout, cin, F32, _stream()), "pack_fwd")
+    return buf
+
+
+def pack_dgrad(w_oihw):
+    _need_cuda(w_oihw)
+    w = w_oihw.contiguous().float()
+    cout, cin = w.shape[:2]
+    buf = torch.empty(lib().osvos_wpack_dgrad_bytes(cout, cin, F32) // 4, device=w.device, dtype=torch.float32)
+    check(lib().osvos_pack_conv3x3_dgrad(_p(w), _p(buf), cout, cin, F32, _stream()), "pack_dgrad")
+    return buf
+
+
+def conv3x3(x, wpk, bias, cout, relu=False, mask=None, y_cs=None, tile=-1):
+    """x [N,H,W,Cin] (Cin % 8 == 0), wpk from pack_fwd / pack_dgrad -> [N,H,W,y_cs]."""
+    _need_cuda(x, wpk, bias, mask)
+    n, h, w, cin = x.shape
+    y_cs = y_cs or cout
+    y = torch.zeros((n, h, w, y_cs), device=x.device, dtype=torch.float32) if y_cs != cout else \
+        torch.empty((n, h, w, y_cs), device=x.device, dtype=torch.float32)
+    check(lib().osvos_conv3x3(_p(x), _p(wpk), _p(bias), _p(mask), _p(y), n, h, w, cin, cout, y_cs, int(relu), F32, tile, _stream()), "conv3x3")
+    return y
+
+
+def conv3x3_wgrad(x, dy, cin, cout, want_bias=True, accumulate_into=None):
+    """x [N,H,W,Cin_s], dy [N,H,W,Cout_s] -> (dW [cout,cin,3,3], db [cout])."""
+    _need_cuda(x, dy)
+    n, h, w, cin_s = x.shape
+    cout_s = dy.shape[3]
+    ws = torch.empty(lib().osvos_wgrad_ws_bytes(n, h, w, cin_s, cout, F32), device=x.device, dtype=torch.uint8)
+    if accumulate_into is not None:
+        dw, db = accumulate_into
+        acc = 1
+    else:
+        dw = torch.empty((cout, cin, 3, 3), device=x.device, dtype=torch.float32)
+        db = torch.empty((cout,), device=x.device, dtype=torch.float32) if want_bias else None
+        acc = 0
+    check(lib().osvos_conv3x3_wgrad(_p(x), _p(dy), _p(ws), _p(dw), _p(db), n, h, w, cin, cin_s, cout, cout_s, acc, F32, _stream()), "wgrad")
+    return dw, db
+
+
+def maxpool2x2(x):
+    _need_cuda(x)
+    n, h, w, c = x.shape
+    y = torch.empty((n, (h + 1) // 2, (w + 1) // 2, c), device=x.device, dtype=torch.float32)
+    check(lib().osvos_maxpool2x2(_p(x), _p(y), n, h, w, c, F32, _stream()), "maxpool")
+    return y
+
+
+def maxpool2x2_bwd(x, dy, dside=None):
+    _need_cuda(x, dy, dside)
+    n, h, w, c = x.shape
+    dx = torch.empty_like(x)
+    check(lib().osvos_maxpool2x2_bwd(_p(x), _p(dy), _p(dside), _p(dx), n, h, w, c, F32, _stream()), "maxpool_bwd")
+    return dx
+
+
+def cbce(output, label, mode=1, want_grad=True):
+    """Returns (loss 0-dim tensor, grad or None).  mode 0 size_average / 1 batch_average / 2 none."""
+    _need_cuda(output, label)
+    out = output.contiguous().float()
+    lab = label.contiguous().float()
+    loss = torch.empty((), device=out.device, dtype=torch.float32)
+    grad = torch.empty_like(out) if want_grad else None
+    scratch = torch.empty(4, device=out.device, dtype=torch.float64)
+    check(lib().osvos_cbce(_p(out), _p(lab), _p(loss), _p(grad), _p(scratch), out.numel(), out.shape[0], mode, _stream()), "cbce")
+    return loss, grad
+
+
+def debug_conv3x3_naive(x, w_oihw, bias, relu=False):
+    _need_cuda(x, w_oihw, bias)
+    n, h, w, cin_s = x.shape
+    cout, cin = w_oihw.shape[:2]
+    y = torch.empty((n, h, w, cout), device=x.device, dtype=torch.float32)
+    check(lib().osvos_debug_conv3x3_naive(_p(x), _p(w_oihw.contiguous()), _p(bias), _p(y), n, h, w, cin, cin_s, cout, int(relu), _stream()), "naive conv")
+    return y
+
+
+def debug_mfma_layout(device="cuda"):
+    out = torch.empty((4, 64, 16), device=device, dtype=torch.float32)
+    check(lib().osvos_debug_mfma_layout(_p(out), _stream()), "mfma layout")
+    return out
+
+
+def sgd_step(p, g, buf, lr, momentum, weight_decay, first):
+    _need_cuda(p, g, buf)
+    check(lib().osvos_sgd_step(_p(p), _p(g), _p(buf), p.numel(), lr, momentum, weight_decay, int(first), _stream()), "sgd_step")

@@ -1,0 +1,87 @@
+"""CPU: the C-ABI library builds for gfx950, loads, and exports every symbol include/osvos_hip.h
+declares; host-side helpers (sizes, layouts, drop-in module tree) behave; nothing computes."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from osvos_pytorch_amd import _lib
+    l = _lib.lib()
+    hdr = open(os.path.join(REPO, "include", "osvos_hip.h")).read()
+    declared = set(re.findall(r"\b(osvos_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 25
+    for name in declared:
+        assert hasattr(l, name), name
+    assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
+    assert l.osvos_version() == 1
+
+
+def test_size_queries():
+    from osvos_pytorch_amd import _lib
+    l = _lib.lib()
+    assert l.osvos_wpack_bytes(64, 3, 0) == 9 * 8 * 64 * 4           # Cin 3 -> 8, Cout 64
+    assert l.osvos_wpack_bytes(16, 512, 0) == 9 * 512 * 32 * 4       # Cout 16 -> 32
+    assert l.osvos_wpack_dgrad_bytes(64, 3, 0) == 9 * 64 * 32 * 4
+    assert l.osvos_net_ws_bytes(1, 480, 854, 0) > 443e6              # at least the saved activations
+    assert l.osvos_net_wbuf_bytes(0) > 2 * 14.7e6 * 4
+    assert l.osvos_conv3x3_num_tiles() == 10
+
+
+def test_argument_errors_are_reported_not_crashed():
+    from osvos_pytorch_amd import _lib
+    l = _lib.lib()
+    rc = l.osvos_conv3x3(None, None, None, None, None, 1, 8, 8, 8, 8, 8, 0, 0, -1, None)
+    assert rc < 0 and b"null" in l.osvos_last_error()
+    with pytest.raises(RuntimeError):
+        _lib.check(rc, "conv3x3")
+
+
+def test_dropin_module_tree_and_state_dict():
+    import networks.vgg_osvos as vo
+    import torch.nn as nn
+    from oracle import torch_ref
+    net = vo.OSVOS(pretrained=0)
+    sd = net.state_dict()
+    assert [k for k, _ in torch_ref.state_dict_spec()] == list(sd.keys())
+    assert [tuple(s) for _, s in torch_ref.state_dict_spec()] == [tuple(v.shape) for v in sd.values()]
+    assert sum(v.numel() for v in sd.values()) == 15267157
+    assert isinstance(net.stages[1][0], nn.MaxPool2d) and net.stages[1][0].ceil_mode
+    assert isinstance(net.stages[0][0], nn.Conv2d) and isinstance(net.upscale[0], nn.ConvTranspose2d)
+    # optimizer-group code of the reference scripts works unchanged (train_online.py:79-88)
+    assert len([p for n, p in net.stages.named_parameters() if 'weight' in n]) == 13
+    assert len([p for n, p in net.side_prep.named_parameters() if 'bias' in n]) == 4
+    # default init: conv N(0, 0.001), bias 0, deconv bilinear on the diagonal (vgg_osvos.py:76-90)
+    assert abs(float(net.stages[2][1].weight.std()) - 1e-3) < 1e-4 and float(net.fuse.bias.abs().max()) == 0
+    f = torch_ref.bilinear_filter(8)
+    np.testing.assert_allclose(net.upscale[1].weight[3, 3].detach().numpy(), f, atol=1e-7)
+    assert float(net.upscale[1].weight[3, 4].abs().max()) == 0
+    with pytest.raises(RuntimeError):
+        net.forward(torch.zeros(1, 3, 8, 8))          # CPU tensors: fail loudly, no fallback
+
+
+def test_layer_helpers_match_reference_golden():
+    from layers.osvos_layers import (center_crop, class_balanced_cross_entropy_loss, interp_surgery, logit, sigmoid_np,
+                                     upsample_filt)
+    h = np.load(os.path.join(REPO, "tests", "golden", "helpers.npz"))
+    for k in (3, 4, 5, 8, 16, 32):
+        np.testing.assert_allclose(upsample_filt(k), h["filt|%d" % k], atol=1e-15)
+    for key in [f for f in h.files if f.startswith("crop|")]:
+        hin, win, ht, wt = [int(v) for v in key[5:].split("_")]
+        t = torch.arange(hin * win, dtype=torch.float32).reshape(1, 1, hin, win)
+        c = center_crop(t, ht, wt)
+        first = int(c[0, 0, 0, 0].item())
+        assert [first // win, first % win, c.shape[2], c.shape[3]] == list(h[key])
+    np.testing.assert_allclose(logit(h["logit|in"]), h["logit|out"])
+    np.testing.assert_allclose(sigmoid_np(np.array([-3.0, 0.0, 2.5])), h["sigmoid|out"])
+    with pytest.raises(ValueError):
+        interp_surgery(torch.nn.ConvTranspose2d(2, 3, 4, bias=False))
+    with pytest.raises(ValueError):
+        interp_surgery(torch.nn.ConvTranspose2d(2, 2, (4, 6), bias=False))
+    with pytest.raises(RuntimeError):
+        class_balanced_cross_entropy_loss(torch.zeros(1, 1, 4, 4), torch.zeros(1, 1, 4, 4))

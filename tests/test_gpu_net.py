@@ -1,0 +1,214 @@
+"""GPU parity tests of the whole hot path through the drop-in API (networks.vgg_osvos.OSVOS +
+layers.osvos_layers.class_balanced_cross_entropy_loss) against
+  (a) the golden vectors produced by the real reference (tests/golden/*.npz), and
+  (b) the torch-CPU functional oracle on the same seeded inputs at larger sizes up to 854x480.
+Tolerances (SURVEY.md 8d, fp32 path): max |dlogit| <= 1e-3 * std(logit), loss rel <= 1e-5,
+per-tensor gradient rel-L2 <= 1e-3, mask IoU(logit > 0) >= 1 - 1e-3."""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import CASES, check_grad, grad_keys, load_case
+
+pytestmark = pytest.mark.gpu
+
+LOGIT_TOL = 1e-3      # x std(logit)
+LOSS_RTOL = 1e-5
+GRAD_RTOL = 1e-3
+IOU_TOL = 1e-3
+
+
+def build_net(wts):
+    import networks.vgg_osvos as vo
+    net = vo.OSVOS(pretrained=0)
+    net.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in wts.items()})
+    return net.cuda()
+
+
+def iou(a, b):
+    a, b = a > 0, b > 0
+    u = np.logical_or(a, b).sum()
+    return 1.0 if u == 0 else np.logical_and(a, b).sum() / u
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_forward_matches_reference_golden(name):
+    from layers.osvos_layers import class_balanced_cross_entropy_loss as cbce
+    g, wts, x, m = load_case(name)
+    net = build_net(wts)
+    with torch.no_grad():
+        outs = net.forward(torch.from_numpy(x).cuda())
+    assert len(outs) == 5
+    gt = torch.from_numpy(m).cuda()
+    for i, o in enumerate(outs):
+        ref = g["f32|out%d" % i]
+        assert tuple(o.shape) == ref.shape
+        err = np.abs(o.cpu().numpy() - ref).max()
+        assert err <= LOGIT_TOL * ref.std(), (name, i, err, ref.std())
+        assert iou(o.cpu().numpy(), ref) >= 1 - IOU_TOL
+        l = cbce(o, gt, size_average=False).item()
+        assert abs(l - g["f32|parent|heads"][i]) <= LOSS_RTOL * abs(g["f32|parent|heads"][i]), (name, i, l)
+
+
+@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("mode", ["online", "parent"])
+def test_gradients_match_reference_golden(name, mode):
+    from layers.osvos_layers import class_balanced_cross_entropy_loss as cbce
+    g, wts, x, m = load_case(name)
+    net = build_net(wts)
+    xin = torch.from_numpy(x)
+    xin.requires_grad_()                      # train_online.py:121-122: requires_grad then .to(device)
+    xd = xin.cuda()
+    gt = torch.from_numpy(m).cuda()
+    outs = net.forward(xd)
+    if mode == "online":
+        loss = cbce(outs[-1], gt, size_average=False)
+    else:
+        losses = [cbce(o, gt, size_average=False) for o in outs]
+        loss = (1 - 60 / 240) * sum(losses[:-1]) + losses[-1]
+    pre = "f32|%s|" % mode
+    assert abs(loss.item() - float(g[pre + "loss"])) <= LOSS_RTOL * abs(float(g[pre + "loss"]))
+    loss /= 5
+    loss.backward()
+    have = {k: v.grad for k, v in net.named_parameters() if v.grad is not None}
+    for k in grad_keys(g, pre + "grad|"):
+        if k == "input":
+            check_grad(g, pre + "grad|", k, xin.grad.numpy(), GRAD_RTOL, what=name)
+        elif k.startswith("upscale"):
+            assert k not in have               # frozen deconvs: gradient intentionally not formed
+        else:
+            check_grad(g, pre + "grad|", k, have[k].cpu().numpy(), GRAD_RTOL, what=name)
+    if mode == "online":
+        assert "score_dsn.0.weight" not in have
+
+
+def test_sgd_trajectory_matches_reference_golden():
+    """2 optimizer steps of the online loop (train_online.py:79-88,112-149) with nAveGrad = 2."""
+    from layers.osvos_layers import class_balanced_cross_entropy_loss as cbce
+    g, wts, x, m = load_case("c48x64")
+    net = build_net(wts)
+    lr, wd = 1e-8, 0.0002
+    opt = torch.optim.SGD([
+        {'params': [pr[1] for pr in net.stages.named_parameters() if 'weight' in pr[0]], 'weight_decay': wd},
+        {'params': [pr[1] for pr in net.stages.named_parameters() if 'bias' in pr[0]], 'lr': lr * 2},
+        {'params': [pr[1] for pr in net.side_prep.named_parameters() if 'weight' in pr[0]], 'weight_decay': wd},
+        {'params': [pr[1] for pr in net.side_prep.named_parameters() if 'bias' in pr[0]], 'lr': lr * 2},
+        {'params': [pr[1] for pr in net.upscale.named_parameters() if 'weight' in pr[0]], 'lr': 0},
+        {'params': [pr[1] for pr in net.upscale_.named_parameters() if 'weight' in pr[0]], 'lr': 0},
+        {'params': net.fuse.weight, 'lr': lr / 100, 'weight_decay': wd},
+        {'params': net.fuse.bias, 'lr': 2 * lr / 100},
+    ], lr=lr, momentum=0.9)
+    w0 = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    losses = []
+    xd, gt = torch.from_numpy(x).cuda(), torch.from_numpy(m).cuda()
+    for it in range(4):
+        outs = net.forward(xd)
+        loss = cbce(outs[-1], gt, size_average=False)
+        losses.append(loss.item())
+        loss /= 2
+        loss.backward()
+        if it % 2 == 1:
+            opt.step()
+            opt.zero_grad()
+    np.testing.assert_allclose(losses, g["sgd|losses"], rtol=2e-5)
+    sd = net.state_dict()
+    for k in w0:
+        check_grad(g, "sgd|delta|", k, (sd[k] - w0[k]).cpu().numpy(), 3e-3, what="sgd")
+
+
+@pytest.mark.parametrize("shape", [(2, 120, 214), (1, 240, 427), (1, 480, 854)])
+def test_full_size_against_cpu_oracle(shape):
+    """Same seeded frame through the torch-CPU oracle and the HIP path; both training modes'
+    gradients are checked in one backward (parent-style deep supervision, side weight 0.5)."""
+    from layers.osvos_layers import class_balanced_cross_entropy_loss as cbce
+    from oracle import synth, torch_ref
+    n, h, w = shape
+    wts, x, m = synth.calibrated_problem(n, h, w, seed=21)
+    p = torch_ref.as_leaf_params(wts)
+    xin = torch.from_numpy(x).requires_grad_()
+    r_outs = torch_ref.forward(p, xin)
+    r_losses = [torch_ref.cbce_loss(o, torch.from_numpy(m), size_average=False) for o in r_outs]
+    (0.5 * sum(r_losses[:-1]) + r_losses[-1]).backward()
+
+    net = build_net(wts)
+    xg = torch.from_numpy(x).requires_grad_()
+    outs = net.forward(xg.cuda())
+    gt = torch.from_numpy(m).cuda()
+    losses = [cbce(o, gt, size_average=False) for o in outs]
+    (0.5 * sum(losses[:-1]) + losses[-1]).backward()
+    for i in range(5):
+        ref = r_outs[i].detach().numpy()
+        got = outs[i].detach().cpu().numpy()
+        assert np.abs(got - ref).max() <= LOGIT_TOL * ref.std(), (shape, i)
+        assert iou(got, ref) >= 1 - IOU_TOL
+        assert abs(losses[i].item() - r_losses[i].item()) <= LOSS_RTOL * abs(r_losses[i].item())
+    worst = ("", 0.0)
+    for k, v in net.named_parameters():
+        if k.startswith("upscale"):
+            continue
+        ref = p[k].grad.double()
+        err = float((v.grad.cpu().double() - ref).norm() / (ref.norm() + 1e-30))
+        if err > worst[1]:
+            worst = (k, err)
+    assert worst[1] <= GRAD_RTOL, worst
+    ref = xin.grad.double()
+    assert float((xg.grad.double() - ref).norm() / ref.norm()) <= GRAD_RTOL
+
+
+def test_intermediate_activations_via_ws_query():
+    """layer-by-layer check of the saved activations (diagnostic granularity for the C orchestration)."""
+    import ctypes as C
+    import torch.nn.functional as F
+    from oracle import synth, torch_ref
+    from osvos_pytorch_amd import _lib
+    from osvos_pytorch_amd.autograd import OSVOSNetFunction
+    n, h, w = 1, 45, 67
+    wts, x, _ = synth.calibrated_problem(n, h, w, seed=5)
+    net = build_net(wts)
+    xg = torch.from_numpy(x).cuda().requires_grad_()
+    outs = net.forward(xg)
+    ws = outs[0].grad_fn.ws
+    p = {k: torch.from_numpy(v) for k, v in wts.items()}
+    cur = torch.from_numpy(x)
+    names = torch_ref.trunk_conv_names()
+    l = 0
+    lib = _lib.lib()
+    for si in range(5):
+        if si > 0:
+            cur = F.max_pool2d(cur, 2, 2, ceil_mode=True)
+        for nm in names[si]:
+            cur = F.relu(F.conv2d(cur, p[nm + ".weight"], p[nm + ".bias"], padding=1))
+            off, el, ch, hh, ww = C.c_size_t(), C.c_size_t(), C.c_int(), C.c_int(), C.c_int()
+            _lib.check(lib.osvos_net_ws_query(n, h, w, 0, l, C.byref(off), C.byref(el), C.byref(ch), C.byref(hh), C.byref(ww)))
+            act = ws[off.value:off.value + 4 * el.value].view(torch.float32).view(n, hh.value, ww.value, ch.value)
+            got = act.permute(0, 3, 1, 2).cpu()
+            err = float((got - cur).abs().max() / (cur.abs().max() + 1e-30))
+            assert err < 1e-4, ("trunk conv", l, err)
+            l += 1
+
+
+def test_refuses_non_diagonal_deconv_and_cpu_tensors():
+    from oracle import synth
+    wts = synth.make_weights(1)
+    wts["upscale.1.weight"] = wts["upscale.1.weight"].copy()
+    wts["upscale.1.weight"][0, 1, 2, 2] = 0.25
+    net = build_net(wts)
+    with pytest.raises(NotImplementedError):
+        net.forward(torch.zeros(1, 3, 16, 16).cuda())
+    net2 = build_net(synth.make_weights(1))
+    with pytest.raises(RuntimeError):
+        net2.forward(torch.zeros(1, 3, 16, 16))       # CPU tensor: no fallback
+
+
+def test_batch_and_odd_sizes_no_grad_inference():
+    """inference path of train_online.py:172-189 (no_grad, sigmoid on the host)"""
+    from oracle import synth, torch_ref
+    from layers.osvos_layers import sigmoid_np
+    for (n, h, w) in [(3, 33, 41), (1, 1, 1), (1, 2, 3), (2, 101, 135)]:
+        wts, x, _ = synth.calibrated_problem(n, h, w, seed=9)
+        net = build_net(wts)
+        with torch.no_grad():
+            got = net.forward(torch.from_numpy(x).cuda())[-1].cpu().numpy()
+            ref = torch_ref.forward({k: torch.from_numpy(v) for k, v in wts.items()}, torch.from_numpy(x))[-1].numpy()
+        assert np.abs(got - ref).max() <= LOGIT_TOL * max(ref.std(), 1e-3), (n, h, w)
+        assert np.abs(sigmoid_np(got) - sigmoid_np(ref)).max() < 1e-4

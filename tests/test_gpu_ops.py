@@ -1,0 +1,182 @@
+"""GPU parity tests, op by op, through the C ABI (osvos_pytorch_amd.ops) against CPU oracles
+(torch float64 functional ops = the reference's ATen semantics; oracle/c_oracle for the loss).
+fp32 tolerances: conv outputs within 2e-5 * rms-scale (fp32 MFMA == fmaf chain), see SURVEY 8d."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    from osvos_pytorch_amd import ops
+    return ops
+
+
+def nhwc(t):  # cpu NCHW -> cuda NHWC contiguous
+    return t.permute(0, 2, 3, 1).contiguous().float().cuda()
+
+
+def nchw(t):  # cuda NHWC -> cpu NCHW float64
+    return t.permute(0, 3, 1, 2).double().cpu()
+
+
+def rel_err(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30)), float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def test_mfma_fragment_layout():
+    """v_mfma_f32_32x32x2_f32: A[i][k] lane = i + 32k, B[k][j] lane = j + 32k,
+    D[row][col]: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)."""
+    out = _ops().debug_mfma_layout().cpu().numpy()
+    lane = np.arange(64)[:, None]
+    r = np.arange(16)[None, :]
+    col = lane & 31
+    row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    for v, (wa, wb) in enumerate([((1, 0), (1, 0)), ((0, 3), (0, 7)), ((1, 3), (1, 7))]):
+        exp = (row + 1) * (col + 1) * 100.0 * (wa[0] * wb[0] + wa[1] * wb[1])
+        np.testing.assert_array_equal(out[v], exp.astype(np.float32))
+
+
+CONV_SHAPES = [
+    # N, H, W, Cin, Cout
+    (1, 9, 11, 8, 32),
+    (2, 17, 35, 16, 64),
+    (1, 33, 70, 64, 128),
+    (1, 8, 8, 24, 16),
+    (1, 40, 45, 32, 96),
+]
+
+
+@pytest.mark.parametrize("shape", CONV_SHAPES)
+@pytest.mark.parametrize("tile", list(range(10)) + [-1])
+def test_conv3x3_forward_all_tiles(shape, tile):
+    ops = _ops()
+    n, h, w, cin, cout = shape
+    g = torch.Generator().manual_seed(hash(shape) % 1000 + 3)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)
+    b = torch.randn(cout, generator=g)
+    ref = F.relu(F.conv2d(x.double(), wt.double(), b.double(), padding=1))
+    y = ops.conv3x3(nhwc(x), ops.pack_fwd(wt.cuda()), b.cuda(), cout, relu=True, tile=tile)
+    emax, el2 = rel_err(nchw(y), ref)
+    assert emax < 2e-5 and el2 < 1e-5, (shape, tile, emax, el2)
+
+
+def test_conv3x3_matches_naive_kernel_and_mask_and_stride():
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    n, h, w, cin, cout = 1, 21, 37, 16, 16
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / 12
+    b = torch.randn(cout, generator=g)
+    xg = nhwc(x)
+    ref = F.conv2d(x.double(), wt.double(), b.double(), padding=1)
+    naive = ops.debug_conv3x3_naive(xg, wt.cuda(), b.cuda())
+    assert rel_err(nchw(naive), ref)[0] < 2e-5
+    y = ops.conv3x3(xg, ops.pack_fwd(wt.cuda()), b.cuda(), cout, relu=False, y_cs=24)
+    assert rel_err(nchw(y[..., :cout]), ref)[0] < 2e-5
+    assert float(y[..., cout:].abs().max()) == 0.0            # channels beyond Cout untouched
+    m = torch.randn(n, cout, h, w, generator=g)
+    ym = ops.conv3x3(xg, ops.pack_fwd(wt.cuda()), b.cuda(), cout, relu=False, mask=nhwc(m))
+    assert rel_err(nchw(ym), ref * (m > 0))[0] < 2e-5
+
+
+@pytest.mark.parametrize("shape", [(1, 9, 11, 8, 32), (2, 17, 35, 16, 64), (1, 20, 33, 3, 64), (1, 12, 13, 64, 16)])
+def test_conv3x3_dgrad_and_wgrad(shape):
+    ops = _ops()
+    n, h, w, cin, cout = shape
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(n, cin, h, w, generator=g, dtype=torch.float64, requires_grad=True)
+    wt = (torch.randn(cout, cin, 3, 3, generator=g, dtype=torch.float64) / (3 * cin ** 0.5)).requires_grad_()
+    b = torch.randn(cout, generator=g, dtype=torch.float64, requires_grad=True)
+    dy = torch.randn(n, cout, h, w, generator=g, dtype=torch.float64)
+    F.conv2d(x, wt, b, padding=1).backward(dy)
+    cin_s = (cin + 7) // 8 * 8
+    xp = torch.zeros(n, cin_s, h, w)
+    xp[:, :cin] = x.detach().float()
+    dyg = nhwc(dy)
+    dx = ops.conv3x3(dyg, ops.pack_dgrad(wt.detach().float().cuda()), None, cin, relu=False, y_cs=max(cin, 4) if cin < 8 else cin)
+    assert rel_err(nchw(dx[..., :cin]), x.grad)[0] < 3e-5, shape
+    dw, db = ops.conv3x3_wgrad(nhwc(xp), dyg, cin, cout)
+    assert rel_err(dw.cpu(), wt.grad)[0] < 3e-5, shape
+    assert rel_err(db.cpu(), b.grad)[0] < 3e-5, shape
+    dw2, db2 = ops.conv3x3_wgrad(nhwc(xp), dyg, cin, cout, accumulate_into=(dw.clone(), db.clone()))
+    assert rel_err(dw2.cpu(), 2 * wt.grad)[0] < 3e-5
+
+
+def test_wgrad_many_patches_and_splits():
+    """long reduction (many 32x2 patches, several splits) keeps fp32-level accuracy"""
+    ops = _ops()
+    g = torch.Generator().manual_seed(12)
+    n, h, w, cin, cout = 2, 60, 107, 64, 64
+    x = torch.randn(n, cin, h, w, generator=g)
+    dy = torch.randn(n, cout, h, w, generator=g)
+    wt = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), wt, None, padding=1).backward(dy.double())
+    dw, db = ops.conv3x3_wgrad(nhwc(x), nhwc(dy), cin, cout)
+    assert rel_err(dw.cpu(), wt.grad)[1] < 1e-5
+    assert rel_err(db.cpu(), dy.double().sum((0, 2, 3)))[0] < 1e-5
+
+
+@pytest.mark.parametrize("hw", [(8, 8), (9, 13), (1, 1), (7, 2), (30, 54), (61, 107)])
+def test_maxpool_forward_backward(hw):
+    ops = _ops()
+    h, w = hw
+    g = torch.Generator().manual_seed(h * 100 + w)
+    c = 8
+    # quantised positive values -> many exact ties; ReLU-like zeros too
+    x = (torch.randint(-2, 4, (2, c, h, w), generator=g).clamp(min=0)).double().requires_grad_()
+    y = F.max_pool2d(x, 2, 2, ceil_mode=True)
+    dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(dy)
+    yg = ops.maxpool2x2(nhwc(x.detach()))
+    assert torch.equal(nchw(yg), y.detach())
+    side = torch.randn(x.shape, generator=g, dtype=torch.float64)
+    dxg = ops.maxpool2x2_bwd(nhwc(x.detach()), nhwc(dy), nhwc(side))
+    ref = (x.grad + side) * (x.detach() > 0)
+    assert rel_err(nchw(dxg), ref)[0] < 1e-6
+    dxg2 = ops.maxpool2x2_bwd(nhwc(x.detach()), nhwc(dy), None)
+    assert rel_err(nchw(dxg2), x.grad * (x.detach() > 0))[0] < 1e-6
+
+
+def test_maxpool_negative_partial_window():
+    """an all-negative clipped window returns the real max (never a padded zero)"""
+    ops = _ops()
+    x = -torch.rand(1, 4, 5, 5) - 1
+    y = ops.maxpool2x2(nhwc(x))
+    assert torch.equal(nchw(y), F.max_pool2d(x.double(), 2, 2, ceil_mode=True))
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("kind", ["bin", "soft", "allneg", "allpos"])
+def test_cbce_loss_and_grad(mode, kind):
+    from oracle import c_oracle
+    ops = _ops()
+    rng = np.random.default_rng(3)
+    logits = (rng.standard_normal((2, 1, 37, 53)) * 4).astype(np.float32)
+    lab = {"bin": (rng.random(logits.shape) > 0.8), "soft": rng.random(logits.shape),
+           "allneg": np.zeros(logits.shape), "allpos": np.ones(logits.shape)}[kind].astype(np.float32)
+    ref_loss, ref_grad = c_oracle.cbce(logits.astype(np.float64), lab.astype(np.float64), mode)
+    loss, grad = ops.cbce(torch.from_numpy(logits).cuda(), torch.from_numpy(lab).cuda(), mode)
+    assert abs(loss.item() - ref_loss) <= 1e-5 * abs(ref_loss) + 1e-12
+    np.testing.assert_allclose(grad.cpu().numpy(), ref_grad, rtol=2e-5, atol=1e-9)
+    if kind == "allneg":
+        assert loss.item() == 0.0
+
+
+def test_fused_sgd_matches_torch():
+    ops = _ops()
+    g = torch.Generator().manual_seed(2)
+    p = torch.randn(1000, generator=g)
+    ref = p.clone().requires_grad_()
+    opt = torch.optim.SGD([ref], lr=1e-2, momentum=0.9, weight_decay=2e-4)
+    pg, buf = p.clone().cuda(), torch.zeros(1000).cuda()
+    for it in range(3):
+        gr = torch.randn(1000, generator=g)
+        ref.grad = gr.clone()
+        opt.step()
+        ops.sgd_step(pg, gr.cuda(), buf, 1e-2, 0.9, 2e-4, it == 0)
+    np.testing.assert_allclose(pg.cpu().numpy(), ref.detach().numpy(), rtol=1e-6, atol=1e-7)
