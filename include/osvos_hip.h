@@ -54,7 +54,8 @@ int osvos_pack_conv3x3_dgrad(const float* w_oihw, void* wpk, int Cout, int Cin, 
  *   bias: fp32 [Cout] or NULL;  relu != 0: epi = max(.,0)  (vgg_osvos.py:143)
  *   mask: NHWC like y or NULL: epi zeroes the result where mask <= 0 (ReLU backward of the
  *         producer layer fused into this layer's data-gradient: aten::threshold_backward)
- *   tile: -1 = automatic, otherwise a tile-config index (tuning / tests) */
+ *   tile: -1 = automatic, otherwise a tile-config index, +100 for the XCD-local spatial
+ *         block mapping (tuning / tests) */
 int osvos_conv3x3(const void* x, const void* wpk, const float* bias, const void* mask, void* y,
                   int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int dtype, int tile, void* stream);
 int osvos_conv3x3_num_tiles(void);
@@ -92,7 +93,8 @@ int osvos_head_upsample(const float* const* score, const float* const* fpart,
                         const float* const* f1, const float* const* f16, const float* fuse_bias,
                         float* const* outs, int N, int H, int W, const int* hs, const int* ws, void* stream);
 /* backward of both, per scale: dprep[N,h,w,16] (NHWC, dtype) = wf*up^T(dfused) + wd*up_^T(dside);
- * accumulates into acc (double[34]: dwf[16], dwd[16], dbd, spare) the weight/bias gradients.
+ * writes per-workgroup partial sums of the weight/bias gradients to acc (double[256][34] at most:
+ * {dwf[16], dwd[16], dbd, spare} per launched workgroup; the whole-network call sums them).
  * dside / dfused: fp32 NCHW [N,1,H,W] or NULL (treated as zero). */
 int osvos_head_bwd(const void* prep, const float* dside, const float* dfused,
                    const float* f1, const float* f16, const float* wd, const float* wf,

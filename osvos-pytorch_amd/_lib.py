@@ -83,6 +83,9 @@ def lib() -> C.CDLL:
     global _lib
     with _lock:
         if _lib is None:
+            # torch first: the process must end up with ONE HIP runtime (the libamdhip64 torch
+            # ships); loading ours before torch's makes hipMemsetAsync & co see no device
+            import torch  # noqa: F401
             if _stale():
                 build()
             try:

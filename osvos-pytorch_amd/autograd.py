@@ -67,6 +67,7 @@ class OSVOSNetFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, rt, x, *params):
+        ctx.set_materialize_grads(False)      # unused heads arrive as None, not as zero maps
         if not x.is_cuda:
             raise RuntimeError("OSVOS (osvos_pytorch_amd) runs on the GPU only: move the module and the input to "
                                "'cuda'; there is no CPU fallback")

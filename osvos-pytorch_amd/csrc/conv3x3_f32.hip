@@ -30,7 +30,7 @@ struct ConvArgs {
   float* y;
   int N, H, W, Cin, Cout, CoutP, y_cs;
   int tiles_x, tiles_y, nct;
-  int relu;
+  int relu, map, nsp;
 };
 
 constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
@@ -69,8 +69,20 @@ __global__ __launch_bounds__(256) void conv3x3_f32_kernel(ConvArgs a) {
   const int li = lane & 31, lh = lane >> 5;
   const int wm = wave / C::WGN, wn = wave % C::WGN;
 
-  int sp = blockIdx.x / a.nct;
-  const int ct = blockIdx.x % a.nct;
+  // blockIdx -> (Cout tile, spatial tile).  map 0: Cout tile in the low bits, so XCD b % 8 keeps
+  // one weight slice hot in its L2 (deep layers: weights >> activations).  map 1: spatial tile
+  // = 8 * (b / (8 nct)) + b % 8, Cout tiles consecutive on the SAME XCD, so the input halo tile is
+  // fetched from HBM once per XCD instead of once per Cout tile (shallow layers).
+  int sp, ct;
+  if (a.map == 0) {
+    sp = blockIdx.x / a.nct;
+    ct = blockIdx.x % a.nct;
+  } else {
+    const int j = blockIdx.x >> 3;
+    ct = j % a.nct;
+    sp = (j / a.nct) * 8 + (blockIdx.x & 7);
+    if (sp >= a.nsp) return;
+  }
   const int tx = sp % a.tiles_x;
   sp /= a.tiles_x;
   const int ty = sp % a.tiles_y;
@@ -223,7 +235,8 @@ int launch_cfg(const ConvArgs& a0, hipStream_t stream) {
   a.tiles_x = ceil_div(a.W, C::TW);
   a.tiles_y = ceil_div(a.H, C::TH);
   a.nct = ceil_div(a.CoutP, C::BN);
-  const long blocks = (long)a.nct * a.tiles_x * a.tiles_y * a.N;
+  a.nsp = a.tiles_x * a.tiles_y * a.N;
+  const long blocks = a.map == 0 ? (long)a.nct * a.nsp : (long)a.nct * ((a.nsp + 7) / 8) * 8;
   OSVOS_ARG_CHECK(blocks > 0 && blocks < (1L << 31), "conv3x3: grid of %ld blocks", blocks);
   hipLaunchKernelGGL(conv3x3_f32_kernel<C>, dim3((unsigned)blocks), dim3(256), C::LDS_BYTES, stream, a);
   OSVOS_LAUNCH_CHECK();
@@ -253,8 +266,10 @@ constexpr TileInfo info() { return TileInfo{C::TW, C::TH, C::BN, C::WM, C::WN, C
 const TileInfo kTiles[kNumTiles] = {info<T0>(), info<T1>(), info<T2>(), info<T3>(), info<T4>(),
                                     info<T5>(), info<T6>(), info<T7>(), info<T8>(), info<T9>()};
 
+// Measured on MI355X (tools/tune_conv.py, profiles/): small tiles with 3-4 co-resident
+// workgroups per CU beat the big register-blocked tiles by up to 2x -- with one wave per SIMD the
+// prologue/epilogue and every barrier are exposed.  The model below prices that in.
 int pick_tile(int N, int H, int W, int Cin, int CoutP) {
-  // crude model: MFMA-issue-bound blocks, `bpc` workgroups co-resident per CU (LDS limited)
   double best = 1e300;
   int best_i = 0;
   for (int i = 0; i < kNumTiles; ++i) {
@@ -262,11 +277,16 @@ int pick_tile(int N, int H, int W, int Cin, int CoutP) {
     if (t.bn > CoutP && t.bn != 32) continue;
     const long tiles = (long)N * ceil_div(H, t.th) * ceil_div(W, t.tw) * ceil_div(CoutP, t.bn);
     int bpc = (int)(160 * 1024 / t.lds);
+    const int acc_regs = t.wm * t.wn * 16;
+    const int reg_bpc = acc_regs >= 128 ? 1 : (acc_regs >= 64 ? 2 : 4);
+    if (bpc > reg_bpc) bpc = reg_bpc;
     if (bpc > 4) bpc = 4;
     if (bpc < 1) bpc = 1;
-    const double per_chunk = t.wm * t.wn * 9.0 * 4.0 * 64.0 + 700.0;
+    static const double eff[5] = {0.0, 0.50, 0.72, 0.84, 0.92};     // MFMA-pipe fill vs waves/SIMD
+    const double per_chunk = t.wm * t.wn * 9.0 * 4.0 * 64.0;
+    const double fixed = 4000.0 + 40.0 * t.wm * t.wn * 16;             // prologue + epilogue stores
     const double rounds = (double)((tiles + 256L * bpc - 1) / (256L * bpc));
-    const double cost = rounds * bpc * per_chunk * (Cin / 8);
+    const double cost = rounds * bpc * (per_chunk * (Cin / 8) / eff[bpc] + fixed);
     if (cost < best) { best = cost; best_i = i; }
   }
   return best_i;
@@ -290,7 +310,11 @@ int osvos_conv3x3_f32(const float* x, const float* wpk, const float* bias, const
   if (tile < 0) {
     const char* env = getenv("OSVOS_CONV_TILE");
     tile = env ? atoi(env) : pick_tile(N, H, W, Cin, a.CoutP);
+    // activations larger than the weights -> keep the halo tile XCD-local
+    if (!env && (double)H * W * Cin > 9.0 * Cin * a.CoutP) tile += 100;
   }
+  a.map = tile >= 100 ? 1 : 0;
+  tile %= 100;
   switch (tile) {
     case 0: return launch_cfg<T0>(a, stream);
     case 1: return launch_cfg<T1>(a, stream);

@@ -11,7 +11,7 @@
 // copies (osvos_layers.py:56) never exist here: two dot-16 per low-res pixel, then one gather of
 // <= 2x2 taps per scale per output pixel.  The caller verifies the diagonal/shared-filter
 // precondition with osvos_deconv_diag_check and refuses to run otherwise.
-#include "common.h"
+#include "kernels.h"
 
 namespace {
 
@@ -96,7 +96,7 @@ struct HbArgs {
   const float* wd;
   const float* wf;
   f32x4* dprep;
-  double* acc;   // [0..15] dwf, [16..31] dwd, [32] dbd, [33] spare
+  double* acc;   // per-workgroup partials [gridDim.x][34]: [0..15] dwf, [16..31] dwd, [32] dbd, [33] spare
   int N, H, W, h, w, s;
 };
 
@@ -158,25 +158,32 @@ __global__ __launch_bounds__(256) void head_bwd_f32_kernel(HbArgs a) {
       pbd += ds;
     }
   }
-  const int lane = threadIdx.x & 63;
+  // workgroup partials (no atomics: deterministic, and 2048 waves hammering 33 addresses with
+  // double atomics cost ~270 us per scale); osvos_head_grads_finalize sums them
+  __shared__ double red[4][34];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
   for (int c = 0; c < 16; ++c) {
     const double s1 = wave_sum((double)pwf[c]);
     const double s2 = wave_sum((double)pwd[c]);
-    if (lane == 0) {
-      atomicAdd(&a.acc[c], s1);
-      atomicAdd(&a.acc[16 + c], s2);
-    }
+    if (lane == 0) { red[wv][c] = s1; red[wv][16 + c] = s2; }
   }
   const double s3 = wave_sum((double)pbd);
-  if (lane == 0) atomicAdd(&a.acc[32], s3);
+  if (lane == 0) { red[wv][32] = s3; red[wv][33] = 0.0; }
+  __syncthreads();
+  if (threadIdx.x < 34)
+    a.acc[(size_t)blockIdx.x * 34 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
-__global__ void sum_to_double_kernel(const float* __restrict__ x, long count, double* acc) {
+// per-workgroup partial sums of x -> part[blockIdx.x]
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ x, long count, double* part) {
+  __shared__ double red[4];
   double s = 0.0;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) s += (double)x[i];
   s = wave_sum(s);
-  if ((threadIdx.x & 63) == 0) atomicAdd(acc, s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
 // out[0] = max |w[ci][co]| over ci != co, out[1] = max |w[c][c] - w[0][0]|   (w: [C][C][k][k])
@@ -238,6 +245,12 @@ extern "C" int osvos_head_upsample(const float* const* score, const float* const
   return 0;
 }
 
+int osvos_head_bwd_blocks(int N, int h, int w, int scale_idx) {
+  const int tpp[4] = {1, 4, 16, 64};
+  const long npix = (long)N * h * w;
+  return grid_for(npix * tpp[scale_idx], OSVOS_HEAD_MAX_BLOCKS);
+}
+
 int osvos_head_bwd_f32(const float* prep, const float* dside, const float* dfused, const float* f1, const float* f16,
                        const float* wd, const float* wf, float* dprep, double* acc, int N, int H, int W, int h, int w,
                        int scale_idx, hipStream_t stream) {
@@ -249,20 +262,22 @@ int osvos_head_bwd_f32(const float* prep, const float* dside, const float* dfuse
   a.dprep = reinterpret_cast<f32x4*>(dprep);
   a.acc = acc;
   a.N = N; a.H = H; a.W = W; a.h = h; a.w = w; a.s = 2 << scale_idx;
-  const long npix = (long)N * h * w;
+  const int g = osvos_head_bwd_blocks(N, h, w, scale_idx);
   switch (scale_idx) {
-    case 0: hipLaunchKernelGGL(head_bwd_f32_kernel<1>, dim3(grid_for(npix, 512)), dim3(256), 0, stream, a); break;
-    case 1: hipLaunchKernelGGL(head_bwd_f32_kernel<4>, dim3(grid_for(npix * 4, 512)), dim3(256), 0, stream, a); break;
-    case 2: hipLaunchKernelGGL(head_bwd_f32_kernel<16>, dim3(grid_for(npix * 16, 512)), dim3(256), 0, stream, a); break;
-    default: hipLaunchKernelGGL(head_bwd_f32_kernel<64>, dim3(grid_for(npix * 64, 512)), dim3(256), 0, stream, a); break;
+    case 0: hipLaunchKernelGGL(head_bwd_f32_kernel<1>, dim3(g), dim3(256), 0, stream, a); break;
+    case 1: hipLaunchKernelGGL(head_bwd_f32_kernel<4>, dim3(g), dim3(256), 0, stream, a); break;
+    case 2: hipLaunchKernelGGL(head_bwd_f32_kernel<16>, dim3(g), dim3(256), 0, stream, a); break;
+    default: hipLaunchKernelGGL(head_bwd_f32_kernel<64>, dim3(g), dim3(256), 0, stream, a); break;
   }
   OSVOS_LAUNCH_CHECK();
   return 0;
 }
 
-int osvos_sum_to_double(const float* x, long count, double* acc, hipStream_t stream) {
-  hipLaunchKernelGGL(sum_to_double_kernel, dim3(grid_for(count, 256)), dim3(256), 0, stream, x, count, acc);
+int osvos_sum_partials(const float* x, long count, double* part, int* nblocks, hipStream_t stream) {
+  const int g = grid_for(count, OSVOS_HEAD_MAX_BLOCKS);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(g), dim3(256), 0, stream, x, count, part);
   OSVOS_LAUNCH_CHECK();
+  *nblocks = g;
   return 0;
 }
 

@@ -23,7 +23,13 @@ __global__ void cbce_count_kernel(const float* __restrict__ label, long count, S
     c += label[i] >= 0.5f ? 1u : 0u;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
-  if ((threadIdx.x & 63) == 0 && c) atomicAdd(&sc->npos, (unsigned long long)c);
+  __shared__ unsigned int red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    c = red[0] + red[1] + red[2] + red[3];
+    if (c) atomicAdd(&sc->npos, (unsigned long long)c);     // one atomic per workgroup (<= 128)
+  }
 }
 
 __global__ void cbce_main_kernel(const float* __restrict__ out, const float* __restrict__ label,
@@ -40,15 +46,21 @@ __global__ void cbce_main_kernel(const float* __restrict__ out, const float* __r
     lpos += (double)(-y * val);
     lneg += (double)(-(1.f - y) * val);
     if (grad != nullptr) {
-      const float sg = 1.f / (1.f + expf(-x));
-      grad[i] = (y > 0.5f ? wpos : wneg) * (sg - y) * inv_div;
+      // d(-val)/dx = (1 - 2g) * sigmoid(-|x|) - (y - g): the form autograd derives from the
+      // reference's expression; no cancellation for saturated logits (sigmoid(x) - y would lose it)
+      const float ez = expf(-fabsf(x));
+      const float sz = ez / (1.f + ez);
+      grad[i] = (y > 0.5f ? wpos : wneg) * ((1.f - 2.f * g) * sz - (y - g)) * inv_div;
     }
   }
   lpos = wave_sum(lpos);
   lneg = wave_sum(lneg);
-  if ((threadIdx.x & 63) == 0) {
-    atomicAdd(&sc->lpos, lpos);
-    atomicAdd(&sc->lneg, lneg);
+  __shared__ double red[4][2];
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = lpos; red[threadIdx.x >> 6][1] = lneg; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(&sc->lpos, red[0][0] + red[1][0] + red[2][0] + red[3][0]);
+    atomicAdd(&sc->lneg, red[0][1] + red[1][1] + red[2][1] + red[3][1]);
   }
 }
 
@@ -90,7 +102,7 @@ extern "C" int osvos_cbce(const float* out, const float* label, float* loss, flo
   const float inv_div = mode == 0 ? 1.f / (float)count : (mode == 1 ? 1.f / (float)N : 1.f);
   Scratch* sc = reinterpret_cast<Scratch*>(scratch);
   OSVOS_HIP_CHECK(hipMemsetAsync(sc, 0, sizeof(Scratch), stream));
-  const int g = grid_for(count, 1024);
+  const int g = grid_for(count, 128);
   hipLaunchKernelGGL(cbce_count_kernel, dim3(g), dim3(256), 0, stream, label, count, sc);
   hipLaunchKernelGGL(cbce_main_kernel, dim3(g), dim3(256), 0, stream, out, label, grad, count, inv_div, sc);
   hipLaunchKernelGGL(cbce_final_kernel, dim3(1), dim3(1), 0, stream, sc, count, inv_div, loss);

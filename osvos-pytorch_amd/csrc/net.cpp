@@ -103,7 +103,7 @@ WsLayout ws_layout(int N, int H, int W, int dtype) {
     if (b > max_wg) max_wg = b;
   }
   L.wgrad = take(max_wg);
-  L.acc = take(sizeof(double) * (4 * 34 + 2));
+  L.acc = take(sizeof(double) * (5 * OSVOS_HEAD_MAX_BLOCKS * 34));   // head_bwd partials: 4 scales + fuse bias
   L.dxin = take(es * N * H * W * 4);
   L.total = off;
   return L;
@@ -118,7 +118,8 @@ inline const char* at(const void* base, size_t off) { return reinterpret_cast<co
 
 // device-side helpers implemented in net_kernels.hip
 int osvos_gather_small(const float* const* srcs, const size_t* dst_off, const int* counts, int n, void* wbuf, hipStream_t stream);
-int osvos_head_grads_finalize(const double* acc, float* const* grads, int accumulate, int have_side, hipStream_t stream);
+int osvos_head_grads_finalize(const double* const* part, const int* nblk, const double* fb_part, int fb_nblk,
+                              float* const* grads, int accumulate, int have_side, hipStream_t stream);
 
 extern "C" {
 
@@ -240,7 +241,8 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
   conv_table(d);
   int rc;
   double* acc = reinterpret_cast<double*>(at(ws, L.acc));
-  OSVOS_HIP_CHECK(hipMemsetAsync(acc, 0, sizeof(double) * (4 * 34 + 2), stream));
+  const double* part[4];
+  int nblk[4], fb_nblk = 0;
   bool have_side = false;
   for (int i = 0; i < 4; ++i) have_side = have_side || douts[i] != nullptr;
   const float* dfused = douts[4];
@@ -250,15 +252,18 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
     const int si = i + 1;
     rc = osvos_head_bwd(at(ws, L.prep[i]), douts[i], dfused, reinterpret_cast<const float*>(at(wbuf, P.f1[i])),
                         reinterpret_cast<const float*>(at(wbuf, P.f16[i])), reinterpret_cast<const float*>(at(wbuf, P.wd[i])),
-                        reinterpret_cast<const float*>(at(wbuf, P.wf)) + 16 * i, at(ws, L.dprep[i]), acc + 34 * i,
+                        reinterpret_cast<const float*>(at(wbuf, P.wf)) + 16 * i, at(ws, L.dprep[i]), acc + (size_t)i * OSVOS_HEAD_MAX_BLOCKS * 34,
                         N, H, W, L.hs[si], L.ws[si], i, dtype, stream);
     if (rc) return rc;
+    part[i] = acc + (size_t)i * OSVOS_HEAD_MAX_BLOCKS * 34;
+    nblk[i] = osvos_head_bwd_blocks(N, L.hs[si], L.ws[si], i);
   }
+  double* fb_part = acc + (size_t)4 * OSVOS_HEAD_MAX_BLOCKS * 34;
   if (dfused != nullptr) {
-    rc = osvos_sum_to_double(dfused, (long)N * H * W, acc + 4 * 34, stream);
+    rc = osvos_sum_partials(dfused, (long)N * H * W, fb_part, &fb_nblk, stream);
     if (rc) return rc;
   }
-  rc = osvos_head_grads_finalize(acc, grads, accumulate, have_side ? 1 : 0, stream);
+  rc = osvos_head_grads_finalize(part, nblk, fb_part, fb_nblk, grads, accumulate, have_side ? 1 : 0, stream);
   if (rc) return rc;
 
   // ---- side_prep convs: weight gradients + data gradients into the stage outputs --------------

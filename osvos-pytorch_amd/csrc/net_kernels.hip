@@ -19,7 +19,9 @@ __global__ void gather_small_kernel(GatherArgs a) {
 }
 
 struct FinalizeArgs {
-  const double* acc;      // 4 x {dwf[16], dwd[16], dbd, spare} then d(fuse.bias)
+  const double* part[4];   // per scale: [nblk[i]][34] partials {dwf[16], dwd[16], dbd, spare}
+  const double* fb_part;   // [fb_nblk] partial sums of dfused
+  int nblk[4], fb_nblk;
   float* fuse_w;
   float* fuse_b;
   float* dsn_w[4];
@@ -28,23 +30,22 @@ struct FinalizeArgs {
 };
 
 __global__ void head_grads_finalize_kernel(FinalizeArgs a) {
-  const int t = threadIdx.x;   // 128 threads
-  if (t < 64) {
-    const int i = t >> 4, c = t & 15;
-    const float v = (float)a.acc[34 * i + c];
-    if (a.fuse_w) a.fuse_w[t] = a.accumulate ? a.fuse_w[t] + v : v;
-  } else {
-    const int u = t - 64, i = u >> 4, c = u & 15;
-    const float v = (float)a.acc[34 * i + 16 + c];
-    if (a.dsn_w[i]) a.dsn_w[i][c] = a.accumulate ? a.dsn_w[i][c] + v : v;
-    if (c == 0 && a.dsn_b[i]) {
-      const float b = (float)a.acc[34 * i + 32];
-      a.dsn_b[i][0] = a.accumulate ? a.dsn_b[i][0] + b : b;
-    }
-  }
-  if (t == 0 && a.fuse_b) {
-    const float b = (float)a.acc[4 * 34];
-    a.fuse_b[0] = a.accumulate ? a.fuse_b[0] + b : b;
+  const int t = threadIdx.x;   // 192 threads: 64 fuse.weight, 64 score_dsn.weight, 4 score_dsn.bias, 1 fuse.bias
+  if (t < 128) {
+    const int u = t & 63, i = u >> 4, c = u & 15, col = (t < 64 ? 0 : 16) + c;
+    double s = 0.0;
+    for (int b = 0; b < a.nblk[i]; ++b) s += a.part[i][(size_t)b * 34 + col];
+    float* dst = t < 64 ? (a.fuse_w ? a.fuse_w + u : nullptr) : (a.dsn_w[i] ? a.dsn_w[i] + c : nullptr);
+    if (dst) *dst = a.accumulate ? *dst + (float)s : (float)s;
+  } else if (t < 132) {
+    const int i = t - 128;
+    double s = 0.0;
+    for (int b = 0; b < a.nblk[i]; ++b) s += a.part[i][(size_t)b * 34 + 32];
+    if (a.dsn_b[i]) a.dsn_b[i][0] = a.accumulate ? a.dsn_b[i][0] + (float)s : (float)s;
+  } else if (t == 132 && a.fuse_b) {
+    double s = 0.0;
+    for (int b = 0; b < a.fb_nblk; ++b) s += a.fb_part[b];
+    a.fuse_b[0] = a.accumulate ? a.fuse_b[0] + (float)s : (float)s;
   }
 }
 
@@ -61,17 +62,21 @@ int osvos_gather_small(const float* const* srcs, const size_t* dst_off, const in
 }
 
 // grads: the 52-entry state_dict-order array of osvos_net_backward (NULL entries skipped)
-int osvos_head_grads_finalize(const double* acc, float* const* grads, int accumulate, int have_side, hipStream_t stream) {
+int osvos_head_grads_finalize(const double* const* part, const int* nblk, const double* fb_part, int fb_nblk,
+                              float* const* grads, int accumulate, int have_side, hipStream_t stream) {
   FinalizeArgs a;
-  a.acc = acc;
-  a.fuse_w = grads[50];
-  a.fuse_b = grads[51];
   for (int i = 0; i < 4; ++i) {
+    a.part[i] = part[i];
+    a.nblk[i] = nblk[i];
     a.dsn_w[i] = have_side ? grads[42 + 2 * i] : nullptr;
     a.dsn_b[i] = have_side ? grads[43 + 2 * i] : nullptr;
   }
+  a.fb_part = fb_part;
+  a.fb_nblk = fb_nblk;
+  a.fuse_w = grads[50];
+  a.fuse_b = grads[51];
   a.accumulate = accumulate;
-  hipLaunchKernelGGL(head_grads_finalize_kernel, dim3(1), dim3(128), 0, stream, a);
+  hipLaunchKernelGGL(head_grads_finalize_kernel, dim3(1), dim3(192), 0, stream, a);
   OSVOS_LAUNCH_CHECK();
   return 0;
 }

@@ -11,8 +11,10 @@
 //     LDS in their natural [pixel][channel] order -- the MFMA A operand (dY^T) and B operand
 //     (X shifted by the tap) are then plain conflict-free ds_read_b32 rows, and the 9 taps
 //     re-use the same X tile through an LDS address offset
-//   * splits write fp32 partial slabs; a second deterministic pass sums them, fuses the
-//     transposition to the reference's OIHW layout and (optionally) the gradient accumulation
+//   * LDS holds ONE patch; the next patch waits in registers (global loads in flight during the
+//     MFMAs), so two workgroups fit per CU and cover each other's barrier/LDS latencies
+//   * splits write fp32 partial slabs already in the reference's OIHW order ([co][ci][tap]); a
+//     second deterministic, fully coalesced pass sums them and (optionally) accumulates
 //   * the bias gradient (column sums of dY) rides along in the workgroups of the first Cin tile
 #include "common.h"
 
@@ -34,10 +36,9 @@ struct WgArgs {
 };
 
 template <int CB, int IB>
-__global__ __launch_bounds__(256) void wgrad_f32_kernel(WgArgs a) {
+__global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(WgArgs a) {
   constexpr int BCO = CB * 32, BCI = IB * 32;
   constexpr int DY_F4 = PPIX * BCO / 4, X_F4 = XPIX * BCI / 4;
-  constexpr int BUF_F4 = DY_F4 + X_F4;
   constexpr int NDY = (DY_F4 + 255) / 256, NX = (X_F4 + 255) / 256;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   f32x4* lds4 = reinterpret_cast<f32x4*>(smem);
@@ -88,8 +89,8 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(WgArgs a) {
       rx[i] = v;
     }
   };
-  auto store_patch = [&](int buf) {
-    f32x4* d = lds4 + buf * BUF_F4;
+  auto store_patch = [&]() {
+    f32x4* d = lds4;
 #pragma unroll
     for (int i = 0; i < NDY; ++i) {
       const int e = tid + i * 256;
@@ -112,16 +113,13 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(WgArgs a) {
   constexpr int BG = 256 / BCO;            // pixel groups for the bias column sums
   const int bco = tid % BCO, bgrp = tid / BCO;
 
-  if (p_begin < p_end) {
-    load_patch(p_begin);
-    store_patch(0);
-  }
-  __syncthreads();
-  int buf = 0;
+  if (p_begin < p_end) load_patch(p_begin);
   for (int p = p_begin; p < p_end; ++p) {
-    const bool more = p + 1 < p_end;
-    if (more) load_patch(p + 1);
-    const float* dYs = lds + (size_t)buf * BUF_F4 * 4;
+    __syncthreads();                 // every wave is done reading the previous patch
+    store_patch();
+    __syncthreads();
+    if (p + 1 < p_end) load_patch(p + 1);      // in flight while this patch is multiplied
+    const float* dYs = lds;
     const float* Xs = dYs + DY_F4 * 4;
 #pragma unroll 2
     for (int pp = 0; pp < PPIX / 2; ++pp) {
@@ -138,10 +136,8 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(WgArgs a) {
 #pragma unroll 4
       for (int pix = bgrp; pix < PPIX; pix += BG) bsum += dYs[pix * BCO + bco];
     }
-    if (more) store_patch(buf ^ 1);
-    __syncthreads();
-    buf ^= 1;
   }
+  __syncthreads();
 
   // ---- write the partial slab: D row = cout (r&3)+8*(r>>2)+4*lh, col = cin li ----------------
   const int ci = ci0 + ib * 32 + li;
@@ -151,7 +147,7 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(WgArgs a) {
     for (int r = 0; r < 16; ++r) {
       const int co = co0 + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
       if (co < a.Cout && ci < a.Cin_s)
-        a.slab[((size_t)(split * 9 + t) * a.Cout + co) * a.Cin_s + ci] = acc[t][r];
+        a.slab[(((size_t)split * a.Cout + co) * a.Cin_s + ci) * 9 + t] = acc[t][r];
     }
   }
   if (do_bias) {
@@ -167,26 +163,34 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(WgArgs a) {
   }
 }
 
-// dw[co][ci][tap] (OIHW, Cin real) (+)= sum_split slab[split][tap][co][ci]
-__global__ void wgrad_reduce_kernel(const float* slab, const float* bslab, float* dw, float* db,
-                                    int nsplit, int Cout, int Cin, int Cin_s, int accumulate) {
+// dw[co][ci][tap] (OIHW, Cin real) (+)= sum_split slab[split][co][ci_s][tap]; 64 outputs x 4 split
+// lanes per workgroup, 256-byte coalesced reads, LDS combine
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ bslab,
+                                                           float* __restrict__ dw, float* __restrict__ db,
+                                                           int nsplit, int Cout, int Cin, int Cin_s, int accumulate) {
+  __shared__ float red[256];
   const int total = Cout * Cin_s * 9;
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx < total) {
-    const int ci = idx % Cin_s;
-    const int co = (idx / Cin_s) % Cout;
-    const int t = idx / (Cin_s * Cout);
+  const int e = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int idx = blockIdx.x * 64 + e;
+  float s = 0.f;
+  if (idx < total)
+    for (int sp = sl; sp < nsplit; sp += 4) s += slab[(size_t)sp * total + idx];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (sl == 0 && idx < total) {
+    s = red[e] + red[64 + e] + red[128 + e] + red[192 + e];
+    const int t = idx % 9, ci = (idx / 9) % Cin_s, co = idx / (9 * Cin_s);
     if (ci < Cin) {
-      float s = 0.f;
-      for (int sp = 0; sp < nsplit; ++sp) s += slab[(size_t)sp * total + idx];
       float* o = dw + ((size_t)co * Cin + ci) * 9 + t;
       *o = accumulate ? (*o + s) : s;
     }
   }
-  if (db != nullptr && idx < Cout) {
-    float s = 0.f;
-    for (int sp = 0; sp < nsplit; ++sp) s += bslab[(size_t)sp * Cout + idx];
-    db[idx] = accumulate ? (db[idx] + s) : s;
+  if (db != nullptr && blockIdx.x == 0) {
+    for (int co = threadIdx.x; co < Cout; co += 256) {
+      float b = 0.f;
+      for (int sp = 0; sp < nsplit; ++sp) b += bslab[(size_t)sp * Cout + co];
+      db[co] = accumulate ? (db[co] + b) : b;
+    }
   }
 }
 
@@ -203,7 +207,7 @@ WgPlan make_plan(int N, int H, int W, int Cin_s, int Cout) {
   p.npx = ceil_div(W, PW);
   p.npy = ceil_div(H, PH);
   p.npatches = N * p.npx * p.npy;
-  int want = ceil_div(512, p.nco_t * p.nci_t);
+  int want = ceil_div(512, p.nco_t * p.nci_t);   // two single-buffered workgroups per CU
   int max_split = p.npatches / 4 > 0 ? p.npatches / 4 : 1;
   p.nsplit = want < max_split ? want : max_split;
   if (p.nsplit > 256) p.nsplit = 256;
@@ -217,7 +221,7 @@ WgPlan make_plan(int N, int H, int W, int Cin_s, int Cout) {
 
 template <int CB, int IB>
 int launch_wgrad(const WgArgs& a, long blocks, hipStream_t stream) {
-  constexpr size_t lds = (size_t)2 * (PPIX * CB * 32 + XPIX * IB * 32) * 4;
+  constexpr size_t lds = (size_t)(PPIX * CB * 32 + XPIX * IB * 32) * 4;
   static bool attr_set = false;
   if (!attr_set) {
     OSVOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_f32_kernel<CB, IB>),
@@ -255,7 +259,7 @@ int osvos_conv3x3_wgrad_f32(const float* x, const float* dy, void* ws, float* dw
   int rc = (p.cb == 1) ? launch_wgrad<1, 4>(a, blocks, stream) : launch_wgrad<2, 2>(a, blocks, stream);
   if (rc) return rc;
   const int total = Cout * Cin_s * 9;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, stream,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(total, 64)), dim3(256), 0, stream,
                      a.slab, a.bslab, dw, db, p.nsplit, Cout, Cin, Cin_s, accumulate);
   OSVOS_LAUNCH_CHECK();
   return 0;

@@ -116,19 +116,37 @@ def test_sgd_trajectory_matches_reference_golden():
         check_grad(g, "sgd|delta|", k, (sd[k] - w0[k]).cpu().numpy(), 3e-3, what="sgd")
 
 
+def _oracle_run(wts, x, m, dtype, channels_last=False):
+    from oracle import torch_ref
+    p = torch_ref.as_leaf_params(wts, dtype=dtype)
+    xin = torch.from_numpy(x).to(dtype)
+    if channels_last:       # the reference CPU path's other ATen/oneDNN code path (different summation order)
+        xin = xin.contiguous(memory_format=torch.channels_last)
+    xin.requires_grad_()
+    outs = torch_ref.forward(p, xin)
+    losses = [torch_ref.cbce_loss(o, torch.from_numpy(m).to(dtype), size_average=False) for o in outs]
+    (0.5 * sum(losses[:-1]) + losses[-1]).backward()
+    grads = {k: v.grad.double() for k, v in p.items() if v.grad is not None and not k.startswith("upscale")}
+    grads["input"] = xin.grad.double()
+    return [o.detach().double().numpy() for o in outs], [l.item() for l in losses], grads
+
+
 @pytest.mark.parametrize("shape", [(2, 120, 214), (1, 240, 427), (1, 480, 854)])
 def test_full_size_against_cpu_oracle(shape):
-    """Same seeded frame through the torch-CPU oracle and the HIP path; both training modes'
-    gradients are checked in one backward (parent-style deep supervision, side weight 0.5)."""
+    """Same seeded frame through the torch-CPU oracle (float64 = ground truth, float32 = the
+    reference CPU path) and the HIP path; parent-style deep supervision (side weight 0.5) so one
+    backward exercises every gradient.  On this un-trained He-init net the reference's OWN fp32
+    gradients sit up to 4e-3 (rel-L2) from float64 for the stage-0 tensors, and move by 10x with
+    the memory format torch happens to run (NCHW vs channels_last kernels: ReLU / arg-max flips at
+    near-ties are chaotic), so the bar is: within 1e-3 of float64, or no worse than 1.5x the
+    reference fp32 CPU path's own distance from float64 (worse of its two code paths)."""
     from layers.osvos_layers import class_balanced_cross_entropy_loss as cbce
-    from oracle import synth, torch_ref
+    from oracle import synth
     n, h, w = shape
     wts, x, m = synth.calibrated_problem(n, h, w, seed=21)
-    p = torch_ref.as_leaf_params(wts)
-    xin = torch.from_numpy(x).requires_grad_()
-    r_outs = torch_ref.forward(p, xin)
-    r_losses = [torch_ref.cbce_loss(o, torch.from_numpy(m), size_average=False) for o in r_outs]
-    (0.5 * sum(r_losses[:-1]) + r_losses[-1]).backward()
+    t_outs, t_losses, t_grads = _oracle_run(wts, x, m, torch.float64)
+    r_outs, r_losses, r_grads = _oracle_run(wts, x, m, torch.float32)
+    _, _, r_grads_cl = _oracle_run(wts, x, m, torch.float32, channels_last=True)
 
     net = build_net(wts)
     xg = torch.from_numpy(x).requires_grad_()
@@ -137,22 +155,23 @@ def test_full_size_against_cpu_oracle(shape):
     losses = [cbce(o, gt, size_average=False) for o in outs]
     (0.5 * sum(losses[:-1]) + losses[-1]).backward()
     for i in range(5):
-        ref = r_outs[i].detach().numpy()
-        got = outs[i].detach().cpu().numpy()
-        assert np.abs(got - ref).max() <= LOGIT_TOL * ref.std(), (shape, i)
-        assert iou(got, ref) >= 1 - IOU_TOL
-        assert abs(losses[i].item() - r_losses[i].item()) <= LOSS_RTOL * abs(r_losses[i].item())
-    worst = ("", 0.0)
-    for k, v in net.named_parameters():
-        if k.startswith("upscale"):
-            continue
-        ref = p[k].grad.double()
-        err = float((v.grad.cpu().double() - ref).norm() / (ref.norm() + 1e-30))
-        if err > worst[1]:
-            worst = (k, err)
-    assert worst[1] <= GRAD_RTOL, worst
-    ref = xin.grad.double()
-    assert float((xg.grad.double() - ref).norm() / ref.norm()) <= GRAD_RTOL
+        truth = t_outs[i]
+        got = outs[i].detach().cpu().double().numpy()
+        ref_err = np.abs(r_outs[i] - truth).max()
+        assert np.abs(got - truth).max() <= max(LOGIT_TOL * truth.std(), 1.5 * ref_err), (shape, i)
+        assert iou(got, truth) >= 1 - IOU_TOL
+        assert abs(losses[i].item() - t_losses[i]) <= max(LOSS_RTOL * abs(t_losses[i]), 1.5 * abs(r_losses[i] - t_losses[i]))
+    have = {k: v.grad.cpu().double() for k, v in net.named_parameters() if v.grad is not None}
+    have["input"] = xg.grad.double()
+    report = []
+    for k, truth in t_grads.items():
+        err = float((have[k] - truth).norm() / (truth.norm() + 1e-30))
+        ref_err = max(float((r_grads[k] - truth).norm() / (truth.norm() + 1e-30)),
+                      float((r_grads_cl[k] - truth).norm() / (truth.norm() + 1e-30)))
+        report.append((err / max(GRAD_RTOL, 1.5 * ref_err), k, err, ref_err))
+    report.sort(reverse=True)
+    print("gradients (ours vs f64 | reference-f32 vs f64):", [(k, "%.1e" % e, "%.1e" % r) for _, k, e, r in report])
+    assert report[0][0] <= 1.0, report[0]
 
 
 def test_intermediate_activations_via_ws_query():
@@ -205,10 +224,13 @@ def test_batch_and_odd_sizes_no_grad_inference():
     from oracle import synth, torch_ref
     from layers.osvos_layers import sigmoid_np
     for (n, h, w) in [(3, 33, 41), (1, 1, 1), (1, 2, 3), (2, 101, 135)]:
-        wts, x, _ = synth.calibrated_problem(n, h, w, seed=9)
+        if h * w >= 64:
+            wts, x, _ = synth.calibrated_problem(n, h, w, seed=9)
+        else:      # head calibration needs a map with a spread; tiny frames use the raw He-init heads
+            wts, x = synth.make_weights(1), synth.make_frame(n, h, w, 9)
         net = build_net(wts)
         with torch.no_grad():
             got = net.forward(torch.from_numpy(x).cuda())[-1].cpu().numpy()
             ref = torch_ref.forward({k: torch.from_numpy(v) for k, v in wts.items()}, torch.from_numpy(x))[-1].numpy()
-        assert np.abs(got - ref).max() <= LOGIT_TOL * max(ref.std(), 1e-3), (n, h, w)
+        assert np.abs(got - ref).max() <= LOGIT_TOL * max(ref.std(), 1e-3 * np.abs(ref).max(), 1e-6), (n, h, w)
         assert np.abs(sigmoid_np(got) - sigmoid_np(ref)).max() < 1e-4

@@ -51,7 +51,7 @@ CONV_SHAPES = [
 
 
 @pytest.mark.parametrize("shape", CONV_SHAPES)
-@pytest.mark.parametrize("tile", list(range(10)) + [-1])
+@pytest.mark.parametrize("tile", list(range(10)) + [100, 103, 109, -1])
 def test_conv3x3_forward_all_tiles(shape, tile):
     ops = _ops()
     n, h, w, cin, cout = shape
@@ -162,7 +162,7 @@ def test_cbce_loss_and_grad(mode, kind):
     ref_loss, ref_grad = c_oracle.cbce(logits.astype(np.float64), lab.astype(np.float64), mode)
     loss, grad = ops.cbce(torch.from_numpy(logits).cuda(), torch.from_numpy(lab).cuda(), mode)
     assert abs(loss.item() - ref_loss) <= 1e-5 * abs(ref_loss) + 1e-12
-    np.testing.assert_allclose(grad.cpu().numpy(), ref_grad, rtol=2e-5, atol=1e-9)
+    np.testing.assert_allclose(grad.cpu().numpy(), ref_grad, rtol=2e-5, atol=2e-8 * np.abs(ref_grad).max())
     if kind == "allneg":
         assert loss.item() == 0.0
 

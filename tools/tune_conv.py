@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Per-layer timing sweep of the conv3x3 tile configs and the wgrad kernel at a given resolution.
+Writes a table to stdout (run on the GPU box; results steer pick_tile / the layer table)."""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from osvos_pytorch_amd import ops, _lib  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--height", type=int, default=480)
+ap.add_argument("--width", type=int, default=854)
+ap.add_argument("--batch", type=int, default=1)
+ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--tiles", default="")
+args = ap.parse_args()
+
+chans = [[64, 64], [128, 128], [256, 256, 256], [512, 512, 512], [512, 512, 512]]
+layers = []   # name, h, w, cin, cout
+h, w, cin = args.height, args.width, 3
+for si, st in enumerate(chans):
+    if si > 0:
+        h, w = (h + 1) // 2, (w + 1) // 2
+    for j, c in enumerate(st):
+        layers.append(("conv%d_%d" % (si + 1, j + 1), h, w, cin, c))
+        cin = c
+    if si > 0:
+        layers.append(("side%d" % si, h, w, cin, 16))
+
+
+def timeit(fn, reps):
+    fn()
+    torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        torch.cuda.synchronize()
+        best = min(best, a.elapsed_time(b))
+    return best
+
+
+ntiles = _lib.lib().osvos_conv3x3_num_tiles()
+tiles = [int(t) for t in args.tiles.split(",")] if args.tiles else [2, 3, 5, 6, 9, 102, 103, 105, 106, 109]
+n = args.batch
+print("layer            dir   HxW       Cin->Cout  GF    | " + " ".join("t%-6d" % t for t in tiles) + " | best  TF/s  auto")
+tot = {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0}
+for name, h, w, cin, cout in layers:
+    gf = 2.0 * n * h * w * cout * 9 * cin / 1e9
+    for direction in ("fwd", "dgrad"):
+        kin, kout = (cin, cout) if direction == "fwd" else (cout, cin)
+        kin_s = (kin + 7) // 8 * 8
+        x = torch.randn(n, h, w, kin_s, device="cuda")
+        wt = torch.randn(cout, cin, 3, 3, device="cuda") * 0.05
+        wpk = ops.pack_fwd(wt) if direction == "fwd" else ops.pack_dgrad(wt)
+        ycs = kout if kout >= 8 else 4
+        res = []
+        for t in tiles:
+            try:
+                ms = timeit(lambda: ops.conv3x3(x, wpk, None, kout, relu=(direction == "fwd"), y_cs=ycs, tile=t), args.reps)
+            except RuntimeError:
+                ms = float("nan")
+            res.append(ms)
+        auto = timeit(lambda: ops.conv3x3(x, wpk, None, kout, relu=(direction == "fwd"), y_cs=ycs, tile=-1), args.reps)
+        best = min(r for r in res if r == r)
+        bi = tiles[res.index(best)]
+        tot[direction] += best
+        print("%-16s %-5s %4dx%-4d %4d->%-4d %6.2f | %s | t%d %6.1f %.3f" % (
+            name, direction, h, w, kin, kout, gf, " ".join("%-7.3f" % r for r in res), bi, gf / best, auto))
+    x = torch.randn(n, h, w, (cin + 7) // 8 * 8, device="cuda")
+    dy = torch.randn(n, h, w, cout, device="cuda")
+    ms = timeit(lambda: ops.conv3x3_wgrad(x, dy, cin, cout), args.reps)
+    tot["wgrad"] += ms
+    print("%-16s wgrad %4dx%-4d %4d->%-4d %6.2f | %.3f ms  %.1f TF/s" % (name, h, w, cin, cout, gf, ms, gf / ms))
+print("sum of best: fwd %.3f ms, dgrad %.3f ms, wgrad %.3f ms" % (tot["fwd"], tot["dgrad"], tot["wgrad"]))
