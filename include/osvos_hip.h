@@ -128,9 +128,12 @@ int osvos_net_forward(const float* x_nchw, const void* wbuf, void* ws, float* co
 /* douts: host array of 5 device pointers (NULL = no gradient for that head).
  * grads: host array of 52 device pointers (NULL entries are skipped; deconv weights are frozen in
  *        both reference scripts -- train_online.py:84-85 -- and are never written).
- * dx_nchw: fp32 [N,3,H,W] or NULL.  accumulate != 0: grads += instead of overwrite. */
+ * dx_nchw: fp32 [N,3,H,W] or NULL.  accumulate != 0: grads += instead of overwrite.
+ * aux_stream: NULL, or a second stream owned by the caller: the weight-gradient kernels are then
+ *   enqueued on it, concurrently with the data-gradient kernel of the same layer (fork/join with
+ *   events; everything has joined `stream` again when the call returns). */
 int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, float* const* grads,
-                       float* dx_nchw, int N, int H, int W, int dtype, int accumulate, void* stream);
+                       float* dx_nchw, int N, int H, int W, int dtype, int accumulate, void* stream, void* aux_stream);
 /* byte offset / element count of a saved activation inside ws (tests): which = 0..12 trunk conv
  * outputs, 13..16 pooled inputs of stages 1-4, 17..20 side_prep outputs, 21 NHWC input */
 int osvos_net_ws_query(int N, int H, int W, int dtype, int which, size_t* offset, size_t* elems, int* channels, int* h, int* w);
@@ -142,7 +145,8 @@ int osvos_sgd_step(float* p, const float* g, float* buf, long count, float lr, f
 
 /* ---- opt-in launch profiler (bench.py only): hipEvent pairs around every kernel family that
  * osvos_net_forward/backward launches, recorded on the caller's stream.  Families: 0 conv3x3
- * forward, 1 conv3x3 data-gradient, 2 weight-gradient (+ slab reduce), 3 spare.
+ * forward launches, 1 backward conv regions (data-gradient kernel || weight-gradient kernel +
+ * slab reduce of one layer, fork to join), 2-3 spare.
  * osvos_prof_stop fills ms[4] (sum of launch durations), flops[4] (algorithmic FLOPs of those
  * launches: 2*N*H*W*Cout*9*Cin) and count[4]; synchronise the stream before calling it. */
 int osvos_prof_start(int max_records);
@@ -152,6 +156,7 @@ int osvos_prof_stop(double* ms, double* flops, long* count);
 int osvos_debug_conv3x3_naive(const float* x, const float* w_oihw, const float* bias, float* y,
                               int N, int H, int W, int Cin, int Cin_s, int Cout, int relu, void* stream);
 int osvos_debug_mfma_layout(float* out /* 4*64*16 floats */, void* stream);
+int osvos_debug_mfma_peak(float* out /* blocks*256 floats */, int blocks, int iters, void* stream);
 
 #ifdef __cplusplus
 }

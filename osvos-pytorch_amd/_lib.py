@@ -45,13 +45,14 @@ PROTOTYPES = {
     "osvos_net_ws_bytes": (_sz, [_i, _i, _i, _i]),
     "osvos_net_pack": (_i, [_vp, _vp, _i, _i, _vp]),
     "osvos_net_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
-    "osvos_net_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "osvos_net_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "osvos_net_ws_query": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "osvos_sgd_step": (_i, [_vp, _vp, _vp, _l, _f, _f, _f, _i, _vp]),
     "osvos_prof_start": (_i, [_i]),
     "osvos_prof_stop": (_i, [_vp, _vp, _vp]),
     "osvos_debug_conv3x3_naive": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "osvos_debug_mfma_layout": (_i, [_vp, _vp]),
+    "osvos_debug_mfma_peak": (_i, [_vp, _i, _i, _vp]),
 }
 
 

@@ -4,6 +4,7 @@ streams and the autograd tape; every FLOP runs in libosvos_hip.so."""
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -27,6 +28,15 @@ class NetRuntime:
         self.key = None
         self.deconv_key = None
         self.dtype = F32
+        self.aux_stream = None        # second HIP stream: wgrad kernels overlap the dgrad kernels
+        self.two_streams = os.environ.get("OSVOS_TWO_STREAMS", "1") != "0"
+
+    def aux(self, device):
+        if not self.two_streams:
+            return None
+        if self.aux_stream is None or self.aux_stream.device != device:
+            self.aux_stream = torch.cuda.Stream(device=device)
+        return C.c_void_p(self.aux_stream.cuda_stream)
 
     def ensure_packed(self, params):
         dev = params[0].device
@@ -112,7 +122,7 @@ class OSVOSNetFunction(torch.autograd.Function):
                                    ptr_array([None if g is None else g.data_ptr() for g in d]),
                                    ptr_array([None if g is None else g.data_ptr() for g in grads]),
                                    C.c_void_p(dx.data_ptr()) if dx is not None else None,
-                                   n, h, w, rt.dtype, 0, _stream()), "net_backward")
+                                   n, h, w, rt.dtype, 0, _stream(), rt.aux(dev)), "net_backward")
         ctx.ws = None
         return (None, dx) + tuple(grads)
 

@@ -44,7 +44,32 @@ __global__ void mfma_layout_kernel(float* out) {
   for (int r = 0; r < 16; ++r) out[(3 * 64 + lane) * 16 + r] = (float)(lane * 16 + r);
 }
 
+// MFMA-only loop: 4 independent 32x32 accumulators per wave, no memory traffic; gives the fp32 MFMA
+// rate this chip sustains at its actual (power-managed) clock -- the practical ceiling of the conv kernels
+__global__ __launch_bounds__(256) void mfma_peak_kernel(float* out, int iters) {
+  f32x16 c0, c1, c2, c3;
+  for (int r = 0; r < 16; ++r) { c0[r] = 0.f; c1[r] = 0.f; c2[r] = 0.f; c3[r] = 0.f; }
+  float a = (float)(threadIdx.x & 7) * 0.01f, b = (float)(threadIdx.x & 3) * 0.02f;
+  for (int i = 0; i < iters; ++i) {
+    c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c1, 0, 0, 0);
+    c2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c2, 0, 0, 0);
+    c3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c3, 0, 0, 0);
+  }
+  float s = 0.f;
+  for (int r = 0; r < 16; ++r) s += c0[r] + c1[r] + c2[r] + c3[r];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 }  // namespace
+
+// runs `blocks` workgroups x 4 waves x iters x 4 MFMAs; FLOPs = blocks*4*iters*4*2*32*32*2
+extern "C" int osvos_debug_mfma_peak(float* out, int blocks, int iters, void* stream) {
+  OSVOS_ARG_CHECK(out && blocks > 0 && iters > 0, "debug mfma peak: bad arguments");
+  hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, out, iters);
+  OSVOS_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int osvos_debug_conv3x3_naive(const float* x, const float* w_oihw, const float* bias, float* y,
                                          int N, int H, int W, int Cin, int Cin_s, int Cout, int relu, void* stream) {

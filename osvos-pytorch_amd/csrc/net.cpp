@@ -109,6 +109,30 @@ WsLayout ws_layout(int N, int H, int W, int dtype) {
   return L;
 }
 
+// events for the fork/join of the two-stream backward: created once per host thread, reused round-robin
+struct EventPool {
+  hipEvent_t ev[64];
+  int n = 0, cur = 0;
+  hipEvent_t next() {
+    if (n < 64) {
+      hipEvent_t e;
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+        osvos_set_error("net_backward: hipEventCreate failed");
+        return nullptr;
+      }
+      ev[n++] = e;
+      return e;
+    }
+    hipEvent_t e = ev[cur];
+    cur = (cur + 1) % 64;
+    return e;
+  }
+};
+EventPool& event_pool() {
+  static thread_local EventPool p;
+  return p;
+}
+
 inline double conv_flops(int N, int h, int w, int cin, int cout) { return 2.0 * N * h * w * (double)cout * 9.0 * cin; }
 
 __attribute__((unused)) inline char* at(void* base, size_t off) { return reinterpret_cast<char*>(base) + off; }
@@ -231,9 +255,32 @@ int osvos_net_forward(const float* x_nchw, const void* wbuf, void* ws, float* co
 }
 
 int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, float* const* grads,
-                       float* dx_nchw, int N, int H, int W, int dtype, int accumulate, void* stream_) {
+                       float* dx_nchw, int N, int H, int W, int dtype, int accumulate, void* stream_, void* aux_stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  hipStream_t aux = aux_stream_ ? (hipStream_t)aux_stream_ : stream;
+  const bool two = aux != stream;
   OSVOS_ARG_CHECK(wbuf && ws && douts && grads, "net_backward: null pointer");
+  // fork: aux waits for everything enqueued on `stream` so far; join: `stream` waits for aux.
+  // The weight-gradient kernels run on aux concurrently with the data-gradient kernel of the same
+  // layer: both are MFMA kernels with independent stalls (barriers, LDS latency, tails), and
+  // together they keep the matrix pipes busier than either does alone.
+  EventPool& evp = event_pool();
+  auto fork = [&]() -> int {
+    if (!two) return 0;
+    hipEvent_t e = evp.next();
+    if (!e) return -1;
+    OSVOS_HIP_CHECK(hipEventRecord(e, stream));
+    OSVOS_HIP_CHECK(hipStreamWaitEvent(aux, e, 0));
+    return 0;
+  };
+  auto join = [&]() -> int {
+    if (!two) return 0;
+    hipEvent_t e = evp.next();
+    if (!e) return -1;
+    OSVOS_HIP_CHECK(hipEventRecord(e, aux));
+    OSVOS_HIP_CHECK(hipStreamWaitEvent(stream, e, 0));
+    return 0;
+  };
   OSVOS_ARG_CHECK(dtype == OSVOS_F32, "net_backward: dtype %d not built", dtype);
   const WbufLayout P = wbuf_layout(dtype);
   const WsLayout L = ws_layout(N, H, W, dtype);
@@ -266,27 +313,32 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
   rc = osvos_head_grads_finalize(part, nblk, fb_part, fb_nblk, grads, accumulate, have_side ? 1 : 0, stream);
   if (rc) return rc;
 
-  // ---- side_prep convs: weight gradients + data gradients into the stage outputs --------------
-  for (int i = 0; i < 4; ++i) {
-    const int si = i + 1, sl = kNumTrunk + i, h = L.hs[si], w = L.ws[si];
-    const int lx = last_of_stage(si);
-    if (grads[d[sl].w_param] != nullptr) {
-      {
-        ProfScope ps(OSVOS_PROF_WGRAD, conv_flops(N, h, w, d[sl].cin, 16), stream);
+  // ---- side_prep convs: weight gradients (aux stream) || data gradients into the stage outputs ---
+  double side_flops = 0.0;
+  for (int i = 0; i < 4; ++i) side_flops += 2.0 * conv_flops(N, L.hs[i + 1], L.ws[i + 1], d[kNumTrunk + i].cin, 16);
+  {
+    ProfScope ps(OSVOS_PROF_CONV_BWD, side_flops, stream);
+    if ((rc = fork())) return rc;
+    for (int i = 0; i < 4; ++i) {
+      const int si = i + 1, sl = kNumTrunk + i, h = L.hs[si], w = L.ws[si];
+      const int lx = last_of_stage(si);
+      if (grads[d[sl].w_param] != nullptr) {
         rc = osvos_conv3x3_wgrad(at(ws, L.act[lx]), at(ws, L.dprep[i]), at(ws, L.wgrad), grads[d[sl].w_param], grads[d[sl].b_param],
-                                 N, h, w, d[sl].cin, d[sl].cin_s, 16, 16, accumulate, dtype, stream);
+                                 N, h, w, d[sl].cin, d[sl].cin_s, 16, 16, accumulate, dtype, aux);
+        if (rc) return rc;
       }
-      if (rc) return rc;
     }
-    // stage 4 has no pool after it: its ReLU mask is applied right here and the result is the
-    // upstream gradient of conv5_3; stages 1-3 are merged in maxpool2x2_bwd below
-    void* dst = (i == 3) ? at(ws, L.gA) : at(ws, L.dside[i]);
-    {
-      ProfScope ps(OSVOS_PROF_CONV_DGRAD, conv_flops(N, h, w, d[sl].cin, 16), stream);
+    for (int i = 0; i < 4; ++i) {
+      const int si = i + 1, sl = kNumTrunk + i, h = L.hs[si], w = L.ws[si];
+      const int lx = last_of_stage(si);
+      // stage 4 has no pool after it: its ReLU mask is applied right here and the result is the
+      // upstream gradient of conv5_3; stages 1-3 are merged in maxpool2x2_bwd below
+      void* dst = (i == 3) ? at(ws, L.gA) : at(ws, L.dside[i]);
       rc = osvos_conv3x3(at(ws, L.dprep[i]), at(wbuf, P.dgrad[sl]), nullptr, (i == 3) ? at(ws, L.act[lx]) : nullptr, dst,
                          N, h, w, 16, d[sl].cin, d[sl].cin, 0, dtype, -1, stream);
+      if (rc) return rc;
     }
-    if (rc) return rc;
+    if ((rc = join())) return rc;
   }
 
   // ---- trunk, deepest layer first; g = dLoss/d(conv output), ReLU mask already applied -------
@@ -296,43 +348,38 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
     const int si = d[l].stage, h = L.hs[si], w = L.ws[si];
     const bool first_of_stage = (l == 0) || d[l - 1].stage != si;
     const void* xin = first_of_stage ? (si == 0 ? at(ws, L.xin) : at(ws, L.pooled[si])) : at(ws, L.act[l - 1]);
+    const bool need_dgrad = (l > 0) || dx_nchw != nullptr;
+    const double fl = conv_flops(N, h, w, d[l].cin, d[l].cout) * ((grads[d[l].w_param] ? 1 : 0) + (need_dgrad ? 1 : 0));
+    ProfScope ps(OSVOS_PROF_CONV_BWD, fl, stream);
     if (grads[d[l].w_param] != nullptr) {
-      {
-        ProfScope ps(OSVOS_PROF_WGRAD, conv_flops(N, h, w, d[l].cin, d[l].cout), stream);
-        rc = osvos_conv3x3_wgrad(xin, g, at(ws, L.wgrad), grads[d[l].w_param], grads[d[l].b_param],
-                                 N, h, w, d[l].cin, d[l].cin_s, d[l].cout, d[l].cout, accumulate, dtype, stream);
-      }
+      if ((rc = fork())) return rc;
+      rc = osvos_conv3x3_wgrad(xin, g, at(ws, L.wgrad), grads[d[l].w_param], grads[d[l].b_param],
+                               N, h, w, d[l].cin, d[l].cin_s, d[l].cout, d[l].cout, accumulate, dtype, aux);
       if (rc) return rc;
     }
     if (l == 0) {
       if (dx_nchw != nullptr) {
-        {
-          ProfScope ps(OSVOS_PROF_CONV_DGRAD, conv_flops(N, h, w, 3, d[0].cout), stream);
-          rc = osvos_conv3x3(g, at(wbuf, P.dgrad[0]), nullptr, nullptr, at(ws, L.dxin), N, h, w, d[0].cout, 3, 4, 0, dtype, -1, stream);
-        }
+        rc = osvos_conv3x3(g, at(wbuf, P.dgrad[0]), nullptr, nullptr, at(ws, L.dxin), N, h, w, d[0].cout, 3, 4, 0, dtype, -1, stream);
         if (rc) return rc;
         rc = osvos_nhwc_to_nchw(at(ws, L.dxin), dx_nchw, N, 3, H, W, 4, dtype, stream);
         if (rc) return rc;
       }
+      if (grads[d[l].w_param] != nullptr && (rc = join())) return rc;
       break;
     }
     if (first_of_stage) {
       // through the pool into the previous stage's output (+ that stage's side branch, + ReLU mask)
-      {
-        ProfScope ps(OSVOS_PROF_CONV_DGRAD, conv_flops(N, h, w, d[l].cin, d[l].cout), stream);
-        rc = osvos_conv3x3(g, at(wbuf, P.dgrad[l]), nullptr, nullptr, other, N, h, w, d[l].cout, d[l].cin, d[l].cin, 0, dtype, -1, stream);
-      }
+      rc = osvos_conv3x3(g, at(wbuf, P.dgrad[l]), nullptr, nullptr, other, N, h, w, d[l].cout, d[l].cin, d[l].cin, 0, dtype, -1, stream);
       if (rc) return rc;
-      const int ps = si - 1;
-      const void* dside = ps >= 1 ? at(ws, L.dside[ps - 1]) : nullptr;
-      rc = osvos_maxpool2x2_bwd(at(ws, L.act[l - 1]), other, dside, g, N, L.hs[ps], L.ws[ps], kStageC[ps], dtype, stream);
+      if (grads[d[l].w_param] != nullptr && (rc = join())) return rc;     // wgrad still reads g: join before it is overwritten
+      const int ps2 = si - 1;
+      const void* dside = ps2 >= 1 ? at(ws, L.dside[ps2 - 1]) : nullptr;
+      rc = osvos_maxpool2x2_bwd(at(ws, L.act[l - 1]), other, dside, g, N, L.hs[ps2], L.ws[ps2], kStageC[ps2], dtype, stream);
       if (rc) return rc;
     } else {
-      {
-        ProfScope ps(OSVOS_PROF_CONV_DGRAD, conv_flops(N, h, w, d[l].cin, d[l].cout), stream);
-        rc = osvos_conv3x3(g, at(wbuf, P.dgrad[l]), nullptr, at(ws, L.act[l - 1]), other, N, h, w, d[l].cout, d[l].cin, d[l].cin, 0, dtype, -1, stream);
-      }
+      rc = osvos_conv3x3(g, at(wbuf, P.dgrad[l]), nullptr, at(ws, L.act[l - 1]), other, N, h, w, d[l].cout, d[l].cin, d[l].cin, 0, dtype, -1, stream);
       if (rc) return rc;
+      if (grads[d[l].w_param] != nullptr && (rc = join())) return rc;     // the next layer's dgrad writes into g's buffer
       void* t = g; g = other; other = t;
     }
   }

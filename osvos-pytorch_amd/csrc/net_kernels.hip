@@ -29,24 +29,29 @@ struct FinalizeArgs {
   int accumulate;
 };
 
-__global__ void head_grads_finalize_kernel(FinalizeArgs a) {
-  const int t = threadIdx.x;   // 192 threads: 64 fuse.weight, 64 score_dsn.weight, 4 score_dsn.bias, 1 fuse.bias
+// one wave per output value: lanes stride over the per-workgroup partials, shuffle-reduce
+__global__ __launch_bounds__(64) void head_grads_finalize_kernel(FinalizeArgs a) {
+  const int t = blockIdx.x, lane = threadIdx.x;   // 133 outputs: 64 fuse.weight, 64 score_dsn.weight, 4 score_dsn.bias, fuse.bias
+  const double* src;
+  int n, stride, col;
+  float* dst;
   if (t < 128) {
-    const int u = t & 63, i = u >> 4, c = u & 15, col = (t < 64 ? 0 : 16) + c;
-    double s = 0.0;
-    for (int b = 0; b < a.nblk[i]; ++b) s += a.part[i][(size_t)b * 34 + col];
-    float* dst = t < 64 ? (a.fuse_w ? a.fuse_w + u : nullptr) : (a.dsn_w[i] ? a.dsn_w[i] + c : nullptr);
-    if (dst) *dst = a.accumulate ? *dst + (float)s : (float)s;
+    const int u = t & 63, i = u >> 4, c = u & 15;
+    src = a.part[i]; n = a.nblk[i]; stride = 34; col = (t < 64 ? 0 : 16) + c;
+    dst = t < 64 ? (a.fuse_w ? a.fuse_w + u : nullptr) : (a.dsn_w[i] ? a.dsn_w[i] + c : nullptr);
   } else if (t < 132) {
     const int i = t - 128;
-    double s = 0.0;
-    for (int b = 0; b < a.nblk[i]; ++b) s += a.part[i][(size_t)b * 34 + 32];
-    if (a.dsn_b[i]) a.dsn_b[i][0] = a.accumulate ? a.dsn_b[i][0] + (float)s : (float)s;
-  } else if (t == 132 && a.fuse_b) {
-    double s = 0.0;
-    for (int b = 0; b < a.fb_nblk; ++b) s += a.fb_part[b];
-    a.fuse_b[0] = a.accumulate ? a.fuse_b[0] + (float)s : (float)s;
+    src = a.part[i]; n = a.nblk[i]; stride = 34; col = 32;
+    dst = a.dsn_b[i];
+  } else {
+    src = a.fb_part; n = a.fb_nblk; stride = 1; col = 0;
+    dst = a.fuse_b;
   }
+  if (dst == nullptr) return;
+  double s = 0.0;
+  for (int b = lane; b < n; b += 64) s += src[(size_t)b * stride + col];
+  s = wave_sum(s);
+  if (lane == 0) *dst = a.accumulate ? *dst + (float)s : (float)s;
 }
 
 }  // namespace
@@ -76,7 +81,7 @@ int osvos_head_grads_finalize(const double* const* part, const int* nblk, const 
   a.fuse_w = grads[50];
   a.fuse_b = grads[51];
   a.accumulate = accumulate;
-  hipLaunchKernelGGL(head_grads_finalize_kernel, dim3(1), dim3(192), 0, stream, a);
+  hipLaunchKernelGGL(head_grads_finalize_kernel, dim3(133), dim3(64), 0, stream, a);
   OSVOS_LAUNCH_CHECK();
   return 0;
 }

@@ -2,7 +2,7 @@
 #include "common.h"
 
 #define OSVOS_PROF_NCAT 4
-enum { OSVOS_PROF_CONV_FWD = 0, OSVOS_PROF_CONV_DGRAD = 1, OSVOS_PROF_WGRAD = 2, OSVOS_PROF_OTHER = 3 };
+enum { OSVOS_PROF_CONV_FWD = 0, OSVOS_PROF_CONV_BWD = 1, OSVOS_PROF_SPARE2 = 2, OSVOS_PROF_OTHER = 3 };
 
 bool osvos_prof_on();
 void osvos_prof_begin(int cat, double flops, hipStream_t stream);

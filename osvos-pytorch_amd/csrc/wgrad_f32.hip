@@ -36,7 +36,7 @@ struct WgArgs {
 };
 
 template <int CB, int IB>
-__global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(WgArgs a) {
+__global__ __launch_bounds__(256, (CB == 2 ? 2 : 1)) void wgrad_f32_kernel(WgArgs a) {
   constexpr int BCO = CB * 32, BCI = IB * 32;
   constexpr int DY_F4 = PPIX * BCO / 4, X_F4 = XPIX * BCI / 4;
   constexpr int NDY = (DY_F4 + 255) / 256, NX = (X_F4 + 255) / 256;
@@ -207,7 +207,13 @@ WgPlan make_plan(int N, int H, int W, int Cin_s, int Cout) {
   p.npx = ceil_div(W, PW);
   p.npy = ceil_div(H, PH);
   p.npatches = N * p.npx * p.npy;
-  int want = ceil_div(512, p.nco_t * p.nci_t);   // two single-buffered workgroups per CU
+  static int target_blocks = 0;
+  if (target_blocks == 0) {
+    const char* env = getenv("OSVOS_WGRAD_BLOCKS");
+    target_blocks = env ? atoi(env) : 512;    // two single-buffered workgroups per CU
+    if (target_blocks < 1) target_blocks = 512;
+  }
+  int want = ceil_div(target_blocks, p.nco_t * p.nci_t);
   int max_split = p.npatches / 4 > 0 ? p.npatches / 4 : 1;
   p.nsplit = want < max_split ? want : max_split;
   if (p.nsplit > 256) p.nsplit = 256;

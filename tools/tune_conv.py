@@ -45,6 +45,13 @@ def timeit(fn, reps):
     return best
 
 
+import ctypes as C
+_out = torch.empty(2048 * 256, device="cuda")
+_it = 2000
+def _peak():
+    _lib.check(_lib.lib().osvos_debug_mfma_peak(C.c_void_p(_out.data_ptr()), 2048, _it, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+ms = timeit(_peak, 3)
+print("fp32 MFMA-only probe: %.1f TFLOP/s (2048 WGs x 4 waves x %d x 4 MFMA 32x32x2)" % (2048 * 4 * _it * 4 * 2 * 32 * 32 * 2 / ms / 1e9, _it))
 ntiles = _lib.lib().osvos_conv3x3_num_tiles()
 tiles = [int(t) for t in args.tiles.split(",")] if args.tiles else [2, 3, 5, 6, 9, 102, 103, 105, 106, 109]
 n = args.batch
