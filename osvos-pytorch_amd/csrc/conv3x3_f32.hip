@@ -176,21 +176,30 @@ __global__ __launch_bounds__(256) void conv3x3_f32_kernel(ConvArgs a) {
     if (more) load_chunk(kc + 1);
     const f32x4* As = lds + (kc & 1) * C::BUF_F4;
     const f32x4* Bs = As + C::A_F4;
+    // taps are software-pipelined: the fragments of tap+1 are requested before the MFMAs of tap issue
+    f32x4 fa[2][C::WM], fb[2][C::WN];
+    auto ldfrag = [&](int tap, int set) {
+      const int r = tap / 3, s = tap % 3;
+#pragma unroll
+      for (int mi = 0; mi < C::WM; ++mi) fa[set][mi] = As[a_idx[mi] + r * C::PITCH + s];
+#pragma unroll
+      for (int ni = 0; ni < C::WN; ++ni) fb[set][ni] = Bs[b_idx + tap * 2 * C::BN + ni * 32];
+    };
+    ldfrag(0, 0);
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-      const int r = tap / 3, s = tap % 3;
-      f32x4 fa[C::WM], fb[C::WN];
-#pragma unroll
-      for (int mi = 0; mi < C::WM; ++mi) fa[mi] = As[a_idx[mi] + r * C::PITCH + s];
-#pragma unroll
-      for (int ni = 0; ni < C::WN; ++ni) fb[ni] = Bs[b_idx + tap * 2 * C::BN + ni * 32];
+      // sched_barrier pins "request tap+1, then multiply tap": hipcc otherwise sinks the ds_reads to
+      // their first use and every tap exposes an LDS round trip to the matrix pipe
+      if (tap + 1 < 9) ldfrag(tap + 1, (tap + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int mi = 0; mi < C::WM; ++mi)
 #pragma unroll
           for (int ni = 0; ni < C::WN; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mi][j], fb[ni][j], acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[tap & 1][mi][j], fb[tap & 1][ni][j], acc[mi][ni], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (more) store_chunk((kc + 1) & 1);
     __syncthreads();

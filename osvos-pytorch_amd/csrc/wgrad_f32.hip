@@ -36,7 +36,7 @@ struct WgArgs {
 };
 
 template <int CB, int IB>
-__global__ __launch_bounds__(256, (CB == 2 ? 2 : 1)) void wgrad_f32_kernel(WgArgs a) {
+__global__ __launch_bounds__(256, 1) void wgrad_f32_kernel(WgArgs a) {
   constexpr int BCO = CB * 32, BCI = IB * 32;
   constexpr int DY_F4 = PPIX * BCO / 4, X_F4 = XPIX * BCI / 4;
   constexpr int NDY = (DY_F4 + 255) / 256, NX = (X_F4 + 255) / 256;
@@ -121,16 +121,32 @@ __global__ __launch_bounds__(256, (CB == 2 ? 2 : 1)) void wgrad_f32_kernel(WgArg
     if (p + 1 < p_end) load_patch(p + 1);      // in flight while this patch is multiplied
     const float* dYs = lds;
     const float* Xs = dYs + DY_F4 * 4;
-#pragma unroll 2
-    for (int pp = 0; pp < PPIX / 2; ++pp) {
+    // software-pipelined over the 32 pixel pairs: the 10 LDS operands of pair pp+1 are requested
+    // before the 9 MFMAs of pair pp issue (two named register sets, loop kept rolled: a full unroll
+    // spills), otherwise every pair exposes 3 LDS round trips to the matrix pipe
+    float av0, av1, bv0[9], bv1[9];
+    auto ld = [&](int pp, float& av, float (&bv)[9]) {
       const int dy = pp / (PW / 2), dx = (pp % (PW / 2)) * 2 + lh;
-      const float av = dYs[(dy * PW + dx) * BCO + cb * 32 + li];
+      av = dYs[(dy * PW + dx) * BCO + cb * 32 + li];
       const float* xb = Xs + (dy * XW + dx) * BCI + ib * 32 + li;
 #pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        const float bv = xb[((t / 3) * XW + (t % 3)) * BCI];
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
-      }
+      for (int t = 0; t < 9; ++t) bv[t] = xb[((t / 3) * XW + (t % 3)) * BCI];
+    };
+    ld(0, av0, bv0);
+#pragma unroll 1
+    for (int pp = 0; pp < PPIX / 2; pp += 2) {
+      // sched_barrier pins "request next operands, then multiply the current ones": left alone,
+      // hipcc sinks the ds_reads down to their first use and the matrix pipe waits on LDS
+      ld(pp + 1, av1, bv1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0, bv0[t], acc[t], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      ld((pp + 2) & (PPIX / 2 - 1), av0, bv0);     // unconditional (wraps to pair 0 at the end) so the waits stay counted
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1, bv1[t], acc[t], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (do_bias) {
 #pragma unroll 4
