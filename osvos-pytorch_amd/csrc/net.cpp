@@ -64,7 +64,7 @@ WbufLayout wbuf_layout(int dtype) {
 struct WsLayout {
   int hs[5], ws[5];
   size_t xin, act[kNumTrunk], pooled[5], prep[4], score[4], fpart[4];
-  size_t gA, gB, dside[4], dprep[4], wgrad, acc, dxin;
+  size_t dy[kNumTrunk], dpool[5], dside[4], dprep[4], wgrad, acc, dxin;
   size_t total;
 };
 
@@ -79,12 +79,11 @@ WsLayout ws_layout(int N, int H, int W, int dtype) {
   ConvDesc d[kNumConv];
   conv_table(d);
   L.xin = take(es * N * H * W * kInPad);
-  size_t max_act = 0, max_wg = 0;
+  size_t max_wg = 0;
   for (int l = 0; l < kNumTrunk; ++l) {
     const int si = d[l].stage;
     const size_t b = es * N * L.hs[si] * L.ws[si] * d[l].cout;
     L.act[l] = take(b);
-    if (b > max_act) max_act = b;
   }
   for (int si = 1; si < 5; ++si) L.pooled[si] = take(es * N * L.hs[si] * L.ws[si] * kStageC[si - 1]);
   for (int i = 0; i < 4; ++i) {
@@ -95,8 +94,11 @@ WsLayout ws_layout(int N, int H, int W, int dtype) {
     L.dprep[i] = take(es * npix * 16);
     L.dside[i] = take(es * npix * kStageC[i + 1]);
   }
-  L.gA = take(max_act);
-  L.gB = take(max_act);
+  // one gradient buffer per trunk conv output (dLoss/d act[l], ReLU mask applied) and per pooled
+  // tensor: no buffer is ever rewritten inside one backward, so the weight-gradient stream can trail
+  // the data-gradient stream by any number of layers without write-after-read hazards
+  for (int l = 0; l < kNumTrunk; ++l) L.dy[l] = take(es * N * L.hs[d[l].stage] * L.ws[d[l].stage] * d[l].cout);
+  for (int si = 1; si < 5; ++si) L.dpool[si] = take(es * N * L.hs[si] * L.ws[si] * kStageC[si - 1]);
   for (int l = 0; l < kNumConv; ++l) {
     const int si = d[l].stage;
     const size_t b = osvos_wgrad_ws_bytes(N, L.hs[si], L.ws[si], d[l].cin_s, d[l].cout, dtype);
@@ -265,14 +267,6 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
   // layer: both are MFMA kernels with independent stalls (barriers, LDS latency, tails), and
   // together they keep the matrix pipes busier than either does alone.
   EventPool& evp = event_pool();
-  auto fork = [&]() -> int {
-    if (!two) return 0;
-    hipEvent_t e = evp.next();
-    if (!e) return -1;
-    OSVOS_HIP_CHECK(hipEventRecord(e, stream));
-    OSVOS_HIP_CHECK(hipStreamWaitEvent(aux, e, 0));
-    return 0;
-  };
   auto join = [&]() -> int {
     if (!two) return 0;
     hipEvent_t e = evp.next();
@@ -313,46 +307,49 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
   rc = osvos_head_grads_finalize(part, nblk, fb_part, fb_nblk, grads, accumulate, have_side ? 1 : 0, stream);
   if (rc) return rc;
 
-  // ---- side_prep convs: weight gradients (aux stream) || data gradients into the stage outputs ---
-  double side_flops = 0.0;
-  for (int i = 0; i < 4; ++i) side_flops += 2.0 * conv_flops(N, L.hs[i + 1], L.ws[i + 1], d[kNumTrunk + i].cin, 16);
-  {
-    ProfScope ps(OSVOS_PROF_CONV_BWD, side_flops, stream);
-    if ((rc = fork())) return rc;
-    for (int i = 0; i < 4; ++i) {
-      const int si = i + 1, sl = kNumTrunk + i, h = L.hs[si], w = L.ws[si];
-      const int lx = last_of_stage(si);
-      if (grads[d[sl].w_param] != nullptr) {
-        rc = osvos_conv3x3_wgrad(at(ws, L.act[lx]), at(ws, L.dprep[i]), at(ws, L.wgrad), grads[d[sl].w_param], grads[d[sl].b_param],
-                                 N, h, w, d[sl].cin, d[sl].cin_s, 16, 16, accumulate, dtype, aux);
-        if (rc) return rc;
-      }
-    }
-    for (int i = 0; i < 4; ++i) {
-      const int si = i + 1, sl = kNumTrunk + i, h = L.hs[si], w = L.ws[si];
-      const int lx = last_of_stage(si);
-      // stage 4 has no pool after it: its ReLU mask is applied right here and the result is the
-      // upstream gradient of conv5_3; stages 1-3 are merged in maxpool2x2_bwd below
-      void* dst = (i == 3) ? at(ws, L.gA) : at(ws, L.dside[i]);
-      rc = osvos_conv3x3(at(ws, L.dprep[i]), at(wbuf, P.dgrad[sl]), nullptr, (i == 3) ? at(ws, L.act[lx]) : nullptr, dst,
-                         N, h, w, 16, d[sl].cin, d[sl].cin, 0, dtype, -1, stream);
+  // ---- data-gradient chain on `stream`, weight gradients trailing on `aux` ----------------------
+  // ready[k]: event recorded on `stream` when the k-th upstream gradient tensor is complete
+  double bwd_flops = 0.0;
+  for (int l = 0; l < kNumConv; ++l) bwd_flops += 2.0 * conv_flops(N, L.hs[d[l].stage], L.ws[d[l].stage], d[l].cin, d[l].cout);
+  if (dx_nchw == nullptr) bwd_flops -= conv_flops(N, H, W, 3, d[0].cout);
+  ProfScope ps(OSVOS_PROF_CONV_BWD, bwd_flops, stream);
+  auto signal = [&]() -> int {          // aux may consume everything `stream` has produced so far
+    if (!two) return 0;
+    hipEvent_t e = evp.next();
+    if (!e) return -1;
+    OSVOS_HIP_CHECK(hipEventRecord(e, stream));
+    OSVOS_HIP_CHECK(hipStreamWaitEvent(aux, e, 0));
+    return 0;
+  };
+  if ((rc = signal())) return rc;       // dprep[0..3] ready
+  for (int i = 0; i < 4; ++i) {
+    const int si = i + 1, sl = kNumTrunk + i, h = L.hs[si], w = L.ws[si];
+    const int lx = last_of_stage(si);
+    if (grads[d[sl].w_param] != nullptr) {
+      rc = osvos_conv3x3_wgrad(at(ws, L.act[lx]), at(ws, L.dprep[i]), at(ws, L.wgrad), grads[d[sl].w_param], grads[d[sl].b_param],
+                               N, h, w, d[sl].cin, d[sl].cin_s, 16, 16, accumulate, dtype, aux);
       if (rc) return rc;
     }
-    if ((rc = join())) return rc;
+  }
+  for (int i = 3; i >= 0; --i) {
+    const int si = i + 1, sl = kNumTrunk + i, h = L.hs[si], w = L.ws[si];
+    const int lx = last_of_stage(si);
+    // stage 4 has no pool after it: its ReLU mask is applied right here and the result is the
+    // upstream gradient of conv5_3; stages 1-3 are merged in maxpool2x2_bwd below
+    void* dst = (i == 3) ? at(ws, L.dy[lx]) : at(ws, L.dside[i]);
+    rc = osvos_conv3x3(at(ws, L.dprep[i]), at(wbuf, P.dgrad[sl]), nullptr, (i == 3) ? at(ws, L.act[lx]) : nullptr, dst,
+                       N, h, w, 16, d[sl].cin, d[sl].cin, 0, dtype, -1, stream);
+    if (rc) return rc;
   }
 
-  // ---- trunk, deepest layer first; g = dLoss/d(conv output), ReLU mask already applied -------
-  void* g = at(ws, L.gA);
-  void* other = at(ws, L.gB);
+  // trunk, deepest layer first; dy[l] = dLoss/d(conv l output), ReLU mask already applied
   for (int l = kNumTrunk - 1; l >= 0; --l) {
     const int si = d[l].stage, h = L.hs[si], w = L.ws[si];
     const bool first_of_stage = (l == 0) || d[l - 1].stage != si;
     const void* xin = first_of_stage ? (si == 0 ? at(ws, L.xin) : at(ws, L.pooled[si])) : at(ws, L.act[l - 1]);
-    const bool need_dgrad = (l > 0) || dx_nchw != nullptr;
-    const double fl = conv_flops(N, h, w, d[l].cin, d[l].cout) * ((grads[d[l].w_param] ? 1 : 0) + (need_dgrad ? 1 : 0));
-    ProfScope ps(OSVOS_PROF_CONV_BWD, fl, stream);
+    const void* g = at(ws, L.dy[l]);
     if (grads[d[l].w_param] != nullptr) {
-      if ((rc = fork())) return rc;
+      if ((rc = signal())) return rc;   // dy[l] ready -> its weight gradient may start on aux
       rc = osvos_conv3x3_wgrad(xin, g, at(ws, L.wgrad), grads[d[l].w_param], grads[d[l].b_param],
                                N, h, w, d[l].cin, d[l].cin_s, d[l].cout, d[l].cout, accumulate, dtype, aux);
       if (rc) return rc;
@@ -364,25 +361,22 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
         rc = osvos_nhwc_to_nchw(at(ws, L.dxin), dx_nchw, N, 3, H, W, 4, dtype, stream);
         if (rc) return rc;
       }
-      if (grads[d[l].w_param] != nullptr && (rc = join())) return rc;
       break;
     }
     if (first_of_stage) {
       // through the pool into the previous stage's output (+ that stage's side branch, + ReLU mask)
-      rc = osvos_conv3x3(g, at(wbuf, P.dgrad[l]), nullptr, nullptr, other, N, h, w, d[l].cout, d[l].cin, d[l].cin, 0, dtype, -1, stream);
+      rc = osvos_conv3x3(g, at(wbuf, P.dgrad[l]), nullptr, nullptr, at(ws, L.dpool[si]), N, h, w, d[l].cout, d[l].cin, d[l].cin, 0, dtype, -1, stream);
       if (rc) return rc;
-      if (grads[d[l].w_param] != nullptr && (rc = join())) return rc;     // wgrad still reads g: join before it is overwritten
       const int ps2 = si - 1;
       const void* dside = ps2 >= 1 ? at(ws, L.dside[ps2 - 1]) : nullptr;
-      rc = osvos_maxpool2x2_bwd(at(ws, L.act[l - 1]), other, dside, g, N, L.hs[ps2], L.ws[ps2], kStageC[ps2], dtype, stream);
+      rc = osvos_maxpool2x2_bwd(at(ws, L.act[l - 1]), at(ws, L.dpool[si]), dside, at(ws, L.dy[l - 1]), N, L.hs[ps2], L.ws[ps2], kStageC[ps2], dtype, stream);
       if (rc) return rc;
     } else {
-      rc = osvos_conv3x3(g, at(wbuf, P.dgrad[l]), nullptr, at(ws, L.act[l - 1]), other, N, h, w, d[l].cout, d[l].cin, d[l].cin, 0, dtype, -1, stream);
+      rc = osvos_conv3x3(g, at(wbuf, P.dgrad[l]), nullptr, at(ws, L.act[l - 1]), at(ws, L.dy[l - 1]), N, h, w, d[l].cout, d[l].cin, d[l].cin, 0, dtype, -1, stream);
       if (rc) return rc;
-      if (grads[d[l].w_param] != nullptr && (rc = join())) return rc;     // the next layer's dgrad writes into g's buffer
-      void* t = g; g = other; other = t;
     }
   }
+  if ((rc = join())) return rc;         // everything is back on `stream` when the call returns
   return 0;
 }
 

@@ -33,12 +33,16 @@ struct WgArgs {
   int N, H, W, Cin_s, Cout, Cout_s;
   int npx, npy, npatches, nsplit, per_split;
   int nco_t, nci_t;
+  int oihw;      // slab element order: 1 = [co][ci][tap] (reference layout), 0 = [tap][co][ci] (coalesced stores)
 };
 
-template <int CB, int IB>
-__global__ __launch_bounds__(256, 1) void wgrad_f32_kernel(WgArgs a) {
+// PIPE: pinned software pipeline of the operand fetch; DBUF: two LDS patch buffers (one barrier per
+// patch) instead of one (two barriers, half the LDS); OCC: __launch_bounds__ waves/SIMD
+template <int CB, int IB, int PIPE, int DBUF, int OCC>
+__global__ __launch_bounds__(256, OCC) void wgrad_f32_kernel(WgArgs a) {
   constexpr int BCO = CB * 32, BCI = IB * 32;
   constexpr int DY_F4 = PPIX * BCO / 4, X_F4 = XPIX * BCI / 4;
+  constexpr int BUF_F4 = DY_F4 + X_F4;
   constexpr int NDY = (DY_F4 + 255) / 256, NX = (X_F4 + 255) / 256;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   f32x4* lds4 = reinterpret_cast<f32x4*>(smem);
@@ -89,8 +93,8 @@ __global__ __launch_bounds__(256, 1) void wgrad_f32_kernel(WgArgs a) {
       rx[i] = v;
     }
   };
-  auto store_patch = [&]() {
-    f32x4* d = lds4;
+  auto store_patch = [&](int buf) {
+    f32x4* d = lds4 + buf * BUF_F4;
 #pragma unroll
     for (int i = 0; i < NDY; ++i) {
       const int e = tid + i * 256;
@@ -113,47 +117,80 @@ __global__ __launch_bounds__(256, 1) void wgrad_f32_kernel(WgArgs a) {
   constexpr int BG = 256 / BCO;            // pixel groups for the bias column sums
   const int bco = tid % BCO, bgrp = tid / BCO;
 
-  if (p_begin < p_end) load_patch(p_begin);
-  for (int p = p_begin; p < p_end; ++p) {
-    __syncthreads();                 // every wave is done reading the previous patch
-    store_patch();
-    __syncthreads();
-    if (p + 1 < p_end) load_patch(p + 1);      // in flight while this patch is multiplied
-    const float* dYs = lds;
+  auto compute = [&](int buf) {
+    const float* dYs = lds + (size_t)buf * BUF_F4 * 4;
     const float* Xs = dYs + DY_F4 * 4;
-    // software-pipelined over the 32 pixel pairs: the 10 LDS operands of pair pp+1 are requested
-    // before the 9 MFMAs of pair pp issue (two named register sets, loop kept rolled: a full unroll
-    // spills), otherwise every pair exposes 3 LDS round trips to the matrix pipe
-    float av0, av1, bv0[9], bv1[9];
-    auto ld = [&](int pp, float& av, float (&bv)[9]) {
-      const int dy = pp / (PW / 2), dx = (pp % (PW / 2)) * 2 + lh;
-      av = dYs[(dy * PW + dx) * BCO + cb * 32 + li];
-      const float* xb = Xs + (dy * XW + dx) * BCI + ib * 32 + li;
+    if (PIPE) {
+      // software-pipelined over the 32 pixel pairs: the 10 LDS operands of pair pp+1 are requested
+      // before the 9 MFMAs of pair pp issue (two named register sets, loop kept rolled: a full
+      // unroll spills); sched_barrier pins that order, hipcc otherwise sinks the ds_reads
+      float av0, av1, bv0[9], bv1[9];
+      auto ld = [&](int pp, float& av, float (&bv)[9]) {
+        const int dy = pp / (PW / 2), dx = (pp % (PW / 2)) * 2 + lh;
+        av = dYs[(dy * PW + dx) * BCO + cb * 32 + li];
+        const float* xb = Xs + (dy * XW + dx) * BCI + ib * 32 + li;
 #pragma unroll
-      for (int t = 0; t < 9; ++t) bv[t] = xb[((t / 3) * XW + (t % 3)) * BCI];
-    };
-    ld(0, av0, bv0);
+        for (int t = 0; t < 9; ++t) bv[t] = xb[((t / 3) * XW + (t % 3)) * BCI];
+      };
+      ld(0, av0, bv0);
 #pragma unroll 1
-    for (int pp = 0; pp < PPIX / 2; pp += 2) {
-      // sched_barrier pins "request next operands, then multiply the current ones": left alone,
-      // hipcc sinks the ds_reads down to their first use and the matrix pipe waits on LDS
-      ld(pp + 1, av1, bv1);
-      __builtin_amdgcn_sched_barrier(0);
+      for (int pp = 0; pp < PPIX / 2; pp += 2) {
+        ld(pp + 1, av1, bv1);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0, bv0[t], acc[t], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      ld((pp + 2) & (PPIX / 2 - 1), av0, bv0);     // unconditional (wraps to pair 0 at the end) so the waits stay counted
-      __builtin_amdgcn_sched_barrier(0);
+        for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0, bv0[t], acc[t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        ld((pp + 2) & (PPIX / 2 - 1), av0, bv0);     // unconditional (wraps at the end): waits stay counted
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1, bv1[t], acc[t], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
+        for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1, bv1[t], acc[t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+#pragma unroll 2
+      for (int pp = 0; pp < PPIX / 2; ++pp) {
+        const int dy = pp / (PW / 2), dx = (pp % (PW / 2)) * 2 + lh;
+        const float av = dYs[(dy * PW + dx) * BCO + cb * 32 + li];
+        const float* xb = Xs + (dy * XW + dx) * BCI + ib * 32 + li;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const float bv = xb[((t / 3) * XW + (t % 3)) * BCI];
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+        }
+      }
     }
     if (do_bias) {
 #pragma unroll 4
       for (int pix = bgrp; pix < PPIX; pix += BG) bsum += dYs[pix * BCO + bco];
     }
+  };
+
+  if (DBUF) {
+    if (p_begin < p_end) {
+      load_patch(p_begin);
+      store_patch(0);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int p = p_begin; p < p_end; ++p) {
+      const bool more = p + 1 < p_end;
+      if (more) load_patch(p + 1);
+      compute(buf);
+      if (more) store_patch(buf ^ 1);
+      __syncthreads();
+      buf ^= 1;
+    }
+  } else {
+    if (p_begin < p_end) load_patch(p_begin);
+    for (int p = p_begin; p < p_end; ++p) {
+      __syncthreads();                 // every wave is done reading the previous patch
+      store_patch(0);
+      __syncthreads();
+      if (p + 1 < p_end) load_patch(p + 1);      // in flight while this patch is multiplied
+      compute(0);
+    }
+    __syncthreads();
   }
-  __syncthreads();
 
   // ---- write the partial slab: D row = cout (r&3)+8*(r>>2)+4*lh, col = cin li ----------------
   const int ci = ci0 + ib * 32 + li;
@@ -162,8 +199,11 @@ __global__ __launch_bounds__(256, 1) void wgrad_f32_kernel(WgArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int co = co0 + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (co < a.Cout && ci < a.Cin_s)
-        a.slab[(((size_t)split * a.Cout + co) * a.Cin_s + ci) * 9 + t] = acc[t][r];
+      if (co < a.Cout && ci < a.Cin_s) {
+        const size_t o = a.oihw ? (((size_t)split * a.Cout + co) * a.Cin_s + ci) * 9 + t
+                                : ((size_t)(split * 9 + t) * a.Cout + co) * a.Cin_s + ci;
+        a.slab[o] = acc[t][r];
+      }
     }
   }
   if (do_bias) {
@@ -183,7 +223,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_f32_kernel(WgArgs a) {
 // lanes per workgroup, 256-byte coalesced reads, LDS combine
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ bslab,
                                                            float* __restrict__ dw, float* __restrict__ db,
-                                                           int nsplit, int Cout, int Cin, int Cin_s, int accumulate) {
+                                                           int nsplit, int Cout, int Cin, int Cin_s, int accumulate, int oihw) {
   __shared__ float red[256];
   const int total = Cout * Cin_s * 9;
   const int e = threadIdx.x & 63, sl = threadIdx.x >> 6;
@@ -195,7 +235,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   __syncthreads();
   if (sl == 0 && idx < total) {
     s = red[e] + red[64 + e] + red[128 + e] + red[192 + e];
-    const int t = idx % 9, ci = (idx / 9) % Cin_s, co = idx / (9 * Cin_s);
+    int t, ci, co;
+    if (oihw) { t = idx % 9; ci = (idx / 9) % Cin_s; co = idx / (9 * Cin_s); }
+    else { ci = idx % Cin_s; co = (idx / Cin_s) % Cout; t = idx / (Cin_s * Cout); }
     if (ci < Cin) {
       float* o = dw + ((size_t)co * Cin + ci) * 9 + t;
       *o = accumulate ? (*o + s) : s;
@@ -223,12 +265,10 @@ WgPlan make_plan(int N, int H, int W, int Cin_s, int Cout) {
   p.npx = ceil_div(W, PW);
   p.npy = ceil_div(H, PH);
   p.npatches = N * p.npx * p.npy;
-  static int target_blocks = 0;
-  if (target_blocks == 0) {
-    const char* env = getenv("OSVOS_WGRAD_BLOCKS");
-    target_blocks = env ? atoi(env) : 512;    // two single-buffered workgroups per CU
-    if (target_blocks < 1) target_blocks = 512;
-  }
+  const char* env = getenv("OSVOS_WGRAD_BLOCKS");
+  // ~2 workgroups per CU; small frames (conv5 at 480p: 30 patches) prefer fewer, longer splits
+  int target_blocks = env ? atoi(env) : (N * ceil_div(W, PW) * ceil_div(H, PH) >= 100 ? 512 : 256);
+  if (target_blocks < 1) target_blocks = 512;
   int want = ceil_div(target_blocks, p.nco_t * p.nci_t);
   int max_split = p.npatches / 4 > 0 ? p.npatches / 4 : 1;
   p.nsplit = want < max_split ? want : max_split;
@@ -241,18 +281,37 @@ WgPlan make_plan(int N, int H, int W, int Cin_s, int Cout) {
   return p;
 }
 
-template <int CB, int IB>
+template <int CB, int IB, int PIPE, int DBUF, int OCC>
 int launch_wgrad(const WgArgs& a, long blocks, hipStream_t stream) {
-  constexpr size_t lds = (size_t)(PPIX * CB * 32 + XPIX * IB * 32) * 4;
+  constexpr size_t lds = (size_t)(DBUF ? 2 : 1) * (PPIX * CB * 32 + XPIX * IB * 32) * 4;
   static bool attr_set = false;
   if (!attr_set) {
-    OSVOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_f32_kernel<CB, IB>),
+    OSVOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_f32_kernel<CB, IB, PIPE, DBUF, OCC>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL((wgrad_f32_kernel<CB, IB>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL((wgrad_f32_kernel<CB, IB, PIPE, DBUF, OCC>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
   OSVOS_LAUNCH_CHECK();
   return 0;
+}
+
+// tuning knob (tools/tune_conv.py): bit0 PIPE, bit1 DBUF, bit2 OCC=2, bit3 reference-order slabs
+int wgrad_variant() {
+  const char* env = getenv("OSVOS_WGRAD_VARIANT");
+  return env ? atoi(env) : 5;     // measured best (tools/tune_wgrad.py): pipelined fetch, one LDS buffer, 2 WGs/CU
+}
+
+template <int CB, int IB>
+int launch_wgrad_variant(const WgArgs& a, long blocks, hipStream_t stream) {
+  switch (wgrad_variant() & 7) {
+    case 0: return launch_wgrad<CB, IB, 0, 0, 1>(a, blocks, stream);
+    case 1: return launch_wgrad<CB, IB, 1, 0, 1>(a, blocks, stream);
+    case 2: return launch_wgrad<CB, IB, 0, 1, 1>(a, blocks, stream);
+    case 3: return launch_wgrad<CB, IB, 1, 1, 1>(a, blocks, stream);
+    case 4: return launch_wgrad<CB, IB, 0, 0, (CB == 2 ? 2 : 1)>(a, blocks, stream);
+    case 5: return launch_wgrad<CB, IB, 1, 0, (CB == 2 ? 2 : 1)>(a, blocks, stream);
+    default: return launch_wgrad<CB, IB, 0, 1, 1>(a, blocks, stream);
+  }
 }
 
 }  // namespace
@@ -278,11 +337,12 @@ int osvos_conv3x3_wgrad_f32(const float* x, const float* dy, void* ws, float* dw
   a.npx = p.npx; a.npy = p.npy; a.npatches = p.npatches; a.nsplit = p.nsplit; a.per_split = p.per_split;
   a.nco_t = p.nco_t; a.nci_t = p.nci_t;
   const long blocks = (long)p.nsplit * p.nco_t * p.nci_t;
-  int rc = (p.cb == 1) ? launch_wgrad<1, 4>(a, blocks, stream) : launch_wgrad<2, 2>(a, blocks, stream);
+  a.oihw = (wgrad_variant() >> 3) & 1;
+  int rc = (p.cb == 1) ? launch_wgrad_variant<1, 4>(a, blocks, stream) : launch_wgrad_variant<2, 2>(a, blocks, stream);
   if (rc) return rc;
   const int total = Cout * Cin_s * 9;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(total, 64)), dim3(256), 0, stream,
-                     a.slab, a.bslab, dw, db, p.nsplit, Cout, Cin, Cin_s, accumulate);
+                     a.slab, a.bslab, dw, db, p.nsplit, Cout, Cin, Cin_s, accumulate, a.oihw);
   OSVOS_LAUNCH_CHECK();
   return 0;
 }
