@@ -1,0 +1,103 @@
+"""Shared pieces of the two entry scripts: the SGD parameter groups and the restated inner loops of
+the reference's train_online.py / train_parent.py, written as functions so the same code serves the
+scripts, the benchmark and the tests.  Data-parallel operation (one process per GPU, gradient
+all-reduce once per optimizer step) is layered on with ``GradientAllReducer``."""
+from __future__ import division
+
+import os
+
+import torch
+import torch.optim as optim
+
+from .layers.osvos_layers import class_balanced_cross_entropy_loss
+from .parallel import GradientAllReducer
+
+
+def make_sgd(net, mode, lr=1e-8, wd=0.0002, momentum=0.9):
+    """Parameter groups of train_online.py:79-88 (mode 'online', score_dsn not optimised) or
+    train_parent.py:87-103 (mode 'parent')."""
+    groups = [
+        {'params': [pr[1] for pr in net.stages.named_parameters() if 'weight' in pr[0]], 'weight_decay': wd, 'initial_lr': lr},
+        {'params': [pr[1] for pr in net.stages.named_parameters() if 'bias' in pr[0]], 'lr': 2 * lr, 'initial_lr': 2 * lr},
+        {'params': [pr[1] for pr in net.side_prep.named_parameters() if 'weight' in pr[0]], 'weight_decay': wd, 'initial_lr': lr},
+        {'params': [pr[1] for pr in net.side_prep.named_parameters() if 'bias' in pr[0]], 'lr': 2 * lr, 'initial_lr': 2 * lr},
+    ]
+    if mode == 'parent':
+        groups += [
+            {'params': [pr[1] for pr in net.score_dsn.named_parameters() if 'weight' in pr[0]], 'lr': lr / 10,
+             'weight_decay': wd, 'initial_lr': lr / 10},
+            {'params': [pr[1] for pr in net.score_dsn.named_parameters() if 'bias' in pr[0]], 'lr': 2 * lr / 10,
+             'initial_lr': 2 * lr / 10},
+        ]
+    groups += [
+        {'params': [pr[1] for pr in net.upscale.named_parameters() if 'weight' in pr[0]], 'lr': 0, 'initial_lr': 0},
+        {'params': [pr[1] for pr in net.upscale_.named_parameters() if 'weight' in pr[0]], 'lr': 0, 'initial_lr': 0},
+        {'params': net.fuse.weight, 'lr': lr / 100, 'initial_lr': lr / 100, 'weight_decay': wd},
+        {'params': net.fuse.bias, 'lr': 2 * lr / 100, 'initial_lr': 2 * lr / 100},
+    ]
+    return optim.SGD(groups, lr=lr, momentum=momentum)
+
+
+class TrainLoop(object):
+    """One micro-batch = forward, loss, ``loss /= nAveGrad``, backward; optimizer step every
+    ``nAveGrad`` micro-batches (train_online.py:116-149, train_parent.py:132-172).  The running loss
+    is kept on the device and only read back when the caller asks for it (the reference's
+    ``loss.item()`` every iteration is a logging artefact that stalls the GPU)."""
+
+    def __init__(self, net, optimizer, mode='online', n_ave_grad=5, n_epochs=240, reducer=None):
+        self.net, self.opt, self.mode = net, optimizer, mode
+        self.n_ave_grad, self.n_epochs = n_ave_grad, n_epochs
+        self.reducer = reducer
+        self.ave = 0
+        dev = next(net.parameters()).device
+        self.running = [torch.zeros((), device=dev) for _ in range(5 if mode == 'parent' else 1)]
+
+    def micro_batch(self, inputs, gts, epoch=0):
+        outputs = self.net.forward(inputs)
+        if self.mode == 'online':
+            loss = class_balanced_cross_entropy_loss(outputs[-1], gts, size_average=False)
+            self.running[0] += loss.detach()
+        else:
+            losses = [class_balanced_cross_entropy_loss(o, gts, size_average=False) for o in outputs]
+            for r, l in zip(self.running, losses):
+                r += l.detach()
+            loss = (1 - epoch / self.n_epochs) * sum(losses[:-1]) + losses[-1]
+        loss /= self.n_ave_grad
+        loss.backward()
+        self.ave += 1
+        stepped = False
+        if self.ave % self.n_ave_grad == 0:
+            if self.reducer is not None:
+                self.reducer.all_reduce()
+            self.opt.step()
+            self.opt.zero_grad()
+            self.ave = 0
+            stepped = True
+        return loss, stepped
+
+    def pop_running(self):
+        vals = [float(r.item()) for r in self.running]
+        for r in self.running:
+            r.zero_()
+        return vals
+
+
+def init_distributed():
+    """One process per GPU (torchrun / torch.distributed.run).  Returns (rank, world, device)."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local)
+        device = torch.device('cuda', local)
+    else:
+        device = torch.device('cpu')
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl' if torch.cuda.is_available() else 'gloo')
+    return rank, world, device
+
+
+def make_reducer(net, world, average=False):
+    return GradientAllReducer(net, average=average) if world > 1 else None

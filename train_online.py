@@ -1,0 +1,128 @@
+"""Online fine-tuning on the first frame of a sequence, then inference on every frame.
+
+Same entry point, knobs and file naming as the reference's train_online.py (SEQ_NAME env var,
+parent checkpoint ``<save_dir>/parent_epoch-239.pth``, result PNGs under ``<save_dir>/Results/<seq>``),
+running on the MI355X-native OSVOS path.  Differences by design:
+  * the dataset / augmentation layer of the reference needs OpenCV (``cv2``), which this image
+    lacks; ``--synthetic`` runs the identical loop on a seeded synthetic frame instead (used for
+    benchmarking); with real data, install the reference's dataloaders next to this file
+  * the loss is accumulated on the device and read back only when it is printed
+  * launched under torchrun with N processes, rank r fine-tunes sequences r, r+N, ... of the
+    comma-separated SEQ_NAME list (independent replicas: online training has no exchange step)
+"""
+from __future__ import division
+
+import argparse
+import os
+import sys
+import timeit
+
+import numpy as np
+import torch
+
+import networks.vgg_osvos as vo
+from layers.osvos_layers import sigmoid_np
+from mypath import Path
+from osvos_pytorch_amd.parallel import shard_indices
+from osvos_pytorch_amd.train_common import TrainLoop, init_distributed, make_sgd
+
+
+def synthetic_loader(h, w, seed):
+    g = torch.Generator().manual_seed(seed)
+    img = torch.randn(1, 3, h, w, generator=g) * 40.0
+    yy, xx = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing='ij')
+    gt = ((((yy - 0.5 * h) / (0.25 * h)) ** 2 + ((xx - 0.5 * w) / (0.25 * w)) ** 2) <= 1).float()[None, None]
+    return [{'image': img, 'gt': gt, 'fname': ['00000']}]
+
+
+def davis_loaders(db_root_dir, seq_name):
+    try:
+        from torchvision import transforms
+        from torch.utils.data import DataLoader
+        from dataloaders import davis_2016 as db
+        from dataloaders import custom_transforms as tr
+    except ImportError as e:
+        raise SystemExit("DAVIS loading needs the reference's dataloaders package + cv2 + torchvision (%s); "
+                         "use --synthetic to run without data" % e)
+    composed = transforms.Compose([tr.RandomHorizontalFlip(), tr.ScaleNRotate(rots=(-30, 30), scales=(.75, 1.25)), tr.ToTensor()])
+    db_train = db.DAVIS2016(train=True, db_root_dir=db_root_dir, transform=composed, seq_name=seq_name)
+    db_test = db.DAVIS2016(train=False, db_root_dir=db_root_dir, transform=tr.ToTensor(), seq_name=seq_name)
+    return DataLoader(db_train, batch_size=1, shuffle=True, num_workers=1), DataLoader(db_test, batch_size=1, shuffle=False, num_workers=1)
+
+
+def save_png(path, pred):
+    """scipy<=1.1 ``imsave`` semantics: min-max byte scaling (train_online.py:187)."""
+    from PIL import Image
+    lo, hi = float(pred.min()), float(pred.max())
+    scaled = np.zeros_like(pred) if hi <= lo else (pred - lo) / (hi - lo)
+    Image.fromarray((scaled * 255.0 + 0.5).astype(np.uint8)).save(path)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--synthetic', action='store_true', help='seeded synthetic 854x480 frame instead of DAVIS')
+    ap.add_argument('--epochs', type=int, default=0, help='0 = reference value 2000 * nAveGrad')
+    ap.add_argument('--height', type=int, default=480)
+    ap.add_argument('--width', type=int, default=854)
+    args = ap.parse_args()
+
+    rank, world, device = init_distributed()
+    seqs = os.environ.get('SEQ_NAME', 'blackswan').split(',')
+    save_dir = Path.save_root_dir()
+    os.makedirs(save_dir, exist_ok=True)
+    nAveGrad = 5
+    nEpochs = args.epochs or 2000 * nAveGrad
+    snapshot = nEpochs
+    parentEpoch = 240
+    seed = 0
+
+    for si in shard_indices(len(seqs), rank, world):
+        seq_name = seqs[si]
+        net = vo.OSVOS(pretrained=0)
+        parent = os.path.join(save_dir, 'parent_epoch-' + str(parentEpoch - 1) + '.pth')
+        if os.path.exists(parent):
+            net.load_state_dict(torch.load(parent, map_location=lambda storage, loc: storage))
+        elif not args.synthetic:
+            raise SystemExit('parent model %s not found' % parent)
+        net.to(device)
+        optimizer = make_sgd(net, 'online')
+        if args.synthetic:
+            trainloader = testloader = synthetic_loader(args.height, args.width, seed + si)
+        else:
+            trainloader, testloader = davis_loaders(Path.db_root_dir(), seq_name)
+        loop = TrainLoop(net, optimizer, mode='online', n_ave_grad=nAveGrad)
+        num_img_tr = len(trainloader)
+        print('Start of Online Training, sequence: ' + seq_name)
+        start_time = timeit.default_timer()
+        for epoch in range(0, nEpochs):
+            np.random.seed(seed + epoch)
+            for ii, sample in enumerate(trainloader):
+                inputs, gts = sample['image'], sample['gt']
+                inputs.requires_grad_()
+                inputs, gts = inputs.to(device), gts.to(device)
+                loop.micro_batch(inputs, gts)
+            if epoch % max(1, nEpochs // 20) == max(1, nEpochs // 20) - 1:
+                running = loop.pop_running()[0] / (num_img_tr * max(1, nEpochs // 20))
+                print('[Epoch: %d, numImages: %5d]' % (epoch + 1, num_img_tr))
+                print('Loss: %f' % running)
+            if (epoch % snapshot) == snapshot - 1 and epoch != 0:
+                torch.save(net.state_dict(), os.path.join(save_dir, seq_name + '_epoch-' + str(epoch) + '.pth'))
+        if device.type == 'cuda':
+            torch.cuda.synchronize()
+        print('Online training time: ' + str(timeit.default_timer() - start_time))
+
+        save_dir_res = os.path.join(save_dir, 'Results', seq_name)
+        os.makedirs(save_dir_res, exist_ok=True)
+        print('Testing Network')
+        with torch.no_grad():
+            for sample in testloader:
+                img, fname = sample['image'], sample['fname']
+                outputs = net.forward(img.to(device))
+                for jj in range(int(img.size()[0])):
+                    pred = np.transpose(outputs[-1].cpu().data.numpy()[jj, :, :, :], (1, 2, 0))
+                    pred = np.squeeze(sigmoid_np(pred))
+                    save_png(os.path.join(save_dir_res, os.path.basename(fname[jj]) + '.png'), pred)
+
+
+if __name__ == '__main__':
+    sys.exit(main())
