@@ -124,7 +124,7 @@ size_t osvos_net_wbuf_bytes(int dtype);
 size_t osvos_net_ws_bytes(int N, int H, int W, int dtype);
 int osvos_net_pack(const float* const* params, void* wbuf, int dtype, int with_dgrad, void* stream);
 int osvos_net_forward(const float* x_nchw, const void* wbuf, void* ws, float* const* outs,
-                      int N, int H, int W, int dtype, void* stream);
+                      int N, int H, int W, int dtype, void* stream, void* aux_stream /* NULL ok: see backward */);
 /* douts: host array of 5 device pointers (NULL = no gradient for that head).
  * grads: host array of 52 device pointers (NULL entries are skipped; deconv weights are frozen in
  *        both reference scripts -- train_online.py:84-85 -- and are never written).

@@ -202,8 +202,11 @@ int osvos_net_pack(const float* const* params, void* wbuf, int dtype, int with_d
 }
 
 int osvos_net_forward(const float* x_nchw, const void* wbuf, void* ws, float* const* outs,
-                      int N, int H, int W, int dtype, void* stream_) {
+                      int N, int H, int W, int dtype, void* stream_, void* aux_stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  hipStream_t aux = aux_stream_ ? (hipStream_t)aux_stream_ : stream;
+  const bool two = aux != stream;
+  EventPool& evp = event_pool();
   OSVOS_ARG_CHECK(x_nchw && wbuf && ws && outs, "net_forward: null pointer");
   OSVOS_ARG_CHECK(dtype == OSVOS_F32, "net_forward: dtype %d not built", dtype);
   OSVOS_ARG_CHECK(N > 0 && H > 0 && W > 0, "net_forward: bad shape %dx%dx%d", N, H, W);
@@ -234,23 +237,37 @@ int osvos_net_forward(const float* x_nchw, const void* wbuf, void* ws, float* co
       cur = at(ws, L.act[l]);
     }
     if (si > 0) {
+      // side branch of this stage (skinny Cout=16 conv + the two 1x1 dots): latency-bound launches
+      // that run on the aux stream in the shadow of the next stage's big convolutions
       const int i = si - 1, sl = kNumTrunk + i;
+      if (two) {
+        hipEvent_t e = evp.next();
+        if (!e) return -1;
+        OSVOS_HIP_CHECK(hipEventRecord(e, stream));
+        OSVOS_HIP_CHECK(hipStreamWaitEvent(aux, e, 0));
+      }
       {
-        ProfScope ps(OSVOS_PROF_CONV_FWD, conv_flops(N, h, w, d[sl].cin, 16), stream);
+        ProfScope ps(OSVOS_PROF_OTHER, conv_flops(N, h, w, d[sl].cin, 16), aux);
         rc = osvos_conv3x3(cur, at(wbuf, P.fwd[sl]), reinterpret_cast<const float*>(at(wbuf, P.bias[sl])), nullptr,
-                           at(ws, L.prep[i]), N, h, w, d[sl].cin_s, 16, 16, 0, dtype, -1, stream);
+                           at(ws, L.prep[i]), N, h, w, d[sl].cin_s, 16, 16, 0, dtype, -1, aux);
       }
       if (rc) return rc;
       float* sc = reinterpret_cast<float*>(at(ws, L.score[i]));
       float* fp = reinterpret_cast<float*>(at(ws, L.fpart[i]));
       rc = osvos_head_lowres(at(ws, L.prep[i]), reinterpret_cast<const float*>(at(wbuf, P.wd[i])),
                              reinterpret_cast<const float*>(at(wbuf, P.bd[i])),
-                             reinterpret_cast<const float*>(at(wbuf, P.wf)) + 16 * i, sc, fp, N, h, w, dtype, stream);
+                             reinterpret_cast<const float*>(at(wbuf, P.wf)) + 16 * i, sc, fp, N, h, w, dtype, aux);
       if (rc) return rc;
       score[i] = sc; fpart[i] = fp;
       f1[i] = reinterpret_cast<const float*>(at(wbuf, P.f1[i]));
       f16[i] = reinterpret_cast<const float*>(at(wbuf, P.f16[i]));
     }
+  }
+  if (two) {
+    hipEvent_t e = evp.next();
+    if (!e) return -1;
+    OSVOS_HIP_CHECK(hipEventRecord(e, aux));
+    OSVOS_HIP_CHECK(hipStreamWaitEvent(stream, e, 0));
   }
   return osvos_head_upsample(score, fpart, f1, f16, reinterpret_cast<const float*>(at(wbuf, P.bf)), outs, N, H, W,
                              &L.hs[1], &L.ws[1], stream);

@@ -316,9 +316,25 @@ int launch_wgrad_variant(const WgArgs& a, long blocks, hipStream_t stream) {
 
 }  // namespace
 
+size_t osvos_wgrad_small_ws_bytes(int N, int H, int W, int Cin_s, int Cout);
+int osvos_conv3x3_wgrad_small_f32(const float* x, const float* dy, void* ws, float* dw, float* db,
+                                  int N, int H, int W, int Cin, int Cin_s, int Cout, int Cout_s,
+                                  int accumulate, hipStream_t stream);
+
+int osvos_wgrad_reduce_launch(const float* slab, const float* bslab, float* dw, float* db, int nsplit, int Cout, int Cin,
+                              int Cin_s, int accumulate, hipStream_t stream) {
+  const int total = Cout * Cin_s * 9;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(total, 64)), dim3(256), 0, stream,
+                     slab, bslab, dw, db, nsplit, Cout, Cin, Cin_s, accumulate, 0);
+  OSVOS_LAUNCH_CHECK();
+  return 0;
+}
+
 size_t osvos_wgrad_ws_bytes_f32(int N, int H, int W, int Cin_s, int Cout) {
   WgPlan p = make_plan(N, H, W, Cin_s, Cout);
-  return align_up((p.slab_floats + p.bslab_floats) * sizeof(float), 256);
+  const size_t generic = align_up((p.slab_floats + p.bslab_floats) * sizeof(float), 256);
+  const size_t small = osvos_wgrad_small_ws_bytes(N, H, W, Cin_s, Cout);
+  return generic > small ? generic : small;
 }
 
 int osvos_conv3x3_wgrad_f32(const float* x, const float* dy, void* ws, float* dw, float* db,
@@ -328,6 +344,13 @@ int osvos_conv3x3_wgrad_f32(const float* x, const float* dy, void* ws, float* dw
   OSVOS_ARG_CHECK(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "wgrad: bad shape");
   OSVOS_ARG_CHECK(Cin_s % 4 == 0 && Cout_s % 4 == 0 && Cout % 4 == 0 && Cin <= Cin_s && Cout <= Cout_s,
                   "wgrad f32: channel strides must be multiples of 4 (Cin %d/%d Cout %d/%d)", Cin, Cin_s, Cout, Cout_s);
+  {
+    const char* env = getenv("OSVOS_WGRAD_GENERIC");     // tuning / tests: force the generic kernel
+    if (!(env && atoi(env))) {
+      const int rc = osvos_conv3x3_wgrad_small_f32(x, dy, ws, dw, db, N, H, W, Cin, Cin_s, Cout, Cout_s, accumulate, stream);
+      if (rc <= 0) return rc;
+    }
+  }
   WgPlan p = make_plan(N, H, W, Cin_s, Cout);
   WgArgs a;
   a.x = x; a.dy = dy;

@@ -84,7 +84,8 @@ def test_conv3x3_matches_naive_kernel_and_mask_and_stride():
     assert rel_err(nchw(ym), ref * (m > 0))[0] < 2e-5
 
 
-@pytest.mark.parametrize("shape", [(1, 9, 11, 8, 32), (2, 17, 35, 16, 64), (1, 20, 33, 3, 64), (1, 12, 13, 64, 16)])
+@pytest.mark.parametrize("shape", [(1, 9, 11, 8, 32), (2, 17, 35, 16, 64), (1, 20, 33, 3, 64), (1, 12, 13, 64, 16),
+                                   (2, 37, 53, 3, 64), (1, 64, 70, 3, 64), (2, 19, 45, 128, 16), (1, 30, 54, 256, 16), (1, 8, 8, 32, 16)])
 def test_conv3x3_dgrad_and_wgrad(shape):
     ops = _ops()
     n, h, w, cin, cout = shape

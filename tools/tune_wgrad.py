@@ -10,9 +10,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from osvos_pytorch_amd import ops  # noqa: E402
 
 layers = [("conv1_2", 480, 854, 64, 64), ("conv2_2", 240, 427, 128, 128), ("conv3_2", 120, 214, 256, 256),
-          ("conv4_2", 60, 107, 512, 512), ("conv5_2", 30, 54, 512, 512), ("side1", 240, 427, 128, 16), ("conv1_1", 480, 854, 3, 64)]
-variants = [0, 1, 2, 3, 4, 5, 10, 11]
-blocks = [512, 256, 1024]
+          ("conv4_2", 60, 107, 512, 512), ("conv5_2", 30, 54, 512, 512), ("side1", 240, 427, 128, 16), ("side2", 120, 214, 256, 16), ("side3", 60, 107, 512, 16), ("side4", 30, 54, 512, 16), ("conv1_1", 480, 854, 3, 64)]
+variants = [4, 5]
+blocks = [512, 256]
 
 
 def run(x, dy, cin, cout):
