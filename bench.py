@@ -165,7 +165,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--mode", default="online", choices=["online", "parent"])
+    ap.add_argument("--mode", default="online", choices=["online", "parent", "infer"],
+                    help="online/parent: restated training loops (fwd+loss+bwd+SGD); infer: forward only under no_grad "
+                         "(BASELINE.json configs[4]: use --height 1080 --width 1920 --batch 4 --graph 1)")
+    ap.add_argument("--graph", type=int, default=0, help="infer mode: replay the forward from a captured hipGraph")
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--width", type=int, default=854)
     ap.add_argument("--batch", type=int, default=1)
@@ -195,7 +198,7 @@ def main():
 
     n_ave = args.n_ave_grad or (5 if args.mode == "online" else 10)
     net, x, gt = synth_problem(args.batch, args.height, args.width, device, seed=rank)
-    opt = make_optimizer(net, args.mode)
+    opt = make_optimizer(net, "online" if args.mode == "infer" else args.mode)
     reducer = GradientAllReducer(net, average=True) if world > 1 else None
     running = torch.zeros((), device=device)
     state = {"ave": 0, "epoch": 0}
@@ -223,10 +226,25 @@ def main():
             opt.zero_grad()
             state["ave"] = 0
 
+    if args.mode == "infer":
+        keep = {}
+
+        def infer_eager():
+            with torch.no_grad():
+                keep["outs"] = net.forward(x)      # train_online.py:172-181 (sigmoid/PNG writing is host I/O)
+        step = infer_eager
+        if args.graph:
+            for _ in range(3):
+                infer_eager()                      # packs weights, creates the aux stream/events, sets kernel attributes
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                infer_eager()
+            step = graph.replay
     for _ in range(args.warmup):
         step()
     lib = _lib.lib()
-    prof = (not args.no_prof)
+    prof = (not args.no_prof) and not (args.mode == "infer" and args.graph)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -253,7 +271,15 @@ def main():
 
     if rank == 0:
         gf_fwd = conv_gflop_forward(args.height, args.width) * args.batch
+        passes = 1 if args.mode == "infer" else 3
         roof = None
+        if args.mode == "infer" and args.graph:
+            # one captured graph per step: the family is the whole forward (17 conv launches + glue)
+            ach = gf_fwd / 1e3 / (elapsed / args.steps)
+            act_gb = 0.904 * (args.height * args.width) / (480.0 * 854.0) * args.batch     # min conv tensor traffic, fp32
+            roof = {"bound": "mfma", "kernel": "hipGraph replay of osvos_net_forward (conv3x3_f32_kernel x17 + pool/head glue)",
+                    "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
+                    "traffic": None, "algorithmic_hbm_GBps": round(act_gb / (elapsed / args.steps), 1), "hbm_peak_GBps": 8000}
         if prof and cnt[0] + cnt[1] > 0:
             # dominant kernel family: the MFMA conv kernels.  Family 0 = conv3x3_f32_kernel forward
             # launches (one event pair per launch); family 1 = backward regions, i.e. the data-gradient
@@ -264,27 +290,34 @@ def main():
             ach = conv_fl / (conv_ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": "conv3x3_f32_kernel fwd launches + (conv3x3_f32_kernel dgrad || wgrad_f32_kernel) backward regions",
                     "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
                     "launches": int(cnt[0] + cnt[1]), "avg_launch_ms": round(conv_ms / (cnt[0] + cnt[1]), 4),
                     "algorithmic_gflop_per_launch": round(conv_fl / (cnt[0] + cnt[1]) / 1e9, 3),
                     "families": {"conv_fwd": {"ms_per_step": round(ms[0] / args.steps, 3), "tflops": round(fl[0] / (ms[0] * 1e-3) / 1e12, 2) if ms[0] else None},
                                  "conv_bwd_dgrad+wgrad": {"ms_per_step": round(ms[1] / args.steps, 3), "tflops": round(fl[1] / (ms[1] * 1e-3) / 1e12, 2) if ms[1] else None}},
-                    "step_conv_fraction_of_fp32_mfma_roofline": round(3 * gf_fwd / 1e3 / (elapsed / args.steps) / FP32_MFMA_PEAK_TFLOPS, 4)}
+                    "step_conv_fraction_of_fp32_mfma_roofline": round(passes * gf_fwd / 1e3 / (elapsed / args.steps) / FP32_MFMA_PEAK_TFLOPS, 4),
+                    # HBM-side bytes per launch from rocprofv3 --pmc (profiles/r01_pmc_conv3_2_conv1_2.txt), conv3_2 forward
+                    # launch: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE; algorithmic 55.0 MB
+                    "traffic": {"conv3_2_fwd_launch_MB": 94.1, "algorithmic_MB": 55.0, "source": "profiles/r01_pmc_conv3_2_conv1_2.txt"}}
         base = None
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and args.mode != "infer":
             try:
                 base = cpu_baseline(args.height, args.width, args.mode, n_ave)
             except Exception as e:  # the GPU result must still be reported
                 base = {"error": repr(e)}
         line = {
-            "metric": "frames/sec (fwd+bwd) OSVOS-VGG16 854x480 per GPU" if (args.height, args.width) == (480, 854) else
-                      "frames/sec (fwd+bwd) OSVOS-VGG16 %dx%d" % (args.width, args.height),
+            "metric": ("frames/sec (fwd+bwd) OSVOS-VGG16 854x480 per GPU" if (args.height, args.width) == (480, 854) else
+                       "frames/sec (fwd+bwd) OSVOS-VGG16 %dx%d" % (args.width, args.height)) if args.mode != "infer" else
+                      "frames/sec (forward only) OSVOS-VGG16 %dx%d" % (args.width, args.height),
             "value": round(value, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%dx%d batch=%d %s fine-tune loop (train_%s.py), fused-head%s loss, nAveGrad=%d, SGD 8-group, "
-                                   "fp32, frame resident in HBM" % (args.width, args.height, args.batch, args.mode, args.mode,
-                                                                    "" if args.mode == "online" else "+4 side", n_ave),
+            "config": {"workload": ("%dx%d batch=%d inference forward (train_online.py:172-181), no_grad, %s, fp32, frames resident in HBM"
+                                    % (args.width, args.height, args.batch, "hipGraph replay" if args.graph else "eager launches"))
+                       if args.mode == "infer" else
+                       "%dx%d batch=%d %s fine-tune loop (train_%s.py), fused-head%s loss, nAveGrad=%d, SGD 8-group, "
+                       "fp32, frame resident in HBM" % (args.width, args.height, args.batch, args.mode, args.mode,
+                                                        "" if args.mode == "online" else "+4 side", n_ave),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                        "grad_allreduce": "per optimizer step" if world > 1 else "none",
                        "loss_item_sync_each_iter": bool(args.item_sync)},

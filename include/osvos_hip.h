@@ -122,6 +122,8 @@ int osvos_scale(const float* x, const float* scalar, float* y, long count, void*
  *   outs:   host array of 5 device pointers, fp32 [N,1,H,W] */
 size_t osvos_net_wbuf_bytes(int dtype);
 size_t osvos_net_ws_bytes(int N, int H, int W, int dtype);
+/* workspace of a forward that will never be followed by osvos_net_backward (inference): a prefix of ws */
+size_t osvos_net_ws_bytes_infer(int N, int H, int W, int dtype);
 int osvos_net_pack(const float* const* params, void* wbuf, int dtype, int with_dgrad, void* stream);
 int osvos_net_forward(const float* x_nchw, const void* wbuf, void* ws, float* const* outs,
                       int N, int H, int W, int dtype, void* stream, void* aux_stream /* NULL ok: see backward */);

@@ -43,6 +43,7 @@ PROTOTYPES = {
     "osvos_scale": (_i, [_vp, _vp, _vp, _l, _vp]),
     "osvos_net_wbuf_bytes": (_sz, [_i]),
     "osvos_net_ws_bytes": (_sz, [_i, _i, _i, _i]),
+    "osvos_net_ws_bytes_infer": (_sz, [_i, _i, _i, _i]),
     "osvos_net_pack": (_i, [_vp, _vp, _i, _i, _vp]),
     "osvos_net_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "osvos_net_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),

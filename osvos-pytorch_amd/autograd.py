@@ -94,7 +94,9 @@ class OSVOSNetFunction(torch.autograd.Function):
                 raise RuntimeError("parameters must be float32 on the input's device")
         rt.ensure_packed(ps)
         n, _, h, w = xin.shape
-        ws = torch.empty(l.osvos_net_ws_bytes(n, h, w, rt.dtype), device=xin.device, dtype=torch.uint8)
+        need_bwd = any(ctx.needs_input_grad)       # False under torch.no_grad(): forward-only workspace
+        nbytes = l.osvos_net_ws_bytes(n, h, w, rt.dtype) if need_bwd else l.osvos_net_ws_bytes_infer(n, h, w, rt.dtype)
+        ws = torch.empty(nbytes, device=xin.device, dtype=torch.uint8)
         outs = [torch.empty((n, 1, h, w), device=xin.device, dtype=torch.float32) for _ in range(5)]
         check(l.osvos_net_forward(C.c_void_p(xin.data_ptr()), C.c_void_p(rt.wbuf.data_ptr()), C.c_void_p(ws.data_ptr()),
                                   ptr_array([o.data_ptr() for o in outs]), n, h, w, rt.dtype, _stream(), rt.aux(xin.device)), "net_forward")

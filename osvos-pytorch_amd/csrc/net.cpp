@@ -65,7 +65,7 @@ struct WsLayout {
   int hs[5], ws[5];
   size_t xin, act[kNumTrunk], pooled[5], prep[4], score[4], fpart[4];
   size_t dy[kNumTrunk], dpool[5], dside[4], dprep[4], wgrad, acc, dxin;
-  size_t total;
+  size_t fwd_total, total;
 };
 
 WsLayout ws_layout(int N, int H, int W, int dtype) {
@@ -91,6 +91,10 @@ WsLayout ws_layout(int N, int H, int W, int dtype) {
     L.prep[i] = take(es * npix * 16);
     L.score[i] = take(sizeof(float) * npix);
     L.fpart[i] = take(sizeof(float) * npix);
+  }
+  L.fwd_total = off;          // everything above is all an inference-only forward touches
+  for (int i = 0; i < 4; ++i) {
+    const size_t npix = (size_t)N * L.hs[i + 1] * L.ws[i + 1];
     L.dprep[i] = take(es * npix * 16);
     L.dside[i] = take(es * npix * kStageC[i + 1]);
   }
@@ -151,6 +155,7 @@ extern "C" {
 
 size_t osvos_net_wbuf_bytes(int dtype) { return wbuf_layout(dtype).total; }
 size_t osvos_net_ws_bytes(int N, int H, int W, int dtype) { return ws_layout(N, H, W, dtype).total; }
+size_t osvos_net_ws_bytes_infer(int N, int H, int W, int dtype) { return ws_layout(N, H, W, dtype).fwd_total; }
 
 int osvos_net_ws_query(int N, int H, int W, int dtype, int which, size_t* offset, size_t* elems, int* channels, int* h, int* w) {
   OSVOS_ARG_CHECK(which >= 0 && which <= 21 && offset && elems && channels && h && w, "ws_query: bad arguments");

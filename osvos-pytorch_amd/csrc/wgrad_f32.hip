@@ -219,28 +219,43 @@ __global__ __launch_bounds__(256, OCC) void wgrad_f32_kernel(WgArgs a) {
   }
 }
 
-// dw[co][ci][tap] (OIHW, Cin real) (+)= sum_split slab[split][co][ci_s][tap]; 64 outputs x 4 split
-// lanes per workgroup, 256-byte coalesced reads, LDS combine
+// dw[co][ci][tap] (OIHW, Cin real) (+)= sum_split slab[split][...]; one workgroup = 32 float4 columns
+// (128 consecutive slab elements) x 8 split lanes: 16-byte coalesced reads with several loads in
+// flight per thread, LDS combine, then the transposing write
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ bslab,
                                                            float* __restrict__ dw, float* __restrict__ db,
                                                            int nsplit, int Cout, int Cin, int Cin_s, int accumulate, int oihw) {
-  __shared__ float red[256];
-  const int total = Cout * Cin_s * 9;
-  const int e = threadIdx.x & 63, sl = threadIdx.x >> 6;
-  const int idx = blockIdx.x * 64 + e;
-  float s = 0.f;
-  if (idx < total)
-    for (int sp = sl; sp < nsplit; sp += 4) s += slab[(size_t)sp * total + idx];
+  __shared__ f32x4 red[256];
+  const int total = Cout * Cin_s * 9;                 // multiple of 4 (Cin_s % 4 == 0)
+  const int e = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int idx = (blockIdx.x * 32 + e) * 4;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (idx < total) {
+    const f32x4* src = reinterpret_cast<const f32x4*>(slab + idx);
+    const size_t stride4 = (size_t)total / 4;
+    int sp = sl;
+    for (; sp + 24 < nsplit; sp += 32) {              // 4 independent loads in flight
+      const f32x4 a = src[(size_t)sp * stride4], b = src[(size_t)(sp + 8) * stride4];
+      const f32x4 c = src[(size_t)(sp + 16) * stride4], d = src[(size_t)(sp + 24) * stride4];
+      s += (a + b) + (c + d);
+    }
+    for (; sp < nsplit; sp += 8) s += src[(size_t)sp * stride4];
+  }
   red[threadIdx.x] = s;
   __syncthreads();
   if (sl == 0 && idx < total) {
-    s = red[e] + red[64 + e] + red[128 + e] + red[192 + e];
-    int t, ci, co;
-    if (oihw) { t = idx % 9; ci = (idx / 9) % Cin_s; co = idx / (9 * Cin_s); }
-    else { ci = idx % Cin_s; co = (idx / Cin_s) % Cout; t = idx / (Cin_s * Cout); }
-    if (ci < Cin) {
-      float* o = dw + ((size_t)co * Cin + ci) * 9 + t;
-      *o = accumulate ? (*o + s) : s;
+#pragma unroll
+    for (int k = 1; k < 8; ++k) s += red[k * 32 + e];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = idx + q;
+      int t, ci, co;
+      if (oihw) { t = i % 9; ci = (i / 9) % Cin_s; co = i / (9 * Cin_s); }
+      else { ci = i % Cin_s; co = (i / Cin_s) % Cout; t = i / (Cin_s * Cout); }
+      if (ci < Cin) {
+        float* o = dw + ((size_t)co * Cin + ci) * 9 + t;
+        *o = accumulate ? (*o + s[q]) : s[q];
+      }
     }
   }
   if (db != nullptr && blockIdx.x == 0) {
@@ -324,7 +339,7 @@ int osvos_conv3x3_wgrad_small_f32(const float* x, const float* dy, void* ws, flo
 int osvos_wgrad_reduce_launch(const float* slab, const float* bslab, float* dw, float* db, int nsplit, int Cout, int Cin,
                               int Cin_s, int accumulate, hipStream_t stream) {
   const int total = Cout * Cin_s * 9;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(total, 64)), dim3(256), 0, stream,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(total, 128)), dim3(256), 0, stream,
                      slab, bslab, dw, db, nsplit, Cout, Cin, Cin_s, accumulate, 0);
   OSVOS_LAUNCH_CHECK();
   return 0;
@@ -364,7 +379,7 @@ int osvos_conv3x3_wgrad_f32(const float* x, const float* dy, void* ws, float* dw
   int rc = (p.cb == 1) ? launch_wgrad_variant<1, 4>(a, blocks, stream) : launch_wgrad_variant<2, 2>(a, blocks, stream);
   if (rc) return rc;
   const int total = Cout * Cin_s * 9;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(total, 64)), dim3(256), 0, stream,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(total, 128)), dim3(256), 0, stream,
                      a.slab, a.bslab, dw, db, p.nsplit, Cout, Cin, Cin_s, accumulate, a.oihw);
   OSVOS_LAUNCH_CHECK();
   return 0;

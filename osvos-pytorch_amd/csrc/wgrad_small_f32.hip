@@ -136,19 +136,25 @@ __global__ __launch_bounds__(256, 2) void wgrad_c3_f32_kernel(C3Args a) {
     a.bslab[(size_t)split * 64 + tid] = bred[tid] + bred[64 + tid] + bred[128 + tid] + bred[192 + tid];
 }
 
-__global__ void wgrad_c3_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ bslab,
-                                       float* __restrict__ dw, float* __restrict__ db, int nsplit, int Cout, int accumulate) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;      // co*27 + ci*9 + tap  (OIHW with Cin = 3)
+// one wave per 4 outputs: lanes stride over the splits, shuffle-reduce (405 splits x 1728 outputs would
+// otherwise be 405 sequential loads per thread)
+__global__ __launch_bounds__(256) void wgrad_c3_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ bslab,
+                                                              float* __restrict__ dw, float* __restrict__ db, int nsplit, int Cout,
+                                                              int accumulate) {
+  const int lane = threadIdx.x & 63;
+  const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);      // co*27 + ci*9 + tap (OIHW, Cin = 3); then Cout bias sums
   if (idx < Cout * 27) {
     const int co = idx / 27, rem = idx % 27, ci = rem / 9, tap = rem % 9;
     float s = 0.f;
-    for (int sp = 0; sp < nsplit; ++sp) s += slab[((size_t)sp * 64 + co) * 32 + tap * 3 + ci];
-    dw[idx] = accumulate ? dw[idx] + s : s;
-  }
-  if (db != nullptr && idx < Cout) {
+    for (int sp = lane; sp < nsplit; sp += 64) s += slab[((size_t)sp * 64 + co) * 32 + tap * 3 + ci];
+    s = wave_sum(s);
+    if (lane == 0) dw[idx] = accumulate ? dw[idx] + s : s;
+  } else if (db != nullptr && idx < Cout * 27 + Cout) {
+    const int co = idx - Cout * 27;
     float s = 0.f;
-    for (int sp = 0; sp < nsplit; ++sp) s += bslab[(size_t)sp * 64 + idx];
-    db[idx] = accumulate ? db[idx] + s : s;
+    for (int sp = lane; sp < nsplit; sp += 64) s += bslab[(size_t)sp * 64 + co];
+    s = wave_sum(s);
+    if (lane == 0) db[co] = accumulate ? db[co] + s : s;
   }
 }
 
@@ -284,7 +290,7 @@ struct SmallPlan {
 SmallPlan plan_c3(int N, int H, int W) {
   SmallPlan p;
   p.npx = ceil_div(W, PW); p.npy = ceil_div(H, C3_PH); p.npatches = N * p.npx * p.npy; p.nci_t = 1;
-  int want = 512;
+  int want = 256;    // runs on the aux stream next to the dgrad chain: fewer, longer splits, smaller slabs
   if (want > p.npatches) want = p.npatches;
   p.per_split = ceil_div(p.npatches, want);
   p.nsplit = ceil_div(p.npatches, p.per_split);
@@ -297,7 +303,7 @@ SmallPlan plan_co16(int N, int H, int W, int Cin_s) {
   SmallPlan p;
   p.npx = ceil_div(W, PW); p.npy = ceil_div(H, S_PH); p.npatches = N * p.npx * p.npy;
   p.nci_t = ceil_div(Cin_s, S_BCI);
-  int want = ceil_div(512, p.nci_t);
+  int want = ceil_div(256, p.nci_t);
   const int max_split = p.npatches / 4 > 0 ? p.npatches / 4 : 1;
   if (want > max_split) want = max_split;
   p.per_split = ceil_div(p.npatches, want);
@@ -346,7 +352,7 @@ int osvos_conv3x3_wgrad_small_f32(const float* x, const float* dy, void* ws, flo
     }
     hipLaunchKernelGGL(wgrad_c3_f32_kernel, dim3(p.nsplit), dim3(256), lds, stream, a);
     OSVOS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(wgrad_c3_reduce_kernel, dim3(ceil_div(Cout * 27, 256)), dim3(256), 0, stream,
+    hipLaunchKernelGGL(wgrad_c3_reduce_kernel, dim3(ceil_div(Cout * 28, 4)), dim3(256), 0, stream,
                        a.slab, a.bslab, dw, db, p.nsplit, Cout, accumulate);
     OSVOS_LAUNCH_CHECK();
     return 0;
