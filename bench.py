@@ -168,6 +168,9 @@ def main():
     ap.add_argument("--mode", default="online", choices=["online", "parent", "infer"],
                     help="online/parent: restated training loops (fwd+loss+bwd+SGD); infer: forward only under no_grad "
                          "(BASELINE.json configs[4]: use --height 1080 --width 1920 --batch 4 --graph 1)")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
+                    help="bf16: conv forward/data-gradient on bf16 MFMA operands (fp32 accumulate, fp32 tensors); "
+                         "the headline configs[1] is fp32")
     ap.add_argument("--graph", type=int, default=0, help="infer mode: replay the forward from a captured hipGraph")
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--width", type=int, default=854)
@@ -198,6 +201,7 @@ def main():
 
     n_ave = args.n_ave_grad or (5 if args.mode == "online" else 10)
     net, x, gt = synth_problem(args.batch, args.height, args.width, device, seed=rank)
+    net.set_precision(args.precision)
     opt = make_optimizer(net, "online" if args.mode == "infer" else args.mode)
     reducer = GradientAllReducer(net, average=True) if world > 1 else None
     running = torch.zeros((), device=device)
@@ -311,7 +315,8 @@ def main():
                       "frames/sec (forward only) OSVOS-VGG16 %dx%d" % (args.width, args.height),
             "value": round(value, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "bf16 MFMA operands (fwd+dgrad), f32 accumulate/tensors/wgrad",
+            "data": "synthetic",
             "config": {"workload": ("%dx%d batch=%d inference forward (train_online.py:172-181), no_grad, %s, fp32, frames resident in HBM"
                                     % (args.width, args.height, args.batch, "hipGraph replay" if args.graph else "eager launches"))
                        if args.mode == "infer" else

@@ -25,7 +25,9 @@ extern "C" {
 
 #define OSVOS_ABI_VERSION 1
 #define OSVOS_F32 0
-#define OSVOS_BF16 1
+#define OSVOS_BF16 1          /* bf16 tensors in HBM: reserved, not built */
+#define OSVOS_F32_BF16MFMA 2  /* fp32 tensors in HBM; conv forward/data-gradient operands rounded to bf16 (RNE) while
+                                 staged into LDS, v_mfma_f32_32x32x16_bf16 with fp32 accumulate; everything else fp32 */
 #define OSVOS_NPARAMS 52 /* tensors of OSVOS.state_dict(), reference order */
 
 int osvos_version(void);

@@ -8,7 +8,7 @@ import os
 
 import torch
 
-from ._lib import F32, NPARAMS, check, lib, ptr_array
+from ._lib import F32, F32_BF16MFMA, NPARAMS, check, lib, ptr_array
 
 # indices (state_dict order) of the frozen transposed-conv weights: lr 0 in both reference
 # scripts (train_online.py:84-85, train_parent.py:99-100); their gradients are never formed
@@ -27,7 +27,9 @@ class NetRuntime:
         self.wbuf = None
         self.key = None
         self.deconv_key = None
-        self.dtype = F32
+        # 'fp32' (exact fp32 MFMA everywhere) or 'bf16' (conv forward / data-gradient operands rounded to bf16,
+        # fp32 accumulate and fp32 tensors; weight gradients, head and loss stay fp32)
+        self.dtype = F32_BF16MFMA if os.environ.get("OSVOS_PRECISION", "fp32").lower() == "bf16" else F32
         self.aux_stream = None        # second HIP stream: wgrad kernels overlap the dgrad kernels
         self.two_streams = os.environ.get("OSVOS_TWO_STREAMS", "1") != "0"
         self.inplace_accumulate = os.environ.get("OSVOS_INPLACE_GRAD", "1") != "0"
@@ -38,6 +40,11 @@ class NetRuntime:
         if self.aux_stream is None or self.aux_stream.device != device:
             self.aux_stream = torch.cuda.Stream(device=device)
         return C.c_void_p(self.aux_stream.cuda_stream)
+
+    def set_precision(self, name):
+        dt = {"fp32": F32, "bf16": F32_BF16MFMA}[name]
+        if dt != self.dtype:
+            self.dtype, self.wbuf, self.key = dt, None, None
 
     def ensure_packed(self, params):
         dev = params[0].device

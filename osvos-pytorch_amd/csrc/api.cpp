@@ -2,8 +2,10 @@
 // points declared in include/osvos_hip.h.  (The whole-network calls live in net.cpp.)
 #include "kernels.h"
 
+// fp32 tensors in HBM for both built dtypes (OSVOS_F32 and OSVOS_F32_BF16MFMA); only the conv / pack entry
+// points behave differently for the latter
 #define NEED_F32(dtype, what)                                                                     \
-  OSVOS_ARG_CHECK((dtype) == OSVOS_F32, "%s: dtype %d not built (this build ships the fp32 path)", what, (int)(dtype))
+  OSVOS_ARG_CHECK(osvos_dtype_built(dtype), "%s: dtype %d not built (fp32 tensors only)", what, (int)(dtype))
 
 extern "C" {
 
@@ -17,23 +19,30 @@ int osvos_nhwc_to_nchw(const void* src, float* dst, int N, int C, int H, int W, 
 }
 
 size_t osvos_wpack_bytes(int Cout, int Cin, int dtype) {
+  if (dtype == OSVOS_F32_BF16MFMA) return (size_t)9 * ((Cin + 31) / 32 * 32) * osvos_cout_pad(Cout) * 2;
   return (size_t)9 * osvos_cin_pad(Cin, dtype) * osvos_cout_pad(Cout) * osvos_elem(dtype);
 }
 size_t osvos_wpack_dgrad_bytes(int Cout, int Cin, int dtype) {
+  if (dtype == OSVOS_F32_BF16MFMA) return (size_t)9 * ((Cout + 31) / 32 * 32) * osvos_cout_pad(Cin) * 2;
   return (size_t)9 * osvos_cin_pad(Cout, dtype) * osvos_cout_pad(Cin) * osvos_elem(dtype);
 }
 int osvos_pack_conv3x3_fwd(const float* w, void* wpk, int Cout, int Cin, int dtype, void* stream) {
   NEED_F32(dtype, "pack_conv3x3_fwd");
+  if (dtype == OSVOS_F32_BF16MFMA) return osvos_pack_fwd_bf16(w, wpk, Cout, Cin, (hipStream_t)stream);
   return osvos_pack_fwd_f32(w, (float*)wpk, Cout, Cin, (hipStream_t)stream);
 }
 int osvos_pack_conv3x3_dgrad(const float* w, void* wpk, int Cout, int Cin, int dtype, void* stream) {
   NEED_F32(dtype, "pack_conv3x3_dgrad");
+  if (dtype == OSVOS_F32_BF16MFMA) return osvos_pack_dgrad_bf16(w, wpk, Cout, Cin, (hipStream_t)stream);
   return osvos_pack_dgrad_f32(w, (float*)wpk, Cout, Cin, (hipStream_t)stream);
 }
 
 int osvos_conv3x3(const void* x, const void* wpk, const float* bias, const void* mask, void* y,
                   int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int dtype, int tile, void* stream) {
   NEED_F32(dtype, "conv3x3");
+  if (dtype == OSVOS_F32_BF16MFMA)
+    return osvos_conv3x3_bf16mfma((const float*)x, wpk, bias, (const float*)mask, (float*)y, N, H, W, Cin, Cout, y_cs, relu, tile,
+                                  (hipStream_t)stream);
   return osvos_conv3x3_f32((const float*)x, (const float*)wpk, bias, (const float*)mask, (float*)y,
                            N, H, W, Cin, Cout, y_cs, relu, tile, (hipStream_t)stream);
 }

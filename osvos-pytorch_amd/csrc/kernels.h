@@ -23,3 +23,10 @@ int osvos_head_bwd_f32(const float* prep, const float* dside, const float* dfuse
 #define OSVOS_HEAD_MAX_BLOCKS 64
 int osvos_head_bwd_blocks(int N, int h, int w, int scale_idx);   // workgroups (= partial rows of 34 doubles) head_bwd launches
 int osvos_sum_partials(const float* x, long count, double* part, int* nblocks, hipStream_t stream);
+
+// bf16-operand MFMA variant of the convolution (fp32 tensors): conv3x3_bf16.hip
+int osvos_pack_fwd_bf16(const float* w, void* wpk, int Cout, int Cin, hipStream_t stream);
+int osvos_pack_dgrad_bf16(const float* w, void* wpk, int Cout, int Cin, hipStream_t stream);
+int osvos_conv3x3_bf16mfma(const float* x, const void* wpk, const float* bias, const float* mask, float* y,
+                           int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int tile, hipStream_t stream);
+int osvos_conv3x3_bf16mfma_num_tiles(void);

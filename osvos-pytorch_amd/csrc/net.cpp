@@ -176,7 +176,7 @@ int osvos_net_ws_query(int N, int H, int W, int dtype, int which, size_t* offset
 int osvos_net_pack(const float* const* params, void* wbuf, int dtype, int with_dgrad, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   OSVOS_ARG_CHECK(params && wbuf, "net_pack: null pointer");
-  OSVOS_ARG_CHECK(dtype == OSVOS_F32, "net_pack: dtype %d not built", dtype);
+  OSVOS_ARG_CHECK(osvos_dtype_built(dtype), "net_pack: dtype %d not built", dtype);
   for (int i = 0; i < OSVOS_NPARAMS; ++i) OSVOS_ARG_CHECK(params[i] != nullptr, "net_pack: params[%d] is null", i);
   WbufLayout L = wbuf_layout(dtype);
   ConvDesc d[kNumConv];
@@ -213,7 +213,7 @@ int osvos_net_forward(const float* x_nchw, const void* wbuf, void* ws, float* co
   const bool two = aux != stream;
   EventPool& evp = event_pool();
   OSVOS_ARG_CHECK(x_nchw && wbuf && ws && outs, "net_forward: null pointer");
-  OSVOS_ARG_CHECK(dtype == OSVOS_F32, "net_forward: dtype %d not built", dtype);
+  OSVOS_ARG_CHECK(osvos_dtype_built(dtype), "net_forward: dtype %d not built", dtype);
   OSVOS_ARG_CHECK(N > 0 && H > 0 && W > 0, "net_forward: bad shape %dx%dx%d", N, H, W);
   for (int i = 0; i < 5; ++i) OSVOS_ARG_CHECK(outs[i] != nullptr, "net_forward: outs[%d] is null", i);
   const WbufLayout P = wbuf_layout(dtype);
@@ -297,7 +297,7 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
     OSVOS_HIP_CHECK(hipStreamWaitEvent(stream, e, 0));
     return 0;
   };
-  OSVOS_ARG_CHECK(dtype == OSVOS_F32, "net_backward: dtype %d not built", dtype);
+  OSVOS_ARG_CHECK(osvos_dtype_built(dtype), "net_backward: dtype %d not built", dtype);
   const WbufLayout P = wbuf_layout(dtype);
   const WsLayout L = ws_layout(N, H, W, dtype);
   ConvDesc d[kNumConv];

@@ -73,6 +73,12 @@ class OSVOS(nn.Module):
         outs = OSVOSNetFunction.apply(self._runtime, x, *self.parameters())
         return list(outs)
 
+    def set_precision(self, name):
+        """'fp32' (default, reference-exact arithmetic) or 'bf16' (bf16 MFMA operands for the conv forward and
+        data-gradient kernels, fp32 accumulate, fp32 tensors).  Not part of the reference's API."""
+        self._runtime.set_precision(name)
+        return self
+
     def _initialize_weights(self, pretrained):
         for m in self.modules():
             if isinstance(m, nn.Conv2d):

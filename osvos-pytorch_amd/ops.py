@@ -10,7 +10,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import F32, check, lib, ptr_array
+from ._lib import F32, F32_BF16MFMA, check, lib, ptr_array
 
 
 def _stream():
@@ -44,32 +44,32 @@ def nhwc_to_nchw(x, c):
     return y
 
 
-def pack_fwd(w_oihw):
+def pack_fwd(w_oihw, dtype=F32):
     _need_cuda(w_oihw)
     w = w_oihw.contiguous().float()
     cout, cin = w.shape[:2]
-    buf = torch.empty(lib().osvos_wpack_bytes(cout, cin, F32) // 4, device=w.device, dtype=torch.float32)
-    check(lib().osvos_pack_conv3x3_fwd(_p(w), _p(buf), cout, cin, F32, _stream()), "pack_fwd")
+    buf = torch.empty(lib().osvos_wpack_bytes(cout, cin, dtype) // 4, device=w.device, dtype=torch.float32)
+    check(lib().osvos_pack_conv3x3_fwd(_p(w), _p(buf), cout, cin, dtype, _stream()), "pack_fwd")
     return buf
 
 
-def pack_dgrad(w_oihw):
+def pack_dgrad(w_oihw, dtype=F32):
     _need_cuda(w_oihw)
     w = w_oihw.contiguous().float()
     cout, cin = w.shape[:2]
-    buf = torch.empty(lib().osvos_wpack_dgrad_bytes(cout, cin, F32) // 4, device=w.device, dtype=torch.float32)
-    check(lib().osvos_pack_conv3x3_dgrad(_p(w), _p(buf), cout, cin, F32, _stream()), "pack_dgrad")
+    buf = torch.empty(lib().osvos_wpack_dgrad_bytes(cout, cin, dtype) // 4, device=w.device, dtype=torch.float32)
+    check(lib().osvos_pack_conv3x3_dgrad(_p(w), _p(buf), cout, cin, dtype, _stream()), "pack_dgrad")
     return buf
 
 
-def conv3x3(x, wpk, bias, cout, relu=False, mask=None, y_cs=None, tile=-1):
+def conv3x3(x, wpk, bias, cout, relu=False, mask=None, y_cs=None, tile=-1, dtype=F32):
     """x [N,H,W,Cin] (Cin % 8 == 0), wpk from pack_fwd / pack_dgrad -> [N,H,W,y_cs]."""
     _need_cuda(x, wpk, bias, mask)
     n, h, w, cin = x.shape
     y_cs = y_cs or cout
     y = torch.zeros((n, h, w, y_cs), device=x.device, dtype=torch.float32) if y_cs != cout else \
         torch.empty((n, h, w, y_cs), device=x.device, dtype=torch.float32)
-    check(lib().osvos_conv3x3(_p(x), _p(wpk), _p(bias), _p(mask), _p(y), n, h, w, cin, cout, y_cs, int(relu), F32, tile, _stream()), "conv3x3")
+    check(lib().osvos_conv3x3(_p(x), _p(wpk), _p(bias), _p(mask), _p(y), n, h, w, cin, cout, y_cs, int(relu), dtype, tile, _stream()), "conv3x3")
     return y
 
 

@@ -181,3 +181,46 @@ def test_fused_sgd_matches_torch():
         opt.step()
         ops.sgd_step(pg, gr.cuda(), buf, 1e-2, 0.9, 2e-4, it == 0)
     np.testing.assert_allclose(pg.cpu().numpy(), ref.detach().numpy(), rtol=1e-6, atol=1e-7)
+
+
+BF16_SHAPES = [(1, 9, 11, 8, 32), (2, 17, 35, 16, 64), (1, 33, 70, 64, 128), (1, 8, 8, 24, 16), (1, 40, 45, 32, 96), (1, 20, 24, 96, 64)]
+
+
+@pytest.mark.parametrize("shape", BF16_SHAPES)
+@pytest.mark.parametrize("tile", list(range(8)) + [100, 106, -1])
+def test_conv3x3_bf16_mfma_forward_all_tiles(shape, tile):
+    """bf16-operand path: with inputs that are already bf16-representable the only difference to a float64
+    convolution is the fp32 accumulation order -> tight tolerance; this pins layout/indexing, not precision"""
+    from osvos_pytorch_amd._lib import F32_BF16MFMA
+    ops = _ops()
+    n, h, w, cin, cout = shape
+    g = torch.Generator().manual_seed(hash(shape) % 1000 + 17)
+    x = torch.randn(n, cin, h, w, generator=g).bfloat16().float()
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)).bfloat16().float()
+    b = torch.randn(cout, generator=g)
+    ref = F.relu(F.conv2d(x.double(), wt.double(), b.double(), padding=1))
+    y = ops.conv3x3(nhwc(x), ops.pack_fwd(wt.cuda(), F32_BF16MFMA), b.cuda(), cout, relu=True, tile=tile, dtype=F32_BF16MFMA)
+    emax, el2 = rel_err(nchw(y), ref)
+    assert emax < 3e-5 and el2 < 1e-5, (shape, tile, emax, el2)
+
+
+def test_conv3x3_bf16_mfma_rounding_and_dgrad():
+    """unrounded fp32 inputs: result equals the convolution of the RNE-bf16-rounded operands; the data-gradient pack
+    (rotated / transposed filter) goes through the same kernel"""
+    from osvos_pytorch_amd._lib import F32_BF16MFMA
+    ops = _ops()
+    g = torch.Generator().manual_seed(23)
+    n, h, w, cin, cout = 2, 19, 27, 64, 32
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / 24
+    ref = F.conv2d(x.bfloat16().double(), wt.bfloat16().double(), None, padding=1)
+    y = ops.conv3x3(nhwc(x), ops.pack_fwd(wt.cuda(), F32_BF16MFMA), None, cout, dtype=F32_BF16MFMA)
+    assert rel_err(nchw(y), ref)[0] < 3e-5
+    exact = F.conv2d(x.double(), wt.double(), None, padding=1)
+    assert 1e-4 < rel_err(nchw(y), exact)[1] < 2e-2          # it really is bf16 arithmetic
+    dy = torch.randn(n, cout, h, w, generator=g)
+    xr = x.double().requires_grad_()
+    F.conv2d(xr, wt.bfloat16().double(), None, padding=1).backward(dy.bfloat16().double())
+    m = torch.randn(n, cin, h, w, generator=g)
+    dx = ops.conv3x3(nhwc(dy), ops.pack_dgrad(wt.cuda(), F32_BF16MFMA), None, cin, mask=nhwc(m), dtype=F32_BF16MFMA)
+    assert rel_err(nchw(dx), xr.grad * (m > 0))[0] < 3e-5
