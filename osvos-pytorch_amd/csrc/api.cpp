@@ -48,13 +48,19 @@ int osvos_conv3x3(const void* x, const void* wpk, const float* bias, const void*
 }
 
 size_t osvos_wgrad_ws_bytes(int N, int H, int W, int Cin, int Cout, int dtype) {
-  (void)dtype;
-  return osvos_wgrad_ws_bytes_f32(N, H, W, Cin, Cout);
+  const size_t f = osvos_wgrad_ws_bytes_f32(N, H, W, Cin, Cout);
+  const size_t b = dtype == OSVOS_F32_BF16MFMA ? osvos_wgrad_bf16_ws_bytes(N, H, W, Cin, Cout) : 0;
+  return f > b ? f : b;
 }
 int osvos_conv3x3_wgrad(const void* x, const void* dy, void* ws, float* dw, float* db,
                         int N, int H, int W, int Cin, int Cin_s, int Cout, int Cout_s,
                         int accumulate, int dtype, void* stream) {
   NEED_F32(dtype, "conv3x3_wgrad");
+  // the wide trunk layers go through the bf16 MFMA kernel; conv1_1 (Cin 3) and side_prep (Cout 16) keep
+  // their exact-fp32 skinny kernels (5 % of the weight-gradient FLOPs)
+  if (dtype == OSVOS_F32_BF16MFMA && Cin == Cin_s && osvos_wgrad_bf16_applicable(Cin_s, Cout))
+    return osvos_conv3x3_wgrad_bf16mfma((const float*)x, (const float*)dy, ws, dw, db, N, H, W, Cin, Cin_s, Cout, Cout_s,
+                                        accumulate, (hipStream_t)stream);
   return osvos_conv3x3_wgrad_f32((const float*)x, (const float*)dy, ws, dw, db, N, H, W, Cin, Cin_s, Cout, Cout_s,
                                  accumulate, (hipStream_t)stream);
 }

@@ -30,3 +30,10 @@ int osvos_pack_dgrad_bf16(const float* w, void* wpk, int Cout, int Cin, hipStrea
 int osvos_conv3x3_bf16mfma(const float* x, const void* wpk, const float* bias, const float* mask, float* y,
                            int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int tile, hipStream_t stream);
 int osvos_conv3x3_bf16mfma_num_tiles(void);
+
+// bf16-operand weight gradient (fp32 tensors): wgrad_bf16.hip
+bool osvos_wgrad_bf16_applicable(int Cin_s, int Cout);
+size_t osvos_wgrad_bf16_ws_bytes(int N, int H, int W, int Cin_s, int Cout);
+int osvos_conv3x3_wgrad_bf16mfma(const float* x, const float* dy, void* ws, float* dw, float* db,
+                                 int N, int H, int W, int Cin, int Cin_s, int Cout, int Cout_s,
+                                 int accumulate, hipStream_t stream);

@@ -1,0 +1,269 @@
+// 3x3 convolution weight gradient with bf16 MFMA operands (dtype OSVOS_F32_BF16MFMA): fp32 NHWC
+// tensors in HBM, operands rounded to bf16 (RNE) and TRANSPOSED while they are staged into LDS, fp32
+// accumulation in v_mfma_f32_32x32x16_bf16, fp32 slabs + the shared deterministic reduce.
+//
+// The reduction index k of D[co][ci] += sum_k dY[k][co] * X[k + tap][ci] is the PIXEL axis, and a bf16
+// MFMA wants 8 consecutive k per lane, so both tiles live in LDS channel-major: [channel][row][x] with
+// x contiguous (one lane = one ds_read_b128 = 8 pixels of one channel).  The transposition happens in
+// registers on the way in: a thread loads 8 pixels x 4 channels (8 coalesced float4 loads) and stores
+// 4 x 16 bytes.  Channel rows are padded by 16 B so the 32 channels a wave reads hit distinct slots.
+// The horizontal tap shift (s = 0,1,2 pixels = 0,2,4 bytes) would misalign a 16-byte read; instead ONE
+// aligned 20-byte window is read per (row, k-step) and the three shifted operands are formed in
+// registers (s = 1: four v_alignbit, s = 0 / 2: plain register selection).
+// Workgroup tile: 64 couts x 64 cins x 9 taps; wave (wc, wi) owns couts 32*wc..+31, cins 32*wi..+31:
+// 9 accumulators, 1 A read + 6 B reads + 12 VALU per 9 MFMAs (a 128-cout tile with 18 accumulators
+// per wave spills: 288 accumulator + 128 staging registers).
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+constexpr int PW = 32, PH = 4, PPIX = PW * PH;
+constexpr int BCO = 64, BCI = 64;
+constexpr int XROWS = PH + 2, XPITCH = 40;                 // halo rows; 40 px (80 B) per row: 5 groups of 8
+constexpr int DY_CSTRIDE = PH * PW * 2 + 16;               // bytes per cout row (+16 B pad -> conflict-free b128 columns)
+constexpr int X_CSTRIDE = XROWS * XPITCH * 2 + 16;         // bytes per cin row
+constexpr int DY_BYTES = BCO * DY_CSTRIDE, X_BYTES = BCI * X_CSTRIDE;
+constexpr int DY_ITEMS = (PPIX / 8) * (BCO / 4);           // (pixel group of 8) x (channel quad): 512
+constexpr int X_ITEMS = XROWS * (XPITCH / 8) * (BCI / 4);  // 480
+constexpr int NDY = DY_ITEMS / 256, NX = (X_ITEMS + 255) / 256;
+
+struct WbArgs {
+  const float* x;
+  const float* dy;
+  float* slab;
+  float* bslab;
+  int N, H, W, Cin_s, Cout, Cout_s;
+  int npx, npy, npatches, per_split, nco_t, nci_t;
+};
+
+__device__ inline unsigned pack2(float lo, float hi) {
+  typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+  bf2 v;
+  v[0] = (__bf16)lo;
+  v[1] = (__bf16)hi;
+  return __builtin_bit_cast(unsigned, v);
+}
+
+__global__ __launch_bounds__(256) void wgrad_bf16_kernel(WbArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* dYs = smem;
+  char* Xs = smem + DY_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wc = wave >> 1, wi = wave & 1;
+
+  int id = blockIdx.x;
+  const int cit = id % a.nci_t;
+  id /= a.nci_t;
+  const int cot = id % a.nco_t;
+  const int split = id / a.nco_t;
+  const int co0 = cot * BCO, ci0 = cit * BCI;
+  const int p_begin = split * a.per_split, p_end = min(p_begin + a.per_split, a.npatches);
+
+  // staging items: item = tid + 256*u -> (group, quad); quad is the same for every u (256 % 16 == 0)
+  const int dq = tid & 15;           // cout quad of this thread's dY item
+  const int xq = tid & 15;           // cin quad of this thread's X items
+  f32x4 rdy[NDY][8], rx[NX][8];
+  f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+  auto load_patch = [&](int p) {
+    const int px = p % a.npx;
+    int t = p / a.npx;
+    const int py = t % a.npy;
+    const int n = t / a.npy;
+    const int x0 = px * PW, y0 = py * PH;
+#pragma unroll
+    for (int u = 0; u < NDY; ++u) {
+      const int grp = (tid >> 4) + 16 * u;                 // 0..15: row = grp / 4, x group = grp % 4
+      const int gy = y0 + (grp >> 2), gx0 = x0 + (grp & 3) * 8, co = co0 + 4 * dq;
+      const bool ok = gy < a.H && co < a.Cout;
+      const float* src = a.dy + ((size_t)(n * a.H + gy) * a.W + gx0) * a.Cout_s + co;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (ok && gx0 + j < a.W) v = *reinterpret_cast<const f32x4*>(src + (size_t)j * a.Cout_s);
+        rdy[u][j] = v;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < NX; ++u) {
+      const int it = tid + 256 * u;
+      const int grp = it >> 4;                             // 0..29: halo row = grp / 5, x group = grp % 5
+      const int hy = grp / 5, hg = grp % 5;
+      const int gy = y0 + hy - 1, gx0 = x0 + hg * 8 - 1, ci = ci0 + 4 * xq;
+      const bool ok = it < X_ITEMS && gy >= 0 && gy < a.H && ci < a.Cin_s;
+      const float* src = a.x + ((size_t)(n * a.H + gy) * a.W + gx0) * a.Cin_s + ci;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (ok && gx0 + j >= 0 && gx0 + j < a.W && hg * 8 + j < PW + 2) v = *reinterpret_cast<const f32x4*>(src + (ptrdiff_t)j * a.Cin_s);
+        rx[u][j] = v;
+      }
+    }
+  };
+  auto store_patch = [&]() {
+#pragma unroll
+    for (int u = 0; u < NDY; ++u) {
+      const int grp = (tid >> 4) + 16 * u;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) bsum += rdy[u][j];        // bias gradient: exact fp32 column sums of dY
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        uint4 v;
+        v.x = pack2(rdy[u][0][c], rdy[u][1][c]);
+        v.y = pack2(rdy[u][2][c], rdy[u][3][c]);
+        v.z = pack2(rdy[u][4][c], rdy[u][5][c]);
+        v.w = pack2(rdy[u][6][c], rdy[u][7][c]);
+        *reinterpret_cast<uint4*>(dYs + (4 * dq + c) * DY_CSTRIDE + grp * 16) = v;       // [co][row*32 + x]
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < NX; ++u) {
+      const int it = tid + 256 * u;
+      if (it < X_ITEMS) {
+        const int grp = it >> 4;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          uint4 v;
+          v.x = pack2(rx[u][0][c], rx[u][1][c]);
+          v.y = pack2(rx[u][2][c], rx[u][3][c]);
+          v.z = pack2(rx[u][4][c], rx[u][5][c]);
+          v.w = pack2(rx[u][6][c], rx[u][7][c]);
+          *reinterpret_cast<uint4*>(Xs + (4 * xq + c) * X_CSTRIDE + grp * 16) = v;        // [ci][hrow*40 + hx]
+        }
+      }
+    }
+  };
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  const char* a_base = dYs + (wc * 32 + li) * DY_CSTRIDE + lh * 16;
+  const char* b_base = Xs + (wi * 32 + li) * X_CSTRIDE + lh * 16;
+
+  if (p_begin < p_end) load_patch(p_begin);
+  for (int p = p_begin; p < p_end; ++p) {
+    __syncthreads();
+    store_patch();
+    __syncthreads();
+    if (p + 1 < p_end) load_patch(p + 1);
+#pragma unroll 1
+    for (int ks = 0; ks < PH * 2; ++ks) {                  // k-step = 16 consecutive pixels of one patch row
+      const int row = ks >> 1, kx = ks & 1;
+      const uint4 a0 = *reinterpret_cast<const uint4*>(a_base + (row * PW + kx * 16) * 2);
+      uint4 w0[3];
+      unsigned w4[3];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const char* src = b_base + ((row + r) * XPITCH + kx * 16) * 2;
+        w0[r] = *reinterpret_cast<const uint4*>(src);
+        w4[r] = *reinterpret_cast<const unsigned*>(src + 16);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        uint4 b[3];
+        b[0] = w0[r];
+        b[1].x = __builtin_amdgcn_alignbit(w0[r].y, w0[r].x, 16);
+        b[1].y = __builtin_amdgcn_alignbit(w0[r].z, w0[r].y, 16);
+        b[1].z = __builtin_amdgcn_alignbit(w0[r].w, w0[r].z, 16);
+        b[1].w = __builtin_amdgcn_alignbit(w4[r], w0[r].w, 16);
+        b[2].x = w0[r].y; b[2].y = w0[r].z; b[2].z = w0[r].w; b[2].w = w4[r];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+          const bf16x8_t bb = __builtin_bit_cast(bf16x8_t, b[s]);
+          acc[r * 3 + s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a0), bb, acc[r * 3 + s], 0, 0, 0);
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  const int ci = ci0 + wi * 32 + li;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + wc * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (co < a.Cout && ci < a.Cin_s) a.slab[((size_t)(split * 9 + t) * a.Cout + co) * a.Cin_s + ci] = acc[t][r];
+    }
+  if (a.bslab != nullptr && cit == 0) {
+    f32x4* red = reinterpret_cast<f32x4*>(smem);          // [16 pixel-group rows][16 quads]
+    red[tid] = bsum;
+    __syncthreads();
+    if (tid < 16) {
+      f32x4 s = red[tid];
+#pragma unroll
+      for (int m = 1; m < 16; ++m) s += red[m * 16 + tid];
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (co0 + 4 * tid + c < a.Cout) a.bslab[(size_t)split * a.Cout + co0 + 4 * tid + c] = s[c];
+    }
+  }
+}
+
+struct WbPlan {
+  int nco_t, nci_t, npx, npy, npatches, nsplit, per_split;
+  size_t slab_floats, bslab_floats;
+};
+
+WbPlan make_plan(int N, int H, int W, int Cin_s, int Cout) {
+  WbPlan p;
+  p.nco_t = ceil_div(Cout, BCO);
+  p.nci_t = ceil_div(Cin_s, BCI);
+  p.npx = ceil_div(W, PW);
+  p.npy = ceil_div(H, PH);
+  p.npatches = N * p.npx * p.npy;
+  int want = ceil_div(512, p.nco_t * p.nci_t);
+  const int max_split = p.npatches / 2 > 0 ? p.npatches / 2 : 1;
+  if (want > max_split) want = max_split;
+  if (want > 256) want = 256;
+  p.per_split = ceil_div(p.npatches, want);
+  p.nsplit = ceil_div(p.npatches, p.per_split);
+  p.slab_floats = (size_t)p.nsplit * 9 * Cout * Cin_s;
+  p.bslab_floats = (size_t)p.nsplit * Cout;
+  return p;
+}
+
+}  // namespace
+
+int osvos_wgrad_reduce_launch(const float* slab, const float* bslab, float* dw, float* db, int nsplit, int Cout, int Cin,
+                              int Cin_s, int accumulate, hipStream_t stream);
+
+// shapes the bf16 kernel takes: the wide trunk layers (Cin_s, Cout multiples of 64); everything else stays on the fp32 kernels
+bool osvos_wgrad_bf16_applicable(int Cin_s, int Cout) { return Cin_s % 64 == 0 && Cout % 64 == 0; }
+
+size_t osvos_wgrad_bf16_ws_bytes(int N, int H, int W, int Cin_s, int Cout) {
+  if (!osvos_wgrad_bf16_applicable(Cin_s, Cout)) return 0;
+  WbPlan p = make_plan(N, H, W, Cin_s, Cout);
+  return align_up((p.slab_floats + p.bslab_floats) * sizeof(float), 256);
+}
+
+int osvos_conv3x3_wgrad_bf16mfma(const float* x, const float* dy, void* ws, float* dw, float* db,
+                                 int N, int H, int W, int Cin, int Cin_s, int Cout, int Cout_s,
+                                 int accumulate, hipStream_t stream) {
+  OSVOS_ARG_CHECK(x && dy && ws && dw, "wgrad bf16: null pointer");
+  OSVOS_ARG_CHECK(osvos_wgrad_bf16_applicable(Cin_s, Cout) && Cin == Cin_s && Cout_s % 4 == 0, "wgrad bf16: unsupported shape");
+  WbPlan p = make_plan(N, H, W, Cin_s, Cout);
+  WbArgs a;
+  a.x = x; a.dy = dy;
+  a.slab = reinterpret_cast<float*>(ws);
+  a.bslab = db ? a.slab + p.slab_floats : nullptr;
+  a.N = N; a.H = H; a.W = W; a.Cin_s = Cin_s; a.Cout = Cout; a.Cout_s = Cout_s;
+  a.npx = p.npx; a.npy = p.npy; a.npatches = p.npatches; a.per_split = p.per_split; a.nco_t = p.nco_t; a.nci_t = p.nci_t;
+  constexpr size_t lds = (size_t)DY_BYTES + X_BYTES;
+  static bool attr_set = false;
+  if (!attr_set) {
+    OSVOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  const long blocks = (long)p.nsplit * p.nco_t * p.nci_t;
+  hipLaunchKernelGGL(wgrad_bf16_kernel, dim3((unsigned)blocks), dim3(256), lds, stream, a);
+  OSVOS_LAUNCH_CHECK();
+  return osvos_wgrad_reduce_launch(a.slab, a.bslab, dw, db, p.nsplit, Cout, Cin, Cin_s, accumulate, stream);
+}

@@ -73,12 +73,12 @@ def conv3x3(x, wpk, bias, cout, relu=False, mask=None, y_cs=None, tile=-1, dtype
     return y
 
 
-def conv3x3_wgrad(x, dy, cin, cout, want_bias=True, accumulate_into=None):
+def conv3x3_wgrad(x, dy, cin, cout, want_bias=True, accumulate_into=None, dtype=F32):
     """x [N,H,W,Cin_s], dy [N,H,W,Cout_s] -> (dW [cout,cin,3,3], db [cout])."""
     _need_cuda(x, dy)
     n, h, w, cin_s = x.shape
     cout_s = dy.shape[3]
-    ws = torch.empty(lib().osvos_wgrad_ws_bytes(n, h, w, cin_s, cout, F32), device=x.device, dtype=torch.uint8)
+    ws = torch.empty(lib().osvos_wgrad_ws_bytes(n, h, w, cin_s, cout, dtype), device=x.device, dtype=torch.uint8)
     if accumulate_into is not None:
         dw, db = accumulate_into
         acc = 1
@@ -86,7 +86,7 @@ def conv3x3_wgrad(x, dy, cin, cout, want_bias=True, accumulate_into=None):
         dw = torch.empty((cout, cin, 3, 3), device=x.device, dtype=torch.float32)
         db = torch.empty((cout,), device=x.device, dtype=torch.float32) if want_bias else None
         acc = 0
-    check(lib().osvos_conv3x3_wgrad(_p(x), _p(dy), _p(ws), _p(dw), _p(db), n, h, w, cin, cin_s, cout, cout_s, acc, F32, _stream()), "wgrad")
+    check(lib().osvos_conv3x3_wgrad(_p(x), _p(dy), _p(ws), _p(dw), _p(db), n, h, w, cin, cin_s, cout, cout_s, acc, dtype, _stream()), "wgrad")
     return dw, db
 
 

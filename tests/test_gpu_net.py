@@ -281,10 +281,13 @@ def test_bf16_mfma_precision_mode(shape):
     gt = torch.from_numpy(m).cuda()
     losses = [cbce(o, gt, size_average=False) for o in outs]
     (0.5 * sum(losses[:-1]) + losses[-1]).backward()
+    lerr = [abs(losses[i].item() - t_losses[i]) / abs(t_losses[i]) for i in range(5)]
+    aerr = [abs(a_losses[i].item() - t_losses[i]) / abs(t_losses[i]) for i in range(5)]
+    print("bf16 loss rel err (ours | torch-CPU autocast):", ["%.1e|%.1e" % (e, a) for e, a in zip(lerr, aerr)])
     for i in range(5):
         got = outs[i].detach().cpu().double().numpy()
         assert np.abs(got - t_outs[i]).max() <= 0.1 * t_outs[i].std(), (shape, i, np.abs(got - t_outs[i]).max())
-        assert abs(losses[i].item() - t_losses[i]) <= 2e-3 * abs(t_losses[i]), (i, losses[i].item(), t_losses[i])
+        assert lerr[i] <= max(2e-3, 1.5 * aerr[i]), (i, losses[i].item(), t_losses[i], a_losses[i].item())
     have = {k: v.grad.cpu().double() for k, v in net.named_parameters() if v.grad is not None}
     rep = sorted(((float((have[k] - t_grads[k]).norm() / t_grads[k].norm()), a_err[k], k) for k in have), reverse=True)
     print("bf16 gradients (ours | torch-CPU autocast) vs f64:", [(k, "%.1e" % e, "%.1e" % a) for e, a, k in rep[:8]],

@@ -224,3 +224,22 @@ def test_conv3x3_bf16_mfma_rounding_and_dgrad():
     m = torch.randn(n, cin, h, w, generator=g)
     dx = ops.conv3x3(nhwc(dy), ops.pack_dgrad(wt.cuda(), F32_BF16MFMA), None, cin, mask=nhwc(m), dtype=F32_BF16MFMA)
     assert rel_err(nchw(dx), xr.grad * (m > 0))[0] < 3e-5
+
+
+@pytest.mark.parametrize("shape", [(1, 9, 11, 64, 64), (2, 17, 35, 64, 128), (1, 33, 70, 128, 64), (1, 60, 107, 192, 128), (3, 8, 40, 64, 64)])
+def test_wgrad_bf16_mfma(shape):
+    """bf16-operand weight gradient: with bf16-representable inputs only the fp32 accumulation order differs from
+    float64 (pins the transposed staging, the in-register tap shifts and the slab layout); bias gradient is exact fp32"""
+    from osvos_pytorch_amd._lib import F32_BF16MFMA
+    ops = _ops()
+    n, h, w, cin, cout = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(n, cin, h, w, generator=g).bfloat16().float()
+    dy = torch.randn(n, cout, h, w, generator=g)
+    wt = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), wt, None, padding=1).backward(dy.bfloat16().double())
+    dw, db = ops.conv3x3_wgrad(nhwc(x), nhwc(dy), cin, cout, dtype=F32_BF16MFMA)
+    assert rel_err(dw.cpu(), wt.grad)[0] < 3e-5, shape
+    assert rel_err(db.cpu(), dy.double().sum((0, 2, 3)))[0] < 1e-5
+    dw2, _ = ops.conv3x3_wgrad(nhwc(x), nhwc(dy), cin, cout, accumulate_into=(dw.clone(), db.clone()), dtype=F32_BF16MFMA)
+    assert rel_err(dw2.cpu(), 2 * wt.grad)[0] < 3e-5
