@@ -36,6 +36,7 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+BF16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense (no 2:1 sparsity)
 # algorithmic FLOPs per 854x480 frame, SURVEY.md 8(d): 3x3 convs only, fwd + dgrad + wgrad
 GFLOP_FWD_480P = 258.229
 
@@ -276,13 +277,15 @@ def main():
     if rank == 0:
         gf_fwd = conv_gflop_forward(args.height, args.width) * args.batch
         passes = 1 if args.mode == "infer" else 3
+        peak = FP32_MFMA_PEAK_TFLOPS if args.precision == "fp32" else BF16_MFMA_PEAK_TFLOPS
+        kname = ("conv3x3_f32_kernel", "wgrad_f32_kernel") if args.precision == "fp32" else ("conv3x3_bf16_kernel", "wgrad_bf16_kernel")
         roof = None
         if args.mode == "infer" and args.graph:
             # one captured graph per step: the family is the whole forward (17 conv launches + glue)
             ach = gf_fwd / 1e3 / (elapsed / args.steps)
             act_gb = 0.904 * (args.height * args.width) / (480.0 * 854.0) * args.batch     # min conv tensor traffic, fp32
-            roof = {"bound": "mfma", "kernel": "hipGraph replay of osvos_net_forward (conv3x3_f32_kernel x17 + pool/head glue)",
-                    "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
+            roof = {"bound": "mfma", "kernel": "hipGraph replay of osvos_net_forward (%s x17 + pool/head glue)" % kname[0],
+                    "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                     "traffic": None, "algorithmic_hbm_GBps": round(act_gb / (elapsed / args.steps), 1), "hbm_peak_GBps": 8000}
         if prof and cnt[0] + cnt[1] > 0:
             # dominant kernel family: the MFMA conv kernels.  Family 0 = conv3x3_f32_kernel forward
@@ -292,14 +295,14 @@ def main():
             conv_ms = ms[0] + ms[1]
             conv_fl = fl[0] + fl[1]
             ach = conv_fl / (conv_ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": "conv3x3_f32_kernel fwd launches + (conv3x3_f32_kernel dgrad || wgrad_f32_kernel) backward regions",
-                    "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
+            roof = {"bound": "mfma", "kernel": "%s fwd launches + (%s dgrad || %s) backward regions" % (kname[0], kname[0], kname[1]),
+                    "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(ach / peak, 4),
                     "launches": int(cnt[0] + cnt[1]), "avg_launch_ms": round(conv_ms / (cnt[0] + cnt[1]), 4),
                     "algorithmic_gflop_per_launch": round(conv_fl / (cnt[0] + cnt[1]) / 1e9, 3),
                     "families": {"conv_fwd": {"ms_per_step": round(ms[0] / args.steps, 3), "tflops": round(fl[0] / (ms[0] * 1e-3) / 1e12, 2) if ms[0] else None},
                                  "conv_bwd_dgrad+wgrad": {"ms_per_step": round(ms[1] / args.steps, 3), "tflops": round(fl[1] / (ms[1] * 1e-3) / 1e12, 2) if ms[1] else None}},
-                    "step_conv_fraction_of_fp32_mfma_roofline": round(passes * gf_fwd / 1e3 / (elapsed / args.steps) / FP32_MFMA_PEAK_TFLOPS, 4),
+                    "step_conv_fraction_of_mfma_roofline": round(passes * gf_fwd / 1e3 / (elapsed / args.steps) / peak, 4),
                     # HBM-side bytes per launch from rocprofv3 --pmc (profiles/r01_pmc_conv3_2_conv1_2.txt), conv3_2 forward
                     # launch: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE; algorithmic 55.0 MB
                     "traffic": {"conv3_2_fwd_launch_MB": 94.1, "algorithmic_MB": 55.0, "source": "profiles/r01_pmc_conv3_2_conv1_2.txt"}}

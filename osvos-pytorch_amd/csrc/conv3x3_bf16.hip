@@ -261,27 +261,18 @@ template <class C>
 constexpr TileInfoB infoB() { return TileInfoB{C::TW, C::TH, C::BN, C::WM, C::WN, C::LDS_BYTES}; }
 const TileInfoB kTilesB[kNumTilesB] = {infoB<B0>(), infoB<B1>(), infoB<B2>(), infoB<B3>(), infoB<B4>(), infoB<B5>(), infoB<B6>(), infoB<B7>()};
 
+// Measured (profiles/r01_tune_bf16_*.txt): B1 (256 px x 64 couts, 4 accumulators, 2 workgroups per CU) wins
+// whenever it yields enough workgroups (up to 825 TFLOP/s on conv3_x/conv4_x at batch 12); the 8-accumulator
+// B0 tile runs one wave per SIMD and loses by 30 %; small frames fall back to 128- and 64-pixel tiles.
 int pick_tile_b(int N, int H, int W, int CoutP) {
-  // prefer the biggest tile that still yields >= 2 workgroups per CU; narrow maps (W <= 128) use 16-wide row blocks
-  const int order_wide[] = {0, 2, 1, 3, 6, 7};
-  const int order_narrow[] = {4, 5, 7, 6};
-  const int* order = W > 128 ? order_wide : order_narrow;
-  const int cnt = W > 128 ? 6 : 4;
-  int fallback = -1;
-  for (int k = 0; k < cnt; ++k) {
+  if (CoutP <= 32) return 6;
+  const int order[] = {1, 5, 7};
+  for (int k = 0; k < 3; ++k) {
     const TileInfoB& t = kTilesB[order[k]];
-    if (t.bn > CoutP && t.bn != 32) continue;
-    if (fallback < 0) fallback = order[k];
     const long tiles = (long)N * ceil_div(H, t.th) * ceil_div(W, t.tw) * ceil_div(CoutP, t.bn);
-    if (tiles >= 512) return order[k];
+    if (tiles >= 400 || k == 2) return order[k];
   }
-  // small problem: the finest tile that fits the channel count
-  for (int k = cnt - 1; k >= 0; --k) {
-    const TileInfoB& t = kTilesB[order[k]];
-    if (t.bn > CoutP && t.bn != 32) continue;
-    return order[k];
-  }
-  return fallback < 0 ? 6 : fallback;
+  return 7;
 }
 
 // wpk[((tap*CG + cg)*CoutP + co)*8 + e] = bf16(W[co][8cg+e][tap])   (zero padded)

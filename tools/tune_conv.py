@@ -16,6 +16,7 @@ ap.add_argument("--width", type=int, default=854)
 ap.add_argument("--batch", type=int, default=1)
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--tiles", default="")
+ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"])
 args = ap.parse_args()
 
 chans = [[64, 64], [128, 128], [256, 256, 256], [512, 512, 512], [512, 512, 512]]
@@ -52,8 +53,9 @@ def _peak():
     _lib.check(_lib.lib().osvos_debug_mfma_peak(C.c_void_p(_out.data_ptr()), 2048, _it, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
 ms = timeit(_peak, 3)
 print("fp32 MFMA-only probe: %.1f TFLOP/s (2048 WGs x 4 waves x %d x 4 MFMA 32x32x2)" % (2048 * 4 * _it * 4 * 2 * 32 * 32 * 2 / ms / 1e9, _it))
-ntiles = _lib.lib().osvos_conv3x3_num_tiles()
-tiles = [int(t) for t in args.tiles.split(",")] if args.tiles else [2, 3, 5, 6, 9, 102, 103, 105, 106, 109]
+DT = _lib.F32 if args.dtype == "fp32" else _lib.F32_BF16MFMA
+default_tiles = [2, 3, 5, 6, 9, 102, 103, 105, 106, 109] if args.dtype == "fp32" else [0, 1, 2, 3, 4, 5, 6, 7, 100, 102]
+tiles = [int(t) for t in args.tiles.split(",")] if args.tiles else default_tiles
 n = args.batch
 print("layer            dir   HxW       Cin->Cout  GF    | " + " ".join("t%-6d" % t for t in tiles) + " | best  TF/s  auto")
 tot = {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0}
@@ -64,16 +66,16 @@ for name, h, w, cin, cout in layers:
         kin_s = (kin + 7) // 8 * 8
         x = torch.randn(n, h, w, kin_s, device="cuda")
         wt = torch.randn(cout, cin, 3, 3, device="cuda") * 0.05
-        wpk = ops.pack_fwd(wt) if direction == "fwd" else ops.pack_dgrad(wt)
+        wpk = ops.pack_fwd(wt, DT) if direction == "fwd" else ops.pack_dgrad(wt, DT)
         ycs = kout if kout >= 8 else 4
         res = []
         for t in tiles:
             try:
-                ms = timeit(lambda: ops.conv3x3(x, wpk, None, kout, relu=(direction == "fwd"), y_cs=ycs, tile=t), args.reps)
+                ms = timeit(lambda: ops.conv3x3(x, wpk, None, kout, relu=(direction == "fwd"), y_cs=ycs, tile=t, dtype=DT), args.reps)
             except RuntimeError:
                 ms = float("nan")
             res.append(ms)
-        auto = timeit(lambda: ops.conv3x3(x, wpk, None, kout, relu=(direction == "fwd"), y_cs=ycs, tile=-1), args.reps)
+        auto = timeit(lambda: ops.conv3x3(x, wpk, None, kout, relu=(direction == "fwd"), y_cs=ycs, tile=-1, dtype=DT), args.reps)
         best = min(r for r in res if r == r)
         bi = tiles[res.index(best)]
         tot[direction] += best
@@ -81,7 +83,7 @@ for name, h, w, cin, cout in layers:
             name, direction, h, w, kin, kout, gf, " ".join("%-7.3f" % r for r in res), bi, gf / best, auto))
     x = torch.randn(n, h, w, (cin + 7) // 8 * 8, device="cuda")
     dy = torch.randn(n, h, w, cout, device="cuda")
-    ms = timeit(lambda: ops.conv3x3_wgrad(x, dy, cin, cout), args.reps)
+    ms = timeit(lambda: ops.conv3x3_wgrad(x, dy, cin, cout, dtype=DT), args.reps)
     tot["wgrad"] += ms
     print("%-16s wgrad %4dx%-4d %4d->%-4d %6.2f | %.3f ms  %.1f TF/s" % (name, h, w, cin, cout, gf, ms, gf / ms))
 print("sum of best: fwd %.3f ms, dgrad %.3f ms, wgrad %.3f ms" % (tot["fwd"], tot["dgrad"], tot["wgrad"]))
