@@ -135,9 +135,12 @@ int osvos_net_forward(const float* x_nchw, const void* wbuf, void* ws, float* co
  * dx_nchw: fp32 [N,3,H,W] or NULL.  accumulate != 0: grads += instead of overwrite.
  * aux_stream: NULL, or a second stream owned by the caller: the weight-gradient kernels are then
  *   enqueued on it, concurrently with the data-gradient kernel of the same layer (fork/join with
- *   events; everything has joined `stream` again when the call returns). */
+ *   events; everything has joined `stream` again when the call returns).
+ * aux2_stream: NULL, or a third stream for the bandwidth-bound slab reduces of the weight gradients, so they
+ *   do not sit between two MFMA weight-gradient kernels on aux_stream. */
 int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, float* const* grads,
-                       float* dx_nchw, int N, int H, int W, int dtype, int accumulate, void* stream, void* aux_stream);
+                       float* dx_nchw, int N, int H, int W, int dtype, int accumulate, void* stream, void* aux_stream,
+                       void* aux2_stream);
 /* byte offset / element count of a saved activation inside ws (tests): which = 0..12 trunk conv
  * outputs, 13..16 pooled inputs of stages 1-4, 17..20 side_prep outputs, 21 NHWC input */
 int osvos_net_ws_query(int N, int H, int W, int dtype, int which, size_t* offset, size_t* elems, int* channels, int* h, int* w);

@@ -46,7 +46,7 @@ PROTOTYPES = {
     "osvos_net_ws_bytes_infer": (_sz, [_i, _i, _i, _i]),
     "osvos_net_pack": (_i, [_vp, _vp, _i, _i, _vp]),
     "osvos_net_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
-    "osvos_net_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "osvos_net_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "osvos_net_ws_query": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "osvos_sgd_step": (_i, [_vp, _vp, _vp, _l, _f, _f, _f, _i, _vp]),
     "osvos_prof_start": (_i, [_i]),

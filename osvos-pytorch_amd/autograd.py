@@ -31,6 +31,7 @@ class NetRuntime:
         # fp32 accumulate and fp32 tensors; weight gradients, head and loss stay fp32)
         self.dtype = F32_BF16MFMA if os.environ.get("OSVOS_PRECISION", "fp32").lower() == "bf16" else F32
         self.aux_stream = None        # second HIP stream: wgrad kernels overlap the dgrad kernels
+        self.aux2_stream = None       # third: the slab reduces of the weight gradients
         self.two_streams = os.environ.get("OSVOS_TWO_STREAMS", "1") != "0"
         self.inplace_accumulate = os.environ.get("OSVOS_INPLACE_GRAD", "1") != "0"
 
@@ -40,6 +41,13 @@ class NetRuntime:
         if self.aux_stream is None or self.aux_stream.device != device:
             self.aux_stream = torch.cuda.Stream(device=device)
         return C.c_void_p(self.aux_stream.cuda_stream)
+
+    def aux2(self, device):
+        if not self.two_streams or os.environ.get("OSVOS_THREE_STREAMS", "1") == "0":
+            return None
+        if self.aux2_stream is None or self.aux2_stream.device != device:
+            self.aux2_stream = torch.cuda.Stream(device=device)
+        return C.c_void_p(self.aux2_stream.cuda_stream)
 
     def set_precision(self, name):
         dt = {"fp32": F32, "bf16": F32_BF16MFMA}[name]
@@ -146,7 +154,7 @@ class OSVOSNetFunction(torch.autograd.Function):
                                    ptr_array([None if g is None else g.data_ptr() for g in d]),
                                    ptr_array([None if g is None else g.data_ptr() for g in targets]),
                                    C.c_void_p(dx.data_ptr()) if dx is not None else None,
-                                   n, h, w, rt.dtype, 1 if inplace else 0, _stream(), rt.aux(dev)), "net_backward")
+                                   n, h, w, rt.dtype, 1 if inplace else 0, _stream(), rt.aux(dev), rt.aux2(dev)), "net_backward")
         ctx.params = None
         ctx.ws = None
         return (None, dx) + tuple(grads)

@@ -14,6 +14,8 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef short bf16x4 __attribute__((ext_vector_type(4)));
 
 void osvos_set_error(const char* fmt, ...);
+int osvos_wgrad_phase();            // 0 both, 1 partial slabs only, 2 slab reduce only (errors.cpp)
+void osvos_wgrad_set_phase(int p);
 
 #define OSVOS_ARG_CHECK(cond, ...)                   \
   do {                                               \

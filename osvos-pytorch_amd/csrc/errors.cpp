@@ -13,3 +13,10 @@ void osvos_set_error(const char* fmt, ...) {
 
 extern "C" const char* osvos_last_error(void) { return g_err; }
 extern "C" int osvos_version(void) { return OSVOS_ABI_VERSION; }
+
+// Which half of a weight-gradient call to enqueue (per host thread): 0 = partial slabs + reduce (default),
+// 1 = partial slabs only, 2 = reduce only.  osvos_net_backward uses 1 / 2 to put the bandwidth-bound slab
+// reduces on their own stream, off the critical path of the MFMA weight-gradient chain.
+static thread_local int g_wgrad_phase = 0;
+int osvos_wgrad_phase() { return g_wgrad_phase; }
+void osvos_wgrad_set_phase(int p) { g_wgrad_phase = p; }

@@ -64,7 +64,7 @@ WbufLayout wbuf_layout(int dtype) {
 struct WsLayout {
   int hs[5], ws[5];
   size_t xin, act[kNumTrunk], pooled[5], prep[4], score[4], fpart[4];
-  size_t dy[kNumTrunk], dpool[5], dside[4], dprep[4], wgrad, acc, dxin;
+  size_t dy[kNumTrunk], dpool[5], dside[4], dprep[4], wgrad[kNumConv], acc, dxin;
   size_t fwd_total, total;
 };
 
@@ -79,7 +79,6 @@ WsLayout ws_layout(int N, int H, int W, int dtype) {
   ConvDesc d[kNumConv];
   conv_table(d);
   L.xin = take(es * N * H * W * kInPad);
-  size_t max_wg = 0;
   for (int l = 0; l < kNumTrunk; ++l) {
     const int si = d[l].stage;
     const size_t b = es * N * L.hs[si] * L.ws[si] * d[l].cout;
@@ -103,12 +102,12 @@ WsLayout ws_layout(int N, int H, int W, int dtype) {
   // the data-gradient stream by any number of layers without write-after-read hazards
   for (int l = 0; l < kNumTrunk; ++l) L.dy[l] = take(es * N * L.hs[d[l].stage] * L.ws[d[l].stage] * d[l].cout);
   for (int si = 1; si < 5; ++si) L.dpool[si] = take(es * N * L.hs[si] * L.ws[si] * kStageC[si - 1]);
+  // one slab workspace per layer: the slab reduce of layer l runs on its own stream while the partial
+  // kernel of the next layer already refills another buffer
   for (int l = 0; l < kNumConv; ++l) {
     const int si = d[l].stage;
-    const size_t b = osvos_wgrad_ws_bytes(N, L.hs[si], L.ws[si], d[l].cin_s, d[l].cout, dtype);
-    if (b > max_wg) max_wg = b;
+    L.wgrad[l] = take(osvos_wgrad_ws_bytes(N, L.hs[si], L.ws[si], d[l].cin_s, d[l].cout, dtype));
   }
-  L.wgrad = take(max_wg);
   L.acc = take(sizeof(double) * (5 * OSVOS_HEAD_MAX_BLOCKS * 34));   // head_bwd partials: 4 scales + fuse bias
   L.dxin = take(es * N * H * W * 4);
   L.total = off;
@@ -279,29 +278,61 @@ int osvos_net_forward(const float* x_nchw, const void* wbuf, void* ws, float* co
 }
 
 int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, float* const* grads,
-                       float* dx_nchw, int N, int H, int W, int dtype, int accumulate, void* stream_, void* aux_stream_) {
+                       float* dx_nchw, int N, int H, int W, int dtype, int accumulate, void* stream_, void* aux_stream_,
+                       void* aux2_stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   hipStream_t aux = aux_stream_ ? (hipStream_t)aux_stream_ : stream;
+  hipStream_t aux2 = aux2_stream_ ? (hipStream_t)aux2_stream_ : aux;
   const bool two = aux != stream;
+  const bool three = aux2 != aux;
   OSVOS_ARG_CHECK(wbuf && ws && douts && grads, "net_backward: null pointer");
+  OSVOS_ARG_CHECK(osvos_dtype_built(dtype), "net_backward: dtype %d not built", dtype);
+  const WbufLayout P = wbuf_layout(dtype);
+  const WsLayout L = ws_layout(N, H, W, dtype);
+  ConvDesc d[kNumConv];
+  conv_table(d);
   // fork: aux waits for everything enqueued on `stream` so far; join: `stream` waits for aux.
   // The weight-gradient kernels run on aux concurrently with the data-gradient kernel of the same
   // layer: both are MFMA kernels with independent stalls (barriers, LDS latency, tails), and
   // together they keep the matrix pipes busier than either does alone.
   EventPool& evp = event_pool();
   auto join = [&]() -> int {
-    if (!two) return 0;
+    if (two) {
+      hipEvent_t e = evp.next();
+      if (!e) return -1;
+      OSVOS_HIP_CHECK(hipEventRecord(e, aux));
+      OSVOS_HIP_CHECK(hipStreamWaitEvent(stream, e, 0));
+    }
+    if (three) {
+      hipEvent_t e = evp.next();
+      if (!e) return -1;
+      OSVOS_HIP_CHECK(hipEventRecord(e, aux2));
+      OSVOS_HIP_CHECK(hipStreamWaitEvent(stream, e, 0));
+    }
+    return 0;
+  };
+  // weight gradient of one layer: partial slabs on aux (MFMA kernel), slab reduce on aux2 (bandwidth kernel)
+  auto wgrad = [&](const void* xin, const void* g, int l, int h, int w) -> int {
+    int r;
+    if (!three) {
+      return osvos_conv3x3_wgrad(xin, g, at(ws, L.wgrad[l]), grads[d[l].w_param], grads[d[l].b_param], N, h, w,
+                                 d[l].cin, d[l].cin_s, d[l].cout, d[l].cout, accumulate, dtype, aux);
+    }
+    osvos_wgrad_set_phase(1);
+    r = osvos_conv3x3_wgrad(xin, g, at(ws, L.wgrad[l]), grads[d[l].w_param], grads[d[l].b_param], N, h, w,
+                            d[l].cin, d[l].cin_s, d[l].cout, d[l].cout, accumulate, dtype, aux);
+    osvos_wgrad_set_phase(0);
+    if (r) return r;
     hipEvent_t e = evp.next();
     if (!e) return -1;
     OSVOS_HIP_CHECK(hipEventRecord(e, aux));
-    OSVOS_HIP_CHECK(hipStreamWaitEvent(stream, e, 0));
-    return 0;
+    OSVOS_HIP_CHECK(hipStreamWaitEvent(aux2, e, 0));
+    osvos_wgrad_set_phase(2);
+    r = osvos_conv3x3_wgrad(xin, g, at(ws, L.wgrad[l]), grads[d[l].w_param], grads[d[l].b_param], N, h, w,
+                            d[l].cin, d[l].cin_s, d[l].cout, d[l].cout, accumulate, dtype, aux2);
+    osvos_wgrad_set_phase(0);
+    return r;
   };
-  OSVOS_ARG_CHECK(osvos_dtype_built(dtype), "net_backward: dtype %d not built", dtype);
-  const WbufLayout P = wbuf_layout(dtype);
-  const WsLayout L = ws_layout(N, H, W, dtype);
-  ConvDesc d[kNumConv];
-  conv_table(d);
   int rc;
   double* acc = reinterpret_cast<double*>(at(ws, L.acc));
   const double* part[4];
@@ -348,8 +379,7 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
     const int si = i + 1, sl = kNumTrunk + i, h = L.hs[si], w = L.ws[si];
     const int lx = last_of_stage(si);
     if (grads[d[sl].w_param] != nullptr) {
-      rc = osvos_conv3x3_wgrad(at(ws, L.act[lx]), at(ws, L.dprep[i]), at(ws, L.wgrad), grads[d[sl].w_param], grads[d[sl].b_param],
-                               N, h, w, d[sl].cin, d[sl].cin_s, 16, 16, accumulate, dtype, aux);
+      rc = wgrad(at(ws, L.act[lx]), at(ws, L.dprep[i]), sl, h, w);
       if (rc) return rc;
     }
   }
@@ -372,8 +402,7 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
     const void* g = at(ws, L.dy[l]);
     if (grads[d[l].w_param] != nullptr) {
       if ((rc = signal())) return rc;   // dy[l] ready -> its weight gradient may start on aux
-      rc = osvos_conv3x3_wgrad(xin, g, at(ws, L.wgrad), grads[d[l].w_param], grads[d[l].b_param],
-                               N, h, w, d[l].cin, d[l].cin_s, d[l].cout, d[l].cout, accumulate, dtype, aux);
+      rc = wgrad(xin, g, l, h, w);
       if (rc) return rc;
     }
     if (l == 0) {

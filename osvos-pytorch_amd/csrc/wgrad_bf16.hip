@@ -263,7 +263,11 @@ int osvos_conv3x3_wgrad_bf16mfma(const float* x, const float* dy, void* ws, floa
     attr_set = true;
   }
   const long blocks = (long)p.nsplit * p.nco_t * p.nci_t;
-  hipLaunchKernelGGL(wgrad_bf16_kernel, dim3((unsigned)blocks), dim3(256), lds, stream, a);
-  OSVOS_LAUNCH_CHECK();
+  const int phase = osvos_wgrad_phase();
+  if (phase != 2) {
+    hipLaunchKernelGGL(wgrad_bf16_kernel, dim3((unsigned)blocks), dim3(256), lds, stream, a);
+    OSVOS_LAUNCH_CHECK();
+  }
+  if (phase == 1) return 0;
   return osvos_wgrad_reduce_launch(a.slab, a.bslab, dw, db, p.nsplit, Cout, Cin, Cin_s, accumulate, stream);
 }

@@ -376,8 +376,12 @@ int osvos_conv3x3_wgrad_f32(const float* x, const float* dy, void* ws, float* dw
   a.nco_t = p.nco_t; a.nci_t = p.nci_t;
   const long blocks = (long)p.nsplit * p.nco_t * p.nci_t;
   a.oihw = (wgrad_variant() >> 3) & 1;
-  int rc = (p.cb == 1) ? launch_wgrad_variant<1, 4>(a, blocks, stream) : launch_wgrad_variant<2, 2>(a, blocks, stream);
-  if (rc) return rc;
+  const int phase = osvos_wgrad_phase();
+  if (phase != 2) {
+    int rc = (p.cb == 1) ? launch_wgrad_variant<1, 4>(a, blocks, stream) : launch_wgrad_variant<2, 2>(a, blocks, stream);
+    if (rc) return rc;
+  }
+  if (phase == 1) return 0;
   const int total = Cout * Cin_s * 9;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(total, 128)), dim3(256), 0, stream,
                      a.slab, a.bslab, dw, db, p.nsplit, Cout, Cin, Cin_s, accumulate, a.oihw);

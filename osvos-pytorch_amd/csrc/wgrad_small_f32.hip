@@ -350,8 +350,12 @@ int osvos_conv3x3_wgrad_small_f32(const float* x, const float* dy, void* ws, flo
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       attr_set = true;
     }
-    hipLaunchKernelGGL(wgrad_c3_f32_kernel, dim3(p.nsplit), dim3(256), lds, stream, a);
-    OSVOS_LAUNCH_CHECK();
+    const int phase = osvos_wgrad_phase();
+    if (phase != 2) {
+      hipLaunchKernelGGL(wgrad_c3_f32_kernel, dim3(p.nsplit), dim3(256), lds, stream, a);
+      OSVOS_LAUNCH_CHECK();
+    }
+    if (phase == 1) return 0;
     hipLaunchKernelGGL(wgrad_c3_reduce_kernel, dim3(ceil_div(Cout * 28, 4)), dim3(256), 0, stream,
                        a.slab, a.bslab, dw, db, p.nsplit, Cout, accumulate);
     OSVOS_LAUNCH_CHECK();
@@ -366,8 +370,12 @@ int osvos_conv3x3_wgrad_small_f32(const float* x, const float* dy, void* ws, flo
     a.N = N; a.H = H; a.W = W; a.Cin_s = Cin_s; a.Cout_s = Cout_s;
     a.npx = p.npx; a.npy = p.npy; a.npatches = p.npatches; a.per_split = p.per_split; a.nci_t = p.nci_t;
     constexpr size_t lds = (size_t)(S_PPIX * S_BCI + S_YPIX * 16) * 4;
-    hipLaunchKernelGGL(wgrad_co16_f32_kernel, dim3(p.nsplit * p.nci_t), dim3(256), lds, stream, a);
-    OSVOS_LAUNCH_CHECK();
+    const int phase = osvos_wgrad_phase();
+    if (phase != 2) {
+      hipLaunchKernelGGL(wgrad_co16_f32_kernel, dim3(p.nsplit * p.nci_t), dim3(256), lds, stream, a);
+      OSVOS_LAUNCH_CHECK();
+    }
+    if (phase == 1) return 0;
     return osvos_wgrad_reduce_launch(a.slab, a.bslab, dw, db, p.nsplit, 16, Cin, Cin_s, accumulate, stream);
   }
   return 1;
