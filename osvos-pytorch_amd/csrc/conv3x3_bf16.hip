@@ -32,9 +32,9 @@ constexpr int pitch_for(int rbw, int hw) {
 
 constexpr int KG = 4;   // 16-byte groups (8 channels each) per K chunk
 
-template <int RBW_, int TBX_, int TBY_, int NB_, int WGM_, int WGN_>
+template <int RBW_, int TBX_, int TBY_, int NB_, int WGM_, int WGN_, int PIPE_ = 1>
 struct CfgB {
-  static constexpr int RBW = RBW_, TBX = TBX_, TBY = TBY_, NB = NB_, WGM = WGM_, WGN = WGN_;
+  static constexpr int RBW = RBW_, TBX = TBX_, TBY = TBY_, NB = NB_, WGM = WGM_, WGN = WGN_, PIPE = PIPE_;
   static constexpr int RBH = 32 / RBW;
   static constexpr int TW = TBX * RBW, TH = TBY * RBH;
   static constexpr int HWD = TW + 2, HHT = TH + 2;
@@ -45,12 +45,13 @@ struct CfgB {
   static constexpr int B_U4 = 9 * KG * BN;
   static constexpr int BUF_U4 = A_U4 + B_U4;
   static constexpr int A_LOAD = HHT * HWD * KG;
-  static constexpr int NA = cdiv(A_LOAD, 256);
-  static constexpr int NBL = cdiv(B_U4, 256);
+  static constexpr int NT = 64 * WGM * WGN;            // 4 or 8 waves per workgroup
+  static constexpr int NA = cdiv(A_LOAD, NT);
+  static constexpr int NBL = cdiv(B_U4, NT);
   static constexpr int MB = TBX * TBY;
   static constexpr int WM = MB / WGM, WN = NB / WGN;
   static constexpr size_t LDS_BYTES = (size_t)BUF_U4 * 16;   // single buffer; the next chunk waits in registers
-  static_assert(WGM * WGN == 4, "4 waves per workgroup");
+  static_assert(WGM * WGN == 4 || WGM * WGN == 8, "4 or 8 waves per workgroup");
   static_assert(MB % WGM == 0 && NB % WGN == 0, "wave grid must divide the tile");
 };
 
@@ -62,7 +63,7 @@ __device__ inline uint4 pack_bf16x8(const f32x4& a, const f32x4& b) {
 }
 
 template <class C>
-__global__ __launch_bounds__(256) void conv3x3_bf16_kernel(ConvArgsB a) {
+__global__ __launch_bounds__(C::NT) void conv3x3_bf16_kernel(ConvArgsB a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint4* lds = reinterpret_cast<uint4*>(smem);
   uint4* As = lds;
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(ConvArgsB a) {
   int a_grp[C::NA];
 #pragma unroll
   for (int i = 0; i < C::NA; ++i) {
-    const int e = tid + i * 256;
+    const int e = tid + i * C::NT;
     a_src[i] = -2; a_dst[i] = 0; a_grp[i] = 0;
     if (e < C::A_LOAD) {
       const int g = e % KG, pix = e / KG;
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(ConvArgsB a) {
   int b_src[C::NBL];
 #pragma unroll
   for (int i = 0; i < C::NBL; ++i) {
-    const int e = tid + i * 256;
+    const int e = tid + i * C::NT;
     b_src[i] = -2;
     if (e < C::B_U4) {
       const int tap = e / (KG * C::BN), rem = e % (KG * C::BN);
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(ConvArgsB a) {
       if (a_src[i] != -2) As[a_dst[i]] = pack_bf16x8(ra[i][0], ra[i][1]);
 #pragma unroll
     for (int i = 0; i < C::NBL; ++i)
-      if (b_src[i] != -2) Bs[tid + i * 256] = rb[i];
+      if (b_src[i] != -2) Bs[tid + i * C::NT] = rb[i];
   };
 
   int a_idx[C::WM];
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(ConvArgsB a) {
     if (kc + 1 < nchunks) load_chunk(kc + 1);      // in flight during the MFMAs below
     // 18 (tap, k-step) stages, software pipelined: operands of stage s+1 are requested before the
     // MFMAs of stage s issue; sched_barrier pins that order
-    uint4 fa[2][C::WM], fb[2][C::WN];
+    uint4 fa[1 + C::PIPE][C::WM], fb[1 + C::PIPE][C::WN];
     auto ldfrag = [&](int st, int set) {
       const int tap = st >> 1, ks = st & 1;
       const int r = tap / 3, s = tap % 3;
@@ -184,18 +185,23 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(ConvArgsB a) {
 #pragma unroll
       for (int ni = 0; ni < C::WN; ++ni) fb[set][ni] = Bs[b_idx + (tap * KG + 2 * ks) * C::BN + ni * 32];
     };
-    ldfrag(0, 0);
+    if (C::PIPE) ldfrag(0, 0);
 #pragma unroll
     for (int st = 0; st < 18; ++st) {
-      if (st + 1 < 18) ldfrag(st + 1, (st + 1) & 1);
-      __builtin_amdgcn_sched_barrier(0);
+      const int cur = C::PIPE ? (st & 1) : 0;
+      if (C::PIPE) {
+        if (st + 1 < 18) ldfrag(st + 1, (st + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+      } else {
+        ldfrag(st, 0);     // 8-wave tiles: two waves per SIMD cover each other's LDS latency, registers are the scarce resource
+      }
 #pragma unroll
       for (int mi = 0; mi < C::WM; ++mi)
 #pragma unroll
         for (int ni = 0; ni < C::WN; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fa[st & 1][mi]),
-                                                                __builtin_bit_cast(bf16x8_t, fb[st & 1][ni]), acc[mi][ni], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fa[cur][mi]),
+                                                                __builtin_bit_cast(bf16x8_t, fb[cur][ni]), acc[mi][ni], 0, 0, 0);
+      if (C::PIPE) __builtin_amdgcn_sched_barrier(0);
     }
   }
 
@@ -240,7 +246,7 @@ int launch_cfg(const ConvArgsB& a0, hipStream_t stream) {
   a.nsp = a.tiles_x * a.tiles_y * a.N;
   const long blocks = a.map == 0 ? (long)a.nct * a.nsp : (long)a.nct * ((a.nsp + 7) / 8) * 8;
   OSVOS_ARG_CHECK(blocks > 0 && blocks < (1L << 31), "conv3x3 bf16: grid of %ld blocks", blocks);
-  hipLaunchKernelGGL(conv3x3_bf16_kernel<C>, dim3((unsigned)blocks), dim3(256), C::LDS_BYTES, stream, a);
+  hipLaunchKernelGGL(conv3x3_bf16_kernel<C>, dim3((unsigned)blocks), dim3(C::NT), C::LDS_BYTES, stream, a);
   OSVOS_LAUNCH_CHECK();
   return 0;
 }
@@ -256,10 +262,14 @@ using B4 = CfgB<16, 1, 4, 4, 2, 2>;   // 16x8 px x 128 co, 2x2
 using B5 = CfgB<16, 1, 4, 2, 2, 2>;   // 16x8 px x  64 co, 2x1
 using B6 = CfgB<32, 1, 8, 1, 4, 1>;   // 256 px x  32 co, 2x1
 using B7 = CfgB<8, 1, 2, 2, 2, 2>;    //  8x8 px x  64 co, 1x1
-constexpr int kNumTilesB = 8;
+// (a 512 px x 128 co, 4x2-accumulator 8-wave tile would need > 256 registers per lane: it spills)
+using B8 = CfgB<32, 1, 16, 2, 4, 2>;  // 512 px x  64 co, 8 waves, 4x1
+using B9 = CfgB<32, 1, 8, 4, 4, 2>;   // 256 px x 128 co, 8 waves, 2x2
+constexpr int kNumTilesB = 10;
 template <class C>
 constexpr TileInfoB infoB() { return TileInfoB{C::TW, C::TH, C::BN, C::WM, C::WN, C::LDS_BYTES}; }
-const TileInfoB kTilesB[kNumTilesB] = {infoB<B0>(), infoB<B1>(), infoB<B2>(), infoB<B3>(), infoB<B4>(), infoB<B5>(), infoB<B6>(), infoB<B7>()};
+const TileInfoB kTilesB[kNumTilesB] = {infoB<B0>(), infoB<B1>(), infoB<B2>(), infoB<B3>(), infoB<B4>(), infoB<B5>(), infoB<B6>(), infoB<B7>(),
+                                       infoB<B8>(), infoB<B9>()};
 
 // Measured (profiles/r01_tune_bf16_*.txt): B1 (256 px x 64 couts, 4 accumulators, 2 workgroups per CU) wins
 // whenever it yields enough workgroups (up to 825 TFLOP/s on conv3_x/conv4_x at batch 12); the 8-accumulator
@@ -360,6 +370,8 @@ int osvos_conv3x3_bf16mfma(const float* x, const void* wpk, const float* bias, c
     case 5: return launch_cfg<B5>(a, stream);
     case 6: return launch_cfg<B6>(a, stream);
     case 7: return launch_cfg<B7>(a, stream);
+    case 8: return launch_cfg<B8>(a, stream);
+    case 9: return launch_cfg<B9>(a, stream);
     default: osvos_set_error("conv3x3 bf16: unknown tile config %d", tile); return -1;
   }
 }
