@@ -178,6 +178,8 @@ def main():
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--n-ave-grad", type=int, default=0, help="0 = reference value (5 online, 10 parent)")
     ap.add_argument("--item-sync", type=int, default=0, help="1 = loss.item() every iteration like the reference's logging")
+    ap.add_argument("--force-dist", action="store_true", help="initialise the nccl (RCCL) process group and run the gradient "
+                    "all-reduce even with one rank (single-GPU check of the multi-GPU path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true")
     args = ap.parse_args()
@@ -185,11 +187,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     else:
         dist = None
     assert torch.cuda.is_available(), "bench.py needs a GPU"
@@ -204,7 +208,7 @@ def main():
     net, x, gt = synth_problem(args.batch, args.height, args.width, device, seed=rank)
     net.set_precision(args.precision)
     opt = make_optimizer(net, "online" if args.mode == "infer" else args.mode)
-    reducer = GradientAllReducer(net, average=True) if world > 1 else None
+    reducer = GradientAllReducer(net, average=True, always=args.force_dist) if dist is not None else None
     running = torch.zeros((), device=device)
     state = {"ave": 0, "epoch": 0}
 
@@ -250,7 +254,7 @@ def main():
         step()
     lib = _lib.lib()
     prof = (not args.no_prof) and not (args.mode == "infer" and args.graph)
-    if world > 1:
+    if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     if prof:
@@ -259,7 +263,7 @@ def main():
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     ms = (C.c_double * 4)()
@@ -267,7 +271,7 @@ def main():
     cnt = (C.c_long * 4)()
     if prof:
         _lib.check(lib.osvos_prof_stop(ms, fl, cnt), "prof_stop")
-    if world > 1:
+    if dist is not None:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -327,13 +331,13 @@ def main():
                        "fp32, frame resident in HBM" % (args.width, args.height, args.batch, args.mode, args.mode,
                                                         "" if args.mode == "online" else "+4 side", n_ave),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world,
-                       "grad_allreduce": "per optimizer step" if world > 1 else "none",
+                       "grad_allreduce": "per optimizer step (RCCL)" if dist is not None else "none",
                        "loss_item_sync_each_iter": bool(args.item_sync)},
             "roofline": roof, "cpu_baseline": base,
             "running_loss": float(running.item()) / max(1, args.steps + args.warmup),
         }
         print(json.dumps(line))
-    if world > 1:
+    if dist is not None:
         dist.destroy_process_group()
 
 

@@ -62,9 +62,13 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WbArgs a) {
   const int co0 = cot * BCO, ci0 = cit * BCI;
   const int p_begin = split * a.per_split, p_end = min(p_begin + a.per_split, a.npatches);
 
-  // staging items: item = tid + 256*u -> (group, quad); quad is the same for every u (256 % 16 == 0)
-  const int dq = tid & 15;           // cout quad of this thread's dY item
-  const int xq = tid & 15;           // cin quad of this thread's X items
+  // staging items (pixel group of 8, channel quad).  tid bits: [0] quad bit 0, [1:2] group bits 0-1, [3:5] quad
+  // bits 1-3, [6:7] group bits 2-3.  Eight consecutive lanes = 2 quads x 4 pixel groups: their transposing
+  // ds_write_b128 land on 8 distinct 16-byte slots (a plain quad-major order is a 4-way bank conflict -- PMC:
+  // 68 % of LDS cycles), while a wave still reads 4 x 256 contiguous bytes per global load instruction.
+  const int sq = (tid & 1) | ((tid >> 2) & 14);          // channel quad 0..15 (dY and X tiles are both 64 channels)
+  const int sg = ((tid >> 1) & 3) | ((tid >> 4) & 12);   // pixel group 0..15
+  const int dq = sq, xq = sq;
   f32x4 rdy[NDY][8], rx[NX][8];
   f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
   auto load_patch = [&](int p) {
@@ -75,7 +79,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WbArgs a) {
     const int x0 = px * PW, y0 = py * PH;
 #pragma unroll
     for (int u = 0; u < NDY; ++u) {
-      const int grp = (tid >> 4) + 16 * u;                 // 0..15: row = grp / 4, x group = grp % 4
+      const int grp = sg + 16 * u;                         // 0..15: row = grp / 4, x group = grp % 4
       const int gy = y0 + (grp >> 2), gx0 = x0 + (grp & 3) * 8, co = co0 + 4 * dq;
       const bool ok = gy < a.H && co < a.Cout;
       const float* src = a.dy + ((size_t)(n * a.H + gy) * a.W + gx0) * a.Cout_s + co;
@@ -88,8 +92,8 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WbArgs a) {
     }
 #pragma unroll
     for (int u = 0; u < NX; ++u) {
-      const int it = tid + 256 * u;
-      const int grp = it >> 4;                             // 0..29: halo row = grp / 5, x group = grp % 5
+      const int grp = sg + 16 * u;                         // 0..29 used: halo row = grp / 5, x group = grp % 5
+      const int it = grp < 30 ? 0 : X_ITEMS;               // groups 30, 31 do not exist
       const int hy = grp / 5, hg = grp % 5;
       const int gy = y0 + hy - 1, gx0 = x0 + hg * 8 - 1, ci = ci0 + 4 * xq;
       const bool ok = it < X_ITEMS && gy >= 0 && gy < a.H && ci < a.Cin_s;
@@ -105,7 +109,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WbArgs a) {
   auto store_patch = [&]() {
 #pragma unroll
     for (int u = 0; u < NDY; ++u) {
-      const int grp = (tid >> 4) + 16 * u;
+      const int grp = sg + 16 * u;
 #pragma unroll
       for (int j = 0; j < 8; ++j) bsum += rdy[u][j];        // bias gradient: exact fp32 column sums of dY
 #pragma unroll
@@ -120,9 +124,8 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WbArgs a) {
     }
 #pragma unroll
     for (int u = 0; u < NX; ++u) {
-      const int it = tid + 256 * u;
-      if (it < X_ITEMS) {
-        const int grp = it >> 4;
+      const int grp = sg + 16 * u;
+      if (grp < 30) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           uint4 v;
@@ -161,7 +164,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WbArgs a) {
       for (int r = 0; r < 3; ++r) {
         const char* src = b_base + ((row + r) * XPITCH + kx * 16) * 2;
         w0[r] = *reinterpret_cast<const uint4*>(src);
-        w4[r] = *reinterpret_cast<const unsigned*>(src + 16);
+        w4[r] = reinterpret_cast<const uint4*>(src + 16)->x;   // a b32 read at this stride is a 4-way bank conflict; the compiler keeps it b32 or widens
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -192,8 +195,8 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WbArgs a) {
       if (co < a.Cout && ci < a.Cin_s) a.slab[((size_t)(split * 9 + t) * a.Cout + co) * a.Cin_s + ci] = acc[t][r];
     }
   if (a.bslab != nullptr && cit == 0) {
-    f32x4* red = reinterpret_cast<f32x4*>(smem);          // [16 pixel-group rows][16 quads]
-    red[tid] = bsum;
+    f32x4* red = reinterpret_cast<f32x4*>(smem);          // [16 pixel groups][16 quads]
+    red[sg * 16 + sq] = bsum;
     __syncthreads();
     if (tid < 16) {
       f32x4 s = red[tid];

@@ -19,15 +19,16 @@ import torch.distributed as dist
 
 
 class GradientAllReducer:
-    def __init__(self, module, average=False, process_group=None):
+    def __init__(self, module, average=False, process_group=None, always=False):
         self.params = [p for p in module.parameters() if p.requires_grad]
         self.average = average
         self.group = process_group
+        self.always = always          # run the collective even in a 1-rank group (exercises RCCL on one GPU)
         self._flat = None
 
     def all_reduce(self):
         """Sum (or average) the .grad of every parameter that has one across all ranks."""
-        if not dist.is_initialized() or dist.get_world_size(self.group) == 1:
+        if not dist.is_initialized() or (dist.get_world_size(self.group) == 1 and not self.always):
             return
         grads = [p.grad for p in self.params if p.grad is not None]
         if not grads:
