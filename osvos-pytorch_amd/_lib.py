@@ -63,9 +63,15 @@ def build(force: bool = False) -> str:
     if not os.path.exists(hipcc):
         raise RuntimeError("libosvos_hip.so is not built and hipcc was not found; run `make -C %s`" % CSRC)
     cmd = ["make", "-C", CSRC, "-j8", "-s", "HIPCC=" + hipcc]
-    if force:
-        subprocess.check_call(cmd + ["clean"])
-    subprocess.check_call(cmd)
+    import fcntl
+    with open(os.path.join(CSRC, ".build.lock"), "w") as lk:      # ranks of one torchrun launch must not race in make
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        try:
+            if force:
+                subprocess.check_call(cmd + ["clean"])
+            subprocess.check_call(cmd)
+        finally:
+            fcntl.flock(lk, fcntl.LOCK_UN)
     return SO_PATH
 
 
@@ -88,7 +94,7 @@ def lib() -> C.CDLL:
             # torch first: the process must end up with ONE HIP runtime (the libamdhip64 torch
             # ships); loading ours before torch's makes hipMemsetAsync & co see no device
             import torch  # noqa: F401
-            if _stale():
+            if _stale() and os.environ.get("OSVOS_AUTOBUILD", "1") != "0":
                 build()
             try:
                 l = C.CDLL(SO_PATH)
