@@ -61,6 +61,13 @@ int osvos_pack_conv3x3_dgrad(const float* w_oihw, void* wpk, int Cout, int Cin, 
 int osvos_conv3x3(const void* x, const void* wpk, const float* bias, const void* mask, void* y,
                   int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int dtype, int tile, void* stream);
 int osvos_conv3x3_num_tiles(void);
+/* same convolution cut into `ksplit` parts along K = 9*Cin (0 = automatic, 1..8): layers too small to balance over
+ * 256 CUs (conv4_x, conv5_x at batch 1) get more, shorter workgroups; partial sums go to part_ws
+ * (osvos_conv3x3_splitk_ws_bytes) and a second kernel applies bias / ReLU / mask.  fp32 only. */
+size_t osvos_conv3x3_splitk_ws_bytes(int N, int H, int W, int Cout, int dtype);
+int osvos_conv3x3_splitk(const void* x, const void* wpk, const float* bias, const void* mask, void* y,
+                         int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int dtype, int tile, int ksplit,
+                         void* part_ws, void* stream);
 
 /* ---- 3x3 weight gradient (weight/bias half of aten::convolution_backward) -----------------
  * dW[co,ci,r,s] = sum_{n,h,w} dY[n,h,w,co] * x[n,h+r-1,w+s-1,ci];  db[co] = sum dY

@@ -31,6 +31,8 @@ PROTOTYPES = {
     "osvos_pack_conv3x3_dgrad": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "osvos_conv3x3": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "osvos_conv3x3_num_tiles": (_i, []),
+    "osvos_conv3x3_splitk_ws_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "osvos_conv3x3_splitk": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "osvos_wgrad_ws_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "osvos_conv3x3_wgrad": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "osvos_maxpool2x2": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),

@@ -47,6 +47,22 @@ int osvos_conv3x3(const void* x, const void* wpk, const float* bias, const void*
                            N, H, W, Cin, Cout, y_cs, relu, tile, (hipStream_t)stream);
 }
 
+size_t osvos_conv3x3_splitk_ws_bytes(int N, int H, int W, int Cout, int dtype) {
+  (void)dtype;
+  return osvos_conv3x3_splitk_ws_bytes_f32(N, H, W, Cout);
+}
+int osvos_conv3x3_splitk(const void* x, const void* wpk, const float* bias, const void* mask, void* y,
+                         int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int dtype, int tile, int ksplit,
+                         void* part_ws, void* stream) {
+  OSVOS_ARG_CHECK(dtype == OSVOS_F32, "conv3x3_splitk: fp32 only (dtype %d)", dtype);
+  OSVOS_ARG_CHECK(part_ws != nullptr && ksplit >= 0 && ksplit <= 8, "conv3x3_splitk: bad ksplit / workspace");
+  osvos_conv3x3_force_ksplit(ksplit);
+  const int rc = osvos_conv3x3_f32_ws((const float*)x, (const float*)wpk, bias, (const float*)mask, (float*)y, N, H, W, Cin, Cout,
+                                      y_cs, relu, tile, part_ws, (hipStream_t)stream);
+  osvos_conv3x3_force_ksplit(0);
+  return rc;
+}
+
 size_t osvos_wgrad_ws_bytes(int N, int H, int W, int Cin, int Cout, int dtype) {
   const size_t f = osvos_wgrad_ws_bytes_f32(N, H, W, Cin, Cout);
   const size_t b = dtype == OSVOS_F32_BF16MFMA ? osvos_wgrad_bf16_ws_bytes(N, H, W, Cin, Cout) : 0;

@@ -31,6 +31,8 @@ struct ConvArgs {
   int N, H, W, Cin, Cout, CoutP, y_cs;
   int tiles_x, tiles_y, nct;
   int relu, map, nsp;
+  int ksplit;         // > 1: blockIdx.y = K part; raw partial sums go to `part`, epilogue runs in conv_splitk_finalize
+  float* part;        // [ksplit][N][H][W][Cout]
 };
 
 constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
@@ -167,11 +169,13 @@ __global__ __launch_bounds__(256) void conv3x3_f32_kernel(ConvArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-  const int nchunks = a.Cin >> 3;
-  load_chunk(0);
-  store_chunk(0);
+  const int nch_all = a.Cin >> 3;
+  const int kc_begin = (int)((long)nch_all * blockIdx.y / a.ksplit);
+  const int nchunks = (int)((long)nch_all * (blockIdx.y + 1) / a.ksplit);      // end (exclusive) of this K part
+  load_chunk(kc_begin);
+  store_chunk(kc_begin & 1);
   __syncthreads();
-  for (int kc = 0; kc < nchunks; ++kc) {
+  for (int kc = kc_begin; kc < nchunks; ++kc) {
     const bool more = kc + 1 < nchunks;
     if (more) load_chunk(kc + 1);
     const f32x4* As = lds + (kc & 1) * C::BUF_F4;
@@ -221,6 +225,10 @@ __global__ __launch_bounds__(256) void conv3x3_f32_kernel(ConvArgs a) {
         const int oy = y0 + mby * C::RBH + prow / C::RBW;
         const int ox = x0 + mbx * C::RBW + prow % C::RBW;
         if (co_ok && oy < a.H && ox < a.W) {
+          if (a.ksplit > 1) {      // split-K: raw partial sum, dense [pixel][Cout]
+            a.part[((size_t)blockIdx.y * a.N * a.H * a.W + (size_t)(n * a.H + oy) * a.W + ox) * a.Cout + co] = acc[mi][ni][r];
+            continue;
+          }
           const size_t o = ((size_t)(n * a.H + oy) * a.W + ox) * a.y_cs + co;
           float v = acc[mi][ni][r] + bv;
           if (a.relu) v = v > 0.f ? v : 0.f;
@@ -247,7 +255,7 @@ int launch_cfg(const ConvArgs& a0, hipStream_t stream) {
   a.nsp = a.tiles_x * a.tiles_y * a.N;
   const long blocks = a.map == 0 ? (long)a.nct * a.nsp : (long)a.nct * ((a.nsp + 7) / 8) * 8;
   OSVOS_ARG_CHECK(blocks > 0 && blocks < (1L << 31), "conv3x3: grid of %ld blocks", blocks);
-  hipLaunchKernelGGL(conv3x3_f32_kernel<C>, dim3((unsigned)blocks), dim3(256), C::LDS_BYTES, stream, a);
+  hipLaunchKernelGGL(conv3x3_f32_kernel<C>, dim3((unsigned)blocks, (unsigned)a.ksplit), dim3(256), C::LDS_BYTES, stream, a);
   OSVOS_LAUNCH_CHECK();
   return 0;
 }
@@ -268,12 +276,18 @@ using T6 = Cfg<16, 1, 2, 2, 2, 2>;   // 16x4 px x 64 co
 using T7 = Cfg<32, 1, 2, 2, 2, 2>;   // 32x2 px x 64 co
 using T8 = Cfg<32, 1, 4, 4, 2, 2>;   // 128 px x 128 co
 using T9 = Cfg<16, 1, 4, 1, 4, 1>;   // 16x8 px x 32 co
-constexpr int kNumTiles = 10;
+// shapes for the narrow deep feature maps (107 and 54 pixels wide at 480p): 32-wide tiles waste 16-20 % there
+using T10 = Cfg<8, 2, 4, 1, 4, 1>;   // 16x16 px x 32 co
+using T11 = Cfg<8, 1, 4, 1, 4, 1>;   //  8x16 px x 32 co
+using T12 = Cfg<16, 1, 8, 1, 4, 1>;  // 16x16 px x 32 co (16x2 row blocks)
+using T13 = Cfg<8, 2, 3, 2, 2, 2>;   // 16x12 px x 64 co
+constexpr int kNumTiles = 14;
 
 template <class C>
 constexpr TileInfo info() { return TileInfo{C::TW, C::TH, C::BN, C::WM, C::WN, C::LDS_BYTES}; }
 const TileInfo kTiles[kNumTiles] = {info<T0>(), info<T1>(), info<T2>(), info<T3>(), info<T4>(),
-                                    info<T5>(), info<T6>(), info<T7>(), info<T8>(), info<T9>()};
+                                    info<T5>(), info<T6>(), info<T7>(), info<T8>(), info<T9>(),
+                                    info<T10>(), info<T11>(), info<T12>(), info<T13>()};
 
 // Measured on MI355X (tools/tune_conv.py, profiles/): small tiles with 3-4 co-resident
 // workgroups per CU beat the big register-blocked tiles by up to 2x -- with one wave per SIMD the
@@ -301,12 +315,62 @@ int pick_tile(int N, int H, int W, int Cin, int CoutP) {
   return best_i;
 }
 
+// y = epi(bias + sum_k part[k]) for the split-K launches: Cout % 4 == 0, y channel stride y_cs
+__global__ void conv_splitk_finalize_kernel(const float* __restrict__ part, const float* __restrict__ bias,
+                                            const float* __restrict__ mask, float* __restrict__ y, long npix, int Cout,
+                                            int y_cs, int ksplit, int relu) {
+  const long total4 = npix * (Cout / 4);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    const long pix = i / (Cout / 4);
+    const int c4 = (int)(i % (Cout / 4)) * 4;
+    f32x4 s = *reinterpret_cast<const f32x4*>(part + pix * Cout + c4);
+    for (int k = 1; k < ksplit; ++k) s += *reinterpret_cast<const f32x4*>(part + ((size_t)k * npix + pix) * Cout + c4);
+    if (bias != nullptr) s += *reinterpret_cast<const f32x4*>(bias + c4);
+    const size_t o = (size_t)pix * y_cs + c4;
+    if (relu)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s[e] = s[e] > 0.f ? s[e] : 0.f;
+    if (mask != nullptr) {
+      const f32x4 m = *reinterpret_cast<const f32x4*>(mask + o);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s[e] = m[e] > 0.f ? s[e] : 0.f;
+    }
+    *reinterpret_cast<f32x4*>(y + o) = s;
+  }
+}
+
+// how many K parts a launch should be cut into so the machine sees >= ~7 workgroups per CU (balance) without
+// drowning in partial-sum traffic; 1 for the big shallow layers
+int pick_ksplit(const TileInfo& t, int N, int H, int W, int Cin, int Cout, int CoutP, int y_cs) {
+  if (Cout % 4 != 0 || y_cs % 4 != 0 || Cin < 256) return 1;
+  const long blocks = (long)N * ceil_div(H, t.th) * ceil_div(W, t.tw) * ceil_div(CoutP, t.bn);
+  int ks = 1;
+  while (ks < 8 && blocks * ks < 1536 && (Cin / 8) / (ks * 2) >= 8) ks *= 2;
+  return ks;
+}
+
 }  // namespace
 
 extern "C" int osvos_conv3x3_num_tiles(void) { return kNumTiles; }
 
+size_t osvos_conv3x3_splitk_ws_bytes_f32(int N, int H, int W, int Cout) {
+  return align_up((size_t)8 * N * H * W * Cout * sizeof(float), 256);      // up to 8 K parts
+}
+
+// part_ws: NULL (never split) or a buffer of osvos_conv3x3_splitk_ws_bytes_f32() for the split-K partial sums
+int osvos_conv3x3_f32_ws(const float* x, const float* wpk, const float* bias, const float* mask, float* y,
+                         int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int tile, void* part_ws, hipStream_t stream);
+
+static thread_local int g_force_ksplit = 0;      // tests / tuning: osvos_conv3x3_splitk(..., ksplit > 0, ...)
+void osvos_conv3x3_force_ksplit(int k) { g_force_ksplit = k; }
+
 int osvos_conv3x3_f32(const float* x, const float* wpk, const float* bias, const float* mask, float* y,
                       int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int tile, hipStream_t stream) {
+  return osvos_conv3x3_f32_ws(x, wpk, bias, mask, y, N, H, W, Cin, Cout, y_cs, relu, tile, nullptr, stream);
+}
+
+int osvos_conv3x3_f32_ws(const float* x, const float* wpk, const float* bias, const float* mask, float* y,
+                         int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int tile, void* part_ws, hipStream_t stream) {
   OSVOS_ARG_CHECK(x && wpk && y, "conv3x3: null pointer");
   OSVOS_ARG_CHECK(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv3x3: bad shape");
   OSVOS_ARG_CHECK(Cin % 8 == 0, "conv3x3 f32: Cin (%d) must be a multiple of 8 (pad the input)", Cin);
@@ -324,17 +388,38 @@ int osvos_conv3x3_f32(const float* x, const float* wpk, const float* bias, const
   }
   a.map = tile >= 100 ? 1 : 0;
   tile %= 100;
+  OSVOS_ARG_CHECK(tile >= 0 && tile < kNumTiles, "conv3x3: unknown tile config %d", tile);
+  a.ksplit = 1;
+  a.part = reinterpret_cast<float*>(part_ws);
+  if (part_ws != nullptr) {
+    const char* env = getenv("OSVOS_CONV_KSPLIT");
+    a.ksplit = g_force_ksplit > 0 ? g_force_ksplit : (env ? atoi(env) : pick_ksplit(kTiles[tile], N, H, W, Cin, Cout, a.CoutP, y_cs));
+    if (a.ksplit < 1 || a.ksplit > 8 || Cout % 4 != 0 || y_cs % 4 != 0 || a.ksplit > (Cin >> 3)) a.ksplit = 1;
+  }
+  int rc;
   switch (tile) {
-    case 0: return launch_cfg<T0>(a, stream);
-    case 1: return launch_cfg<T1>(a, stream);
-    case 2: return launch_cfg<T2>(a, stream);
-    case 3: return launch_cfg<T3>(a, stream);
-    case 4: return launch_cfg<T4>(a, stream);
-    case 5: return launch_cfg<T5>(a, stream);
-    case 6: return launch_cfg<T6>(a, stream);
-    case 7: return launch_cfg<T7>(a, stream);
-    case 8: return launch_cfg<T8>(a, stream);
-    case 9: return launch_cfg<T9>(a, stream);
+    case 0: rc = launch_cfg<T0>(a, stream); break;
+    case 1: rc = launch_cfg<T1>(a, stream); break;
+    case 2: rc = launch_cfg<T2>(a, stream); break;
+    case 3: rc = launch_cfg<T3>(a, stream); break;
+    case 4: rc = launch_cfg<T4>(a, stream); break;
+    case 5: rc = launch_cfg<T5>(a, stream); break;
+    case 6: rc = launch_cfg<T6>(a, stream); break;
+    case 7: rc = launch_cfg<T7>(a, stream); break;
+    case 8: rc = launch_cfg<T8>(a, stream); break;
+    case 9: rc = launch_cfg<T9>(a, stream); break;
+    case 10: rc = launch_cfg<T10>(a, stream); break;
+    case 11: rc = launch_cfg<T11>(a, stream); break;
+    case 12: rc = launch_cfg<T12>(a, stream); break;
+    case 13: rc = launch_cfg<T13>(a, stream); break;
     default: osvos_set_error("conv3x3: unknown tile config %d", tile); return -1;
   }
+  if (rc || a.ksplit == 1) return rc;
+  const long npix = (long)N * H * W;
+  long blocks = (npix * (Cout / 4) + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(conv_splitk_finalize_kernel, dim3((unsigned)blocks), dim3(256), 0, stream,
+                     a.part, bias, mask, y, npix, Cout, y_cs, a.ksplit, relu);
+  OSVOS_LAUNCH_CHECK();
+  return 0;
 }

@@ -4,6 +4,10 @@
 
 int osvos_conv3x3_f32(const float* x, const float* wpk, const float* bias, const float* mask, float* y,
                       int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int tile, hipStream_t stream);
+size_t osvos_conv3x3_splitk_ws_bytes_f32(int N, int H, int W, int Cout);
+void osvos_conv3x3_force_ksplit(int k);
+int osvos_conv3x3_f32_ws(const float* x, const float* wpk, const float* bias, const float* mask, float* y,
+                         int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int tile, void* part_ws, hipStream_t stream);
 size_t osvos_wgrad_ws_bytes_f32(int N, int H, int W, int Cin_s, int Cout);
 int osvos_conv3x3_wgrad_f32(const float* x, const float* dy, void* ws, float* dw, float* db,
                             int N, int H, int W, int Cin, int Cin_s, int Cout, int Cout_s,

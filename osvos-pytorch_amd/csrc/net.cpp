@@ -64,6 +64,7 @@ WbufLayout wbuf_layout(int dtype) {
 struct WsLayout {
   int hs[5], ws[5];
   size_t xin, act[kNumTrunk], pooled[5], prep[4], score[4], fpart[4];
+  size_t conv_part;          // split-K partial sums of the small deep layers (forward prefix: inference uses it too)
   size_t dy[kNumTrunk], dpool[5], dside[4], dprep[4], wgrad[kNumConv], acc, dxin;
   size_t fwd_total, total;
 };
@@ -90,6 +91,15 @@ WsLayout ws_layout(int N, int H, int W, int dtype) {
     L.prep[i] = take(es * npix * 16);
     L.score[i] = take(sizeof(float) * npix);
     L.fpart[i] = take(sizeof(float) * npix);
+  }
+  {
+    size_t mx = 0;
+    for (int l = 0; l < kNumTrunk; ++l)
+      if (d[l].cin >= 256) {
+        const size_t b = osvos_conv3x3_splitk_ws_bytes_f32(N, L.hs[d[l].stage], L.ws[d[l].stage], d[l].cout > d[l].cin ? d[l].cout : d[l].cin);
+        if (b > mx) mx = b;
+      }
+    L.conv_part = take(mx);
   }
   L.fwd_total = off;          // everything above is all an inference-only forward touches
   for (int i = 0; i < 4; ++i) {
@@ -136,6 +146,16 @@ struct EventPool {
 EventPool& event_pool() {
   static thread_local EventPool p;
   return p;
+}
+
+// 3x3 conv on the main stream: fp32 launches may be cut along K (split-K, partial sums in `part`) when the layer
+// is too small to balance across 256 CUs; the bf16-MFMA dtype goes through the public entry point
+inline int conv_main(const void* x, const void* wpk, const float* bias, const void* mask, void* y, int N, int h, int w,
+                     int cin, int cout, int y_cs, int relu, int dtype, void* part, hipStream_t stream) {
+  if (dtype == OSVOS_F32)
+    return osvos_conv3x3_f32_ws((const float*)x, (const float*)wpk, bias, (const float*)mask, (float*)y, N, h, w, cin, cout, y_cs,
+                                relu, -1, part, stream);
+  return osvos_conv3x3(x, wpk, bias, mask, y, N, h, w, cin, cout, y_cs, relu, dtype, -1, stream);
 }
 
 inline double conv_flops(int N, int h, int w, int cin, int cout) { return 2.0 * N * h * w * (double)cout * 9.0 * cin; }
@@ -234,8 +254,8 @@ int osvos_net_forward(const float* x_nchw, const void* wbuf, void* ws, float* co
     for (int j = 0; j < kStageN[si]; ++j, ++l) {
       {
         ProfScope ps(OSVOS_PROF_CONV_FWD, conv_flops(N, h, w, d[l].cin, d[l].cout), stream);
-        rc = osvos_conv3x3(cur, at(wbuf, P.fwd[l]), reinterpret_cast<const float*>(at(wbuf, P.bias[l])), nullptr,
-                           at(ws, L.act[l]), N, h, w, d[l].cin_s, d[l].cout, d[l].cout, 1, dtype, -1, stream);
+        rc = conv_main(cur, at(wbuf, P.fwd[l]), reinterpret_cast<const float*>(at(wbuf, P.bias[l])), nullptr,
+                       at(ws, L.act[l]), N, h, w, d[l].cin_s, d[l].cout, d[l].cout, 1, dtype, at(ws, L.conv_part), stream);
       }
       if (rc) return rc;
       cur = at(ws, L.act[l]);
@@ -416,14 +436,16 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
     }
     if (first_of_stage) {
       // through the pool into the previous stage's output (+ that stage's side branch, + ReLU mask)
-      rc = osvos_conv3x3(g, at(wbuf, P.dgrad[l]), nullptr, nullptr, at(ws, L.dpool[si]), N, h, w, d[l].cout, d[l].cin, d[l].cin, 0, dtype, -1, stream);
+      rc = conv_main(g, at(wbuf, P.dgrad[l]), nullptr, nullptr, at(ws, L.dpool[si]), N, h, w, d[l].cout, d[l].cin, d[l].cin, 0, dtype,
+                     at(ws, L.conv_part), stream);
       if (rc) return rc;
       const int ps2 = si - 1;
       const void* dside = ps2 >= 1 ? at(ws, L.dside[ps2 - 1]) : nullptr;
       rc = osvos_maxpool2x2_bwd(at(ws, L.act[l - 1]), at(ws, L.dpool[si]), dside, at(ws, L.dy[l - 1]), N, L.hs[ps2], L.ws[ps2], kStageC[ps2], dtype, stream);
       if (rc) return rc;
     } else {
-      rc = osvos_conv3x3(g, at(wbuf, P.dgrad[l]), nullptr, at(ws, L.act[l - 1]), at(ws, L.dy[l - 1]), N, h, w, d[l].cout, d[l].cin, d[l].cin, 0, dtype, -1, stream);
+      rc = conv_main(g, at(wbuf, P.dgrad[l]), nullptr, at(ws, L.act[l - 1]), at(ws, L.dy[l - 1]), N, h, w, d[l].cout, d[l].cin, d[l].cin, 0,
+                     dtype, at(ws, L.conv_part), stream);
       if (rc) return rc;
     }
   }
