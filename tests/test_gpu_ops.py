@@ -243,3 +243,21 @@ def test_wgrad_bf16_mfma(shape):
     assert rel_err(db.cpu(), dy.double().sum((0, 2, 3)))[0] < 1e-5
     dw2, _ = ops.conv3x3_wgrad(nhwc(x), nhwc(dy), cin, cout, accumulate_into=(dw.clone(), db.clone()), dtype=F32_BF16MFMA)
     assert rel_err(dw2.cpu(), 2 * wt.grad)[0] < 3e-5
+
+
+@pytest.mark.parametrize("ksplit", [0, 2, 3, 4, 8])
+def test_conv3x3_split_k(ksplit):
+    """K cut into parts + finalize kernel (bias, ReLU, mask) equals the single-pass result up to fp32 summation order"""
+    ops = _ops()
+    g = torch.Generator().manual_seed(31)
+    n, h, w, cin, cout = 2, 30, 54, 256, 64
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / 48
+    b = torch.randn(cout, generator=g)
+    m = torch.randn(n, cout, h, w, generator=g)
+    ref = F.relu(F.conv2d(x.double(), wt.double(), b.double(), padding=1))
+    y = ops.conv3x3_splitk(nhwc(x), ops.pack_fwd(wt.cuda()), b.cuda(), cout, ksplit, relu=True, tile=9)
+    assert rel_err(nchw(y), ref)[0] < 2e-5
+    ym = ops.conv3x3_splitk(nhwc(x), ops.pack_fwd(wt.cuda()), None, cout, ksplit, relu=False, mask=nhwc(m))
+    ref2 = F.conv2d(x.double(), wt.double(), None, padding=1) * (m > 0)
+    assert rel_err(nchw(ym), ref2)[0] < 2e-5
