@@ -345,7 +345,9 @@ int pick_ksplit(const TileInfo& t, int N, int H, int W, int Cin, int Cout, int C
   if (Cout % 4 != 0 || y_cs % 4 != 0 || Cin < 256) return 1;
   const long blocks = (long)N * ceil_div(H, t.th) * ceil_div(W, t.tw) * ceil_div(CoutP, t.bn);
   int ks = 1;
-  while (ks < 8 && blocks * ks < 1536 && (Cin / 8) / (ks * 2) >= 8) ks *= 2;
+  // measured (tools/tune_splitk.py): only grids of about one workgroup per CU gain (conv5_x at batch 1, 0.099 -> 0.090 ms);
+  // 6420-pixel and larger layers are MFMA-issue bound, not fill bound, and lose the finalize pass
+  while (ks < 8 && blocks * ks < 512 && (Cin / 8) / (ks * 2) >= 8) ks *= 2;
   return ks;
 }
 
