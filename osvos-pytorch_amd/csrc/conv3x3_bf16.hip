@@ -9,10 +9,12 @@
 //     and the L2->LDS weight stream, not the matrix pipe, are what has to be rationed
 //   * numerics equal a bf16-activation pipeline: rounding happens right before the MFMA either way
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
 
 struct ConvArgsB {
   const float* x;        // fp32 NHWC, channel stride Cin (multiple of 8)
@@ -23,6 +25,7 @@ struct ConvArgsB {
   int N, H, W, Cin, CinP, Cout, CoutP, y_cs;
   int tiles_x, tiles_y, nct, nsp, map;
   int relu;
+  unsigned long long* prof;   // phase cycle counters (only read by builds with -DOSVOS_CONV_PROF; tools/conv_phase_probe.py)
 };
 
 constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
@@ -30,11 +33,17 @@ constexpr int pitch_for(int rbw, int hw) {
   return rbw == 32 ? hw : (rbw == 16 ? cdiv(hw, 16) * 16 : cdiv(hw - 8, 16) * 16 + 8);
 }
 
-constexpr int KG = 4;   // 16-byte groups (8 channels each) per K chunk
 
-template <int RBW_, int TBX_, int TBY_, int NB_, int WGM_, int WGN_, int PIPE_ = 1>
+template <int RBW_, int TBX_, int TBY_, int NB_, int WGM_, int WGN_, int PIPE_ = 1, int RR_ = 0, int OCC_ = 1, int ILV_ = 0, int KG_ = 4>
 struct CfgB {
+  static constexpr int KG = KG_;                       // 16-byte groups (8 bf16 channels each) per K chunk: 4 = 32 channels, 2 = 16
+  static constexpr int KS = KG_ / 2;                   // MFMA k-steps (16 channels) per tap and chunk
+  static_assert(KG_ == 2 || KG_ == 4, "chunk of 16 or 32 channels");
+  static constexpr int ILV = ILV_;                     // 1: next chunk's global loads are issued one per MFMA inside the stage loop
+  static constexpr int OCC = OCC_;                     // waves per SIMD the register allocation must allow
   static constexpr int RBW = RBW_, TBX = TBX_, TBY = TBY_, NB = NB_, WGM = WGM_, WGN = WGN_, PIPE = PIPE_;
+  static constexpr int RR = RR_;                       // row re-use loop (needs one image row per M block)
+  static_assert(RR_ == 0 || (RBW_ == 32 && TBX_ == 1), "row re-use needs RBW = 32, TBX = 1");
   static constexpr int RBH = 32 / RBW;
   static constexpr int TW = TBX * RBW, TH = TBY * RBH;
   static constexpr int HWD = TW + 2, HHT = TH + 2;
@@ -50,7 +59,7 @@ struct CfgB {
   static constexpr int NBL = cdiv(B_U4, NT);
   static constexpr int MB = TBX * TBY;
   static constexpr int WM = MB / WGM, WN = NB / WGN;
-  static constexpr size_t LDS_BYTES = (size_t)BUF_U4 * 16;   // single buffer; the next chunk waits in registers
+  static constexpr size_t LDS_BYTES = (size_t)(BUF_U4 + 1) * 16;   // single buffer (+ one spare slot); the next chunk waits in registers
   static_assert(WGM * WGN == 4 || WGM * WGN == 8, "4 or 8 waves per workgroup");
   static_assert(MB % WGM == 0 && NB % WGN == 0, "wave grid must divide the tile");
 };
@@ -63,7 +72,7 @@ __device__ inline uint4 pack_bf16x8(const f32x4& a, const f32x4& b) {
 }
 
 template <class C>
-__global__ __launch_bounds__(C::NT) void conv3x3_bf16_kernel(ConvArgsB a) {
+__global__ __launch_bounds__(C::NT, C::OCC) void conv3x3_bf16_kernel(ConvArgsB a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint4* lds = reinterpret_cast<uint4*>(smem);
   uint4* As = lds;
@@ -90,63 +99,79 @@ __global__ __launch_bounds__(C::NT) void conv3x3_bf16_kernel(ConvArgsB a) {
   const int CG = a.CinP >> 3;                     // 8-channel groups in the weight pack
   const float* ximg = a.x + (size_t)n * a.H * a.W * a.Cin;
 
-  int a_src[C::NA], a_dst[C::NA];                // element offset of group 0, -1 zero fill, -2 none
-  int a_grp[C::NA];
+  // Staging goes through raw buffer loads: a lane whose halo pixel lies outside the image (or that has no
+  // slot at all) gets byte offset 0x80000000 -- beyond num_records -- and the hardware returns zeros.  No
+  // per-load branch or select is left in the K loop (hipcc turns every `if (ok) v = *p` into an exec-mask
+  // branch pair: 36 of them per chunk before).  The chunk advance rides in the scalar offset.
+  constexpr unsigned OOB = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ximg), 0, (int)((size_t)a.H * a.W * a.Cin * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(a.wpk), 0, (int)((size_t)9 * CG * a.CoutP * 16), 0x00020000);
+  // (A measured alternative -- consecutive lanes on consecutive 16-byte pieces, 8-byte LDS stores -- was no faster:
+  // the cost of the activation loads is their L2 miss rate, not their lane pattern.)
+  unsigned a_off[C::NA];                         // byte offset of the slot's 8 channels in chunk 0
+  int a_dst[C::NA];
+  static_assert(C::NT % C::KG == 0, "a thread keeps the same channel group in every round");
+  const int a_grp = tid % C::KG;
 #pragma unroll
   for (int i = 0; i < C::NA; ++i) {
     const int e = tid + i * C::NT;
-    a_src[i] = -2; a_dst[i] = 0; a_grp[i] = 0;
-    if (e < C::A_LOAD) {
-      const int g = e % KG, pix = e / KG;
-      const int hy = pix / C::HWD, hx = pix % C::HWD;
-      const int gy = y0 + hy - 1, gx = x0 + hx - 1;
-      a_dst[i] = g * C::PLANE + hy * C::PITCH + hx;
-      a_grp[i] = g;
-      a_src[i] = (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? ((gy * a.W + gx) * a.Cin + 8 * g) : -1;
-    }
+    const int g = e % C::KG, pix = e / C::KG;
+    const int hy = pix / C::HWD, hx = pix % C::HWD;
+    const int gy = y0 + hy - 1, gx = x0 + hx - 1;
+    const bool slot = e < C::A_LOAD;
+    a_dst[i] = slot ? g * C::PLANE + hy * C::PITCH + hx : C::BUF_U4;      // lanes without a slot write the spare slot
+    a_off[i] = (slot && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? (unsigned)(((gy * a.W + gx) * a.Cin + 8 * g) * 4) : OOB;
   }
-  int b_src[C::NBL];
+  unsigned b_off[C::NBL];
 #pragma unroll
   for (int i = 0; i < C::NBL; ++i) {
     const int e = tid + i * C::NT;
-    b_src[i] = -2;
-    if (e < C::B_U4) {
-      const int tap = e / (KG * C::BN), rem = e % (KG * C::BN);
-      const int g = rem / C::BN, nn = rem % C::BN;
-      b_src[i] = (co0 + nn < a.CoutP) ? (tap * CG + g) * a.CoutP + co0 + nn : -1;
-    }
+    const int tap = e / (C::KG * C::BN), rem = e % (C::KG * C::BN);
+    const int g = rem / C::BN, nn = rem % C::BN;
+    b_off[i] = (e < C::B_U4 && co0 + nn < a.CoutP) ? (unsigned)(((tap * CG + g) * a.CoutP + co0 + nn) * 16) : OOB;
   }
+  const int cin_groups = a.Cin >> 3;             // 8-channel groups that exist in x (the pack is zero padded to CinP)
 
-  f32x4 ra[C::NA][2];
-  uint4 rb[C::NBL];
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 ra[C::NA][2];
+  u32x4 rb[C::NBL];
+#ifdef OSVOS_PROF_NO_A       // probe builds only: out-of-range offsets = zero fill without memory traffic
+#pragma unroll
+  for (int i = 0; i < C::NA; ++i) a_off[i] = OOB;
+#endif
+#ifdef OSVOS_PROF_NO_B
+#pragma unroll
+  for (int i = 0; i < C::NBL; ++i) b_off[i] = OOB;
+#endif
   auto load_chunk = [&](int kc) {
-    const int c0 = kc * 8 * KG;
 #pragma unroll
     for (int i = 0; i < C::NA; ++i) {
-      f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
-      if (a_src[i] >= 0 && c0 + 8 * a_grp[i] < a.Cin) {
-        const float* p = ximg + a_src[i] + c0;
-        v0 = *reinterpret_cast<const f32x4*>(p);
-        v1 = *reinterpret_cast<const f32x4*>(p + 4);
-      }
-      ra[i][0] = v0;
-      ra[i][1] = v1;
+      const unsigned off = (kc * C::KG + a_grp >= cin_groups) ? OOB : a_off[i];
+      ra[i][0] = __builtin_amdgcn_raw_buffer_load_b128(xrs, off, kc * (8 * C::KG * 4), 0);
+      ra[i][1] = __builtin_amdgcn_raw_buffer_load_b128(xrs, off + 16, kc * (8 * C::KG * 4), 0);
     }
-    const uint4* wq = a.wpk + (size_t)(c0 >> 3) * a.CoutP;
 #pragma unroll
-    for (int i = 0; i < C::NBL; ++i) {
-      uint4 v = {0u, 0u, 0u, 0u};
-      if (b_src[i] >= 0) v = wq[b_src[i]];
-      rb[i] = v;
+    for (int i = 0; i < C::NBL; ++i) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(wrs, b_off[i], kc * C::KG * a.CoutP * 16, 0);
+  };
+  constexpr int NL = 2 * C::NA + C::NBL;           // single load instructions per chunk
+  // (past the last chunk `dead` = OOB pushes every offset out of range: the loads return zeros without touching memory)
+  auto load_op = [&](int op, int kc, unsigned dead) {      // op is a compile-time constant after unrolling
+    if (op < 2 * C::NA) {
+      const int i = op >> 1;
+      const unsigned off = ((kc * C::KG + a_grp >= cin_groups) ? OOB : a_off[i]) | dead;
+      ra[i][op & 1] = __builtin_amdgcn_raw_buffer_load_b128(xrs, off + 16 * (op & 1), kc * (8 * C::KG * 4), 0);
+    } else {
+      const int i = op - 2 * C::NA;
+      rb[i] = __builtin_amdgcn_raw_buffer_load_b128(wrs, b_off[i] | dead, kc * C::KG * a.CoutP * 16, 0);
     }
   };
   auto store_chunk = [&]() {
 #pragma unroll
     for (int i = 0; i < C::NA; ++i)
-      if (a_src[i] != -2) As[a_dst[i]] = pack_bf16x8(ra[i][0], ra[i][1]);
+      As[a_dst[i]] = pack_bf16x8(__builtin_bit_cast(f32x4, ra[i][0]), __builtin_bit_cast(f32x4, ra[i][1]));
 #pragma unroll
     for (int i = 0; i < C::NBL; ++i)
-      if (b_src[i] != -2) Bs[tid + i * C::NT] = rb[i];
+      if (C::B_U4 % C::NT == 0 || tid + i * C::NT < C::B_U4) Bs[tid + i * C::NT] = __builtin_bit_cast(uint4, rb[i]);
   };
 
   int a_idx[C::WM];
@@ -167,68 +192,192 @@ __global__ __launch_bounds__(C::NT) void conv3x3_bf16_kernel(ConvArgsB a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-  const int nchunks = a.CinP / (8 * KG);
+  const int nchunks = a.CinP / (8 * C::KG);
+#ifdef OSVOS_CONV_PROF
+  unsigned long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tq, tp = __builtin_amdgcn_s_memtime();
+  const unsigned long long t_begin = tp;
+#define PROF_MARK(k) do { tq = __builtin_amdgcn_s_memtime(); pt[k] += tq - tp; tp = tq; } while (0)
+#else
+#define PROF_MARK(k) do { } while (0)
+#endif
   load_chunk(0);
+  PROF_MARK(0);
   for (int kc = 0; kc < nchunks; ++kc) {
     __syncthreads();                     // every wave is done with the previous chunk's tiles
+    PROF_MARK(1);
+#ifdef OSVOS_CONV_PROF
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    PROF_MARK(2);
+#endif
     store_chunk();
+    PROF_MARK(3);
     __syncthreads();
-    if (kc + 1 < nchunks) load_chunk(kc + 1);      // in flight during the MFMAs below
-    // 18 (tap, k-step) stages, software pipelined: operands of stage s+1 are requested before the
-    // MFMAs of stage s issue; sched_barrier pins that order
-    uint4 fa[1 + C::PIPE][C::WM], fb[1 + C::PIPE][C::WN];
-    auto ldfrag = [&](int st, int set) {
-      const int tap = st >> 1, ks = st & 1;
-      const int r = tap / 3, s = tap % 3;
+    PROF_MARK(4);
+    const bool more = kc + 1 < nchunks;
+    if (!C::ILV && more) load_chunk(kc + 1);       // in flight during the MFMAs below
+    PROF_MARK(5);
+    // ILV: the next chunk's loads are issued INSIDE the stage loop, one after each MFMA -- the matrix pipe executes
+    // (32 cycles per MFMA) while the wave spends its issue slots on the memory pipe; as a separate phase the 21 loads
+    // of the 256 px x 64 co tile cost 1900 cycles per chunk against 2304 cycles of MFMA (tools/conv_phase_probe.py)
+    auto stages = [&](auto more_c) {
+      constexpr bool ISSUE = decltype(more_c)::value && C::ILV;
+      auto fill = [&](int op) {      // op = index of the MFMA just issued
+        if (ISSUE && op < NL) {
+          load_op(op, kc + 1, more ? 0u : OOB);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      };
+      if constexpr (C::RR) {
+        // Row re-use: an M block is one image row of 32 pixels, so tap row r of output row m reads halo row m + r --
+        // the SAME fragment that tap row r-1 of output row m+1 reads.  Per (tap column s, k-step) stage a wave
+        // fetches WM + 2 halo-row fragments and 3 weight fragments per cout block and issues 3*WM*WN MFMAs:
+        // (WM + 2 + 3 WN) LDS reads per 3 WM WN MFMAs instead of 3 (WM + WN) -- 9 vs 15 for the 4x1 wave tile.
+        constexpr int NR = C::WM + 2;
+        uint4 fa[1 + C::PIPE][NR], fb[1 + C::PIPE][3][C::WN];
+        const int a_row0 = lh * C::PLANE + (wm * C::WM) * C::PITCH + li;
+        auto ldfrag = [&](int st, int set) {
+          const int s = st / C::KS, ks = st % C::KS;
 #pragma unroll
-      for (int mi = 0; mi < C::WM; ++mi) fa[set][mi] = As[a_idx[mi] + 2 * ks * C::PLANE + r * C::PITCH + s];
+          for (int q = 0; q < NR; ++q) fa[set][q] = As[a_row0 + 2 * ks * C::PLANE + q * C::PITCH + s];
 #pragma unroll
-      for (int ni = 0; ni < C::WN; ++ni) fb[set][ni] = Bs[b_idx + (tap * KG + 2 * ks) * C::BN + ni * 32];
-    };
-    if (C::PIPE) ldfrag(0, 0);
+          for (int r = 0; r < 3; ++r)
 #pragma unroll
-    for (int st = 0; st < 18; ++st) {
-      const int cur = C::PIPE ? (st & 1) : 0;
-      if (C::PIPE) {
-        if (st + 1 < 18) ldfrag(st + 1, (st + 1) & 1);
-        __builtin_amdgcn_sched_barrier(0);
+            for (int ni = 0; ni < C::WN; ++ni) fb[set][r][ni] = Bs[b_idx + ((r * 3 + s) * C::KG + 2 * ks) * C::BN + ni * 32];
+        };
+        if (C::PIPE) ldfrag(0, 0);
+#pragma unroll
+        for (int st = 0; st < 3 * C::KS; ++st) {
+          const int cur = C::PIPE ? (st & 1) : 0;
+          if (C::PIPE) {
+            if (st + 1 < 3 * C::KS) ldfrag(st + 1, (st + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+          } else {
+            ldfrag(st, 0);
+          }
+#pragma unroll
+          for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int mi = 0; mi < C::WM; ++mi)
+#pragma unroll
+              for (int ni = 0; ni < C::WN; ++ni) {
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fb[cur][r][ni]),
+                                                                      __builtin_bit_cast(bf16x8_t, fa[cur][mi + r]), acc[mi][ni], 0, 0, 0);
+                fill(((st * 3 + r) * C::WM + mi) * C::WN + ni);
+              }
+          if (C::PIPE) __builtin_amdgcn_sched_barrier(0);
+        }
       } else {
-        ldfrag(st, 0);     // 8-wave tiles: two waves per SIMD cover each other's LDS latency, registers are the scarce resource
+        // 18 (tap, k-step) stages, software pipelined: operands of stage s+1 are requested before the
+        // MFMAs of stage s issue; sched_barrier pins that order
+        uint4 fa[1 + C::PIPE][C::WM], fb[1 + C::PIPE][C::WN];
+        auto ldfrag = [&](int st, int set) {
+          const int tap = st / C::KS, ks = st % C::KS;
+          const int r = tap / 3, s = tap % 3;
+#pragma unroll
+          for (int mi = 0; mi < C::WM; ++mi) fa[set][mi] = As[a_idx[mi] + 2 * ks * C::PLANE + r * C::PITCH + s];
+#pragma unroll
+          for (int ni = 0; ni < C::WN; ++ni) fb[set][ni] = Bs[b_idx + (tap * C::KG + 2 * ks) * C::BN + ni * 32];
+        };
+        if (C::PIPE) ldfrag(0, 0);
+#pragma unroll
+        for (int st = 0; st < 9 * C::KS; ++st) {
+          const int cur = C::PIPE ? (st & 1) : 0;
+          if (C::PIPE) {
+            if (st + 1 < 9 * C::KS) ldfrag(st + 1, (st + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+          } else {
+            ldfrag(st, 0);     // 8-wave tiles: two waves per SIMD cover each other's LDS latency, registers are the scarce resource
+          }
+#pragma unroll
+          for (int mi = 0; mi < C::WM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < C::WN; ++ni) {
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fb[cur][ni]),
+                                                                    __builtin_bit_cast(bf16x8_t, fa[cur][mi]), acc[mi][ni], 0, 0, 0);
+              fill((st * C::WM + mi) * C::WN + ni);
+            }
+          if (C::PIPE) __builtin_amdgcn_sched_barrier(0);
+        }
       }
-#pragma unroll
-      for (int mi = 0; mi < C::WM; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < C::WN; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fa[cur][mi]),
-                                                                __builtin_bit_cast(bf16x8_t, fb[cur][ni]), acc[mi][ni], 0, 0, 0);
-      if (C::PIPE) __builtin_amdgcn_sched_barrier(0);
-    }
+      static_assert(!C::ILV || NL <= 9 * C::KS * C::WM * C::WN, "more loads than MFMAs in a chunk");
+    };
+    if constexpr (C::ILV) stages(std::true_type{}); else stages(std::false_type{});
+    PROF_MARK(6);
   }
 
+  // ---- epilogue.  The weight fragment is the FIRST MFMA operand, so D = [cout rows][pixel columns]: lane (li, lh)
+  // holds pixel li of its M block and, per accumulator, couts 8 q + 4 lh + (0..3) in registers 4q..4q+3 -- four
+  // consecutive NHWC channels = one 16-byte store.  Stores (and bias / mask loads) are raw buffer accesses whose
+  // offset is pushed out of range for pixels outside the image and couts past Cout: no branches, no 64-bit
+  // address arithmetic (the former per-element dword epilogue took 40 % of a wave's lifetime at Cin = 256).
+  const size_t img_elems = (size_t)a.H * a.W * a.y_cs;
+  if ((a.Cout & 3) == 0 && (a.y_cs & 3) == 0) {
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(a.y + n * img_elems, 0, (int)(img_elems * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.mask != nullptr ? a.mask + n * img_elems : a.y), 0,
+                                                                         a.mask != nullptr ? (int)(img_elems * 4) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bias != nullptr ? a.bias : a.y), 0,
+                                                                         a.bias != nullptr ? a.Cout * 4 : 0, 0x00020000);
 #pragma unroll
-  for (int ni = 0; ni < C::WN; ++ni) {
-    const int co = co0 + (wn * C::WN + ni) * 32 + li;
-    const bool co_ok = co < a.Cout;
-    const float bv = (a.bias != nullptr && co_ok) ? a.bias[co] : 0.f;
+    for (int ni = 0; ni < C::WN; ++ni) {
+      const int cb = co0 + (wn * C::WN + ni) * 32 + 4 * lh;
+      f32x4 bv[4];
 #pragma unroll
-    for (int mi = 0; mi < C::WM; ++mi) {
-      const int mb = wm * C::WM + mi;
-      const int mbx = mb % C::TBX, mby = mb / C::TBX;
+      for (int q = 0; q < 4; ++q) bv[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brs, (cb + 8 * q) * 4, 0, 0));
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int prow = (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const int oy = y0 + mby * C::RBH + prow / C::RBW;
-        const int ox = x0 + mbx * C::RBW + prow % C::RBW;
-        if (co_ok && oy < a.H && ox < a.W) {
-          const size_t o = ((size_t)(n * a.H + oy) * a.W + ox) * a.y_cs + co;
-          float v = acc[mi][ni][r] + bv;
-          if (a.relu) v = v > 0.f ? v : 0.f;
-          if (a.mask != nullptr) v = a.mask[o] > 0.f ? v : 0.f;
-          a.y[o] = v;
+      for (int mi = 0; mi < C::WM; ++mi) {
+        const int mb = wm * C::WM + mi;
+        const int oy = y0 + (mb / C::TBX) * C::RBH + li / C::RBW;
+        const int ox = x0 + (mb % C::TBX) * C::RBW + li % C::RBW;
+        const unsigned pix = (oy < a.H && ox < a.W) ? (unsigned)((oy * a.W + ox) * a.y_cs) * 4u : OOB;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int co = cb + 8 * q;
+          const unsigned off = co < a.Cout ? pix + (unsigned)co * 4u : OOB;
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[e] = acc[mi][ni][4 * q + e] + bv[q][e];
+            if (a.relu) v[e] = v[e] > 0.f ? v[e] : 0.f;
+          }
+          if (a.mask != nullptr) {
+            const f32x4 m = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(mrs, off, 0, 0));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = m[e] > 0.f ? v[e] : 0.f;
+          }
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, off, 0, 0);
         }
       }
     }
+  } else {      // ragged channel counts (the 3-channel input gradient): element-wise
+#pragma unroll
+    for (int ni = 0; ni < C::WN; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < C::WM; ++mi) {
+        const int mb = wm * C::WM + mi;
+        const int oy = y0 + (mb / C::TBX) * C::RBH + li / C::RBW;
+        const int ox = x0 + (mb % C::TBX) * C::RBW + li % C::RBW;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = co0 + (wn * C::WN + ni) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (co < a.Cout && oy < a.H && ox < a.W) {
+            const size_t o = n * img_elems + ((size_t)oy * a.W + ox) * a.y_cs + co;
+            float v = acc[mi][ni][r] + (a.bias != nullptr ? a.bias[co] : 0.f);
+            if (a.relu) v = v > 0.f ? v : 0.f;
+            if (a.mask != nullptr) v = a.mask[o] > 0.f ? v : 0.f;
+            a.y[o] = v;
+          }
+        }
+      }
   }
+#ifdef OSVOS_CONV_PROF
+  PROF_MARK(7);
+  if (a.prof != nullptr && lane == 0) {
+    unsigned long long* q = a.prof + ((size_t)blockIdx.x * (C::NT / 64) + wave) * 10;
+    for (int k = 0; k < 8; ++k) q[k] = pt[k];
+    q[8] = t_begin;
+    q[9] = tp;
+  }
+#endif
 }
 
 template <class C>
@@ -265,11 +414,27 @@ using B7 = CfgB<8, 1, 2, 2, 2, 2>;    //  8x8 px x  64 co, 1x1
 // (a 512 px x 128 co, 4x2-accumulator 8-wave tile would need > 256 registers per lane: it spills)
 using B8 = CfgB<32, 1, 16, 2, 4, 2>;  // 512 px x  64 co, 8 waves, 4x1
 using B9 = CfgB<32, 1, 8, 4, 4, 2>;   // 256 px x 128 co, 8 waves, 2x2
-constexpr int kNumTilesB = 10;
+// row re-use loop (RR = 1)
+using B10 = CfgB<32, 1, 8, 2, 2, 2, 1, 1, 2>;   // B1 shape
+using B11 = CfgB<32, 1, 8, 2, 2, 2, 0, 1, 2>;   // B1 shape, no register double buffering
+using B12 = CfgB<32, 1, 8, 4, 2, 2, 0, 1>;   // B0 shape (4x2 accumulators)
+using B13 = CfgB<32, 1, 8, 4, 2, 2, 1, 1>;
+using B14 = CfgB<32, 1, 4, 4, 2, 2, 1, 1>;   // B2 shape (2x2)
+using B15 = CfgB<32, 1, 8, 4, 1, 4, 0, 1>;   // 256 px x 128 co, every wave all 8 rows x 1 cout block (8x1)
+using B16 = CfgB<32, 1, 8, 2, 2, 2, 1, 0, 2, 1>;   // B1 + interleaved loads
+using B17 = CfgB<32, 1, 8, 2, 2, 2, 0, 1, 2, 1>;   // B11 + interleaved loads
+using B18 = CfgB<32, 1, 4, 2, 2, 2, 1, 0, 1, 1>;   // B3 + interleaved loads
+using B19 = CfgB<16, 1, 4, 2, 2, 2, 1, 0, 1, 1>;   // B5 + interleaved loads
+using B20 = CfgB<32, 1, 8, 4, 2, 2, 0, 0, 2, 0, 2>;  // 256 px x 128 co, 4x2 accumulators, 16-channel chunks, 2 workgroups per CU
+using B21 = CfgB<32, 1, 8, 4, 2, 2, 1, 0, 2, 0, 2>;
+using B22 = CfgB<32, 1, 8, 4, 2, 2, 0, 1, 2, 0, 2>;  // + row re-use
+using B23 = CfgB<32, 1, 8, 2, 2, 2, 1, 0, 3, 0, 2>;  // B1 with 16-channel chunks (3 workgroups per CU)
+constexpr int kNumTilesB = 24;
 template <class C>
 constexpr TileInfoB infoB() { return TileInfoB{C::TW, C::TH, C::BN, C::WM, C::WN, C::LDS_BYTES}; }
 const TileInfoB kTilesB[kNumTilesB] = {infoB<B0>(), infoB<B1>(), infoB<B2>(), infoB<B3>(), infoB<B4>(), infoB<B5>(), infoB<B6>(), infoB<B7>(),
-                                       infoB<B8>(), infoB<B9>()};
+                                       infoB<B8>(), infoB<B9>(),
+                                       infoB<B10>(), infoB<B11>(), infoB<B12>(), infoB<B13>(), infoB<B14>(), infoB<B15>(), infoB<B16>(), infoB<B17>(), infoB<B18>(), infoB<B19>(), infoB<B20>(), infoB<B21>(), infoB<B22>(), infoB<B23>()};
 
 // Measured (profiles/r01_tune_bf16_*.txt): B1 (256 px x 64 couts, 4 accumulators, 2 workgroups per CU) wins
 // whenever it yields enough workgroups (up to 825 TFLOP/s on conv3_x/conv4_x at batch 12); the 8-accumulator
@@ -342,6 +507,9 @@ int osvos_pack_dgrad_bf16(const float* w, void* wpk, int Cout, int Cin, hipStrea
   return 0;
 }
 
+static unsigned long long* g_conv_prof = nullptr;
+extern "C" void osvos_debug_set_conv_prof(void* p) { g_conv_prof = (unsigned long long*)p; }
+
 // x fp32 NHWC (stride Cin, multiple of 8), wpk from osvos_pack_{fwd,dgrad}_bf16 with the same Cin/Cout roles
 int osvos_conv3x3_bf16mfma(const float* x, const void* wpk, const float* bias, const float* mask, float* y,
                            int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int tile, hipStream_t stream) {
@@ -349,11 +517,13 @@ int osvos_conv3x3_bf16mfma(const float* x, const void* wpk, const float* bias, c
   OSVOS_ARG_CHECK(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv3x3 bf16: bad shape");
   OSVOS_ARG_CHECK(Cin % 8 == 0, "conv3x3 bf16: Cin (%d) must be a multiple of 8", Cin);
   OSVOS_ARG_CHECK(y_cs >= Cout, "conv3x3 bf16: y channel stride %d < Cout %d", y_cs, Cout);
-  OSVOS_ARG_CHECK((long)H * W * Cin < (1L << 31), "conv3x3 bf16: image too large for 32-bit offsets");
+  OSVOS_ARG_CHECK((long)H * W * Cin < (1L << 29), "conv3x3 bf16: image too large for 31-bit byte offsets");
+  OSVOS_ARG_CHECK((long)H * W * y_cs < (1L << 29), "conv3x3 bf16: output image too large for 31-bit byte offsets");
   ConvArgsB a;
   a.x = x; a.wpk = reinterpret_cast<const uint4*>(wpk); a.bias = bias; a.mask = mask; a.y = y;
   a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.CinP = (Cin + 31) / 32 * 32; a.Cout = Cout; a.CoutP = osvos_cout_pad(Cout); a.y_cs = y_cs;
   a.relu = relu;
+  a.prof = g_conv_prof;
   if (tile < 0) {
     const char* env = getenv("OSVOS_CONV_TILE_BF16");
     tile = env ? atoi(env) : pick_tile_b(N, H, W, a.CoutP);
@@ -372,6 +542,27 @@ int osvos_conv3x3_bf16mfma(const float* x, const void* wpk, const float* bias, c
     case 7: return launch_cfg<B7>(a, stream);
     case 8: return launch_cfg<B8>(a, stream);
     case 9: return launch_cfg<B9>(a, stream);
+    case 10: return launch_cfg<B10>(a, stream);
+    case 11: return launch_cfg<B11>(a, stream);
+    case 12: return launch_cfg<B12>(a, stream);
+    case 13: return launch_cfg<B13>(a, stream);
+    case 14: return launch_cfg<B14>(a, stream);
+    case 15: return launch_cfg<B15>(a, stream);
+    case 16: return launch_cfg<B16>(a, stream);
+    case 17: return launch_cfg<B17>(a, stream);
+    case 18: return launch_cfg<B18>(a, stream);
+    case 19: return launch_cfg<B19>(a, stream);
+    case 20: return launch_cfg<B20>(a, stream);
+    case 21: return launch_cfg<B21>(a, stream);
+    case 22: return launch_cfg<B22>(a, stream);
+    case 23: return launch_cfg<B23>(a, stream);
     default: osvos_set_error("conv3x3 bf16: unknown tile config %d", tile); return -1;
   }
 }
+
+#ifdef OSVOS_CONV_PROF   // C entry points of the scratch library tools/conv_phase_probe.py builds from this file alone
+extern "C" int osvos_prof_pack_fwd_bf16(const float* w, void* wpk, int Cout, int Cin) { return osvos_pack_fwd_bf16(w, wpk, Cout, Cin, nullptr); }
+extern "C" int osvos_prof_conv3x3_bf16mfma(const float* x, const void* wpk, float* y, int N, int H, int W, int Cin, int Cout, int tile) {
+  return osvos_conv3x3_bf16mfma(x, wpk, nullptr, nullptr, y, N, H, W, Cin, Cout, Cout, 1, tile, nullptr);
+}
+#endif

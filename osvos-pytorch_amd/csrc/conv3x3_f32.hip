@@ -58,7 +58,7 @@ struct Cfg {
   static constexpr int NBL = cdiv(B_F4, 256);
   static constexpr int MB = TBX * TBY;
   static constexpr int WM = MB / WGM, WN = NB / WGN;
-  static constexpr size_t LDS_BYTES = (size_t)2 * BUF_F4 * 16;
+  static constexpr size_t LDS_BYTES = (size_t)2 * (BUF_F4 + 1) * 16;   // two buffers, each with one spare slot
   static_assert(WGM * WGN == 4, "4 waves per workgroup");
   static_assert(MB % WGM == 0 && NB % WGN == 0, "wave grid must divide the tile");
 };
@@ -95,59 +95,49 @@ __global__ __launch_bounds__(256) void conv3x3_f32_kernel(ConvArgs a) {
   const float* ximg = a.x + (size_t)n * a.H * a.W * a.Cin;
 
   // ---- per-thread staging descriptors (invariant over K chunks) --------------------------
-  int a_src[C::NA];   // element offset inside the image, -1 = zero fill, -2 = no element
+  // Staging uses raw buffer loads: a lane whose halo pixel is outside the image (or that has no slot) carries byte
+  // offset 0x80000000 -- past num_records -- and the hardware returns zeros.  No per-load branch is left in the K loop
+  // (hipcc turns `if (ok) v = *p` into an exec-mask branch pair per load); the chunk advance rides in the scalar offset.
+  constexpr unsigned OOB = 0x80000000u;
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ximg), 0, (int)((size_t)a.H * a.W * a.Cin * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wpk), 0, (int)((size_t)9 * CQ * a.CoutP * 16), 0x00020000);
+  unsigned a_off[C::NA];
   int a_dst[C::NA];
 #pragma unroll
   for (int i = 0; i < C::NA; ++i) {
     const int e = tid + i * 256;
-    a_src[i] = -2;
-    a_dst[i] = 0;
-    if (e < C::A_LOAD) {
-      const int h = e & 1, pix = e >> 1;
-      const int hy = pix / C::HWD, hx = pix % C::HWD;
-      const int gy = y0 + hy - 1, gx = x0 + hx - 1;
-      a_dst[i] = h * C::PLANE + hy * C::PITCH + hx;
-      a_src[i] = (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? ((gy * a.W + gx) * a.Cin + 4 * h) : -1;
-    }
+    const int h = e & 1, pix = e >> 1;
+    const int hy = pix / C::HWD, hx = pix % C::HWD;
+    const int gy = y0 + hy - 1, gx = x0 + hx - 1;
+    const bool slot = e < C::A_LOAD;
+    a_dst[i] = slot ? h * C::PLANE + hy * C::PITCH + hx : C::BUF_F4;       // lanes without a slot write the spare slot of their buffer
+    a_off[i] = (slot && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? (unsigned)(((gy * a.W + gx) * a.Cin + 4 * h) * 4) : OOB;
   }
-  int b_src[C::NBL];  // float4 index into wpk for chunk 0, -2 = none
+  unsigned b_off[C::NBL];
 #pragma unroll
   for (int i = 0; i < C::NBL; ++i) {
     const int e = tid + i * 256;
-    b_src[i] = -2;
-    if (e < C::B_F4) {
-      const int tap = e / (2 * C::BN), rem = e % (2 * C::BN);
-      const int h = rem / C::BN, nn = rem % C::BN;
-      b_src[i] = (co0 + nn < a.CoutP) ? (tap * CQ + h) * a.CoutP + co0 + nn : -1;
-    }
+    const int tap = e / (2 * C::BN), rem = e % (2 * C::BN);
+    const int h = rem / C::BN, nn = rem % C::BN;
+    b_off[i] = (e < C::B_F4 && co0 + nn < a.CoutP) ? (unsigned)(((tap * CQ + h) * a.CoutP + co0 + nn) * 16) : OOB;
   }
 
-  f32x4 ra[C::NA], rb[C::NBL];
+  u32x4 ra[C::NA], rb[C::NBL];
   auto load_chunk = [&](int kc) {
-    const int c0 = kc * 8;
 #pragma unroll
-    for (int i = 0; i < C::NA; ++i) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (a_src[i] >= 0) v = *reinterpret_cast<const f32x4*>(ximg + a_src[i] + c0);
-      ra[i] = v;
-    }
-    const f32x4* wq = reinterpret_cast<const f32x4*>(a.wpk) + (size_t)(c0 >> 2) * a.CoutP;
+    for (int i = 0; i < C::NA; ++i) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(xrs, a_off[i], kc * 32, 0);
 #pragma unroll
-    for (int i = 0; i < C::NBL; ++i) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (b_src[i] >= 0) v = wq[b_src[i]];
-      rb[i] = v;
-    }
+    for (int i = 0; i < C::NBL; ++i) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(wrs, b_off[i], kc * 2 * a.CoutP * 16, 0);
   };
   auto store_chunk = [&](int buf) {
-    f32x4* As = lds + buf * C::BUF_F4;
+    f32x4* As = lds + buf * (C::BUF_F4 + 1);
     f32x4* Bs = As + C::A_F4;
 #pragma unroll
-    for (int i = 0; i < C::NA; ++i)
-      if (a_src[i] != -2) As[a_dst[i]] = ra[i];
+    for (int i = 0; i < C::NA; ++i) As[a_dst[i]] = __builtin_bit_cast(f32x4, ra[i]);
 #pragma unroll
     for (int i = 0; i < C::NBL; ++i)
-      if (b_src[i] != -2) Bs[tid + i * 256] = rb[i];
+      if (C::B_F4 % 256 == 0 || tid + i * 256 < C::B_F4) Bs[tid + i * 256] = __builtin_bit_cast(f32x4, rb[i]);
   };
 
   // ---- per-lane fragment addresses ---------------------------------------------------------
@@ -178,7 +168,7 @@ __global__ __launch_bounds__(256) void conv3x3_f32_kernel(ConvArgs a) {
   for (int kc = kc_begin; kc < nchunks; ++kc) {
     const bool more = kc + 1 < nchunks;
     if (more) load_chunk(kc + 1);
-    const f32x4* As = lds + (kc & 1) * C::BUF_F4;
+    const f32x4* As = lds + (kc & 1) * (C::BUF_F4 + 1);
     const f32x4* Bs = As + C::A_F4;
     // taps are software-pipelined: the fragments of tap+1 are requested before the MFMAs of tap issue
     f32x4 fa[2][C::WM], fb[2][C::WN];
@@ -202,41 +192,82 @@ __global__ __launch_bounds__(256) void conv3x3_f32_kernel(ConvArgs a) {
         for (int mi = 0; mi < C::WM; ++mi)
 #pragma unroll
           for (int ni = 0; ni < C::WN; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[tap & 1][mi][j], fb[tap & 1][ni][j], acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[tap & 1][ni][j], fa[tap & 1][mi][j], acc[mi][ni], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
     if (more) store_chunk((kc + 1) & 1);
     __syncthreads();
   }
 
-  // ---- epilogue: D[row = pixel][col = cout]; lane holds col li, rows (r&3) + 8*(r>>2) + 4*lh ---
+  // ---- epilogue.  The weight fragment is the FIRST MFMA operand, so D = [cout rows][pixel columns]: lane (li, lh) holds
+  // pixel li of its M block and, per accumulator, couts 8 q + 4 lh + (0..3) in registers 4q..4q+3 -- four consecutive
+  // NHWC channels = one 16-byte store.  Stores (and bias / mask loads) are raw buffer accesses whose offset is pushed
+  // out of range for pixels outside the image and couts past Cout: no branches, no 64-bit address arithmetic (the
+  // former per-element dword epilogue cost a wave 500 cycles per store instruction, tools/conv_phase_probe.py).
+  const size_t img_elems = (size_t)a.H * a.W * a.y_cs;
+  if (a.ksplit > 1 || ((a.Cout & 3) == 0 && (a.y_cs & 3) == 0)) {
+    const bool split = a.ksplit > 1;       // split-K: raw partial sums, dense [part][n][pixel][Cout]; epilogue in the finalize kernel
+    const int cs = split ? a.Cout : a.y_cs;
+    const size_t out_elems = (size_t)a.H * a.W * cs;
+    float* obase = split ? a.part + ((size_t)blockIdx.y * a.N + n) * out_elems : a.y + n * out_elems;
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(obase, 0, (int)(out_elems * 4), 0x00020000);
+    const bool use_mask = !split && a.mask != nullptr;
+    const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(use_mask ? a.mask + n * img_elems : a.y), 0,
+                                                                         use_mask ? (int)(img_elems * 4) : 0, 0x00020000);
+    const bool use_bias = !split && a.bias != nullptr;
+    const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(use_bias ? a.bias : a.y), 0, use_bias ? a.Cout * 4 : 0, 0x00020000);
+    const bool relu = !split && a.relu;
 #pragma unroll
-  for (int ni = 0; ni < C::WN; ++ni) {
-    const int co = co0 + (wn * C::WN + ni) * 32 + li;
-    const bool co_ok = co < a.Cout;
-    const float bv = (a.bias != nullptr && co_ok) ? a.bias[co] : 0.f;
+    for (int ni = 0; ni < C::WN; ++ni) {
+      const int cb = co0 + (wn * C::WN + ni) * 32 + 4 * lh;
+      f32x4 bv[4];
 #pragma unroll
-    for (int mi = 0; mi < C::WM; ++mi) {
-      const int mb = wm * C::WM + mi;
-      const int mbx = mb % C::TBX, mby = mb / C::TBX;
+      for (int q = 0; q < 4; ++q) bv[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brs, (cb + 8 * q) * 4, 0, 0));
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int prow = (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const int oy = y0 + mby * C::RBH + prow / C::RBW;
-        const int ox = x0 + mbx * C::RBW + prow % C::RBW;
-        if (co_ok && oy < a.H && ox < a.W) {
-          if (a.ksplit > 1) {      // split-K: raw partial sum, dense [pixel][Cout]
-            a.part[((size_t)blockIdx.y * a.N * a.H * a.W + (size_t)(n * a.H + oy) * a.W + ox) * a.Cout + co] = acc[mi][ni][r];
-            continue;
+      for (int mi = 0; mi < C::WM; ++mi) {
+        const int mb = wm * C::WM + mi;
+        const int oy = y0 + (mb / C::TBX) * C::RBH + li / C::RBW;
+        const int ox = x0 + (mb % C::TBX) * C::RBW + li % C::RBW;
+        const unsigned pix = (oy < a.H && ox < a.W) ? (unsigned)((oy * a.W + ox) * cs) * 4u : OOB;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int co = cb + 8 * q;
+          const unsigned off = co < a.Cout ? pix + (unsigned)co * 4u : OOB;
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[e] = acc[mi][ni][4 * q + e] + bv[q][e];
+            if (relu) v[e] = v[e] > 0.f ? v[e] : 0.f;
           }
-          const size_t o = ((size_t)(n * a.H + oy) * a.W + ox) * a.y_cs + co;
-          float v = acc[mi][ni][r] + bv;
-          if (a.relu) v = v > 0.f ? v : 0.f;
-          if (a.mask != nullptr) v = a.mask[o] > 0.f ? v : 0.f;
-          a.y[o] = v;
+          if (use_mask) {
+            const f32x4 m = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(mrs, off, 0, 0));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = m[e] > 0.f ? v[e] : 0.f;
+          }
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, off, 0, 0);
         }
       }
     }
+  } else {      // ragged channel counts (the 3-channel input gradient): element-wise
+#pragma unroll
+    for (int ni = 0; ni < C::WN; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < C::WM; ++mi) {
+        const int mb = wm * C::WM + mi;
+        const int oy = y0 + (mb / C::TBX) * C::RBH + li / C::RBW;
+        const int ox = x0 + (mb % C::TBX) * C::RBW + li % C::RBW;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = co0 + (wn * C::WN + ni) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (co < a.Cout && oy < a.H && ox < a.W) {
+            const size_t o = n * img_elems + ((size_t)oy * a.W + ox) * a.y_cs + co;
+            float v = acc[mi][ni][r] + (a.bias != nullptr ? a.bias[co] : 0.f);
+            if (a.relu) v = v > 0.f ? v : 0.f;
+            if (a.mask != nullptr) v = a.mask[o] > 0.f ? v : 0.f;
+            a.y[o] = v;
+          }
+        }
+      }
   }
 }
 
@@ -377,7 +408,7 @@ int osvos_conv3x3_f32_ws(const float* x, const float* wpk, const float* bias, co
   OSVOS_ARG_CHECK(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv3x3: bad shape");
   OSVOS_ARG_CHECK(Cin % 8 == 0, "conv3x3 f32: Cin (%d) must be a multiple of 8 (pad the input)", Cin);
   OSVOS_ARG_CHECK(y_cs >= Cout, "conv3x3: y channel stride %d < Cout %d", y_cs, Cout);
-  OSVOS_ARG_CHECK((long)H * W * Cin < (1L << 31), "conv3x3: image too large for 32-bit offsets");
+  OSVOS_ARG_CHECK((long)H * W * Cin < (1L << 29) && (long)H * W * y_cs < (1L << 29), "conv3x3: image too large for 31-bit byte offsets");
   ConvArgs a;
   a.x = x; a.wpk = wpk; a.bias = bias; a.mask = mask; a.y = y;
   a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.CoutP = osvos_cout_pad(Cout); a.y_cs = y_cs;

@@ -187,7 +187,7 @@ BF16_SHAPES = [(1, 9, 11, 8, 32), (2, 17, 35, 16, 64), (1, 33, 70, 64, 128), (1,
 
 
 @pytest.mark.parametrize("shape", BF16_SHAPES)
-@pytest.mark.parametrize("tile", list(range(10)) + [100, 106, 109, -1])
+@pytest.mark.parametrize("tile", list(range(24)) + [100, 106, 109, 120, -1])
 def test_conv3x3_bf16_mfma_forward_all_tiles(shape, tile):
     """bf16-operand path: with inputs that are already bf16-representable the only difference to a float64
     convolution is the fp32 accumulation order -> tight tolerance; this pins layout/indexing, not precision"""
