@@ -138,12 +138,12 @@ __global__ __launch_bounds__(256, OCC) void wgrad_f32_kernel(WgArgs a) {
         ld(pp + 1, av1, bv1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0, bv0[t], acc[t], 0, 0, 0);
+        for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv0[t], av0, acc[t], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         ld((pp + 2) & (PPIX / 2 - 1), av0, bv0);     // unconditional (wraps at the end): waits stay counted
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1, bv1[t], acc[t], 0, 0, 0);
+        for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv1[t], av1, acc[t], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
     } else {
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256, OCC) void wgrad_f32_kernel(WgArgs a) {
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
           const float bv = xb[((t / 3) * XW + (t % 3)) * BCI];
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv, av, acc[t], 0, 0, 0);
         }
       }
     }
@@ -192,19 +192,35 @@ __global__ __launch_bounds__(256, OCC) void wgrad_f32_kernel(WgArgs a) {
     __syncthreads();
   }
 
-  // ---- write the partial slab: D row = cout (r&3)+8*(r>>2)+4*lh, col = cin li ----------------
-  const int ci = ci0 + ib * 32 + li;
+  // ---- write the partial slab.  The x fragment is the FIRST MFMA operand, so D = [cin rows][cout columns]: lane
+  // (li, lh) holds cout li and, per tap, cins 8 q + 4 lh + (0..3) in registers 4q..4q+3 = one 16-byte piece of the
+  // coalesced [tap][co][ci] slab.  Raw buffer stores, offset out of range past Cout / Cin_s: no branches, no 64-bit
+  // address arithmetic (144 guarded dword stores per wave before).
+  const int co = co0 + cb * 32 + li;
+  if (!a.oihw) {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const size_t slab_elems = (size_t)9 * a.Cout * a.Cin_s;
+    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(a.slab + (size_t)split * slab_elems, 0, (int)(slab_elems * 4), 0x00020000);
+    const int cib = ci0 + ib * 32 + 4 * lh;
+    const unsigned row = co < a.Cout ? (unsigned)(co * a.Cin_s) * 4u : 0x80000000u;
+    const unsigned tap_stride = (unsigned)(a.Cout * a.Cin_s) * 4u;
 #pragma unroll
-  for (int t = 0; t < 9; ++t) {
+    for (int t = 0; t < 9; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int co = co0 + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (co < a.Cout && ci < a.Cin_s) {
-        const size_t o = a.oihw ? (((size_t)split * a.Cout + co) * a.Cin_s + ci) * 9 + t
-                                : ((size_t)(split * 9 + t) * a.Cout + co) * a.Cin_s + ci;
-        a.slab[o] = acc[t][r];
+      for (int q = 0; q < 4; ++q) {
+        const int ci = cib + 8 * q;
+        const unsigned off = ci < a.Cin_s ? row + (unsigned)t * tap_stride + (unsigned)ci * 4u : 0x80000000u;
+        f32x4 v = {acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), srs, off, 0, 0);
       }
-    }
+  } else {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ci = ci0 + ib * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (co < a.Cout && ci < a.Cin_s) a.slab[(((size_t)split * a.Cout + co) * a.Cin_s + ci) * 9 + t] = acc[t][r];
+      }
   }
   if (do_bias) {
     float* red = reinterpret_cast<float*>(smem);   // all LDS reads are behind the last barrier
