@@ -69,6 +69,21 @@ int osvos_conv3x3_splitk(const void* x, const void* wpk, const float* bias, cons
                          int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int dtype, int tile, int ksplit,
                          void* part_ws, void* stream);
 
+/* ---- bf16 operand storage for the bf16-MFMA path (dtype OSVOS_F32_BF16MFMA) ------------------------------------------
+ * The convolutions of that path round their operands to bf16 anyway; producers can hand the rounded tensor over
+ * directly so that the consumer reads half the bytes and skips the conversion (same numbers, RNE either way).
+ *   osvos_conv3x3_bf16io: x fp32 (x_is_bf16 = 0) or bf16 NHWC; y fp32 and, when y_bf16 != NULL, a bf16 copy of y
+ *     with the same channel stride (needs Cout % 4 == 0, y_cs % 4 == 0).  Other arguments as osvos_conv3x3.
+ *     With x_is_bf16 only the tile ids osvos_conv3x3_bf16io_tiles() reports are built.
+ *   *_bf16copy: the fp32 kernel plus a bf16 copy of its output (NULL = none). */
+int osvos_conv3x3_bf16io(const void* x, int x_is_bf16, const void* wpk, const float* bias, const float* mask, float* y, void* y_bf16,
+                         int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int tile, void* stream);
+int osvos_conv3x3_bf16io_tiles(int* tiles, int max);
+int osvos_nchw_to_nhwc_bf16copy(const float* src, void* dst, void* dst_bf16, int N, int C, int H, int W, int cpad, void* stream);
+int osvos_maxpool2x2_bf16copy(const float* x, float* y, void* y_bf16, int N, int H, int W, int C, void* stream);
+int osvos_maxpool2x2_bwd_bf16copy(const float* x, const float* dy, const float* dside, float* dx, void* dx_bf16,
+                                  int N, int H, int W, int C, void* stream);
+
 /* ---- 3x3 weight gradient (weight/bias half of aten::convolution_backward) -----------------
  * dW[co,ci,r,s] = sum_{n,h,w} dY[n,h,w,co] * x[n,h+r-1,w+s-1,ci];  db[co] = sum dY
  *   x: NHWC stride Cin_s (only ci < Cin used); dy: NHWC stride Cout_s (already ReLU-masked)

@@ -11,7 +11,10 @@ extern "C" {
 
 int osvos_nchw_to_nhwc(const float* src, void* dst, int N, int C, int H, int W, int cpad, int dtype, void* stream) {
   NEED_F32(dtype, "nchw_to_nhwc");
-  return osvos_nchw_to_nhwc_f32(src, (float*)dst, N, C, H, W, cpad, (hipStream_t)stream);
+  return osvos_nchw_to_nhwc_f32(src, (float*)dst, nullptr, N, C, H, W, cpad, (hipStream_t)stream);
+}
+int osvos_nchw_to_nhwc_bf16copy(const float* src, void* dst, void* dst_bf16, int N, int C, int H, int W, int cpad, void* stream) {
+  return osvos_nchw_to_nhwc_f32(src, (float*)dst, dst_bf16, N, C, H, W, cpad, (hipStream_t)stream);
 }
 int osvos_nhwc_to_nchw(const void* src, float* dst, int N, int C, int H, int W, int cs, int dtype, void* stream) {
   NEED_F32(dtype, "nhwc_to_nchw");
@@ -46,6 +49,14 @@ int osvos_conv3x3(const void* x, const void* wpk, const float* bias, const void*
   return osvos_conv3x3_f32((const float*)x, (const float*)wpk, bias, (const float*)mask, (float*)y,
                            N, H, W, Cin, Cout, y_cs, relu, tile, (hipStream_t)stream);
 }
+
+// bf16-MFMA convolution with explicit operand / result formats: x fp32 (x_is_bf16 = 0) or bf16 NHWC; y fp32 and,
+// when y_bf16 != NULL, a bf16 copy of y with the same channel stride (the operand of the next convolution)
+int osvos_conv3x3_bf16io(const void* x, int x_is_bf16, const void* wpk, const float* bias, const float* mask, float* y, void* y_bf16,
+                         int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int tile, void* stream) {
+  return osvos_conv3x3_bf16mfma_io(x, x_is_bf16 ? 1 : 0, wpk, bias, mask, y, y_bf16, N, H, W, Cin, Cout, y_cs, relu, tile, (hipStream_t)stream);
+}
+int osvos_conv3x3_bf16io_tiles(int* tiles, int max) { return osvos_conv3x3_bf16mfma_xb_tiles(tiles, max); }
 
 size_t osvos_conv3x3_splitk_ws_bytes(int N, int H, int W, int Cout, int dtype) {
   (void)dtype;
@@ -83,12 +94,19 @@ int osvos_conv3x3_wgrad(const void* x, const void* dy, void* ws, float* dw, floa
 
 int osvos_maxpool2x2(const void* x, void* y, int N, int H, int W, int C, int dtype, void* stream) {
   NEED_F32(dtype, "maxpool2x2");
-  return osvos_maxpool2x2_f32((const float*)x, (float*)y, N, H, W, C, (hipStream_t)stream);
+  return osvos_maxpool2x2_f32((const float*)x, (float*)y, nullptr, N, H, W, C, (hipStream_t)stream);
+}
+int osvos_maxpool2x2_bf16copy(const float* x, float* y, void* y_bf16, int N, int H, int W, int C, void* stream) {
+  return osvos_maxpool2x2_f32(x, y, y_bf16, N, H, W, C, (hipStream_t)stream);
 }
 int osvos_maxpool2x2_bwd(const void* x, const void* dy, const void* dside, void* dx,
                          int N, int H, int W, int C, int dtype, void* stream) {
   NEED_F32(dtype, "maxpool2x2_bwd");
-  return osvos_maxpool2x2_bwd_f32((const float*)x, (const float*)dy, (const float*)dside, (float*)dx, N, H, W, C, (hipStream_t)stream);
+  return osvos_maxpool2x2_bwd_f32((const float*)x, (const float*)dy, (const float*)dside, (float*)dx, nullptr, N, H, W, C, (hipStream_t)stream);
+}
+int osvos_maxpool2x2_bwd_bf16copy(const float* x, const float* dy, const float* dside, float* dx, void* dx_bf16,
+                                  int N, int H, int W, int C, void* stream) {
+  return osvos_maxpool2x2_bwd_f32(x, dy, dside, dx, dx_bf16, N, H, W, C, (hipStream_t)stream);
 }
 
 int osvos_head_lowres(const void* prep, const float* wd, const float* bd, const float* wf,

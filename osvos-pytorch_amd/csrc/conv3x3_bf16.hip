@@ -15,13 +15,15 @@ namespace {
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 struct ConvArgsB {
-  const float* x;        // fp32 NHWC, channel stride Cin (multiple of 8)
+  const void* x;         // NHWC, channel stride Cin (multiple of 8): fp32 (XB = 0) or bf16 (XB = 1)
   const uint4* wpk;      // bf16 pack [9][CinP/8][CoutP][8], CinP = Cin rounded up to 32
   const float* bias;
   const float* mask;
   float* y;
+  bf16_t* ybf;           // optional bf16 copy of y (same channel stride): the next convolution's operand
   int N, H, W, Cin, CinP, Cout, CoutP, y_cs;
   int tiles_x, tiles_y, nct, nsp, map;
   int relu;
@@ -71,7 +73,7 @@ __device__ inline uint4 pack_bf16x8(const f32x4& a, const f32x4& b) {
   return __builtin_bit_cast(uint4, v);
 }
 
-template <class C>
+template <class C, int XB>      // XB = 1: the input tensor is already bf16 (half the bytes, no conversion while staging)
 __global__ __launch_bounds__(C::NT, C::OCC) void conv3x3_bf16_kernel(ConvArgsB a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint4* lds = reinterpret_cast<uint4*>(smem);
@@ -97,14 +99,15 @@ __global__ __launch_bounds__(C::NT, C::OCC) void conv3x3_bf16_kernel(ConvArgsB a
   const int n = sp / a.tiles_y;
   const int x0 = tx * C::TW, y0 = ty * C::TH, co0 = ct * C::BN;
   const int CG = a.CinP >> 3;                     // 8-channel groups in the weight pack
-  const float* ximg = a.x + (size_t)n * a.H * a.W * a.Cin;
+  constexpr int XE = XB ? 2 : 4;                  // bytes per input element
+  const char* ximg = reinterpret_cast<const char*>(a.x) + (size_t)n * a.H * a.W * a.Cin * XE;
 
   // Staging goes through raw buffer loads: a lane whose halo pixel lies outside the image (or that has no
   // slot at all) gets byte offset 0x80000000 -- beyond num_records -- and the hardware returns zeros.  No
   // per-load branch or select is left in the K loop (hipcc turns every `if (ok) v = *p` into an exec-mask
   // branch pair: 36 of them per chunk before).  The chunk advance rides in the scalar offset.
   constexpr unsigned OOB = 0x80000000u;
-  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ximg), 0, (int)((size_t)a.H * a.W * a.Cin * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(ximg), 0, (int)((size_t)a.H * a.W * a.Cin * XE), 0x00020000);
   const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(a.wpk), 0, (int)((size_t)9 * CG * a.CoutP * 16), 0x00020000);
   // (A measured alternative -- consecutive lanes on consecutive 16-byte pieces, 8-byte LDS stores -- was no faster:
   // the cost of the activation loads is their L2 miss rate, not their lane pattern.)
@@ -120,7 +123,7 @@ __global__ __launch_bounds__(C::NT, C::OCC) void conv3x3_bf16_kernel(ConvArgsB a
     const int gy = y0 + hy - 1, gx = x0 + hx - 1;
     const bool slot = e < C::A_LOAD;
     a_dst[i] = slot ? g * C::PLANE + hy * C::PITCH + hx : C::BUF_U4;      // lanes without a slot write the spare slot
-    a_off[i] = (slot && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? (unsigned)(((gy * a.W + gx) * a.Cin + 8 * g) * 4) : OOB;
+    a_off[i] = (slot && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? (unsigned)(((gy * a.W + gx) * a.Cin + 8 * g) * XE) : OOB;
   }
   unsigned b_off[C::NBL];
 #pragma unroll
@@ -147,28 +150,29 @@ __global__ __launch_bounds__(C::NT, C::OCC) void conv3x3_bf16_kernel(ConvArgsB a
 #pragma unroll
     for (int i = 0; i < C::NA; ++i) {
       const unsigned off = (kc * C::KG + a_grp >= cin_groups) ? OOB : a_off[i];
-      ra[i][0] = __builtin_amdgcn_raw_buffer_load_b128(xrs, off, kc * (8 * C::KG * 4), 0);
-      ra[i][1] = __builtin_amdgcn_raw_buffer_load_b128(xrs, off + 16, kc * (8 * C::KG * 4), 0);
+      ra[i][0] = __builtin_amdgcn_raw_buffer_load_b128(xrs, off, kc * (8 * C::KG * XE), 0);
+      if (!XB) ra[i][1] = __builtin_amdgcn_raw_buffer_load_b128(xrs, off + 16, kc * (8 * C::KG * XE), 0);
     }
 #pragma unroll
     for (int i = 0; i < C::NBL; ++i) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(wrs, b_off[i], kc * C::KG * a.CoutP * 16, 0);
   };
-  constexpr int NL = 2 * C::NA + C::NBL;           // single load instructions per chunk
+  constexpr int NLA = (XB ? 1 : 2) * C::NA;        // activation load instructions per chunk
+  constexpr int NL = NLA + C::NBL;                 // all load instructions per chunk
   // (past the last chunk `dead` = OOB pushes every offset out of range: the loads return zeros without touching memory)
   auto load_op = [&](int op, int kc, unsigned dead) {      // op is a compile-time constant after unrolling
-    if (op < 2 * C::NA) {
-      const int i = op >> 1;
+    if (op < NLA) {
+      const int i = XB ? op : op >> 1, h = XB ? 0 : op & 1;
       const unsigned off = ((kc * C::KG + a_grp >= cin_groups) ? OOB : a_off[i]) | dead;
-      ra[i][op & 1] = __builtin_amdgcn_raw_buffer_load_b128(xrs, off + 16 * (op & 1), kc * (8 * C::KG * 4), 0);
+      ra[i][h] = __builtin_amdgcn_raw_buffer_load_b128(xrs, off + 16 * h, kc * (8 * C::KG * XE), 0);
     } else {
-      const int i = op - 2 * C::NA;
+      const int i = op - NLA;
       rb[i] = __builtin_amdgcn_raw_buffer_load_b128(wrs, b_off[i] | dead, kc * C::KG * a.CoutP * 16, 0);
     }
   };
   auto store_chunk = [&]() {
 #pragma unroll
     for (int i = 0; i < C::NA; ++i)
-      As[a_dst[i]] = pack_bf16x8(__builtin_bit_cast(f32x4, ra[i][0]), __builtin_bit_cast(f32x4, ra[i][1]));
+      As[a_dst[i]] = XB ? __builtin_bit_cast(uint4, ra[i][0]) : pack_bf16x8(__builtin_bit_cast(f32x4, ra[i][0]), __builtin_bit_cast(f32x4, ra[i][1]));
 #pragma unroll
     for (int i = 0; i < C::NBL; ++i)
       if (C::B_U4 % C::NT == 0 || tid + i * C::NT < C::B_U4) Bs[tid + i * C::NT] = __builtin_bit_cast(uint4, rb[i]);
@@ -317,6 +321,8 @@ __global__ __launch_bounds__(C::NT, C::OCC) void conv3x3_bf16_kernel(ConvArgsB a
                                                                          a.mask != nullptr ? (int)(img_elems * 4) : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bias != nullptr ? a.bias : a.y), 0,
                                                                          a.bias != nullptr ? a.Cout * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(a.ybf != nullptr ? (void*)(a.ybf + n * img_elems) : (void*)a.y, 0,
+                                                                         a.ybf != nullptr ? (int)(img_elems * 2) : 0, 0x00020000);
 #pragma unroll
     for (int ni = 0; ni < C::WN; ++ni) {
       const int cb = co0 + (wn * C::WN + ni) * 32 + 4 * lh;
@@ -345,6 +351,11 @@ __global__ __launch_bounds__(C::NT, C::OCC) void conv3x3_bf16_kernel(ConvArgsB a
             for (int e = 0; e < 4; ++e) v[e] = m[e] > 0.f ? v[e] : 0.f;
           }
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, off, 0, 0);
+          if (a.ybf != nullptr) {      // (offset 0x80000000 >> 1 is still past the bf16 tensor's num_records)
+            bf16x4_t h;
+            h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, h), hrs, off >> 1, 0, 0);
+          }
         }
       }
     }
@@ -380,11 +391,11 @@ __global__ __launch_bounds__(C::NT, C::OCC) void conv3x3_bf16_kernel(ConvArgsB a
 #endif
 }
 
-template <class C>
+template <class C, int XB = 0>
 int launch_cfg(const ConvArgsB& a0, hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
-    OSVOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16_kernel<C>),
+    OSVOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16_kernel<C, XB>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
     attr_set = true;
   }
@@ -395,7 +406,7 @@ int launch_cfg(const ConvArgsB& a0, hipStream_t stream) {
   a.nsp = a.tiles_x * a.tiles_y * a.N;
   const long blocks = a.map == 0 ? (long)a.nct * a.nsp : (long)a.nct * ((a.nsp + 7) / 8) * 8;
   OSVOS_ARG_CHECK(blocks > 0 && blocks < (1L << 31), "conv3x3 bf16: grid of %ld blocks", blocks);
-  hipLaunchKernelGGL(conv3x3_bf16_kernel<C>, dim3((unsigned)blocks), dim3(C::NT), C::LDS_BYTES, stream, a);
+  hipLaunchKernelGGL((conv3x3_bf16_kernel<C, XB>), dim3((unsigned)blocks), dim3(C::NT), C::LDS_BYTES, stream, a);
   OSVOS_LAUNCH_CHECK();
   return 0;
 }
@@ -429,23 +440,29 @@ using B20 = CfgB<32, 1, 8, 4, 2, 2, 0, 0, 2, 0, 2>;  // 256 px x 128 co, 4x2 acc
 using B21 = CfgB<32, 1, 8, 4, 2, 2, 1, 0, 2, 0, 2>;
 using B22 = CfgB<32, 1, 8, 4, 2, 2, 0, 1, 2, 0, 2>;  // + row re-use
 using B23 = CfgB<32, 1, 8, 2, 2, 2, 1, 0, 3, 0, 2>;  // B1 with 16-channel chunks (3 workgroups per CU)
-constexpr int kNumTilesB = 24;
+using B24 = CfgB<32, 1, 16, 4, 4, 2, 0, 0, 2, 0, 2>;  // 512 px x 128 co, 8 waves (4x2 accumulators each), 16-channel chunks: one workgroup per CU
+using B25 = CfgB<32, 1, 16, 4, 4, 2, 0, 0, 2, 1, 2>;  // + loads interleaved with the MFMAs
+using B26 = CfgB<32, 1, 16, 4, 4, 2, 0, 1, 2, 1, 2>;  // + row re-use
+using B27 = CfgB<32, 1, 16, 4, 4, 2, 1, 0, 2, 1, 2>;  // + fragment double buffering
+constexpr int kNumTilesB = 28;
 template <class C>
 constexpr TileInfoB infoB() { return TileInfoB{C::TW, C::TH, C::BN, C::WM, C::WN, C::LDS_BYTES}; }
 const TileInfoB kTilesB[kNumTilesB] = {infoB<B0>(), infoB<B1>(), infoB<B2>(), infoB<B3>(), infoB<B4>(), infoB<B5>(), infoB<B6>(), infoB<B7>(),
                                        infoB<B8>(), infoB<B9>(),
-                                       infoB<B10>(), infoB<B11>(), infoB<B12>(), infoB<B13>(), infoB<B14>(), infoB<B15>(), infoB<B16>(), infoB<B17>(), infoB<B18>(), infoB<B19>(), infoB<B20>(), infoB<B21>(), infoB<B22>(), infoB<B23>()};
+                                       infoB<B10>(), infoB<B11>(), infoB<B12>(), infoB<B13>(), infoB<B14>(), infoB<B15>(), infoB<B16>(), infoB<B17>(), infoB<B18>(), infoB<B19>(), infoB<B20>(), infoB<B21>(), infoB<B22>(), infoB<B23>(), infoB<B24>(), infoB<B25>(), infoB<B26>(), infoB<B27>()};
 
-// Measured (profiles/r01_tune_bf16_*.txt): B1 (256 px x 64 couts, 4 accumulators, 2 workgroups per CU) wins
-// whenever it yields enough workgroups (up to 825 TFLOP/s on conv3_x/conv4_x at batch 12); the 8-accumulator
-// B0 tile runs one wave per SIMD and loses by 30 %; small frames fall back to 128- and 64-pixel tiles.
+// Measured (profiles/r01_tune_bf16_*.txt): with >= 128 couts the 256 px x 128 co tile on 16-channel chunks (B20: 4x2
+// accumulators per wave, two workgroups per CU) moves the fewest bytes per MFMA and wins whenever it yields enough
+// workgroups (up to 990 TFLOP/s on conv3_x/conv4_x at batch 12); B1 (256 px x 64 co, 4 accumulators) covers the
+// 64-cout layers and the frames that are too small for B20; tiny frames fall back to 128- and 64-pixel tiles.
 int pick_tile_b(int N, int H, int W, int CoutP) {
   if (CoutP <= 32) return 6;
-  const int order[] = {1, 5, 7};
-  for (int k = 0; k < 3; ++k) {
+  const int order[] = {20, 1, 5, 7};
+  for (int k = 0; k < 4; ++k) {
     const TileInfoB& t = kTilesB[order[k]];
+    if (t.bn > CoutP) continue;
     const long tiles = (long)N * ceil_div(H, t.th) * ceil_div(W, t.tw) * ceil_div(CoutP, t.bn);
-    if (tiles >= 400 || k == 2) return order[k];
+    if (tiles >= 400 || k == 3) return order[k];
   }
   return 7;
 }
@@ -511,16 +528,18 @@ static unsigned long long* g_conv_prof = nullptr;
 extern "C" void osvos_debug_set_conv_prof(void* p) { g_conv_prof = (unsigned long long*)p; }
 
 // x fp32 NHWC (stride Cin, multiple of 8), wpk from osvos_pack_{fwd,dgrad}_bf16 with the same Cin/Cout roles
-int osvos_conv3x3_bf16mfma(const float* x, const void* wpk, const float* bias, const float* mask, float* y,
-                           int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int tile, hipStream_t stream) {
+// xb = 0: x fp32, xb = 1: x bf16; ybf (optional) receives a bf16 copy of y
+int osvos_conv3x3_bf16mfma_io(const void* x, int xb, const void* wpk, const float* bias, const float* mask, float* y, void* ybf,
+                              int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int tile, hipStream_t stream) {
   OSVOS_ARG_CHECK(x && wpk && y, "conv3x3 bf16: null pointer");
   OSVOS_ARG_CHECK(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv3x3 bf16: bad shape");
   OSVOS_ARG_CHECK(Cin % 8 == 0, "conv3x3 bf16: Cin (%d) must be a multiple of 8", Cin);
   OSVOS_ARG_CHECK(y_cs >= Cout, "conv3x3 bf16: y channel stride %d < Cout %d", y_cs, Cout);
   OSVOS_ARG_CHECK((long)H * W * Cin < (1L << 29), "conv3x3 bf16: image too large for 31-bit byte offsets");
   OSVOS_ARG_CHECK((long)H * W * y_cs < (1L << 29), "conv3x3 bf16: output image too large for 31-bit byte offsets");
+  OSVOS_ARG_CHECK(ybf == nullptr || (Cout % 4 == 0 && y_cs % 4 == 0), "conv3x3 bf16: the bf16 output copy needs Cout and y_cs multiples of 4");
   ConvArgsB a;
-  a.x = x; a.wpk = reinterpret_cast<const uint4*>(wpk); a.bias = bias; a.mask = mask; a.y = y;
+  a.x = x; a.wpk = reinterpret_cast<const uint4*>(wpk); a.bias = bias; a.mask = mask; a.y = y; a.ybf = reinterpret_cast<bf16_t*>(ybf);
   a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.CinP = (Cin + 31) / 32 * 32; a.Cout = Cout; a.CoutP = osvos_cout_pad(Cout); a.y_cs = y_cs;
   a.relu = relu;
   a.prof = g_conv_prof;
@@ -531,6 +550,20 @@ int osvos_conv3x3_bf16mfma(const float* x, const void* wpk, const float* bias, c
   }
   a.map = tile >= 100 ? 1 : 0;
   tile %= 100;
+  if (xb) {      // bf16 activations: the tiles the network uses
+    switch (tile) {
+      case 1: return launch_cfg<B1, 1>(a, stream);
+      case 3: return launch_cfg<B3, 1>(a, stream);
+      case 5: return launch_cfg<B5, 1>(a, stream);
+      case 6: return launch_cfg<B6, 1>(a, stream);
+      case 7: return launch_cfg<B7, 1>(a, stream);
+      case 11: return launch_cfg<B11, 1>(a, stream);
+      case 20: return launch_cfg<B20, 1>(a, stream);
+      case 22: return launch_cfg<B22, 1>(a, stream);
+      case 23: return launch_cfg<B23, 1>(a, stream);
+      default: osvos_set_error("conv3x3 bf16: tile config %d is not built for bf16 activations (1, 3, 5, 6, 7, 11, 20, 22, 23 are)", tile); return -1;
+    }
+  }
   switch (tile) {
     case 0: return launch_cfg<B0>(a, stream);
     case 1: return launch_cfg<B1>(a, stream);
@@ -556,8 +589,25 @@ int osvos_conv3x3_bf16mfma(const float* x, const void* wpk, const float* bias, c
     case 21: return launch_cfg<B21>(a, stream);
     case 22: return launch_cfg<B22>(a, stream);
     case 23: return launch_cfg<B23>(a, stream);
+    case 24: return launch_cfg<B24>(a, stream);
+    case 25: return launch_cfg<B25>(a, stream);
+    case 26: return launch_cfg<B26>(a, stream);
+    case 27: return launch_cfg<B27>(a, stream);
     default: osvos_set_error("conv3x3 bf16: unknown tile config %d", tile); return -1;
   }
+}
+
+int osvos_conv3x3_bf16mfma_xb_tiles(int* tiles, int max) {      // tile ids built for bf16 activations
+  static const int t[] = {1, 3, 5, 6, 7, 11, 20, 22, 23};
+  int n = 0;
+  for (; n < (int)(sizeof(t) / sizeof(t[0])) && n < max; ++n) tiles[n] = t[n];
+  return n;
+}
+
+// x fp32 NHWC (stride Cin, multiple of 8), wpk from osvos_pack_{fwd,dgrad}_bf16 with the same Cin/Cout roles
+int osvos_conv3x3_bf16mfma(const float* x, const void* wpk, const float* bias, const float* mask, float* y,
+                           int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int tile, hipStream_t stream) {
+  return osvos_conv3x3_bf16mfma_io(x, 0, wpk, bias, mask, y, nullptr, N, H, W, Cin, Cout, y_cs, relu, tile, stream);
 }
 
 #ifdef OSVOS_CONV_PROF   // C entry points of the scratch library tools/conv_phase_probe.py builds from this file alone

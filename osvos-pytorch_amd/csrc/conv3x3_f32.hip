@@ -33,6 +33,7 @@ struct ConvArgs {
   int relu, map, nsp;
   int ksplit;         // > 1: blockIdx.y = K part; raw partial sums go to `part`, epilogue runs in conv_splitk_finalize
   float* part;        // [ksplit][N][H][W][Cout]
+  unsigned long long* prof;   // phase cycle counters (-DOSVOS_CONV_PROF builds only; tools/conv_phase_probe.py)
 };
 
 constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
@@ -162,12 +163,21 @@ __global__ __launch_bounds__(256) void conv3x3_f32_kernel(ConvArgs a) {
   const int nch_all = a.Cin >> 3;
   const int kc_begin = (int)((long)nch_all * blockIdx.y / a.ksplit);
   const int nchunks = (int)((long)nch_all * (blockIdx.y + 1) / a.ksplit);      // end (exclusive) of this K part
+#ifdef OSVOS_CONV_PROF
+  unsigned long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tq, tp = __builtin_amdgcn_s_memtime();
+  const unsigned long long t_begin = tp;
+#define PROF_MARK(k) do { tq = __builtin_amdgcn_s_memtime(); pt[k] += tq - tp; tp = tq; } while (0)
+#else
+#define PROF_MARK(k) do { } while (0)
+#endif
   load_chunk(kc_begin);
   store_chunk(kc_begin & 1);
   __syncthreads();
+  PROF_MARK(0);
   for (int kc = kc_begin; kc < nchunks; ++kc) {
     const bool more = kc + 1 < nchunks;
     if (more) load_chunk(kc + 1);
+    PROF_MARK(5);
     const f32x4* As = lds + (kc & 1) * (C::BUF_F4 + 1);
     const f32x4* Bs = As + C::A_F4;
     // taps are software-pipelined: the fragments of tap+1 are requested before the MFMAs of tap issue
@@ -195,8 +205,15 @@ __global__ __launch_bounds__(256) void conv3x3_f32_kernel(ConvArgs a) {
             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[tap & 1][ni][j], fa[tap & 1][mi][j], acc[mi][ni], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
+    PROF_MARK(6);
+#ifdef OSVOS_CONV_PROF
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    PROF_MARK(2);
+#endif
     if (more) store_chunk((kc + 1) & 1);
+    PROF_MARK(3);
     __syncthreads();
+    PROF_MARK(1);
   }
 
   // ---- epilogue.  The weight fragment is the FIRST MFMA operand, so D = [cout rows][pixel columns]: lane (li, lh) holds
@@ -269,6 +286,15 @@ __global__ __launch_bounds__(256) void conv3x3_f32_kernel(ConvArgs a) {
         }
       }
   }
+#ifdef OSVOS_CONV_PROF
+  PROF_MARK(7);
+  if (a.prof != nullptr && lane == 0) {
+    unsigned long long* q = a.prof + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 10;
+    for (int k = 0; k < 8; ++k) q[k] = pt[k];
+    q[8] = t_begin;
+    q[9] = tp;
+  }
+#endif
 }
 
 template <class C>
@@ -377,6 +403,8 @@ size_t osvos_conv3x3_splitk_ws_bytes_f32(int N, int H, int W, int Cout) {
 int osvos_conv3x3_f32_ws(const float* x, const float* wpk, const float* bias, const float* mask, float* y,
                          int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int tile, void* part_ws, hipStream_t stream);
 
+static unsigned long long* g_conv_prof_f32 = nullptr;
+extern "C" void osvos_debug_set_conv_prof_f32(void* p) { g_conv_prof_f32 = (unsigned long long*)p; }
 static thread_local int g_force_ksplit = 0;      // tests / tuning: osvos_conv3x3_splitk(..., ksplit > 0, ...)
 void osvos_conv3x3_force_ksplit(int k) { g_force_ksplit = k; }
 
@@ -406,6 +434,8 @@ int osvos_conv3x3_f32_ws(const float* x, const float* wpk, const float* bias, co
   tile %= 100;
   OSVOS_ARG_CHECK(tile >= 0 && tile < kNumTiles, "conv3x3: unknown tile config %d", tile);
   a.ksplit = 1;
+  a.prof = g_conv_prof_f32;
+  a.prof = g_conv_prof_f32;
   a.part = reinterpret_cast<float*>(part_ws);
   if (part_ws != nullptr) {
     const char* env = getenv("OSVOS_CONV_KSPLIT");
@@ -439,3 +469,26 @@ int osvos_conv3x3_f32_ws(const float* x, const float* wpk, const float* bias, co
   OSVOS_LAUNCH_CHECK();
   return 0;
 }
+
+#ifdef OSVOS_CONV_PROF   // C entry points of the scratch library tools/conv_phase_probe.py builds from this file alone
+__global__ void prof_pack_fwd_f32_kernel(const float* __restrict__ w, float* __restrict__ wpk, int Cout, int Cin, int CinP, int CoutP) {
+  const long total = 9L * CinP * CoutP;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int e = (int)(i & 3);
+    long t = i >> 2;
+    const int co = (int)(t % CoutP);
+    t /= CoutP;
+    const int cq = (int)(t % (CinP / 4));
+    const int tap = (int)(t / (CinP / 4));
+    const int ci = cq * 4 + e;
+    wpk[i] = (co < Cout && ci < Cin) ? w[((long)co * Cin + ci) * 9 + tap] : 0.f;
+  }
+}
+extern "C" int osvos_prof_pack_fwd_f32(const float* w, float* wpk, int Cout, int Cin) {
+  hipLaunchKernelGGL(prof_pack_fwd_f32_kernel, dim3(1024), dim3(256), 0, nullptr, w, wpk, Cout, Cin, (Cin + 7) / 8 * 8, osvos_cout_pad(Cout));
+  return (int)hipGetLastError();
+}
+extern "C" int osvos_prof_conv3x3_f32(const float* x, const float* wpk, float* y, int N, int H, int W, int Cin, int Cout, int tile) {
+  return osvos_conv3x3_f32(x, wpk, nullptr, nullptr, y, N, H, W, Cin, Cout, Cout, 1, tile, nullptr);
+}
+#endif

@@ -12,12 +12,12 @@ size_t osvos_wgrad_ws_bytes_f32(int N, int H, int W, int Cin_s, int Cout);
 int osvos_conv3x3_wgrad_f32(const float* x, const float* dy, void* ws, float* dw, float* db,
                             int N, int H, int W, int Cin, int Cin_s, int Cout, int Cout_s,
                             int accumulate, hipStream_t stream);
-int osvos_nchw_to_nhwc_f32(const float* src, float* dst, int N, int C, int H, int W, int cpad, hipStream_t stream);
+int osvos_nchw_to_nhwc_f32(const float* src, float* dst, void* dstbf, int N, int C, int H, int W, int cpad, hipStream_t stream);
 int osvos_nhwc_to_nchw_f32(const float* src, float* dst, int N, int C, int H, int W, int cs, hipStream_t stream);
 int osvos_pack_fwd_f32(const float* w, float* wpk, int Cout, int Cin, hipStream_t stream);
 int osvos_pack_dgrad_f32(const float* w, float* wpk, int Cout, int Cin, hipStream_t stream);
-int osvos_maxpool2x2_f32(const float* x, float* y, int N, int H, int W, int C, hipStream_t stream);
-int osvos_maxpool2x2_bwd_f32(const float* x, const float* dy, const float* dside, float* dx,
+int osvos_maxpool2x2_f32(const float* x, float* y, void* ybf, int N, int H, int W, int C, hipStream_t stream);
+int osvos_maxpool2x2_bwd_f32(const float* x, const float* dy, const float* dside, float* dx, void* dxbf,
                              int N, int H, int W, int C, hipStream_t stream);
 int osvos_head_lowres_f32(const float* prep, const float* wd, const float* bd, const float* wf,
                           float* score, float* fpart, int N, int h, int w, hipStream_t stream);
@@ -34,6 +34,10 @@ int osvos_pack_dgrad_bf16(const float* w, void* wpk, int Cout, int Cin, hipStrea
 int osvos_conv3x3_bf16mfma(const float* x, const void* wpk, const float* bias, const float* mask, float* y,
                            int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int tile, hipStream_t stream);
 int osvos_conv3x3_bf16mfma_num_tiles(void);
+// xb = 1: x is bf16 NHWC; ybf (optional): bf16 copy of y
+int osvos_conv3x3_bf16mfma_io(const void* x, int xb, const void* wpk, const float* bias, const float* mask, float* y, void* ybf,
+                              int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int tile, hipStream_t stream);
+int osvos_conv3x3_bf16mfma_xb_tiles(int* tiles, int max);
 
 // bf16-operand weight gradient (fp32 tensors): wgrad_bf16.hip
 bool osvos_wgrad_bf16_applicable(int Cin_s, int Cout);

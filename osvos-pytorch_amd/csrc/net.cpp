@@ -66,6 +66,9 @@ struct WsLayout {
   size_t xin, act[kNumTrunk], pooled[5], prep[4], score[4], fpart[4];
   size_t conv_part;          // split-K partial sums of the small deep layers (forward prefix: inference uses it too)
   size_t dy[kNumTrunk], dpool[5], dside[4], dprep[4], wgrad[kNumConv], acc, dxin;
+  // bf16 copies of the conv operands (dtype OSVOS_F32_BF16MFMA only): written by the producer's epilogue, read by the
+  // consuming convolution instead of the fp32 tensor (half the bytes, no conversion while staging)
+  size_t xin_b, act_b[kNumTrunk], pooled_b[5], dy_b[kNumTrunk];
   size_t fwd_total, total;
 };
 
@@ -79,13 +82,19 @@ WsLayout ws_layout(int N, int H, int W, int dtype) {
   auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
   ConvDesc d[kNumConv];
   conv_table(d);
+  const bool shadow = dtype == OSVOS_F32_BF16MFMA;
   L.xin = take(es * N * H * W * kInPad);
+  if (shadow) L.xin_b = take((size_t)2 * N * H * W * kInPad);
   for (int l = 0; l < kNumTrunk; ++l) {
     const int si = d[l].stage;
     const size_t b = es * N * L.hs[si] * L.ws[si] * d[l].cout;
     L.act[l] = take(b);
+    if (shadow) L.act_b[l] = take(b / es * 2);
   }
-  for (int si = 1; si < 5; ++si) L.pooled[si] = take(es * N * L.hs[si] * L.ws[si] * kStageC[si - 1]);
+  for (int si = 1; si < 5; ++si) {
+    L.pooled[si] = take(es * N * L.hs[si] * L.ws[si] * kStageC[si - 1]);
+    if (shadow) L.pooled_b[si] = take((size_t)2 * N * L.hs[si] * L.ws[si] * kStageC[si - 1]);
+  }
   for (int i = 0; i < 4; ++i) {
     const size_t npix = (size_t)N * L.hs[i + 1] * L.ws[i + 1];
     L.prep[i] = take(es * npix * 16);
@@ -110,7 +119,10 @@ WsLayout ws_layout(int N, int H, int W, int dtype) {
   // one gradient buffer per trunk conv output (dLoss/d act[l], ReLU mask applied) and per pooled
   // tensor: no buffer is ever rewritten inside one backward, so the weight-gradient stream can trail
   // the data-gradient stream by any number of layers without write-after-read hazards
-  for (int l = 0; l < kNumTrunk; ++l) L.dy[l] = take(es * N * L.hs[d[l].stage] * L.ws[d[l].stage] * d[l].cout);
+  for (int l = 0; l < kNumTrunk; ++l) {
+    L.dy[l] = take(es * N * L.hs[d[l].stage] * L.ws[d[l].stage] * d[l].cout);
+    if (shadow) L.dy_b[l] = take((size_t)2 * N * L.hs[d[l].stage] * L.ws[d[l].stage] * d[l].cout);
+  }
   for (int si = 1; si < 5; ++si) L.dpool[si] = take(es * N * L.hs[si] * L.ws[si] * kStageC[si - 1]);
   // one slab workspace per layer: the slab reduce of layer l runs on its own stream while the partial
   // kernel of the next layer already refills another buffer
@@ -150,12 +162,14 @@ EventPool& event_pool() {
 
 // 3x3 conv on the main stream: fp32 launches may be cut along K (split-K, partial sums in `part`) when the layer
 // is too small to balance across 256 CUs; the bf16-MFMA dtype goes through the public entry point
-inline int conv_main(const void* x, const void* wpk, const float* bias, const void* mask, void* y, int N, int h, int w,
-                     int cin, int cout, int y_cs, int relu, int dtype, void* part, hipStream_t stream) {
+// (x_b: bf16 copy of x, preferred when present; y_b: where the bf16 copy of y goes, NULL = none)
+inline int conv_main(const void* x, const void* x_b, const void* wpk, const float* bias, const void* mask, void* y, void* y_b, int N, int h,
+                     int w, int cin, int cout, int y_cs, int relu, int dtype, void* part, hipStream_t stream) {
   if (dtype == OSVOS_F32)
     return osvos_conv3x3_f32_ws((const float*)x, (const float*)wpk, bias, (const float*)mask, (float*)y, N, h, w, cin, cout, y_cs,
                                 relu, -1, part, stream);
-  return osvos_conv3x3(x, wpk, bias, mask, y, N, h, w, cin, cout, y_cs, relu, dtype, -1, stream);
+  return osvos_conv3x3_bf16mfma_io(x_b ? x_b : x, x_b ? 1 : 0, wpk, bias, (const float*)mask, (float*)y, y_b, N, h, w, cin, cout, y_cs, relu,
+                                   -1, stream);
 }
 
 inline double conv_flops(int N, int h, int w, int cin, int cout) { return 2.0 * N * h * w * (double)cout * 9.0 * cin; }
@@ -239,26 +253,32 @@ int osvos_net_forward(const float* x_nchw, const void* wbuf, void* ws, float* co
   const WsLayout L = ws_layout(N, H, W, dtype);
   ConvDesc d[kNumConv];
   conv_table(d);
-  int rc = osvos_nchw_to_nhwc(x_nchw, at(ws, L.xin), N, 3, H, W, kInPad, dtype, stream);
+  const bool shadow = dtype == OSVOS_F32_BF16MFMA;
+  auto sh = [&](size_t off) -> void* { return shadow ? at(ws, off) : nullptr; };
+  int rc = osvos_nchw_to_nhwc_f32(x_nchw, reinterpret_cast<float*>(at(ws, L.xin)), sh(L.xin_b), N, 3, H, W, kInPad, stream);
   if (rc) return rc;
   const void* cur = at(ws, L.xin);
+  const void* cur_b = sh(L.xin_b);
   int l = 0;
   const float* score[4]; const float* fpart[4]; const float* f1[4]; const float* f16[4];
   for (int si = 0; si < 5; ++si) {
     const int h = L.hs[si], w = L.ws[si];
     if (si > 0) {
-      rc = osvos_maxpool2x2(cur, at(ws, L.pooled[si]), N, L.hs[si - 1], L.ws[si - 1], kStageC[si - 1], dtype, stream);
+      rc = osvos_maxpool2x2_f32(reinterpret_cast<const float*>(cur), reinterpret_cast<float*>(at(ws, L.pooled[si])), sh(L.pooled_b[si]), N,
+                                L.hs[si - 1], L.ws[si - 1], kStageC[si - 1], stream);
       if (rc) return rc;
       cur = at(ws, L.pooled[si]);
+      cur_b = sh(L.pooled_b[si]);
     }
     for (int j = 0; j < kStageN[si]; ++j, ++l) {
       {
         ProfScope ps(OSVOS_PROF_CONV_FWD, conv_flops(N, h, w, d[l].cin, d[l].cout), stream);
-        rc = conv_main(cur, at(wbuf, P.fwd[l]), reinterpret_cast<const float*>(at(wbuf, P.bias[l])), nullptr,
-                       at(ws, L.act[l]), N, h, w, d[l].cin_s, d[l].cout, d[l].cout, 1, dtype, at(ws, L.conv_part), stream);
+        rc = conv_main(cur, cur_b, at(wbuf, P.fwd[l]), reinterpret_cast<const float*>(at(wbuf, P.bias[l])), nullptr,
+                       at(ws, L.act[l]), sh(L.act_b[l]), N, h, w, d[l].cin_s, d[l].cout, d[l].cout, 1, dtype, at(ws, L.conv_part), stream);
       }
       if (rc) return rc;
       cur = at(ws, L.act[l]);
+      cur_b = sh(L.act_b[l]);
     }
     if (si > 0) {
       // side branch of this stage (skinny Cout=16 conv + the two 1x1 dots): latency-bound launches
@@ -272,8 +292,8 @@ int osvos_net_forward(const float* x_nchw, const void* wbuf, void* ws, float* co
       }
       {
         ProfScope ps(OSVOS_PROF_OTHER, conv_flops(N, h, w, d[sl].cin, 16), aux);
-        rc = osvos_conv3x3(cur, at(wbuf, P.fwd[sl]), reinterpret_cast<const float*>(at(wbuf, P.bias[sl])), nullptr,
-                           at(ws, L.prep[i]), N, h, w, d[sl].cin_s, 16, 16, 0, dtype, -1, aux);
+        rc = conv_main(cur, cur_b, at(wbuf, P.fwd[sl]), reinterpret_cast<const float*>(at(wbuf, P.bias[sl])), nullptr,
+                       at(ws, L.prep[i]), nullptr, N, h, w, d[sl].cin_s, 16, 16, 0, dtype, nullptr, aux);
       }
       if (rc) return rc;
       float* sc = reinterpret_cast<float*>(at(ws, L.score[i]));
@@ -354,6 +374,8 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
     return r;
   };
   int rc;
+  const bool shadow = dtype == OSVOS_F32_BF16MFMA;
+  auto sh = [&](size_t off) -> void* { return shadow ? at(ws, off) : nullptr; };
   double* acc = reinterpret_cast<double*>(at(ws, L.acc));
   const double* part[4];
   int nblk[4], fb_nblk = 0;
@@ -409,8 +431,8 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
     // stage 4 has no pool after it: its ReLU mask is applied right here and the result is the
     // upstream gradient of conv5_3; stages 1-3 are merged in maxpool2x2_bwd below
     void* dst = (i == 3) ? at(ws, L.dy[lx]) : at(ws, L.dside[i]);
-    rc = osvos_conv3x3(at(ws, L.dprep[i]), at(wbuf, P.dgrad[sl]), nullptr, (i == 3) ? at(ws, L.act[lx]) : nullptr, dst,
-                       N, h, w, 16, d[sl].cin, d[sl].cin, 0, dtype, -1, stream);
+    rc = conv_main(at(ws, L.dprep[i]), nullptr, at(wbuf, P.dgrad[sl]), nullptr, (i == 3) ? at(ws, L.act[lx]) : nullptr, dst,
+                   (i == 3) ? sh(L.dy_b[lx]) : nullptr, N, h, w, 16, d[sl].cin, d[sl].cin, 0, dtype, nullptr, stream);
     if (rc) return rc;
   }
 
@@ -420,6 +442,7 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
     const bool first_of_stage = (l == 0) || d[l - 1].stage != si;
     const void* xin = first_of_stage ? (si == 0 ? at(ws, L.xin) : at(ws, L.pooled[si])) : at(ws, L.act[l - 1]);
     const void* g = at(ws, L.dy[l]);
+    const void* g_b = sh(L.dy_b[l]);
     if (grads[d[l].w_param] != nullptr) {
       if ((rc = signal())) return rc;   // dy[l] ready -> its weight gradient may start on aux
       rc = wgrad(xin, g, l, h, w);
@@ -427,7 +450,7 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
     }
     if (l == 0) {
       if (dx_nchw != nullptr) {
-        rc = osvos_conv3x3(g, at(wbuf, P.dgrad[0]), nullptr, nullptr, at(ws, L.dxin), N, h, w, d[0].cout, 3, 4, 0, dtype, -1, stream);
+        rc = conv_main(g, g_b, at(wbuf, P.dgrad[0]), nullptr, nullptr, at(ws, L.dxin), nullptr, N, h, w, d[0].cout, 3, 4, 0, dtype, nullptr, stream);
         if (rc) return rc;
         rc = osvos_nhwc_to_nchw(at(ws, L.dxin), dx_nchw, N, 3, H, W, 4, dtype, stream);
         if (rc) return rc;
@@ -436,16 +459,18 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
     }
     if (first_of_stage) {
       // through the pool into the previous stage's output (+ that stage's side branch, + ReLU mask)
-      rc = conv_main(g, at(wbuf, P.dgrad[l]), nullptr, nullptr, at(ws, L.dpool[si]), N, h, w, d[l].cout, d[l].cin, d[l].cin, 0, dtype,
-                     at(ws, L.conv_part), stream);
+      rc = conv_main(g, g_b, at(wbuf, P.dgrad[l]), nullptr, nullptr, at(ws, L.dpool[si]), nullptr, N, h, w, d[l].cout, d[l].cin, d[l].cin, 0,
+                     dtype, at(ws, L.conv_part), stream);
       if (rc) return rc;
       const int ps2 = si - 1;
       const void* dside = ps2 >= 1 ? at(ws, L.dside[ps2 - 1]) : nullptr;
-      rc = osvos_maxpool2x2_bwd(at(ws, L.act[l - 1]), at(ws, L.dpool[si]), dside, at(ws, L.dy[l - 1]), N, L.hs[ps2], L.ws[ps2], kStageC[ps2], dtype, stream);
+      rc = osvos_maxpool2x2_bwd_f32(reinterpret_cast<const float*>(at(ws, L.act[l - 1])), reinterpret_cast<const float*>(at(ws, L.dpool[si])),
+                                    reinterpret_cast<const float*>(dside), reinterpret_cast<float*>(at(ws, L.dy[l - 1])), sh(L.dy_b[l - 1]), N,
+                                    L.hs[ps2], L.ws[ps2], kStageC[ps2], stream);
       if (rc) return rc;
     } else {
-      rc = conv_main(g, at(wbuf, P.dgrad[l]), nullptr, at(ws, L.act[l - 1]), at(ws, L.dy[l - 1]), N, h, w, d[l].cout, d[l].cin, d[l].cin, 0,
-                     dtype, at(ws, L.conv_part), stream);
+      rc = conv_main(g, g_b, at(wbuf, P.dgrad[l]), nullptr, at(ws, L.act[l - 1]), at(ws, L.dy[l - 1]), sh(L.dy_b[l - 1]), N, h, w, d[l].cout,
+                     d[l].cin, d[l].cin, 0, dtype, at(ws, L.conv_part), stream);
       if (rc) return rc;
     }
   }

@@ -5,7 +5,7 @@
 
 namespace {
 
-__global__ void nchw_to_nhwc_f32_kernel(const float* __restrict__ src, float* __restrict__ dst,
+__global__ void nchw_to_nhwc_f32_kernel(const float* __restrict__ src, float* __restrict__ dst, bf16_t* __restrict__ dstbf,
                                         int N, int C, int H, int W, int cpad) {
   const long total = (long)N * H * W * cpad;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -13,7 +13,9 @@ __global__ void nchw_to_nhwc_f32_kernel(const float* __restrict__ src, float* __
     const long pix = i / cpad;
     const long hw = (long)H * W;
     const long n = pix / hw, p = pix % hw;
-    dst[i] = c < C ? src[(n * C + c) * hw + p] : 0.f;
+    const float v = c < C ? src[(n * C + c) * hw + p] : 0.f;
+    dst[i] = v;
+    if (dstbf != nullptr) dstbf[i] = f32_to_bf16(v);
   }
 }
 
@@ -71,9 +73,9 @@ inline int grid_for(long total) {
 
 }  // namespace
 
-int osvos_nchw_to_nhwc_f32(const float* src, float* dst, int N, int C, int H, int W, int cpad, hipStream_t stream) {
+int osvos_nchw_to_nhwc_f32(const float* src, float* dst, void* dstbf, int N, int C, int H, int W, int cpad, hipStream_t stream) {
   OSVOS_ARG_CHECK(src && dst && N > 0 && C > 0 && H > 0 && W > 0 && cpad >= C, "nchw_to_nhwc: bad arguments");
-  hipLaunchKernelGGL(nchw_to_nhwc_f32_kernel, dim3(grid_for((long)N * H * W * cpad)), dim3(256), 0, stream, src, dst, N, C, H, W, cpad);
+  hipLaunchKernelGGL(nchw_to_nhwc_f32_kernel, dim3(grid_for((long)N * H * W * cpad)), dim3(256), 0, stream, src, dst, reinterpret_cast<bf16_t*>(dstbf), N, C, H, W, cpad);
   OSVOS_LAUNCH_CHECK();
   return 0;
 }

@@ -7,7 +7,15 @@
 
 namespace {
 
-__global__ void maxpool_f32_kernel(const f32x4* __restrict__ x, f32x4* __restrict__ y,
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+__device__ inline uint2 to_bf16x4(const f32x4& v) {
+  bf16x4_t h;
+  h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
+  return __builtin_bit_cast(uint2, h);
+}
+
+// ybf / dxbf (optional): bf16 copy of the result, the operand format of the bf16-MFMA convolutions that consume it
+__global__ void maxpool_f32_kernel(const f32x4* __restrict__ x, f32x4* __restrict__ y, uint2* __restrict__ ybf,
                                    int N, int H, int W, int C4) {
   const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
   const long total = (long)N * Ho * Wo * C4;
@@ -29,12 +37,13 @@ __global__ void maxpool_f32_kernel(const f32x4* __restrict__ x, f32x4* __restric
       if (vx) { f32x4 u = p[(long)W * C4 + C4]; for (int k = 0; k < 4; ++k) m[k] = u[k] > m[k] ? u[k] : m[k]; }
     }
     y[i] = m;
+    if (ybf != nullptr) ybf[i] = to_bf16x4(m);
   }
 }
 
 // dx[pos] = (x[pos] > 0) * ( (pos == first argmax of the window) * dy + dside[pos] )
 __global__ void maxpool_bwd_f32_kernel(const f32x4* __restrict__ x, const f32x4* __restrict__ dy,
-                                       const f32x4* __restrict__ dside, f32x4* __restrict__ dx,
+                                       const f32x4* __restrict__ dside, f32x4* __restrict__ dx, uint2* __restrict__ dxbf,
                                        int N, int H, int W, int C4) {
   const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
   const long total = (long)N * Ho * Wo * C4;
@@ -72,7 +81,10 @@ __global__ void maxpool_bwd_f32_kernel(const f32x4* __restrict__ x, const f32x4*
       }
     }
     for (int q = 0; q < 4; ++q)
-      if (valid[q]) dx[off[q]] = out[q];
+      if (valid[q]) {
+        dx[off[q]] = out[q];
+        if (dxbf != nullptr) dxbf[off[q]] = to_bf16x4(out[q]);
+      }
   }
 }
 
@@ -83,22 +95,22 @@ inline int grid_for(long total) {
 
 }  // namespace
 
-int osvos_maxpool2x2_f32(const float* x, float* y, int N, int H, int W, int C, hipStream_t stream) {
+int osvos_maxpool2x2_f32(const float* x, float* y, void* ybf, int N, int H, int W, int C, hipStream_t stream) {
   OSVOS_ARG_CHECK(x && y && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "maxpool: bad arguments (C=%d)", C);
   const long total = (long)N * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4);
   hipLaunchKernelGGL(maxpool_f32_kernel, dim3(grid_for(total)), dim3(256), 0, stream,
-                     reinterpret_cast<const f32x4*>(x), reinterpret_cast<f32x4*>(y), N, H, W, C / 4);
+                     reinterpret_cast<const f32x4*>(x), reinterpret_cast<f32x4*>(y), reinterpret_cast<uint2*>(ybf), N, H, W, C / 4);
   OSVOS_LAUNCH_CHECK();
   return 0;
 }
 
-int osvos_maxpool2x2_bwd_f32(const float* x, const float* dy, const float* dside, float* dx,
+int osvos_maxpool2x2_bwd_f32(const float* x, const float* dy, const float* dside, float* dx, void* dxbf,
                              int N, int H, int W, int C, hipStream_t stream) {
   OSVOS_ARG_CHECK(x && dy && dx && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "maxpool_bwd: bad arguments (C=%d)", C);
   const long total = (long)N * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4);
   hipLaunchKernelGGL(maxpool_bwd_f32_kernel, dim3(grid_for(total)), dim3(256), 0, stream,
                      reinterpret_cast<const f32x4*>(x), reinterpret_cast<const f32x4*>(dy),
-                     reinterpret_cast<const f32x4*>(dside), reinterpret_cast<f32x4*>(dx), N, H, W, C / 4);
+                     reinterpret_cast<const f32x4*>(dside), reinterpret_cast<f32x4*>(dx), reinterpret_cast<uint2*>(dxbf), N, H, W, C / 4);
   OSVOS_LAUNCH_CHECK();
   return 0;
 }

@@ -84,6 +84,52 @@ def conv3x3(x, wpk, bias, cout, relu=False, mask=None, y_cs=None, tile=-1, dtype
     return y
 
 
+def conv3x3_bf16io(x, wpk, bias, cout, relu=False, mask=None, y_cs=None, tile=-1, want_bf16=True):
+    """bf16-MFMA convolution with explicit formats: x fp32 or torch.bfloat16 [N,H,W,Cin]; returns (y fp32, y bf16 | None)."""
+    _need_cuda(x, wpk, bias, mask)
+    n, h, w, cin = x.shape
+    y_cs = y_cs or cout
+    y = torch.zeros((n, h, w, y_cs), device=x.device, dtype=torch.float32)
+    yb = torch.zeros((n, h, w, y_cs), device=x.device, dtype=torch.bfloat16) if want_bf16 else None
+    check(lib().osvos_conv3x3_bf16io(_p(x), int(x.dtype == torch.bfloat16), _p(wpk), _p(bias), _p(mask), _p(y), _p(yb), n, h, w, cin, cout,
+                                     y_cs, int(relu), tile, _stream()), "conv3x3_bf16io")
+    return y, yb
+
+
+def conv3x3_bf16io_tiles():
+    import ctypes
+    buf = (ctypes.c_int * 64)()
+    n = lib().osvos_conv3x3_bf16io_tiles(buf, 64)
+    return [buf[i] for i in range(n)]
+
+
+def nchw_to_nhwc_bf16copy(x, cpad):
+    _need_cuda(x)
+    n, c, h, w = x.shape
+    y = torch.empty((n, h, w, cpad), device=x.device, dtype=torch.float32)
+    yb = torch.empty((n, h, w, cpad), device=x.device, dtype=torch.bfloat16)
+    check(lib().osvos_nchw_to_nhwc_bf16copy(_p(x.contiguous()), _p(y), _p(yb), n, c, h, w, cpad, _stream()), "nchw_to_nhwc_bf16copy")
+    return y, yb
+
+
+def maxpool2x2_bf16copy(x):
+    _need_cuda(x)
+    n, h, w, c = x.shape
+    y = torch.empty((n, (h + 1) // 2, (w + 1) // 2, c), device=x.device, dtype=torch.float32)
+    yb = torch.empty_like(y, dtype=torch.bfloat16)
+    check(lib().osvos_maxpool2x2_bf16copy(_p(x), _p(y), _p(yb), n, h, w, c, _stream()), "maxpool_bf16copy")
+    return y, yb
+
+
+def maxpool2x2_bwd_bf16copy(x, dy, dside=None):
+    _need_cuda(x, dy, dside)
+    n, h, w, c = x.shape
+    dx = torch.empty_like(x)
+    dxb = torch.empty_like(x, dtype=torch.bfloat16)
+    check(lib().osvos_maxpool2x2_bwd_bf16copy(_p(x), _p(dy), _p(dside), _p(dx), _p(dxb), n, h, w, c, _stream()), "maxpool_bwd_bf16copy")
+    return dx, dxb
+
+
 def conv3x3_wgrad(x, dy, cin, cout, want_bias=True, accumulate_into=None, dtype=F32):
     """x [N,H,W,Cin_s], dy [N,H,W,Cout_s] -> (dW [cout,cin,3,3], db [cout])."""
     _need_cuda(x, dy)

@@ -187,7 +187,7 @@ BF16_SHAPES = [(1, 9, 11, 8, 32), (2, 17, 35, 16, 64), (1, 33, 70, 64, 128), (1,
 
 
 @pytest.mark.parametrize("shape", BF16_SHAPES)
-@pytest.mark.parametrize("tile", list(range(24)) + [100, 106, 109, 120, -1])
+@pytest.mark.parametrize("tile", list(range(28)) + [100, 106, 109, 120, -1])
 def test_conv3x3_bf16_mfma_forward_all_tiles(shape, tile):
     """bf16-operand path: with inputs that are already bf16-representable the only difference to a float64
     convolution is the fp32 accumulation order -> tight tolerance; this pins layout/indexing, not precision"""
@@ -261,3 +261,48 @@ def test_conv3x3_split_k(ksplit):
     ym = ops.conv3x3_splitk(nhwc(x), ops.pack_fwd(wt.cuda()), None, cout, ksplit, relu=False, mask=nhwc(m))
     ref2 = F.conv2d(x.double(), wt.double(), None, padding=1) * (m > 0)
     assert rel_err(nchw(ym), ref2)[0] < 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(1, 9, 11, 8, 32), (2, 17, 35, 16, 64), (1, 33, 70, 64, 128), (1, 8, 8, 24, 16), (1, 20, 24, 96, 64), (1, 36, 40, 128, 256)])
+def test_conv3x3_bf16io_bf16_input_and_copy(shape):
+    """bf16 activations in HBM: same numbers as the fp32-input kernel fed with the same (bf16-representable) values,
+    for every tile built for bf16 input; the bf16 output copy is the RNE rounding of the fp32 output"""
+    from osvos_pytorch_amd._lib import F32_BF16MFMA
+    ops = _ops()
+    n, h, w, cin, cout = shape
+    g = torch.Generator().manual_seed(hash(shape) % 1000 + 29)
+    x = torch.randn(n, cin, h, w, generator=g).bfloat16().float()
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)).bfloat16().float()
+    b = torch.randn(cout, generator=g)
+    m = torch.randn(n, cout, h, w, generator=g)
+    ref = F.relu(F.conv2d(x.double(), wt.double(), b.double(), padding=1)) * (m > 0)
+    wpk = ops.pack_fwd(wt.cuda(), F32_BF16MFMA)
+    xg = nhwc(x)
+    tiles = ops.conv3x3_bf16io_tiles()
+    assert 1 in tiles and 20 in tiles
+    for tile in tiles + [-1, 101, 120]:
+        y32, yb32 = ops.conv3x3_bf16io(xg, wpk, b.cuda(), cout, relu=True, mask=nhwc(m), tile=tile)
+        y16, yb16 = ops.conv3x3_bf16io(xg.bfloat16(), wpk, b.cuda(), cout, relu=True, mask=nhwc(m), tile=tile)
+        assert rel_err(nchw(y16), ref)[0] < 3e-5, (shape, tile)
+        assert torch.equal(y16, y32), (shape, tile)                  # identical arithmetic, only the staging differs
+        assert torch.equal(yb16, y16.bfloat16()) and torch.equal(yb32, y32.bfloat16()), (shape, tile)
+    with pytest.raises(RuntimeError):
+        ops.conv3x3_bf16io(xg.bfloat16(), wpk, b.cuda(), cout, tile=0)      # not built for bf16 input
+
+
+@pytest.mark.gpu
+def test_bf16copy_outputs_of_pool_and_layout_kernels():
+    ops = _ops()
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(2, 16, 9, 13, generator=g)
+    xg = nhwc(x)
+    y, yb = ops.maxpool2x2_bf16copy(xg)
+    assert torch.equal(y, ops.maxpool2x2(xg)) and torch.equal(yb, y.bfloat16())
+    dy = torch.randn(2, 16, 5, 7, generator=g)
+    ds = torch.randn(2, 16, 9, 13, generator=g)
+    dx, dxb = ops.maxpool2x2_bwd_bf16copy(xg, nhwc(dy), nhwc(ds))
+    assert torch.equal(dx, ops.maxpool2x2_bwd(xg, nhwc(dy), nhwc(ds))) and torch.equal(dxb, dx.bfloat16())
+    img = torch.randn(2, 3, 7, 5, generator=g).cuda()
+    a, ab = ops.nchw_to_nhwc_bf16copy(img, 8)
+    assert torch.equal(a, ops.nchw_to_nhwc(img, 8)) and torch.equal(ab, a.bfloat16())
