@@ -73,7 +73,7 @@ int osvos_conv3x3_splitk(const void* x, const void* wpk, const float* bias, cons
  * The convolutions of that path round their operands to bf16 anyway; producers can hand the rounded tensor over
  * directly so that the consumer reads half the bytes and skips the conversion (same numbers, RNE either way).
  *   osvos_conv3x3_bf16io: x fp32 (x_is_bf16 = 0) or bf16 NHWC; y fp32 and, when y_bf16 != NULL, a bf16 copy of y
- *     with the same channel stride (needs Cout % 4 == 0, y_cs % 4 == 0).  Other arguments as osvos_conv3x3.
+ *     with the same channel stride (needs Cout % 8 == 0, y_cs % 8 == 0).  Other arguments as osvos_conv3x3.
  *     With x_is_bf16 only the tile ids osvos_conv3x3_bf16io_tiles() reports are built.
  *   *_bf16copy: the fp32 kernel plus a bf16 copy of its output (NULL = none). */
 int osvos_conv3x3_bf16io(const void* x, int x_is_bf16, const void* wpk, const float* bias, const float* mask, float* y, void* y_bf16,

@@ -335,6 +335,7 @@ __global__ __launch_bounds__(C::NT, C::OCC) void conv3x3_bf16_kernel(ConvArgsB a
         const int oy = y0 + (mb / C::TBX) * C::RBH + li / C::RBW;
         const int ox = x0 + (mb % C::TBX) * C::RBW + li % C::RBW;
         const unsigned pix = (oy < a.H && ox < a.W) ? (unsigned)((oy * a.W + ox) * a.y_cs) * 4u : OOB;
+        uint2 hb[4];               // bf16 copy: couts 8q + 4lh + (0..3) of this lane, packed
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int co = cb + 8 * q;
@@ -351,10 +352,22 @@ __global__ __launch_bounds__(C::NT, C::OCC) void conv3x3_bf16_kernel(ConvArgsB a
             for (int e = 0; e < 4; ++e) v[e] = m[e] > 0.f ? v[e] : 0.f;
           }
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, off, 0, 0);
-          if (a.ybf != nullptr) {      // (offset 0x80000000 >> 1 is still past the bf16 tensor's num_records)
-            bf16x4_t h;
-            h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, h), hrs, off >> 1, 0, 0);
+          bf16x4_t h;
+          h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
+          hb[q] = __builtin_bit_cast(uint2, h);
+        }
+        if (a.ybf != nullptr) {
+          // lanes l and l+32 hold the two halves of every 8-cout group: v_permlane32_swap trades the odd-q quad of the
+          // lower lane for the even-q quad of the upper one, after which each lane owns 8 consecutive couts
+          // (16 p + 8 lh .. + 7) = one 16-byte store instead of two 8-byte ones
+#pragma unroll
+          for (int pq = 0; pq < 2; ++pq) {
+            const auto sx = __builtin_amdgcn_permlane32_swap(hb[2 * pq].x, hb[2 * pq + 1].x, false, false);
+            const auto sy = __builtin_amdgcn_permlane32_swap(hb[2 * pq].y, hb[2 * pq + 1].y, false, false);
+            const u32x4 o = {sx[0], sy[0], sx[1], sy[1]};
+            const int co = co0 + (wn * C::WN + ni) * 32 + 16 * pq + 8 * lh;
+            const unsigned off = co < a.Cout ? (pix >> 1) + (unsigned)co * 2u : OOB;       // (a.Cout % 8 == 0 checked on the host)
+            __builtin_amdgcn_raw_buffer_store_b128(o, hrs, off, 0, 0);
           }
         }
       }
@@ -537,7 +550,7 @@ int osvos_conv3x3_bf16mfma_io(const void* x, int xb, const void* wpk, const floa
   OSVOS_ARG_CHECK(y_cs >= Cout, "conv3x3 bf16: y channel stride %d < Cout %d", y_cs, Cout);
   OSVOS_ARG_CHECK((long)H * W * Cin < (1L << 29), "conv3x3 bf16: image too large for 31-bit byte offsets");
   OSVOS_ARG_CHECK((long)H * W * y_cs < (1L << 29), "conv3x3 bf16: output image too large for 31-bit byte offsets");
-  OSVOS_ARG_CHECK(ybf == nullptr || (Cout % 4 == 0 && y_cs % 4 == 0), "conv3x3 bf16: the bf16 output copy needs Cout and y_cs multiples of 4");
+  OSVOS_ARG_CHECK(ybf == nullptr || (Cout % 8 == 0 && y_cs % 8 == 0), "conv3x3 bf16: the bf16 output copy needs Cout and y_cs multiples of 8");
   ConvArgsB a;
   a.x = x; a.wpk = reinterpret_cast<const uint4*>(wpk); a.bias = bias; a.mask = mask; a.y = y; a.ybf = reinterpret_cast<bf16_t*>(ybf);
   a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.CinP = (Cin + 31) / 32 * 32; a.Cout = Cout; a.CoutP = osvos_cout_pad(Cout); a.y_cs = y_cs;

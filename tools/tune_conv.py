@@ -17,6 +17,9 @@ ap.add_argument("--batch", type=int, default=1)
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--tiles", default="")
 ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"])
+ap.add_argument("--noyb", type=int, default=0, help="with --xb: do not write the bf16 output copy")
+ap.add_argument("--layers", default="", help="comma separated layer-name filter")
+ap.add_argument("--xb", type=int, default=0, help="bf16 dtype only: 1 = bf16 activations in HBM (input read as bf16, bf16 copy of the output written)")
 args = ap.parse_args()
 
 chans = [[64, 64], [128, 128], [256, 256, 256], [512, 512, 512], [512, 512, 512]]
@@ -60,6 +63,8 @@ n = args.batch
 print("layer            dir   HxW       Cin->Cout  GF    | " + " ".join("t%-6d" % t for t in tiles) + " | best  TF/s  auto")
 tot = {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0}
 for name, h, w, cin, cout in layers:
+    if args.layers and name not in args.layers.split(","):
+        continue
     gf = 2.0 * n * h * w * cout * 9 * cin / 1e9
     for direction in ("fwd", "dgrad"):
         kin, kout = (cin, cout) if direction == "fwd" else (cout, cin)
@@ -68,14 +73,26 @@ for name, h, w, cin, cout in layers:
         wt = torch.randn(cout, cin, 3, 3, device="cuda") * 0.05
         wpk = ops.pack_fwd(wt, DT) if direction == "fwd" else ops.pack_dgrad(wt, DT)
         ycs = kout if kout >= 8 else 4
+        if args.xb:
+            xb = x.bfloat16()
+            yo = torch.empty(n, h, w, ycs, device="cuda")
+            yb = torch.empty(n, h, w, ycs, device="cuda", dtype=torch.bfloat16) if (kout % 8 == 0 and not args.noyb) else None
+            vp = C.c_void_p
+            def run(t):
+                _lib.check(_lib.lib().osvos_conv3x3_bf16io(vp((xb if args.xb == 1 else x).data_ptr()), int(args.xb == 1), vp(wpk.data_ptr()), None, None, vp(yo.data_ptr()),
+                                                          vp(yb.data_ptr()) if yb is not None else None, n, h, w, kin_s, kout, ycs,
+                                                          int(direction == "fwd"), t, vp(torch.cuda.current_stream().cuda_stream)), "conv")
+        else:
+            def run(t):
+                ops.conv3x3(x, wpk, None, kout, relu=(direction == "fwd"), y_cs=ycs, tile=t, dtype=DT)
         res = []
         for t in tiles:
             try:
-                ms = timeit(lambda: ops.conv3x3(x, wpk, None, kout, relu=(direction == "fwd"), y_cs=ycs, tile=t, dtype=DT), args.reps)
+                ms = timeit(lambda: run(t), args.reps)
             except RuntimeError:
                 ms = float("nan")
             res.append(ms)
-        auto = timeit(lambda: ops.conv3x3(x, wpk, None, kout, relu=(direction == "fwd"), y_cs=ycs, tile=-1, dtype=DT), args.reps)
+        auto = timeit(lambda: run(-1), args.reps)
         best = min(r for r in res if r == r)
         bi = tiles[res.index(best)]
         tot[direction] += best
