@@ -112,6 +112,9 @@ def make_optimizer(net, mode):
         {'params': net.fuse.weight, 'lr': lr / 100, 'weight_decay': wd},
         {'params': net.fuse.bias, 'lr': 2 * lr / 100},
     ]
+    if os.environ.get("OSVOS_FUSED_SGD", "1") != "0":
+        from osvos_pytorch_amd.optim import FusedSGD
+        return FusedSGD(groups, lr=lr, momentum=0.9)
     return torch.optim.SGD(groups, lr=lr, momentum=0.9)
 
 

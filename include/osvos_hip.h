@@ -171,6 +171,12 @@ int osvos_net_ws_query(int N, int H, int W, int dtype, int which, size_t* offset
  * for each i: d = g + wd*p; buf = first ? d : momentum*buf + d; p -= lr*buf      (flat tensors) */
 int osvos_sgd_step(float* p, const float* g, float* buf, long count, float lr, float momentum,
                    float weight_decay, int first, void* stream);
+/* the same update for a whole list of tensors in one launch (per-tensor lr / weight decay = the reference's 8 SGD
+ * parameter groups); host arrays of n device pointers / counts / rates; tensors whose group has lr = 0 and no
+ * weight decay can simply be left out.  `first` != 0: the momentum buffers are initialised (buf = d). */
+#define OSVOS_SGD_MAX_TENSORS 64
+int osvos_sgd_step_multi(float* const* params, const float* const* grads, float* const* bufs, const long* counts,
+                         const float* lrs, const float* wds, int n, float momentum, int first, void* stream);
 
 /* ---- opt-in launch profiler (bench.py only): hipEvent pairs around every kernel family that
  * osvos_net_forward/backward launches, recorded on the caller's stream.  Families: 0 conv3x3

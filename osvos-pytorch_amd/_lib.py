@@ -56,6 +56,7 @@ PROTOTYPES = {
     "osvos_net_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "osvos_net_ws_query": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "osvos_sgd_step": (_i, [_vp, _vp, _vp, _l, _f, _f, _f, _i, _vp]),
+    "osvos_sgd_step_multi": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _i, _vp]),
     "osvos_prof_start": (_i, [_i]),
     "osvos_prof_stop": (_i, [_vp, _vp, _vp]),
     "osvos_debug_conv3x3_naive": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),

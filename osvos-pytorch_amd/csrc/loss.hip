@@ -79,11 +79,15 @@ __global__ void scale_kernel(const float* __restrict__ x, const float* __restric
 __global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, long count,
                            float lr, float momentum, float wd, int first) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
+    // roundings exactly as torch.optim.SGD's foreach kernels: d and p are fused multiply-adds (a + alpha*b), the momentum
+    // buffer is buf.mul_(m) THEN .add_(d) -- two roundings (checked bit for bit against torch on the GPU)
+#pragma clang fp contract(off)
     const float pv = p[i];
-    float d = g[i] + wd * pv;
-    const float b = first ? d : momentum * buf[i] + d;
+    const float d = __builtin_fmaf(wd, pv, g[i]);
+    const float mb = momentum * buf[i];
+    const float b = first ? d : mb + d;
     buf[i] = b;
-    p[i] = pv - lr * b;
+    p[i] = __builtin_fmaf(-lr, b, pv);
   }
 }
 
@@ -114,6 +118,65 @@ extern "C" int osvos_scale(const float* x, const float* scalar, float* y, long c
   OSVOS_ARG_CHECK(x && scalar && y && count > 0, "scale: bad arguments");
   hipLaunchKernelGGL(scale_kernel, dim3(grid_for(count, 2048)), dim3(256), 0, (hipStream_t)stream, x, scalar, y, count);
   OSVOS_LAUNCH_CHECK();
+  return 0;
+}
+
+// Every parameter tensor of the network in ONE launch: the tensor table rides in the kernel arguments (<= 64 entries),
+// a workgroup walks the flat index space [0, total) in 1024-element blocks and finds its tensor by scanning the
+// prefix sums.  Replaces torch.optim.SGD's per-group foreach kernels (train_online.py:79-88,147; train_parent.py:87-103,170).
+struct SgdTable {
+  float* p[OSVOS_SGD_MAX_TENSORS];
+  const float* g[OSVOS_SGD_MAX_TENSORS];
+  float* buf[OSVOS_SGD_MAX_TENSORS];
+  long start[OSVOS_SGD_MAX_TENSORS + 1];      // in 1024-element blocks
+  float lr[OSVOS_SGD_MAX_TENSORS], wd[OSVOS_SGD_MAX_TENSORS];
+  long count[OSVOS_SGD_MAX_TENSORS];
+  int n;
+};
+
+__global__ __launch_bounds__(256) void sgd_multi_kernel(SgdTable t, float momentum, int first) {
+  for (long blk = blockIdx.x; blk < t.start[t.n]; blk += gridDim.x) {
+    int k = 0;
+    while (blk >= t.start[k + 1]) ++k;                       // uniform per workgroup: scalar loop
+    const long base = (blk - t.start[k]) * 1024;
+    float* __restrict__ p = t.p[k];
+    const float* __restrict__ g = t.g[k];
+    float* __restrict__ buf = t.buf[k];
+    const float lr = t.lr[k], wd = t.wd[k];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const long i = base + j * 256 + threadIdx.x;
+      if (i < t.count[k]) {
+#pragma clang fp contract(off)      // same roundings as sgd_kernel above
+        const float pv = p[i];
+        const float d = __builtin_fmaf(wd, pv, g[i]);
+        const float mb = momentum * buf[i];
+        const float b = first ? d : mb + d;
+        buf[i] = b;
+        p[i] = __builtin_fmaf(-lr, b, pv);
+      }
+    }
+  }
+}
+
+extern "C" int osvos_sgd_step_multi(float* const* params, const float* const* grads, float* const* bufs, const long* counts,
+                                    const float* lrs, const float* wds, int n, float momentum, int first, void* stream) {
+  OSVOS_ARG_CHECK(params && grads && bufs && counts && lrs && wds && n >= 0, "sgd_step_multi: null table");
+  for (int at = 0; at < n; at += OSVOS_SGD_MAX_TENSORS) {
+    SgdTable t;
+    t.n = n - at < OSVOS_SGD_MAX_TENSORS ? n - at : OSVOS_SGD_MAX_TENSORS;
+    t.start[0] = 0;
+    for (int k = 0; k < t.n; ++k) {
+      OSVOS_ARG_CHECK(params[at + k] && grads[at + k] && bufs[at + k] && counts[at + k] > 0, "sgd_step_multi: tensor %d is null / empty", at + k);
+      t.p[k] = params[at + k]; t.g[k] = grads[at + k]; t.buf[k] = bufs[at + k];
+      t.count[k] = counts[at + k]; t.lr[k] = lrs[at + k]; t.wd[k] = wds[at + k];
+      t.start[k + 1] = t.start[k] + (counts[at + k] + 1023) / 1024;
+    }
+    if (t.n == 0) break;
+    const long blocks = t.start[t.n] < 4096 ? t.start[t.n] : 4096;
+    hipLaunchKernelGGL(sgd_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, t, momentum, first);
+    OSVOS_LAUNCH_CHECK();
+  }
   return 0;
 }
 

@@ -13,9 +13,12 @@ from .layers.osvos_layers import class_balanced_cross_entropy_loss
 from .parallel import GradientAllReducer
 
 
-def make_sgd(net, mode, lr=1e-8, wd=0.0002, momentum=0.9):
+def make_sgd(net, mode, lr=1e-8, wd=0.0002, momentum=0.9, fused=None):
     """Parameter groups of train_online.py:79-88 (mode 'online', score_dsn not optimised) or
-    train_parent.py:87-103 (mode 'parent')."""
+    train_parent.py:87-103 (mode 'parent').  ``fused`` (default: on, OSVOS_FUSED_SGD=0 turns it off) selects
+    ``FusedSGD`` -- one launch for all tensors, same numbers and state_dict -- over ``torch.optim.SGD``."""
+    if fused is None:
+        fused = os.environ.get("OSVOS_FUSED_SGD", "1") != "0"
     groups = [
         {'params': [pr[1] for pr in net.stages.named_parameters() if 'weight' in pr[0]], 'weight_decay': wd, 'initial_lr': lr},
         {'params': [pr[1] for pr in net.stages.named_parameters() if 'bias' in pr[0]], 'lr': 2 * lr, 'initial_lr': 2 * lr},
@@ -35,6 +38,9 @@ def make_sgd(net, mode, lr=1e-8, wd=0.0002, momentum=0.9):
         {'params': net.fuse.weight, 'lr': lr / 100, 'initial_lr': lr / 100, 'weight_decay': wd},
         {'params': net.fuse.bias, 'lr': 2 * lr / 100, 'initial_lr': 2 * lr / 100},
     ]
+    if fused:
+        from .optim import FusedSGD
+        return FusedSGD(groups, lr=lr, momentum=momentum)
     return optim.SGD(groups, lr=lr, momentum=momentum)
 
 

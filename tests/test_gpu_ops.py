@@ -306,3 +306,48 @@ def test_bf16copy_outputs_of_pool_and_layout_kernels():
     img = torch.randn(2, 3, 7, 5, generator=g).cuda()
     a, ab = ops.nchw_to_nhwc_bf16copy(img, 8)
     assert torch.equal(a, ops.nchw_to_nhwc(img, 8)) and torch.equal(ab, a.bfloat16())
+
+
+@pytest.mark.gpu
+def test_fused_sgd_matches_torch_optim_sgd_and_shares_state_dict():
+    """8 parameter groups as the reference builds them (train_online.py:79-88): bit-identical trajectory to
+    torch.optim.SGD over several steps, interchangeable state_dict, version counters bumped"""
+    from osvos_pytorch_amd.optim import FusedSGD
+    g = torch.Generator().manual_seed(41)
+    shapes = [(64, 3, 3, 3), (64,), (128, 64, 3, 3), (128,), (16, 128, 3, 3), (16,), (1, 16, 1, 1), (1,), (1, 64, 1, 1), (1,), (5000,)]
+    lr, wd = 1e-3, 2e-4
+    def groups(ps):
+        return [{"params": ps[0:4:2], "weight_decay": wd, "lr": lr}, {"params": ps[1:4:2], "lr": 2 * lr},
+                {"params": ps[4:6], "weight_decay": wd, "lr": lr}, {"params": ps[6:8], "lr": lr / 10, "weight_decay": wd},
+                {"params": ps[8:10], "lr": lr / 100}, {"params": ps[10:], "lr": 0.0}]
+    init = [torch.randn(s, generator=g) for s in shapes]
+    pa = [t.clone().cuda().requires_grad_() for t in init]
+    pb = [t.clone().cuda().requires_grad_() for t in init]
+    oa = torch.optim.SGD(groups(pa), lr=lr, momentum=0.9)
+    ob = FusedSGD(groups(pb), lr=lr, momentum=0.9)
+    for step in range(4):
+        if step == 2:          # swap optimizer state through state_dict mid-run
+            ob2 = FusedSGD(groups(pb), lr=lr, momentum=0.9)
+            import copy
+            ob2.load_state_dict(copy.deepcopy(oa.state_dict()))      # (load_state_dict aliases tensors that need no cast)
+            for x, y in zip(pa, pb):
+                assert torch.equal(oa.state[x]["momentum_buffer"], ob2.state[y]["momentum_buffer"])
+            ob = ob2
+        for x, y in zip(pa, pb):
+            gr = torch.randn(x.shape, generator=g).cuda()
+            x.grad = gr.clone() if not (step == 1 and x.numel() == 16) else None      # a tensor without gradient is skipped
+            y.grad = None if x.grad is None else gr.clone()
+        v0 = [y._version for y in pb]
+        oa.step(); ob.step()
+        for i, (x, y) in enumerate(zip(pa, pb)):
+            assert torch.equal(x.detach(), y.detach()), (step, i)
+            if y.grad is not None:
+                assert y._version > v0[i]
+    assert set(ob.state_dict()["state"][0].keys()) == {"momentum_buffer"}
+    with pytest.raises(ValueError):
+        FusedSGD(groups(pb), lr=lr, momentum=0.9, nesterov=True)
+    with pytest.raises(RuntimeError):
+        cpu = [torch.zeros(3, requires_grad=True)]
+        o = FusedSGD(cpu, lr=0.1)
+        cpu[0].grad = torch.ones(3)
+        o.step()
