@@ -72,12 +72,20 @@ int osvos_conv3x3_splitk(const void* x, const void* wpk, const float* bias, cons
 /* ---- bf16 operand storage for the bf16-MFMA path (dtype OSVOS_F32_BF16MFMA) ------------------------------------------
  * The convolutions of that path round their operands to bf16 anyway; producers can hand the rounded tensor over
  * directly so that the consumer reads half the bytes and skips the conversion (same numbers, RNE either way).
- *   osvos_conv3x3_bf16io: x fp32 (x_is_bf16 = 0) or bf16 NHWC; y fp32 and, when y_bf16 != NULL, a bf16 copy of y
- *     with the same channel stride (needs Cout % 8 == 0, y_cs % 8 == 0).  Other arguments as osvos_conv3x3.
- *     With x_is_bf16 only the tile ids osvos_conv3x3_bf16io_tiles() reports are built.
- *   *_bf16copy: the fp32 kernel plus a bf16 copy of its output (NULL = none). */
-int osvos_conv3x3_bf16io(const void* x, int x_is_bf16, const void* wpk, const float* bias, const float* mask, float* y, void* y_bf16,
-                         int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int tile, void* stream);
+ *   osvos_conv3x3_bf16io: x fp32 (x_is_bf16 = 0) or bf16 NHWC; mask fp32 or (mask_is_bf16) bf16; y fp32 and/or y_bf16
+ *     (either may be NULL; y_bf16 has the same channel stride and needs Cout % 8 == 0, y_cs % 8 == 0).  Other
+ *     arguments as osvos_conv3x3.  With x_is_bf16 only the tile ids osvos_conv3x3_bf16io_tiles() reports are built.
+ *   *_bf16copy: the fp32 kernel plus a bf16 copy of its output (NULL = none).
+ *   *_bf16act: pooling on bf16 tensors (C % 8 == 0); the backward adds in fp32 and rounds once (RNE). */
+int osvos_conv3x3_bf16io(const void* x, int x_is_bf16, const void* wpk, const float* bias, const void* mask, int mask_is_bf16, float* y,
+                         void* y_bf16, int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int tile, void* stream);
+int osvos_maxpool2x2_bf16act(const void* x_bf16, void* y_bf16, int N, int H, int W, int C, void* stream);
+/* weight gradient of the wide layers (Cin_s and Cout multiples of 64, Cin == Cin_s) from bf16 x AND dy; workspace of
+ * osvos_wgrad_ws_bytes(.., OSVOS_F32_BF16MFMA); dw/db fp32 as osvos_conv3x3_wgrad (db = fp32 sums of the bf16 dy) */
+int osvos_conv3x3_wgrad_bf16act(const void* x_bf16, const void* dy_bf16, void* ws, float* dw, float* db, int N, int H, int W, int Cin, int Cin_s,
+                                int Cout, int Cout_s, int accumulate, void* stream);
+int osvos_maxpool2x2_bwd_bf16act(const void* x_bf16, const void* dy_bf16, const void* dside_bf16, void* dx_bf16, int N, int H, int W, int C,
+                                 void* stream);
 int osvos_conv3x3_bf16io_tiles(int* tiles, int max);
 int osvos_nchw_to_nhwc_bf16copy(const float* src, void* dst, void* dst_bf16, int N, int C, int H, int W, int cpad, void* stream);
 int osvos_maxpool2x2_bf16copy(const float* x, float* y, void* y_bf16, int N, int H, int W, int C, void* stream);
@@ -117,9 +125,10 @@ int osvos_head_upsample(const float* const* score, const float* const* fpart,
                         const float* const* f1, const float* const* f16, const float* fuse_bias,
                         float* const* outs, int N, int H, int W, const int* hs, const int* ws, void* stream);
 /* backward of both, per scale: dprep[N,h,w,16] (NHWC, dtype) = wf*up^T(dfused) + wd*up_^T(dside);
- * writes per-workgroup partial sums of the weight/bias gradients to acc (double[256][34] at most:
+ * writes per-workgroup partial sums of the weight/bias gradients to acc (double[OSVOS_HEAD_MAX_BLOCKS][34] at most:
  * {dwf[16], dwd[16], dbd, spare} per launched workgroup; the whole-network call sums them).
  * dside / dfused: fp32 NCHW [N,1,H,W] or NULL (treated as zero). */
+#define OSVOS_HEAD_MAX_BLOCKS 1024
 int osvos_head_bwd(const void* prep, const float* dside, const float* dfused,
                    const float* f1, const float* f16, const float* wd, const float* wf,
                    void* dprep, double* acc, int N, int H, int W, int h, int w, int scale_idx,

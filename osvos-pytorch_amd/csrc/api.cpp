@@ -52,9 +52,22 @@ int osvos_conv3x3(const void* x, const void* wpk, const float* bias, const void*
 
 // bf16-MFMA convolution with explicit operand / result formats: x fp32 (x_is_bf16 = 0) or bf16 NHWC; y fp32 and,
 // when y_bf16 != NULL, a bf16 copy of y with the same channel stride (the operand of the next convolution)
-int osvos_conv3x3_bf16io(const void* x, int x_is_bf16, const void* wpk, const float* bias, const float* mask, float* y, void* y_bf16,
-                         int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int tile, void* stream) {
-  return osvos_conv3x3_bf16mfma_io(x, x_is_bf16 ? 1 : 0, wpk, bias, mask, y, y_bf16, N, H, W, Cin, Cout, y_cs, relu, tile, (hipStream_t)stream);
+int osvos_conv3x3_bf16io(const void* x, int x_is_bf16, const void* wpk, const float* bias, const void* mask, int mask_is_bf16, float* y,
+                         void* y_bf16, int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int tile, void* stream) {
+  return osvos_conv3x3_bf16mfma_io(x, x_is_bf16 ? 1 : 0, wpk, bias, mask, mask_is_bf16, y, y_bf16, N, H, W, Cin, Cout, y_cs, relu, tile,
+                                   (hipStream_t)stream);
+}
+// weight gradient of the wide layers (Cin_s, Cout multiples of 64) from bf16 x AND dy; dw/db fp32 as osvos_conv3x3_wgrad
+int osvos_conv3x3_wgrad_bf16act(const void* x_bf16, const void* dy_bf16, void* ws, float* dw, float* db, int N, int H, int W, int Cin, int Cin_s,
+                                int Cout, int Cout_s, int accumulate, void* stream) {
+  return osvos_conv3x3_wgrad_bf16mfma_io(x_bf16, dy_bf16, 1, ws, dw, db, N, H, W, Cin, Cin_s, Cout, Cout_s, accumulate, (hipStream_t)stream);
+}
+int osvos_maxpool2x2_bf16act(const void* x_bf16, void* y_bf16, int N, int H, int W, int C, void* stream) {
+  return osvos_maxpool2x2_bf16(x_bf16, y_bf16, N, H, W, C, (hipStream_t)stream);
+}
+int osvos_maxpool2x2_bwd_bf16act(const void* x_bf16, const void* dy_bf16, const void* dside_bf16, void* dx_bf16, int N, int H, int W, int C,
+                                 void* stream) {
+  return osvos_maxpool2x2_bwd_bf16(x_bf16, dy_bf16, dside_bf16, dx_bf16, N, H, W, C, (hipStream_t)stream);
 }
 int osvos_conv3x3_bf16io_tiles(int* tiles, int max) { return osvos_conv3x3_bf16mfma_xb_tiles(tiles, max); }
 

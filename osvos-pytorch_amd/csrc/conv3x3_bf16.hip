@@ -21,12 +21,12 @@ struct ConvArgsB {
   const void* x;         // NHWC, channel stride Cin (multiple of 8): fp32 (XB = 0) or bf16 (XB = 1)
   const uint4* wpk;      // bf16 pack [9][CinP/8][CoutP][8], CinP = Cin rounded up to 32
   const float* bias;
-  const float* mask;
-  float* y;
+  const void* mask;      // NHWC like y: fp32, or bf16 when mask_bf16 != 0
+  float* y;              // may be NULL when ybf is given (bf16-only result)
   bf16_t* ybf;           // optional bf16 copy of y (same channel stride): the next convolution's operand
   int N, H, W, Cin, CinP, Cout, CoutP, y_cs;
   int tiles_x, tiles_y, nct, nsp, map;
-  int relu;
+  int relu, mask_bf16;
   unsigned long long* prof;   // phase cycle counters (only read by builds with -DOSVOS_CONV_PROF; tools/conv_phase_probe.py)
 };
 
@@ -316,12 +316,17 @@ __global__ __launch_bounds__(C::NT, C::OCC) void conv3x3_bf16_kernel(ConvArgsB a
   // address arithmetic (the former per-element dword epilogue took 40 % of a wave's lifetime at Cin = 256).
   const size_t img_elems = (size_t)a.H * a.W * a.y_cs;
   if ((a.Cout & 3) == 0 && (a.y_cs & 3) == 0) {
-    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(a.y + n * img_elems, 0, (int)(img_elems * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.mask != nullptr ? a.mask + n * img_elems : a.y), 0,
-                                                                         a.mask != nullptr ? (int)(img_elems * 4) : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bias != nullptr ? a.bias : a.y), 0,
+    // (a descriptor with num_records = 0 drops every access: absent tensors need no branch)
+    void* const anyp = const_cast<uint4*>(a.wpk);
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(a.y != nullptr ? (void*)(a.y + n * img_elems) : anyp, 0,
+                                                                         a.y != nullptr ? (int)(img_elems * 4) : 0, 0x00020000);
+    const int msz = a.mask_bf16 ? 2 : 4;
+    const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc(
+        a.mask != nullptr ? (void*)(reinterpret_cast<char*>(const_cast<void*>(a.mask)) + n * img_elems * msz) : anyp, 0,
+        a.mask != nullptr ? (int)(img_elems * msz) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(a.bias != nullptr ? (void*)const_cast<float*>(a.bias) : anyp, 0,
                                                                          a.bias != nullptr ? a.Cout * 4 : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(a.ybf != nullptr ? (void*)(a.ybf + n * img_elems) : (void*)a.y, 0,
+    const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(a.ybf != nullptr ? (void*)(a.ybf + n * img_elems) : anyp, 0,
                                                                          a.ybf != nullptr ? (int)(img_elems * 2) : 0, 0x00020000);
 #pragma unroll
     for (int ni = 0; ni < C::WN; ++ni) {
@@ -347,11 +352,18 @@ __global__ __launch_bounds__(C::NT, C::OCC) void conv3x3_bf16_kernel(ConvArgsB a
             if (a.relu) v[e] = v[e] > 0.f ? v[e] : 0.f;
           }
           if (a.mask != nullptr) {
-            const f32x4 m = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(mrs, off, 0, 0));
+            if (a.mask_bf16) {       // post-ReLU activations stored as bf16: > 0 <=> the 16-bit pattern is a positive integer
+              typedef short s16x4 __attribute__((ext_vector_type(4)));
+              const s16x4 m = __builtin_bit_cast(s16x4, __builtin_amdgcn_raw_buffer_load_b64(mrs, off >> 1, 0, 0));
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = m[e] > 0.f ? v[e] : 0.f;
+              for (int e = 0; e < 4; ++e) v[e] = m[e] > 0 ? v[e] : 0.f;
+            } else {
+              const f32x4 m = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(mrs, off, 0, 0));
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = m[e] > 0.f ? v[e] : 0.f;
+            }
           }
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, off, 0, 0);
+          if (a.y != nullptr) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, off, 0, 0);
           bf16x4_t h;
           h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
           hb[q] = __builtin_bit_cast(uint2, h);
@@ -387,7 +399,7 @@ __global__ __launch_bounds__(C::NT, C::OCC) void conv3x3_bf16_kernel(ConvArgsB a
             const size_t o = n * img_elems + ((size_t)oy * a.W + ox) * a.y_cs + co;
             float v = acc[mi][ni][r] + (a.bias != nullptr ? a.bias[co] : 0.f);
             if (a.relu) v = v > 0.f ? v : 0.f;
-            if (a.mask != nullptr) v = a.mask[o] > 0.f ? v : 0.f;
+            if (a.mask != nullptr) v = reinterpret_cast<const float*>(a.mask)[o] > 0.f ? v : 0.f;
             a.y[o] = v;
           }
         }
@@ -542,9 +554,11 @@ extern "C" void osvos_debug_set_conv_prof(void* p) { g_conv_prof = (unsigned lon
 
 // x fp32 NHWC (stride Cin, multiple of 8), wpk from osvos_pack_{fwd,dgrad}_bf16 with the same Cin/Cout roles
 // xb = 0: x fp32, xb = 1: x bf16; ybf (optional) receives a bf16 copy of y
-int osvos_conv3x3_bf16mfma_io(const void* x, int xb, const void* wpk, const float* bias, const float* mask, float* y, void* ybf,
+int osvos_conv3x3_bf16mfma_io(const void* x, int xb, const void* wpk, const float* bias, const void* mask, int mask_bf16, float* y, void* ybf,
                               int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int tile, hipStream_t stream) {
-  OSVOS_ARG_CHECK(x && wpk && y, "conv3x3 bf16: null pointer");
+  OSVOS_ARG_CHECK(x && wpk && (y || ybf), "conv3x3 bf16: null pointer");
+  OSVOS_ARG_CHECK((Cout % 4 == 0 && y_cs % 4 == 0) || (y != nullptr && !(mask && mask_bf16)),
+                  "conv3x3 bf16: ragged channel counts (Cout %d, stride %d) support fp32 outputs and masks only", Cout, y_cs);
   OSVOS_ARG_CHECK(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv3x3 bf16: bad shape");
   OSVOS_ARG_CHECK(Cin % 8 == 0, "conv3x3 bf16: Cin (%d) must be a multiple of 8", Cin);
   OSVOS_ARG_CHECK(y_cs >= Cout, "conv3x3 bf16: y channel stride %d < Cout %d", y_cs, Cout);
@@ -552,7 +566,8 @@ int osvos_conv3x3_bf16mfma_io(const void* x, int xb, const void* wpk, const floa
   OSVOS_ARG_CHECK((long)H * W * y_cs < (1L << 29), "conv3x3 bf16: output image too large for 31-bit byte offsets");
   OSVOS_ARG_CHECK(ybf == nullptr || (Cout % 8 == 0 && y_cs % 8 == 0), "conv3x3 bf16: the bf16 output copy needs Cout and y_cs multiples of 8");
   ConvArgsB a;
-  a.x = x; a.wpk = reinterpret_cast<const uint4*>(wpk); a.bias = bias; a.mask = mask; a.y = y; a.ybf = reinterpret_cast<bf16_t*>(ybf);
+  a.x = x; a.wpk = reinterpret_cast<const uint4*>(wpk); a.bias = bias; a.mask = mask; a.mask_bf16 = mask_bf16 ? 1 : 0; a.y = y;
+  a.ybf = reinterpret_cast<bf16_t*>(ybf);
   a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.CinP = (Cin + 31) / 32 * 32; a.Cout = Cout; a.CoutP = osvos_cout_pad(Cout); a.y_cs = y_cs;
   a.relu = relu;
   a.prof = g_conv_prof;
@@ -620,7 +635,7 @@ int osvos_conv3x3_bf16mfma_xb_tiles(int* tiles, int max) {      // tile ids buil
 // x fp32 NHWC (stride Cin, multiple of 8), wpk from osvos_pack_{fwd,dgrad}_bf16 with the same Cin/Cout roles
 int osvos_conv3x3_bf16mfma(const float* x, const void* wpk, const float* bias, const float* mask, float* y,
                            int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int tile, hipStream_t stream) {
-  return osvos_conv3x3_bf16mfma_io(x, 0, wpk, bias, mask, y, nullptr, N, H, W, Cin, Cout, y_cs, relu, tile, stream);
+  return osvos_conv3x3_bf16mfma_io(x, 0, wpk, bias, mask, 0, y, nullptr, N, H, W, Cin, Cout, y_cs, relu, tile, stream);
 }
 
 #ifdef OSVOS_CONV_PROF   // C entry points of the scratch library tools/conv_phase_probe.py builds from this file alone

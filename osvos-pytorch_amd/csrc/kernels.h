@@ -19,12 +19,13 @@ int osvos_pack_dgrad_f32(const float* w, float* wpk, int Cout, int Cin, hipStrea
 int osvos_maxpool2x2_f32(const float* x, float* y, void* ybf, int N, int H, int W, int C, hipStream_t stream);
 int osvos_maxpool2x2_bwd_f32(const float* x, const float* dy, const float* dside, float* dx, void* dxbf,
                              int N, int H, int W, int C, hipStream_t stream);
+int osvos_maxpool2x2_bf16(const void* x, void* y, int N, int H, int W, int C, hipStream_t stream);
+int osvos_maxpool2x2_bwd_bf16(const void* x, const void* dy, const void* dside, void* dx, int N, int H, int W, int C, hipStream_t stream);
 int osvos_head_lowres_f32(const float* prep, const float* wd, const float* bd, const float* wf,
                           float* score, float* fpart, int N, int h, int w, hipStream_t stream);
 int osvos_head_bwd_f32(const float* prep, const float* dside, const float* dfused, const float* f1, const float* f16,
                        const float* wd, const float* wf, float* dprep, double* acc, int N, int H, int W, int h, int w,
                        int scale_idx, hipStream_t stream);
-#define OSVOS_HEAD_MAX_BLOCKS 64
 int osvos_head_bwd_blocks(int N, int h, int w, int scale_idx);   // workgroups (= partial rows of 34 doubles) head_bwd launches
 int osvos_sum_partials(const float* x, long count, double* part, int* nblocks, hipStream_t stream);
 
@@ -35,13 +36,21 @@ int osvos_conv3x3_bf16mfma(const float* x, const void* wpk, const float* bias, c
                            int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int tile, hipStream_t stream);
 int osvos_conv3x3_bf16mfma_num_tiles(void);
 // xb = 1: x is bf16 NHWC; ybf (optional): bf16 copy of y
-int osvos_conv3x3_bf16mfma_io(const void* x, int xb, const void* wpk, const float* bias, const float* mask, float* y, void* ybf,
+int osvos_conv3x3_bf16mfma_io(const void* x, int xb, const void* wpk, const float* bias, const void* mask, int mask_bf16, float* y, void* ybf,
                               int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int tile, hipStream_t stream);
 int osvos_conv3x3_bf16mfma_xb_tiles(int* tiles, int max);
 
 // bf16-operand weight gradient (fp32 tensors): wgrad_bf16.hip
 bool osvos_wgrad_bf16_applicable(int Cin_s, int Cout);
 size_t osvos_wgrad_bf16_ws_bytes(int N, int H, int W, int Cin_s, int Cout);
+// bf16-store mode of the network: the trunk tensors are bf16.  xb: x AND dy are bf16 (wide layers); the skinny fp32 kernels take
+// their WIDE operand (dy of conv1_1, x of side_prep) as bf16 and the narrow one as fp32
+int osvos_conv3x3_wgrad_bf16mfma_io(const void* x, const void* dy, int xb, void* ws, float* dw, float* db,
+                                    int N, int H, int W, int Cin, int Cin_s, int Cout, int Cout_s,
+                                    int accumulate, hipStream_t stream);
+int osvos_conv3x3_wgrad_small_f32(const void* x, const void* dy, int wide_bf16, void* ws, float* dw, float* db,
+                                  int N, int H, int W, int Cin, int Cin_s, int Cout, int Cout_s,
+                                  int accumulate, hipStream_t stream);
 int osvos_conv3x3_wgrad_bf16mfma(const float* x, const float* dy, void* ws, float* dw, float* db,
                                  int N, int H, int W, int Cin, int Cin_s, int Cout, int Cout_s,
                                  int accumulate, hipStream_t stream);

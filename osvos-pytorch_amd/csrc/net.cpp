@@ -70,6 +70,14 @@ inline bool use_shadow(int dtype) {
   return dtype == OSVOS_F32_BF16MFMA && on;
 }
 
+// bf16-ONLY trunk tensors (activations, pooled tensors and their gradients are stored as bf16; nothing fp32 is written for them):
+// OSVOS_BF16_STORE=1.  Producers write half the bytes, consumers read half the bytes; pooling and its backward run on bf16;
+// bias / skinny weight gradients are formed from the bf16 tensors.
+inline bool use_store(int dtype) {
+  static const bool on = [] { const char* e = getenv("OSVOS_BF16_STORE"); return e && e[0] == '1'; }();
+  return dtype == OSVOS_F32_BF16MFMA && on;
+}
+
 struct WsLayout {
   int hs[5], ws[5];
   size_t xin, act[kNumTrunk], pooled[5], prep[4], score[4], fpart[4];
@@ -77,7 +85,7 @@ struct WsLayout {
   size_t dy[kNumTrunk], dpool[5], dside[4], dprep[4], wgrad[kNumConv], acc, dxin;
   // bf16 copies of the conv operands (dtype OSVOS_F32_BF16MFMA only): written by the producer's epilogue, read by the
   // consuming convolution instead of the fp32 tensor (half the bytes, no conversion while staging)
-  size_t xin_b, act_b[kNumTrunk], pooled_b[5], dy_b[kNumTrunk];
+  size_t xin_b, act_b[kNumTrunk], pooled_b[5], dy_b[kNumTrunk], dpool_b[5], dside_b[4];
   size_t fwd_total, total;
 };
 
@@ -91,18 +99,20 @@ WsLayout ws_layout(int N, int H, int W, int dtype) {
   auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
   ConvDesc d[kNumConv];
   conv_table(d);
-  const bool shadow = use_shadow(dtype);
+  const bool store = use_store(dtype), shadow = use_shadow(dtype) && !store;
+  const size_t te = store ? 2 : es;          // element size of the trunk tensors
   L.xin = take(es * N * H * W * kInPad);
-  if (shadow) L.xin_b = take((size_t)2 * N * H * W * kInPad);
+  if (shadow || store) L.xin_b = take((size_t)2 * N * H * W * kInPad);
   for (int l = 0; l < kNumTrunk; ++l) {
     const int si = d[l].stage;
-    const size_t b = es * N * L.hs[si] * L.ws[si] * d[l].cout;
-    L.act[l] = take(b);
-    if (shadow) L.act_b[l] = take(b / es * 2);
+    const size_t e = (size_t)N * L.hs[si] * L.ws[si] * d[l].cout;
+    L.act[l] = take(te * e);
+    L.act_b[l] = store ? L.act[l] : (shadow ? take(2 * e) : 0);
   }
   for (int si = 1; si < 5; ++si) {
-    L.pooled[si] = take(es * N * L.hs[si] * L.ws[si] * kStageC[si - 1]);
-    if (shadow) L.pooled_b[si] = take((size_t)2 * N * L.hs[si] * L.ws[si] * kStageC[si - 1]);
+    const size_t e = (size_t)N * L.hs[si] * L.ws[si] * kStageC[si - 1];
+    L.pooled[si] = take(te * e);
+    L.pooled_b[si] = store ? L.pooled[si] : (shadow ? take(2 * e) : 0);
   }
   for (int i = 0; i < 4; ++i) {
     const size_t npix = (size_t)N * L.hs[i + 1] * L.ws[i + 1];
@@ -123,16 +133,21 @@ WsLayout ws_layout(int N, int H, int W, int dtype) {
   for (int i = 0; i < 4; ++i) {
     const size_t npix = (size_t)N * L.hs[i + 1] * L.ws[i + 1];
     L.dprep[i] = take(es * npix * 16);
-    L.dside[i] = take(es * npix * kStageC[i + 1]);
+    L.dside[i] = take(te * npix * kStageC[i + 1]);
+    L.dside_b[i] = store ? L.dside[i] : 0;
   }
   // one gradient buffer per trunk conv output (dLoss/d act[l], ReLU mask applied) and per pooled
   // tensor: no buffer is ever rewritten inside one backward, so the weight-gradient stream can trail
   // the data-gradient stream by any number of layers without write-after-read hazards
   for (int l = 0; l < kNumTrunk; ++l) {
-    L.dy[l] = take(es * N * L.hs[d[l].stage] * L.ws[d[l].stage] * d[l].cout);
-    if (shadow) L.dy_b[l] = take((size_t)2 * N * L.hs[d[l].stage] * L.ws[d[l].stage] * d[l].cout);
+    const size_t e = (size_t)N * L.hs[d[l].stage] * L.ws[d[l].stage] * d[l].cout;
+    L.dy[l] = take(te * e);
+    L.dy_b[l] = store ? L.dy[l] : (shadow ? take(2 * e) : 0);
   }
-  for (int si = 1; si < 5; ++si) L.dpool[si] = take(es * N * L.hs[si] * L.ws[si] * kStageC[si - 1]);
+  for (int si = 1; si < 5; ++si) {
+    L.dpool[si] = take(te * N * L.hs[si] * L.ws[si] * kStageC[si - 1]);
+    L.dpool_b[si] = store ? L.dpool[si] : 0;
+  }
   // one slab workspace per layer: the slab reduce of layer l runs on its own stream while the partial
   // kernel of the next layer already refills another buffer
   for (int l = 0; l < kNumConv; ++l) {
@@ -172,12 +187,14 @@ EventPool& event_pool() {
 // 3x3 conv on the main stream: fp32 launches may be cut along K (split-K, partial sums in `part`) when the layer
 // is too small to balance across 256 CUs; the bf16-MFMA dtype goes through the public entry point
 // (x_b: bf16 copy of x, preferred when present; y_b: where the bf16 copy of y goes, NULL = none)
-inline int conv_main(const void* x, const void* x_b, const void* wpk, const float* bias, const void* mask, void* y, void* y_b, int N, int h,
-                     int w, int cin, int cout, int y_cs, int relu, int dtype, void* part, hipStream_t stream) {
+// (mask_b: bf16 mask, takes precedence over the fp32 `mask`; y may be NULL in the bf16 modes when y_b is given)
+inline int conv_main(const void* x, const void* x_b, const void* wpk, const float* bias, const void* mask, const void* mask_b, void* y, void* y_b,
+                     int N, int h, int w, int cin, int cout, int y_cs, int relu, int dtype, void* part, hipStream_t stream) {
   if (dtype == OSVOS_F32)
     return osvos_conv3x3_f32_ws((const float*)x, (const float*)wpk, bias, (const float*)mask, (float*)y, N, h, w, cin, cout, y_cs,
                                 relu, -1, part, stream);
-  return osvos_conv3x3_bf16mfma_io(x_b ? x_b : x, x_b ? 1 : 0, wpk, bias, (const float*)mask, (float*)y, y_b, N, h, w, cin, cout, y_cs, relu,
+  return osvos_conv3x3_bf16mfma_io(x_b ? x_b : x, x_b ? 1 : 0, wpk, bias, mask_b ? mask_b : mask, mask_b ? 1 : 0, (float*)y, y_b, N, h, w, cin,
+                                   cout, y_cs, relu,
                                    -1, stream);
 }
 
@@ -262,8 +279,9 @@ int osvos_net_forward(const float* x_nchw, const void* wbuf, void* ws, float* co
   const WsLayout L = ws_layout(N, H, W, dtype);
   ConvDesc d[kNumConv];
   conv_table(d);
-  const bool shadow = use_shadow(dtype);
-  auto sh = [&](size_t off) -> void* { return shadow ? at(ws, off) : nullptr; };
+  const bool store = use_store(dtype), shadow = use_shadow(dtype) && !store;
+  auto sh = [&](size_t off) -> void* { return (shadow || store) ? at(ws, off) : nullptr; };      // bf16 tensor (copy, or the only one)
+  auto f32 = [&](size_t off) -> void* { return store ? nullptr : at(ws, off); };                  // fp32 trunk tensor (absent in store mode)
   int rc = osvos_nchw_to_nhwc_f32(x_nchw, reinterpret_cast<float*>(at(ws, L.xin)), sh(L.xin_b), N, 3, H, W, kInPad, stream);
   if (rc) return rc;
   const void* cur = at(ws, L.xin);
@@ -273,8 +291,11 @@ int osvos_net_forward(const float* x_nchw, const void* wbuf, void* ws, float* co
   for (int si = 0; si < 5; ++si) {
     const int h = L.hs[si], w = L.ws[si];
     if (si > 0) {
-      rc = osvos_maxpool2x2_f32(reinterpret_cast<const float*>(cur), reinterpret_cast<float*>(at(ws, L.pooled[si])), sh(L.pooled_b[si]), N,
-                                L.hs[si - 1], L.ws[si - 1], kStageC[si - 1], stream);
+      if (store)
+        rc = osvos_maxpool2x2_bf16(cur_b, at(ws, L.pooled_b[si]), N, L.hs[si - 1], L.ws[si - 1], kStageC[si - 1], stream);
+      else
+        rc = osvos_maxpool2x2_f32(reinterpret_cast<const float*>(cur), reinterpret_cast<float*>(at(ws, L.pooled[si])), sh(L.pooled_b[si]), N,
+                                  L.hs[si - 1], L.ws[si - 1], kStageC[si - 1], stream);
       if (rc) return rc;
       cur = at(ws, L.pooled[si]);
       cur_b = sh(L.pooled_b[si]);
@@ -282,8 +303,8 @@ int osvos_net_forward(const float* x_nchw, const void* wbuf, void* ws, float* co
     for (int j = 0; j < kStageN[si]; ++j, ++l) {
       {
         ProfScope ps(OSVOS_PROF_CONV_FWD, conv_flops(N, h, w, d[l].cin, d[l].cout), stream);
-        rc = conv_main(cur, cur_b, at(wbuf, P.fwd[l]), reinterpret_cast<const float*>(at(wbuf, P.bias[l])), nullptr,
-                       at(ws, L.act[l]), sh(L.act_b[l]), N, h, w, d[l].cin_s, d[l].cout, d[l].cout, 1, dtype, at(ws, L.conv_part), stream);
+        rc = conv_main(cur, cur_b, at(wbuf, P.fwd[l]), reinterpret_cast<const float*>(at(wbuf, P.bias[l])), nullptr, nullptr,
+                       f32(L.act[l]), sh(L.act_b[l]), N, h, w, d[l].cin_s, d[l].cout, d[l].cout, 1, dtype, at(ws, L.conv_part), stream);
       }
       if (rc) return rc;
       cur = at(ws, L.act[l]);
@@ -301,7 +322,7 @@ int osvos_net_forward(const float* x_nchw, const void* wbuf, void* ws, float* co
       }
       {
         ProfScope ps(OSVOS_PROF_OTHER, conv_flops(N, h, w, d[sl].cin, 16), aux);
-        rc = conv_main(cur, cur_b, at(wbuf, P.fwd[sl]), reinterpret_cast<const float*>(at(wbuf, P.bias[sl])), nullptr,
+        rc = conv_main(cur, cur_b, at(wbuf, P.fwd[sl]), reinterpret_cast<const float*>(at(wbuf, P.bias[sl])), nullptr, nullptr,
                        at(ws, L.prep[i]), nullptr, N, h, w, d[sl].cin_s, 16, 16, 0, dtype, nullptr, aux);
       }
       if (rc) return rc;
@@ -340,6 +361,11 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
   const WsLayout L = ws_layout(N, H, W, dtype);
   ConvDesc d[kNumConv];
   conv_table(d);
+  const bool store = use_store(dtype), shadow = use_shadow(dtype) && !store;
+  auto sh = [&](size_t off) -> void* { return (shadow || store) ? at(ws, off) : nullptr; };
+  auto f32 = [&](size_t off) -> void* { return store ? nullptr : at(ws, off); };
+  auto mk32 = [&](size_t off) -> const void* { return store ? nullptr : at(ws, off); };           // ReLU mask operand: fp32 ...
+  auto mk16 = [&](size_t off) -> const void* { return store ? at(ws, off) : nullptr; };           // ... or bf16
   // fork: aux waits for everything enqueued on `stream` so far; join: `stream` waits for aux.
   // The weight-gradient kernels run on aux concurrently with the data-gradient kernel of the same
   // layer: both are MFMA kernels with independent stalls (barriers, LDS latency, tails), and
@@ -361,15 +387,26 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
     return 0;
   };
   // weight gradient of one layer: partial slabs on aux (MFMA kernel), slab reduce on aux2 (bandwidth kernel)
+  // (store mode: the wide layers read both operands as bf16; conv1_1 and side_prep keep their exact-fp32 skinny kernels, fed
+  //  with the bf16 tensor on the wide side -- xin stays fp32 for conv1_1, dprep for side_prep)
+  auto wgrad_launch = [&](const void* xin, const void* g, int l, int h, int w, hipStream_t st) -> int {
+    if (store) {
+      if (osvos_wgrad_bf16_applicable(d[l].cin_s, d[l].cout) && d[l].cin == d[l].cin_s)
+        return osvos_conv3x3_wgrad_bf16mfma_io(xin, g, 1, at(ws, L.wgrad[l]), grads[d[l].w_param], grads[d[l].b_param], N, h, w,
+                                               d[l].cin, d[l].cin_s, d[l].cout, d[l].cout, accumulate, st);
+      const int r = osvos_conv3x3_wgrad_small_f32(xin, g, 1, at(ws, L.wgrad[l]), grads[d[l].w_param], grads[d[l].b_param], N, h, w,
+                                                  d[l].cin, d[l].cin_s, d[l].cout, d[l].cout, accumulate, st);
+      if (r == 1) osvos_set_error("net_backward: no bf16-store weight-gradient kernel for layer %d", l);
+      return r;
+    }
+    return osvos_conv3x3_wgrad(xin, g, at(ws, L.wgrad[l]), grads[d[l].w_param], grads[d[l].b_param], N, h, w,
+                               d[l].cin, d[l].cin_s, d[l].cout, d[l].cout, accumulate, dtype, st);
+  };
   auto wgrad = [&](const void* xin, const void* g, int l, int h, int w) -> int {
     int r;
-    if (!three) {
-      return osvos_conv3x3_wgrad(xin, g, at(ws, L.wgrad[l]), grads[d[l].w_param], grads[d[l].b_param], N, h, w,
-                                 d[l].cin, d[l].cin_s, d[l].cout, d[l].cout, accumulate, dtype, aux);
-    }
+    if (!three) return wgrad_launch(xin, g, l, h, w, aux);
     osvos_wgrad_set_phase(1);
-    r = osvos_conv3x3_wgrad(xin, g, at(ws, L.wgrad[l]), grads[d[l].w_param], grads[d[l].b_param], N, h, w,
-                            d[l].cin, d[l].cin_s, d[l].cout, d[l].cout, accumulate, dtype, aux);
+    r = wgrad_launch(xin, g, l, h, w, aux);
     osvos_wgrad_set_phase(0);
     if (r) return r;
     hipEvent_t e = evp.next();
@@ -377,14 +414,11 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
     OSVOS_HIP_CHECK(hipEventRecord(e, aux));
     OSVOS_HIP_CHECK(hipStreamWaitEvent(aux2, e, 0));
     osvos_wgrad_set_phase(2);
-    r = osvos_conv3x3_wgrad(xin, g, at(ws, L.wgrad[l]), grads[d[l].w_param], grads[d[l].b_param], N, h, w,
-                            d[l].cin, d[l].cin_s, d[l].cout, d[l].cout, accumulate, dtype, aux2);
+    r = wgrad_launch(xin, g, l, h, w, aux2);
     osvos_wgrad_set_phase(0);
     return r;
   };
   int rc;
-  const bool shadow = use_shadow(dtype);
-  auto sh = [&](size_t off) -> void* { return shadow ? at(ws, off) : nullptr; };
   double* acc = reinterpret_cast<double*>(at(ws, L.acc));
   const double* part[4];
   int nblk[4], fb_nblk = 0;
@@ -439,9 +473,10 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
     const int lx = last_of_stage(si);
     // stage 4 has no pool after it: its ReLU mask is applied right here and the result is the
     // upstream gradient of conv5_3; stages 1-3 are merged in maxpool2x2_bwd below
-    void* dst = (i == 3) ? at(ws, L.dy[lx]) : at(ws, L.dside[i]);
-    rc = conv_main(at(ws, L.dprep[i]), nullptr, at(wbuf, P.dgrad[sl]), nullptr, (i == 3) ? at(ws, L.act[lx]) : nullptr, dst,
-                   (i == 3) ? sh(L.dy_b[lx]) : nullptr, N, h, w, 16, d[sl].cin, d[sl].cin, 0, dtype, nullptr, stream);
+    void* dst = (i == 3) ? f32(L.dy[lx]) : f32(L.dside[i]);
+    void* dst_b = (i == 3) ? sh(L.dy_b[lx]) : (store ? at(ws, L.dside_b[i]) : nullptr);
+    rc = conv_main(at(ws, L.dprep[i]), nullptr, at(wbuf, P.dgrad[sl]), nullptr, (i == 3) ? mk32(L.act[lx]) : nullptr,
+                   (i == 3) ? mk16(L.act_b[lx]) : nullptr, dst, dst_b, N, h, w, 16, d[sl].cin, d[sl].cin, 0, dtype, nullptr, stream);
     if (rc) return rc;
   }
 
@@ -459,7 +494,8 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
     }
     if (l == 0) {
       if (dx_nchw != nullptr) {
-        rc = conv_main(g, g_b, at(wbuf, P.dgrad[0]), nullptr, nullptr, at(ws, L.dxin), nullptr, N, h, w, d[0].cout, 3, 4, 0, dtype, nullptr, stream);
+        rc = conv_main(g, g_b, at(wbuf, P.dgrad[0]), nullptr, nullptr, nullptr, at(ws, L.dxin), nullptr, N, h, w, d[0].cout, 3, 4, 0, dtype,
+                       nullptr, stream);
         if (rc) return rc;
         rc = osvos_nhwc_to_nchw(at(ws, L.dxin), dx_nchw, N, 3, H, W, 4, dtype, stream);
         if (rc) return rc;
@@ -468,18 +504,22 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
     }
     if (first_of_stage) {
       // through the pool into the previous stage's output (+ that stage's side branch, + ReLU mask)
-      rc = conv_main(g, g_b, at(wbuf, P.dgrad[l]), nullptr, nullptr, at(ws, L.dpool[si]), nullptr, N, h, w, d[l].cout, d[l].cin, d[l].cin, 0,
-                     dtype, at(ws, L.conv_part), stream);
+      rc = conv_main(g, g_b, at(wbuf, P.dgrad[l]), nullptr, nullptr, nullptr, f32(L.dpool[si]), store ? at(ws, L.dpool_b[si]) : nullptr, N, h, w,
+                     d[l].cout, d[l].cin, d[l].cin, 0, dtype, at(ws, L.conv_part), stream);
       if (rc) return rc;
       const int ps2 = si - 1;
       const void* dside = ps2 >= 1 ? at(ws, L.dside[ps2 - 1]) : nullptr;
-      rc = osvos_maxpool2x2_bwd_f32(reinterpret_cast<const float*>(at(ws, L.act[l - 1])), reinterpret_cast<const float*>(at(ws, L.dpool[si])),
-                                    reinterpret_cast<const float*>(dside), reinterpret_cast<float*>(at(ws, L.dy[l - 1])), sh(L.dy_b[l - 1]), N,
-                                    L.hs[ps2], L.ws[ps2], kStageC[ps2], stream);
+      if (store)
+        rc = osvos_maxpool2x2_bwd_bf16(at(ws, L.act_b[l - 1]), at(ws, L.dpool_b[si]), dside, at(ws, L.dy_b[l - 1]), N, L.hs[ps2], L.ws[ps2],
+                                       kStageC[ps2], stream);
+      else
+        rc = osvos_maxpool2x2_bwd_f32(reinterpret_cast<const float*>(at(ws, L.act[l - 1])), reinterpret_cast<const float*>(at(ws, L.dpool[si])),
+                                      reinterpret_cast<const float*>(dside), reinterpret_cast<float*>(at(ws, L.dy[l - 1])), sh(L.dy_b[l - 1]), N,
+                                      L.hs[ps2], L.ws[ps2], kStageC[ps2], stream);
       if (rc) return rc;
     } else {
-      rc = conv_main(g, g_b, at(wbuf, P.dgrad[l]), nullptr, at(ws, L.act[l - 1]), at(ws, L.dy[l - 1]), sh(L.dy_b[l - 1]), N, h, w, d[l].cout,
-                     d[l].cin, d[l].cin, 0, dtype, at(ws, L.conv_part), stream);
+      rc = conv_main(g, g_b, at(wbuf, P.dgrad[l]), nullptr, mk32(L.act[l - 1]), mk16(L.act_b[l - 1]), f32(L.dy[l - 1]), sh(L.dy_b[l - 1]), N, h, w,
+                     d[l].cout, d[l].cin, d[l].cin, 0, dtype, at(ws, L.conv_part), stream);
       if (rc) return rc;
     }
   }

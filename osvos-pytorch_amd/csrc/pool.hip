@@ -88,6 +88,84 @@ __global__ void maxpool_bwd_f32_kernel(const f32x4* __restrict__ x, const f32x4*
   }
 }
 
+// ---- bf16 tensors (trunk activations / gradients of the bf16-store mode): one thread per (window, 8-channel group) ----
+__device__ inline float bf2f(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
+__device__ inline unsigned short f2bf(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
+struct U8 { unsigned short v[8]; };
+static_assert(sizeof(U8) == 16, "8 bf16 = 16 bytes");
+
+__global__ void maxpool_bf16_kernel(const uint4* __restrict__ x, uint4* __restrict__ y, int N, int H, int W, int C8) {
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  const long total = (long)N * Ho * Wo * C8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C8);
+    long t = i / C8;
+    const int ox = (int)(t % Wo);
+    t /= Wo;
+    const int oy = (int)(t % Ho);
+    const long n = t / Ho;
+    const int iy = 2 * oy, ix = 2 * ox;
+    const bool vx = ix + 1 < W, vy = iy + 1 < H;
+    const uint4* p = x + ((n * H + iy) * W + ix) * C8 + c;
+    U8 m = __builtin_bit_cast(U8, p[0]);
+    auto upd = [&](const uint4& q) {
+      const U8 v = __builtin_bit_cast(U8, q);
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (bf2f(v.v[k]) > bf2f(m.v[k])) m.v[k] = v.v[k];
+    };
+    if (vx) upd(p[C8]);
+    if (vy) {
+      upd(p[(long)W * C8]);
+      if (vx) upd(p[(long)W * C8 + C8]);
+    }
+    y[i] = __builtin_bit_cast(uint4, m);
+  }
+}
+
+// same rule as maxpool_bwd_f32_kernel, arithmetic in fp32, result rounded to bf16 (RNE)
+__global__ void maxpool_bwd_bf16_kernel(const uint4* __restrict__ x, const uint4* __restrict__ dy, const uint4* __restrict__ dside,
+                                        uint4* __restrict__ dx, int N, int H, int W, int C8) {
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  const long total = (long)N * Ho * Wo * C8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C8);
+    long t = i / C8;
+    const int ox = (int)(t % Wo);
+    t /= Wo;
+    const int oy = (int)(t % Ho);
+    const long n = t / Ho;
+    const int iy = 2 * oy, ix = 2 * ox;
+    const bool vx = ix + 1 < W, vy = iy + 1 < H;
+    const long o00 = ((n * H + iy) * W + ix) * C8 + c;
+    const long off[4] = {o00, o00 + C8, o00 + (long)W * C8, o00 + (long)W * C8 + C8};
+    const bool valid[4] = {true, vx, vy, vx && vy};
+    U8 v[4], s[4];
+    for (int q = 0; q < 4; ++q) {
+      v[q] = U8{{0, 0, 0, 0, 0, 0, 0, 0}};
+      s[q] = U8{{0, 0, 0, 0, 0, 0, 0, 0}};
+      if (valid[q]) {
+        v[q] = __builtin_bit_cast(U8, x[off[q]]);
+        if (dside != nullptr) s[q] = __builtin_bit_cast(U8, dside[off[q]]);
+      }
+    }
+    const U8 g = __builtin_bit_cast(U8, dy[i]);
+    U8 out[4];
+    for (int k = 0; k < 8; ++k) {
+      int bi = 0;
+      float best = bf2f(v[0].v[k]);
+      for (int q = 1; q < 4; ++q)
+        if (valid[q] && bf2f(v[q].v[k]) > best) { best = bf2f(v[q].v[k]); bi = q; }
+      for (int q = 0; q < 4; ++q) {
+        const float gq = (q == bi ? bf2f(g.v[k]) : 0.f) + bf2f(s[q].v[k]);
+        out[q].v[k] = bf2f(v[q].v[k]) > 0.f ? f2bf(gq) : (unsigned short)0;
+      }
+    }
+    for (int q = 0; q < 4; ++q)
+      if (valid[q]) dx[off[q]] = __builtin_bit_cast(uint4, out[q]);
+  }
+}
+
 inline int grid_for(long total) {
   long b = (total + 255) / 256;
   return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
@@ -111,6 +189,24 @@ int osvos_maxpool2x2_bwd_f32(const float* x, const float* dy, const float* dside
   hipLaunchKernelGGL(maxpool_bwd_f32_kernel, dim3(grid_for(total)), dim3(256), 0, stream,
                      reinterpret_cast<const f32x4*>(x), reinterpret_cast<const f32x4*>(dy),
                      reinterpret_cast<const f32x4*>(dside), reinterpret_cast<f32x4*>(dx), reinterpret_cast<uint2*>(dxbf), N, H, W, C / 4);
+  OSVOS_LAUNCH_CHECK();
+  return 0;
+}
+
+int osvos_maxpool2x2_bf16(const void* x, void* y, int N, int H, int W, int C, hipStream_t stream) {
+  OSVOS_ARG_CHECK(x && y && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "maxpool bf16: bad arguments (C=%d)", C);
+  const long total = (long)N * ((H + 1) / 2) * ((W + 1) / 2) * (C / 8);
+  hipLaunchKernelGGL(maxpool_bf16_kernel, dim3(grid_for(total)), dim3(256), 0, stream, reinterpret_cast<const uint4*>(x),
+                     reinterpret_cast<uint4*>(y), N, H, W, C / 8);
+  OSVOS_LAUNCH_CHECK();
+  return 0;
+}
+
+int osvos_maxpool2x2_bwd_bf16(const void* x, const void* dy, const void* dside, void* dx, int N, int H, int W, int C, hipStream_t stream) {
+  OSVOS_ARG_CHECK(x && dy && dx && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "maxpool_bwd bf16: bad arguments (C=%d)", C);
+  const long total = (long)N * ((H + 1) / 2) * ((W + 1) / 2) * (C / 8);
+  hipLaunchKernelGGL(maxpool_bwd_bf16_kernel, dim3(grid_for(total)), dim3(256), 0, stream, reinterpret_cast<const uint4*>(x),
+                     reinterpret_cast<const uint4*>(dy), reinterpret_cast<const uint4*>(dside), reinterpret_cast<uint4*>(dx), N, H, W, C / 8);
   OSVOS_LAUNCH_CHECK();
   return 0;
 }

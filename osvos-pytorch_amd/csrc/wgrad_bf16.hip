@@ -14,6 +14,7 @@
 // 9 accumulators, 1 A read + 6 B reads + 12 VALU per 9 MFMAs (a 128-cout tile with 18 accumulators
 // per wave spills: 288 accumulator + 128 staging registers).
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -30,8 +31,8 @@ constexpr int X_ITEMS = XROWS * (XPITCH / 8) * (BCI / 4);  // 480
 constexpr int NDY = DY_ITEMS / 256, NX = (X_ITEMS + 255) / 256;
 
 struct WbArgs {
-  const float* x;
-  const float* dy;
+  const void* x;         // NHWC: fp32 (XB = 0) or bf16 (XB = 1)
+  const void* dy;
   float* slab;
   float* bslab;
   int N, H, W, Cin_s, Cout, Cout_s;
@@ -46,7 +47,9 @@ __device__ inline unsigned pack2(float lo, float hi) {
   return __builtin_bit_cast(unsigned, v);
 }
 
-__global__ __launch_bounds__(256) void wgrad_bf16_kernel(WbArgs a) {
+// XB = 1: x and dy are already bf16 in HBM -- half the bytes, half the staging registers (two workgroups per CU fit)
+template <int XB>
+__global__ __launch_bounds__(256, XB ? 2 : 1) void wgrad_bf16_kernel(WbArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* dYs = smem;
   char* Xs = smem + DY_BYTES;
@@ -69,8 +72,19 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WbArgs a) {
   const int sq = (tid & 1) | ((tid >> 2) & 14);          // channel quad 0..15 (dY and X tiles are both 64 channels)
   const int sg = ((tid >> 1) & 3) | ((tid >> 4) & 12);   // pixel group 0..15
   const int dq = sq, xq = sq;
-  f32x4 rdy[NDY][8], rx[NX][8];
+  // staging registers: 8 pixels x 4 channels per item -- float4 per pixel (fp32 source) or 4 bf16 = uint2 (bf16 source)
+  typedef typename std::conditional<XB != 0, uint2, f32x4>::type stage_t;
+  stage_t rdy[NDY][8], rx[NX][8];
   f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+  const bool want_bias = a.bslab != nullptr && cit == 0;
+  auto ldg = [&](const void* base, size_t elem) -> stage_t {
+    if constexpr (XB != 0) return *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(base) + elem);
+    else return *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(base) + elem);
+  };
+  auto zero = [&]() -> stage_t {
+    if constexpr (XB != 0) return uint2{0u, 0u};
+    else return f32x4{0.f, 0.f, 0.f, 0.f};
+  };
   auto load_patch = [&](int p) {
     const int px = p % a.npx;
     int t = p / a.npx;
@@ -82,11 +96,11 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WbArgs a) {
       const int grp = sg + 16 * u;                         // 0..15: row = grp / 4, x group = grp % 4
       const int gy = y0 + (grp >> 2), gx0 = x0 + (grp & 3) * 8, co = co0 + 4 * dq;
       const bool ok = gy < a.H && co < a.Cout;
-      const float* src = a.dy + ((size_t)(n * a.H + gy) * a.W + gx0) * a.Cout_s + co;
+      const size_t src = ((size_t)(n * a.H + gy) * a.W + gx0) * a.Cout_s + co;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (ok && gx0 + j < a.W) v = *reinterpret_cast<const f32x4*>(src + (size_t)j * a.Cout_s);
+        stage_t v = zero();
+        if (ok && gx0 + j < a.W) v = ldg(a.dy, src + (size_t)j * a.Cout_s);
         rdy[u][j] = v;
       }
     }
@@ -97,28 +111,47 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WbArgs a) {
       const int hy = grp / 5, hg = grp % 5;
       const int gy = y0 + hy - 1, gx0 = x0 + hg * 8 - 1, ci = ci0 + 4 * xq;
       const bool ok = it < X_ITEMS && gy >= 0 && gy < a.H && ci < a.Cin_s;
-      const float* src = a.x + ((size_t)(n * a.H + gy) * a.W + gx0) * a.Cin_s + ci;
+      const ptrdiff_t src = ((ptrdiff_t)(n * a.H + gy) * a.W + gx0) * a.Cin_s + ci;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (ok && gx0 + j >= 0 && gx0 + j < a.W && hg * 8 + j < PW + 2) v = *reinterpret_cast<const f32x4*>(src + (ptrdiff_t)j * a.Cin_s);
+        stage_t v = zero();
+        if (ok && gx0 + j >= 0 && gx0 + j < a.W && hg * 8 + j < PW + 2) v = ldg(a.x, (size_t)(src + (ptrdiff_t)j * a.Cin_s));
         rx[u][j] = v;
       }
+    }
+  };
+  // channel c of the pixel pair (j, j+1) -> one dword of two bf16: cvt_pk from fp32, v_perm_b32 byte select from bf16
+  auto pair = [&](const stage_t& lo, const stage_t& hi, int c) -> unsigned {
+    if constexpr (XB != 0) {
+      const unsigned l = c < 2 ? lo.x : lo.y, h = c < 2 ? hi.x : hi.y;
+      return __builtin_amdgcn_perm(h, l, (c & 1) ? 0x07060302u : 0x05040100u);
+    } else {
+      return pack2(lo[c], hi[c]);
     }
   };
   auto store_patch = [&]() {
 #pragma unroll
     for (int u = 0; u < NDY; ++u) {
       const int grp = sg + 16 * u;
+      if constexpr (XB != 0) {
+        if (want_bias) {                                  // bias gradient: fp32 column sums of the (bf16) dY
 #pragma unroll
-      for (int j = 0; j < 8; ++j) bsum += rdy[u][j];        // bias gradient: exact fp32 column sums of dY
+          for (int j = 0; j < 8; ++j) {
+            bsum[0] += __uint_as_float(rdy[u][j].x << 16); bsum[1] += __uint_as_float(rdy[u][j].x & 0xffff0000u);
+            bsum[2] += __uint_as_float(rdy[u][j].y << 16); bsum[3] += __uint_as_float(rdy[u][j].y & 0xffff0000u);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bsum += rdy[u][j];        // bias gradient: exact fp32 column sums of dY
+      }
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         uint4 v;
-        v.x = pack2(rdy[u][0][c], rdy[u][1][c]);
-        v.y = pack2(rdy[u][2][c], rdy[u][3][c]);
-        v.z = pack2(rdy[u][4][c], rdy[u][5][c]);
-        v.w = pack2(rdy[u][6][c], rdy[u][7][c]);
+        v.x = pair(rdy[u][0], rdy[u][1], c);
+        v.y = pair(rdy[u][2], rdy[u][3], c);
+        v.z = pair(rdy[u][4], rdy[u][5], c);
+        v.w = pair(rdy[u][6], rdy[u][7], c);
         *reinterpret_cast<uint4*>(dYs + (4 * dq + c) * DY_CSTRIDE + grp * 16) = v;       // [co][row*32 + x]
       }
     }
@@ -129,10 +162,10 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WbArgs a) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           uint4 v;
-          v.x = pack2(rx[u][0][c], rx[u][1][c]);
-          v.y = pack2(rx[u][2][c], rx[u][3][c]);
-          v.z = pack2(rx[u][4][c], rx[u][5][c]);
-          v.w = pack2(rx[u][6][c], rx[u][7][c]);
+          v.x = pair(rx[u][0], rx[u][1], c);
+          v.y = pair(rx[u][2], rx[u][3], c);
+          v.z = pair(rx[u][4], rx[u][5], c);
+          v.w = pair(rx[u][6], rx[u][7], c);
           *reinterpret_cast<uint4*>(Xs + (4 * xq + c) * X_CSTRIDE + grp * 16) = v;        // [ci][hrow*40 + hx]
         }
       }
@@ -179,21 +212,33 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WbArgs a) {
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
           const bf16x8_t bb = __builtin_bit_cast(bf16x8_t, b[s]);
-          acc[r * 3 + s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a0), bb, acc[r * 3 + s], 0, 0, 0);
+          acc[r * 3 + s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bb, __builtin_bit_cast(bf16x8_t, a0), acc[r * 3 + s], 0, 0, 0);
         }
       }
     }
   }
   __syncthreads();
 
-  const int ci = ci0 + wi * 32 + li;
+  // slab epilogue: the X fragment is the first MFMA operand -> D = [cin rows][cout columns]; lane (li, lh) holds cout li and
+  // cins 8 q + 4 lh + (0..3) per register quad = one 16-byte piece of the [tap][co][ci] slab (raw buffer stores, no branches)
+  {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const size_t slab_elems = (size_t)9 * a.Cout * a.Cin_s;
+    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(a.slab + (size_t)split * slab_elems, 0, (int)(slab_elems * 4), 0x00020000);
+    const int co = co0 + wc * 32 + li;
+    const int cib = ci0 + wi * 32 + 4 * lh;
+    const unsigned row = co < a.Cout ? (unsigned)(co * a.Cin_s) * 4u : 0x80000000u;
+    const unsigned tap_stride = (unsigned)(a.Cout * a.Cin_s) * 4u;
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < 9; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int co = co0 + wc * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (co < a.Cout && ci < a.Cin_s) a.slab[((size_t)(split * 9 + t) * a.Cout + co) * a.Cin_s + ci] = acc[t][r];
-    }
+      for (int q = 0; q < 4; ++q) {
+        const int ci = cib + 8 * q;
+        const unsigned off = ci < a.Cin_s ? row + (unsigned)t * tap_stride + (unsigned)ci * 4u : 0x80000000u;
+        const f32x4 v = {acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), srs, off, 0, 0);
+      }
+  }
   if (a.bslab != nullptr && cit == 0) {
     f32x4* red = reinterpret_cast<f32x4*>(smem);          // [16 pixel groups][16 quads]
     red[sg * 16 + sq] = bsum;
@@ -246,9 +291,10 @@ size_t osvos_wgrad_bf16_ws_bytes(int N, int H, int W, int Cin_s, int Cout) {
   return align_up((p.slab_floats + p.bslab_floats) * sizeof(float), 256);
 }
 
-int osvos_conv3x3_wgrad_bf16mfma(const float* x, const float* dy, void* ws, float* dw, float* db,
-                                 int N, int H, int W, int Cin, int Cin_s, int Cout, int Cout_s,
-                                 int accumulate, hipStream_t stream) {
+// xb = 0: x and dy fp32; xb = 1: both bf16
+int osvos_conv3x3_wgrad_bf16mfma_io(const void* x, const void* dy, int xb, void* ws, float* dw, float* db,
+                                    int N, int H, int W, int Cin, int Cin_s, int Cout, int Cout_s,
+                                    int accumulate, hipStream_t stream) {
   OSVOS_ARG_CHECK(x && dy && ws && dw, "wgrad bf16: null pointer");
   OSVOS_ARG_CHECK(osvos_wgrad_bf16_applicable(Cin_s, Cout) && Cin == Cin_s && Cout_s % 4 == 0, "wgrad bf16: unsupported shape");
   WbPlan p = make_plan(N, H, W, Cin_s, Cout);
@@ -261,16 +307,25 @@ int osvos_conv3x3_wgrad_bf16mfma(const float* x, const float* dy, void* ws, floa
   constexpr size_t lds = (size_t)DY_BYTES + X_BYTES;
   static bool attr_set = false;
   if (!attr_set) {
-    OSVOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16_kernel),
+    OSVOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16_kernel<0>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    OSVOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16_kernel<1>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
   const long blocks = (long)p.nsplit * p.nco_t * p.nci_t;
   const int phase = osvos_wgrad_phase();
   if (phase != 2) {
-    hipLaunchKernelGGL(wgrad_bf16_kernel, dim3((unsigned)blocks), dim3(256), lds, stream, a);
+    if (xb) hipLaunchKernelGGL(wgrad_bf16_kernel<1>, dim3((unsigned)blocks), dim3(256), lds, stream, a);
+    else hipLaunchKernelGGL(wgrad_bf16_kernel<0>, dim3((unsigned)blocks), dim3(256), lds, stream, a);
     OSVOS_LAUNCH_CHECK();
   }
   if (phase == 1) return 0;
   return osvos_wgrad_reduce_launch(a.slab, a.bslab, dw, db, p.nsplit, Cout, Cin, Cin_s, accumulate, stream);
+}
+
+int osvos_conv3x3_wgrad_bf16mfma(const float* x, const float* dy, void* ws, float* dw, float* db,
+                                 int N, int H, int W, int Cin, int Cin_s, int Cout, int Cout_s,
+                                 int accumulate, hipStream_t stream) {
+  return osvos_conv3x3_wgrad_bf16mfma_io(x, dy, 0, ws, dw, db, N, H, W, Cin, Cin_s, Cout, Cout_s, accumulate, stream);
 }

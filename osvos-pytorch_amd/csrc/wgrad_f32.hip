@@ -348,7 +348,7 @@ int launch_wgrad_variant(const WgArgs& a, long blocks, hipStream_t stream) {
 }  // namespace
 
 size_t osvos_wgrad_small_ws_bytes(int N, int H, int W, int Cin_s, int Cout);
-int osvos_conv3x3_wgrad_small_f32(const float* x, const float* dy, void* ws, float* dw, float* db,
+int osvos_conv3x3_wgrad_small_f32(const void* x, const void* dy, int wide_bf16, void* ws, float* dw, float* db,
                                   int N, int H, int W, int Cin, int Cin_s, int Cout, int Cout_s,
                                   int accumulate, hipStream_t stream);
 
@@ -378,7 +378,7 @@ int osvos_conv3x3_wgrad_f32(const float* x, const float* dy, void* ws, float* dw
   {
     const char* env = getenv("OSVOS_WGRAD_GENERIC");     // tuning / tests: force the generic kernel
     if (!(env && atoi(env))) {
-      const int rc = osvos_conv3x3_wgrad_small_f32(x, dy, ws, dw, db, N, H, W, Cin, Cin_s, Cout, Cout_s, accumulate, stream);
+      const int rc = osvos_conv3x3_wgrad_small_f32(x, dy, 0, ws, dw, db, N, H, W, Cin, Cin_s, Cout, Cout_s, accumulate, stream);
       if (rc <= 0) return rc;
     }
   }

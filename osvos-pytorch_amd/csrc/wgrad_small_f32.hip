@@ -23,9 +23,19 @@ constexpr int PW = 32;
 constexpr int C3_PH = 8, C3_PPIX = PW * C3_PH;                 // 256-pixel patch
 constexpr int C3_XW = PW + 2, C3_XH = C3_PH + 2, C3_XPIX = C3_XW * C3_XH;
 
+// 4 consecutive channels at element offset `e`: fp32 tensor, or (bf16-store mode of the network) a bf16 tensor widened on load
+__device__ inline f32x4 ld4(const void* base, size_t e, int is_bf16) {
+  if (is_bf16) {
+    const uint2 r = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(base) + e);
+    return f32x4{__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u)};
+  }
+  return *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(base) + e);
+}
+
 struct C3Args {
   const float* x;      // NHWC8
-  const float* dy;     // NHWC, stride Cout_s
+  const void* dy;      // NHWC, stride Cout_s; bf16 when dy_bf16
+  int dy_bf16;
   float* slab;         // [nsplit][64][32]
   float* bslab;        // [nsplit][64] or null
   int N, H, W, Cout, Cout_s;
@@ -64,7 +74,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_c3_f32_kernel(C3Args a) {
       const int gy = y0 + pix / PW, gx = x0 + pix % PW, co = 4 * q;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (gy < a.H && gx < a.W && co < a.Cout)
-        v = *reinterpret_cast<const f32x4*>(a.dy + ((size_t)(n * a.H + gy) * a.W + gx) * a.Cout_s + co);
+        v = ld4(a.dy, ((size_t)(n * a.H + gy) * a.W + gx) * a.Cout_s + co, a.dy_bf16);
       rdy[i] = v;
     }
 #pragma unroll
@@ -166,7 +176,8 @@ constexpr int S_YW = PW + 2, S_YH = S_PH + 2, S_YPIX = S_YW * S_YH;   // dY halo
 constexpr int S_BCI = 128;                                     // cins per workgroup (one 32-block per wave)
 
 struct S16Args {
-  const float* x;      // NHWC stride Cin_s
+  const void* x;       // NHWC stride Cin_s; bf16 when x_bf16
+  int x_bf16;
   const float* dy;     // NHWC stride Cout_s, 16 channels used
   float* slab;         // [nsplit][9][16][Cin_s]
   float* bslab;        // [nsplit][16] or null
@@ -215,7 +226,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_co16_f32_kernel(S16Args a) {
       const int gy = y0 + pix / PW, gx = x0 + pix % PW, ci = ci0 + 4 * q;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (gy < a.H && gx < a.W && ci < a.Cin_s)
-        v = *reinterpret_cast<const f32x4*>(a.x + ((size_t)(n * a.H + gy) * a.W + gx) * a.Cin_s + ci);
+        v = ld4(a.x, ((size_t)(n * a.H + gy) * a.W + gx) * a.Cin_s + ci, a.x_bf16);
       rx[i] = v;
     }
 #pragma unroll
@@ -332,13 +343,14 @@ size_t osvos_wgrad_small_ws_bytes(int N, int H, int W, int Cin_s, int Cout) {
 }
 
 // returns 1 if the shape is not one of the two special cases (caller falls through to the generic kernel)
-int osvos_conv3x3_wgrad_small_f32(const float* x, const float* dy, void* ws, float* dw, float* db,
+// wide_bf16: the WIDE operand is a bf16 tensor (dy of the Cin = 3 layer, x of the Cout = 16 layers); the narrow one stays fp32
+int osvos_conv3x3_wgrad_small_f32(const void* x, const void* dy, int wide_bf16, void* ws, float* dw, float* db,
                                   int N, int H, int W, int Cin, int Cin_s, int Cout, int Cout_s,
                                   int accumulate, hipStream_t stream) {
   if (Cin == 3 && Cin_s == 8 && Cout <= 64 && Cout % 4 == 0) {
     SmallPlan p = plan_c3(N, H, W);
     C3Args a;
-    a.x = x; a.dy = dy;
+    a.x = reinterpret_cast<const float*>(x); a.dy = dy; a.dy_bf16 = wide_bf16;
     a.slab = reinterpret_cast<float*>(ws);
     a.bslab = db ? a.slab + p.slab_floats : nullptr;
     a.N = N; a.H = H; a.W = W; a.Cout = Cout; a.Cout_s = Cout_s;
@@ -364,7 +376,7 @@ int osvos_conv3x3_wgrad_small_f32(const float* x, const float* dy, void* ws, flo
   if (Cout == 16 && Cout_s % 4 == 0 && Cin_s % 32 == 0 && Cin == Cin_s) {
     SmallPlan p = plan_co16(N, H, W, Cin_s);
     S16Args a;
-    a.x = x; a.dy = dy;
+    a.x = x; a.x_bf16 = wide_bf16; a.dy = reinterpret_cast<const float*>(dy);
     a.slab = reinterpret_cast<float*>(ws);
     a.bslab = db ? a.slab + p.slab_floats : nullptr;
     a.N = N; a.H = H; a.W = W; a.Cin_s = Cin_s; a.Cout_s = Cout_s;

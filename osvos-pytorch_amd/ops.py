@@ -84,16 +84,47 @@ def conv3x3(x, wpk, bias, cout, relu=False, mask=None, y_cs=None, tile=-1, dtype
     return y
 
 
-def conv3x3_bf16io(x, wpk, bias, cout, relu=False, mask=None, y_cs=None, tile=-1, want_bf16=True):
-    """bf16-MFMA convolution with explicit formats: x fp32 or torch.bfloat16 [N,H,W,Cin]; returns (y fp32, y bf16 | None)."""
+def conv3x3_bf16io(x, wpk, bias, cout, relu=False, mask=None, y_cs=None, tile=-1, want_bf16=True, want_f32=True):
+    """bf16-MFMA convolution with explicit formats: x and mask fp32 or torch.bfloat16 [N,H,W,C]; returns (y fp32 | None, y bf16 | None)."""
     _need_cuda(x, wpk, bias, mask)
     n, h, w, cin = x.shape
     y_cs = y_cs or cout
-    y = torch.zeros((n, h, w, y_cs), device=x.device, dtype=torch.float32)
+    y = torch.zeros((n, h, w, y_cs), device=x.device, dtype=torch.float32) if want_f32 else None
     yb = torch.zeros((n, h, w, y_cs), device=x.device, dtype=torch.bfloat16) if want_bf16 else None
-    check(lib().osvos_conv3x3_bf16io(_p(x), int(x.dtype == torch.bfloat16), _p(wpk), _p(bias), _p(mask), _p(y), _p(yb), n, h, w, cin, cout,
+    check(lib().osvos_conv3x3_bf16io(_p(x), int(x.dtype == torch.bfloat16), _p(wpk), _p(bias), _p(mask),
+                                     int(mask is not None and mask.dtype == torch.bfloat16), _p(y), _p(yb), n, h, w, cin, cout,
                                      y_cs, int(relu), tile, _stream()), "conv3x3_bf16io")
     return y, yb
+
+
+def conv3x3_wgrad_bf16act(x, dy, cin, cout, want_bias=True):
+    """x, dy torch.bfloat16 NHWC (wide layers) -> (dW fp32 [cout,cin,3,3], db fp32)"""
+    _need_cuda(x, dy)
+    assert x.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16
+    n, h, w, cin_s = x.shape
+    ws = torch.empty(lib().osvos_wgrad_ws_bytes(n, h, w, cin_s, cout, F32_BF16MFMA), device=x.device, dtype=torch.uint8)
+    dw = torch.empty((cout, cin, 3, 3), device=x.device, dtype=torch.float32)
+    db = torch.empty((cout,), device=x.device, dtype=torch.float32) if want_bias else None
+    check(lib().osvos_conv3x3_wgrad_bf16act(_p(x), _p(dy), _p(ws), _p(dw), _p(db), n, h, w, cin, cin_s, cout, dy.shape[3], 0, _stream()), "wgrad_bf16act")
+    return dw, db
+
+
+def maxpool2x2_bf16act(x):
+    _need_cuda(x)
+    assert x.dtype == torch.bfloat16
+    n, h, w, c = x.shape
+    y = torch.empty((n, (h + 1) // 2, (w + 1) // 2, c), device=x.device, dtype=torch.bfloat16)
+    check(lib().osvos_maxpool2x2_bf16act(_p(x), _p(y), n, h, w, c, _stream()), "maxpool_bf16act")
+    return y
+
+
+def maxpool2x2_bwd_bf16act(x, dy, dside=None):
+    _need_cuda(x, dy, dside)
+    assert x.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16 and (dside is None or dside.dtype == torch.bfloat16)
+    n, h, w, c = x.shape
+    dx = torch.empty_like(x)
+    check(lib().osvos_maxpool2x2_bwd_bf16act(_p(x), _p(dy), _p(dside), _p(dx), n, h, w, c, _stream()), "maxpool_bwd_bf16act")
+    return dx
 
 
 def conv3x3_bf16io_tiles():

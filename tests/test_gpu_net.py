@@ -328,3 +328,54 @@ def test_bf16_operand_copies_do_not_change_the_numbers(tmp_path):
     assert got["0"].keys() == got["1"].keys() and len(got["0"]) > 30
     for k in got["0"]:
         assert np.array_equal(got["0"][k], got["1"][k]), k
+
+
+def test_bf16_store_mode_within_the_bf16_bars(tmp_path):
+    """OSVOS_BF16_STORE=1: trunk activations / gradients live in HBM as bf16 only.  Same bars against float64 as the default
+    bf16 mode (logits <= 0.1 std, loss rel <= 1e-2, gradient rel-L2 <= 0.25), and close to the default bf16 mode itself."""
+    import os, subprocess, sys, textwrap
+    code = textwrap.dedent('''
+        import sys, numpy as np, torch
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        import test_gpu_net as T
+        from oracle import synth
+        from layers.osvos_layers import class_balanced_cross_entropy_loss as cbce
+        wts, x, m = synth.calibrated_problem(2, 120, 214, seed=21)
+        net = T.build_net(wts).set_precision("bf16")
+        xg = torch.from_numpy(x).cuda().requires_grad_()
+        outs = net.forward(xg)
+        gt = torch.from_numpy(m).cuda()
+        losses = [cbce(o, gt, size_average=False) for o in outs]
+        (0.5 * sum(losses[:-1]) + losses[-1]).backward()
+        res = {"out%%d" %% i: o.detach().cpu().numpy() for i, o in enumerate(outs)}
+        res.update({"loss%%d" %% i: np.array(l.item()) for i, l in enumerate(losses)})
+        res.update({"g:" + k: v.grad.cpu().numpy() for k, v in net.named_parameters() if v.grad is not None})
+        res["dx"] = xg.grad.cpu().numpy()
+        np.savez(sys.argv[1], **res)
+    ''') % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    got = {}
+    for flag in ("0", "1"):
+        out = str(tmp_path / ("s%s.npz" % flag))
+        subprocess.run([sys.executable, "-c", code, out], check=True, env=dict(os.environ, OSVOS_BF16_STORE=flag), timeout=900)
+        got[flag] = dict(np.load(out))
+    from oracle import synth
+    wts, x, m = synth.calibrated_problem(2, 120, 214, seed=21)
+    t_outs, t_losses, t_grads = _oracle_run(wts, x, m, torch.float64)
+    a, b = got["0"], got["1"]
+    for i in range(5):
+        assert np.abs(b["out%d" % i] - t_outs[i]).max() <= 0.1 * t_outs[i].std(), i
+        assert abs(float(b["loss%d" % i]) - t_losses[i]) / abs(t_losses[i]) <= 1e-2, i
+    worst = []
+    for k, tg in t_grads.items():
+        if "g:" + k not in b:
+            continue
+        e1 = float(np.linalg.norm(b["g:" + k].astype(np.float64) - tg.numpy()) / np.linalg.norm(tg.numpy()))
+        e0 = float(np.linalg.norm(a["g:" + k].astype(np.float64) - tg.numpy()) / np.linalg.norm(tg.numpy()))
+        worst.append((e1, e0, k))
+        assert e1 <= 0.25 and e1 <= max(2.0 * e0, 6e-2), (k, e1, e0)
+    assert len(worst) > 30
+    worst.sort(reverse=True)
+    print("bf16-store gradients vs f64 (store | default bf16):", [(k, "%.1e" % e1, "%.1e" % e0) for e1, e0, k in worst[:6]])
+    rel = float(np.linalg.norm(b["dx"] - a["dx"]) / np.linalg.norm(a["dx"]))
+    print("input gradient, store vs default bf16 mode: rel-L2 %.2e" % rel)
+    assert np.isfinite(b["dx"]).all() and rel <= 0.5

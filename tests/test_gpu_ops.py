@@ -351,3 +351,68 @@ def test_fused_sgd_matches_torch_optim_sgd_and_shares_state_dict():
         o = FusedSGD(cpu, lr=0.1)
         cpu[0].grad = torch.ones(3)
         o.step()
+
+
+@pytest.mark.gpu
+def test_bf16act_pooling_matches_fp32_rule_on_bf16_values():
+    """bf16 tensors in, bf16 out: forward = same elements the fp32 kernel picks; backward = fp32 arithmetic of the
+    fp32 kernel on the same (bf16-representable) values, rounded once"""
+    ops = _ops()
+    g = torch.Generator().manual_seed(43)
+    for shape in [(2, 16, 9, 13), (1, 64, 8, 8), (1, 8, 1, 1), (1, 24, 7, 2)]:
+        n, c, h, w = shape
+        x = F.relu(torch.randn(shape, generator=g)).bfloat16()
+        xg = nhwc(x.float()).bfloat16()
+        y = ops.maxpool2x2_bf16act(xg)
+        assert torch.equal(y.float(), ops.maxpool2x2(xg.float()))
+        dy = torch.randn(n, c, (h + 1) // 2, (w + 1) // 2, generator=g).bfloat16()
+        ds = torch.randn(shape, generator=g).bfloat16()
+        dx = ops.maxpool2x2_bwd_bf16act(xg, nhwc(dy.float()).bfloat16(), nhwc(ds.float()).bfloat16())
+        ref = ops.maxpool2x2_bwd(xg.float(), nhwc(dy.float()), nhwc(ds.float()))
+        assert torch.equal(dx, ref.bfloat16())
+        dx0 = ops.maxpool2x2_bwd_bf16act(xg, nhwc(dy.float()).bfloat16())
+        assert torch.equal(dx0, ops.maxpool2x2_bwd(xg.float(), nhwc(dy.float())).bfloat16())
+
+
+@pytest.mark.gpu
+def test_conv3x3_bf16io_bf16_mask_and_bf16_only_output():
+    from osvos_pytorch_amd._lib import F32_BF16MFMA
+    ops = _ops()
+    g = torch.Generator().manual_seed(47)
+    n, h, w, cin, cout = 2, 19, 27, 64, 64
+    x = torch.randn(n, cin, h, w, generator=g).bfloat16()
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / 24
+    m = F.relu(torch.randn(n, cout, h, w, generator=g)).bfloat16()           # a post-ReLU activation as the mask
+    wpk = ops.pack_dgrad(wt.cuda(), F32_BF16MFMA) if False else ops.pack_fwd(wt.cuda(), F32_BF16MFMA)
+    xg, mg = nhwc(x.float()).bfloat16(), nhwc(m.float()).bfloat16()
+    for tile in (-1, 1, 20):
+        y_ref, yb_ref = ops.conv3x3_bf16io(xg, wpk, None, cout, mask=mg.float(), tile=tile)   # (accumulation order differs between tiles)
+        y, yb = ops.conv3x3_bf16io(xg, wpk, None, cout, mask=mg, tile=tile)                   # bf16 mask
+        assert torch.equal(y, y_ref) and torch.equal(yb, yb_ref)
+        y2, yb2 = ops.conv3x3_bf16io(xg, wpk, None, cout, mask=mg, tile=tile, want_f32=False)   # bf16-only result
+        assert y2 is None and torch.equal(yb2, yb_ref)
+    ref = F.conv2d(x.double(), wt.bfloat16().double(), None, padding=1) * (m > 0)
+    assert rel_err(nchw(y_ref), ref)[0] < 3e-5
+    with pytest.raises(RuntimeError):
+        ops.conv3x3_bf16io(xg, wpk, None, cout, want_f32=False, want_bf16=False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(1, 9, 11, 64, 64), (2, 17, 35, 64, 128), (1, 33, 70, 128, 64), (3, 8, 40, 64, 64)])
+def test_wgrad_bf16act_equals_fp32_input_kernel_on_bf16_values(shape):
+    """bf16 x and dy in HBM: the weight gradient is bit-identical to the bf16-MFMA kernel fed with the same values as fp32
+    (same products, same accumulation order); the bias gradient is the fp32 sum of the bf16 dy"""
+    from osvos_pytorch_amd._lib import F32_BF16MFMA
+    ops = _ops()
+    n, h, w, cin, cout = shape
+    g = torch.Generator().manual_seed(53)
+    x = torch.randn(n, cin, h, w, generator=g).bfloat16()
+    dy = torch.randn(n, cout, h, w, generator=g).bfloat16()
+    xg, dyg = nhwc(x.float()), nhwc(dy.float())
+    dw32, db32 = ops.conv3x3_wgrad(xg, dyg, cin, cout, dtype=F32_BF16MFMA)
+    dw16, db16 = ops.conv3x3_wgrad_bf16act(xg.bfloat16(), dyg.bfloat16(), cin, cout)
+    assert torch.equal(dw16, dw32)
+    assert rel_err(db16.cpu(), dy.double().sum((0, 2, 3)))[0] < 1e-5
+    wt = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), wt, None, padding=1).backward(dy.double())
+    assert rel_err(dw16.cpu(), wt.grad)[0] < 3e-5
