@@ -173,7 +173,7 @@ def main():
                     help="online/parent: restated training loops (fwd+loss+bwd+SGD); infer: forward only under no_grad "
                          "(BASELINE.json configs[4]: use --height 1080 --width 1920 --batch 4 --graph 1)")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
-                    help="bf16: conv forward/data-gradient on bf16 MFMA operands (fp32 accumulate, fp32 tensors); "
+                    help="bf16: the three conv passes on bf16 MFMA operands, trunk tensors stored as bf16 (fp32 accumulate); "
                          "the headline configs[1] is fp32")
     ap.add_argument("--graph", type=int, default=0, help="infer mode: replay the forward from a captured hipGraph")
     ap.add_argument("--height", type=int, default=480)
@@ -325,7 +325,7 @@ def main():
                       "frames/sec (forward only) OSVOS-VGG16 %dx%d" % (args.width, args.height),
             "value": round(value, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "bf16 MFMA operands (fwd+dgrad), f32 accumulate/tensors/wgrad",
+            "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "bf16 MFMA operands and bf16 trunk tensors (fwd+dgrad+wgrad), f32 accumulate; head/loss/skinny wgrads/parameters f32",
             "data": "synthetic",
             "config": {"workload": ("%dx%d batch=%d inference forward (train_online.py:172-181), no_grad, %s, fp32, frames resident in HBM"
                                     % (args.width, args.height, args.batch, "hipGraph replay" if args.graph else "eager launches"))

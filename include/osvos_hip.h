@@ -173,7 +173,8 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
                        float* dx_nchw, int N, int H, int W, int dtype, int accumulate, void* stream, void* aux_stream,
                        void* aux2_stream);
 /* byte offset / element count of a saved activation inside ws (tests): which = 0..12 trunk conv
- * outputs, 13..16 pooled inputs of stages 1-4, 17..20 side_prep outputs, 21 NHWC input */
+ * outputs, 13..16 pooled inputs of stages 1-4, 17..20 side_prep outputs, 21 NHWC input.  (fp32 elements; with dtype
+ * OSVOS_F32_BF16MFMA the trunk tensors 0..16 are bf16 unless OSVOS_BF16_STORE=0.) */
 int osvos_net_ws_query(int N, int H, int W, int dtype, int which, size_t* offset, size_t* elems, int* channels, int* h, int* w);
 
 /* ---- fused SGD (torch.optim.SGD semantics, train_online.py:79-88,147) ----------------------

@@ -49,7 +49,7 @@ __device__ inline unsigned pack2(float lo, float hi) {
 
 // XB = 1: x and dy are already bf16 in HBM -- half the bytes, half the staging registers (two workgroups per CU fit)
 template <int XB>
-__global__ __launch_bounds__(256, XB ? 2 : 1) void wgrad_bf16_kernel(WbArgs a) {
+__global__ __launch_bounds__(256) void wgrad_bf16_kernel(WbArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* dYs = smem;
   char* Xs = smem + DY_BYTES;
@@ -187,34 +187,49 @@ __global__ __launch_bounds__(256, XB ? 2 : 1) void wgrad_bf16_kernel(WbArgs a) {
     store_patch();
     __syncthreads();
     if (p + 1 < p_end) load_patch(p + 1);
-#pragma unroll 1
-    for (int ks = 0; ks < PH * 2; ++ks) {                  // k-step = 16 consecutive pixels of one patch row
+    // k-step = 16 consecutive pixels of one patch row.  One wave per SIMD (288 registers), so the loop is software
+    // pipelined by hand: the 7 LDS reads of k-step ks+1 are requested before the 9 MFMAs of k-step ks issue
+    // (two named register sets, sched_barrier pins the order -- hipcc otherwise sinks the reads to their first use)
+    struct Frag { uint4 a0; uint4 w0[3]; unsigned w4[3]; };
+    auto ldk = [&](int ks, Frag& f) {
       const int row = ks >> 1, kx = ks & 1;
-      const uint4 a0 = *reinterpret_cast<const uint4*>(a_base + (row * PW + kx * 16) * 2);
-      uint4 w0[3];
-      unsigned w4[3];
+      f.a0 = *reinterpret_cast<const uint4*>(a_base + (row * PW + kx * 16) * 2);
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
         const char* src = b_base + ((row + r) * XPITCH + kx * 16) * 2;
-        w0[r] = *reinterpret_cast<const uint4*>(src);
-        w4[r] = reinterpret_cast<const uint4*>(src + 16)->x;   // a b32 read at this stride is a 4-way bank conflict; the compiler keeps it b32 or widens
+        f.w0[r] = *reinterpret_cast<const uint4*>(src);
+        f.w4[r] = reinterpret_cast<const uint4*>(src + 16)->x;
       }
-      __builtin_amdgcn_sched_barrier(0);
+    };
+    auto mm = [&](const Frag& f) {
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
         uint4 b[3];
-        b[0] = w0[r];
-        b[1].x = __builtin_amdgcn_alignbit(w0[r].y, w0[r].x, 16);
-        b[1].y = __builtin_amdgcn_alignbit(w0[r].z, w0[r].y, 16);
-        b[1].z = __builtin_amdgcn_alignbit(w0[r].w, w0[r].z, 16);
-        b[1].w = __builtin_amdgcn_alignbit(w4[r], w0[r].w, 16);
-        b[2].x = w0[r].y; b[2].y = w0[r].z; b[2].z = w0[r].w; b[2].w = w4[r];
+        b[0] = f.w0[r];
+        b[1].x = __builtin_amdgcn_alignbit(f.w0[r].y, f.w0[r].x, 16);
+        b[1].y = __builtin_amdgcn_alignbit(f.w0[r].z, f.w0[r].y, 16);
+        b[1].z = __builtin_amdgcn_alignbit(f.w0[r].w, f.w0[r].z, 16);
+        b[1].w = __builtin_amdgcn_alignbit(f.w4[r], f.w0[r].w, 16);
+        b[2].x = f.w0[r].y; b[2].y = f.w0[r].z; b[2].z = f.w0[r].w; b[2].w = f.w4[r];
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
           const bf16x8_t bb = __builtin_bit_cast(bf16x8_t, b[s]);
-          acc[r * 3 + s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bb, __builtin_bit_cast(bf16x8_t, a0), acc[r * 3 + s], 0, 0, 0);
+          acc[r * 3 + s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bb, __builtin_bit_cast(bf16x8_t, f.a0), acc[r * 3 + s], 0, 0, 0);
         }
       }
+    };
+    Frag f0, f1;
+    ldk(0, f0);
+#pragma unroll 1
+    for (int ks = 0; ks < PH * 2; ks += 2) {
+      ldk(ks + 1, f1);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(f0);
+      __builtin_amdgcn_sched_barrier(0);
+      ldk((ks + 2) & (PH * 2 - 1), f0);                    // unconditional (wraps at the end): the waits stay counted
+      __builtin_amdgcn_sched_barrier(0);
+      mm(f1);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   __syncthreads();

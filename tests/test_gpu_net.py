@@ -322,7 +322,7 @@ def test_bf16_operand_copies_do_not_change_the_numbers(tmp_path):
     got = {}
     for flag in ("0", "1"):
         out = str(tmp_path / ("r%s.npz" % flag))
-        env = dict(os.environ, OSVOS_BF16_SHADOW=flag)
+        env = dict(os.environ, OSVOS_BF16_SHADOW=flag, OSVOS_BF16_STORE="0")
         subprocess.run([sys.executable, "-c", code, out], check=True, env=env, timeout=600)
         got[flag] = dict(np.load(out))
     assert got["0"].keys() == got["1"].keys() and len(got["0"]) > 30
@@ -331,7 +331,7 @@ def test_bf16_operand_copies_do_not_change_the_numbers(tmp_path):
 
 
 def test_bf16_store_mode_within_the_bf16_bars(tmp_path):
-    """OSVOS_BF16_STORE=1: trunk activations / gradients live in HBM as bf16 only.  Same bars against float64 as the default
+    """bf16-store mode (the default of precision 'bf16'; OSVOS_BF16_STORE=0 = fp32 tensors): trunk activations / gradients live in HBM as bf16 only.  Same bars against float64 as the default
     bf16 mode (logits <= 0.1 std, loss rel <= 1e-2, gradient rel-L2 <= 0.25), and close to the default bf16 mode itself."""
     import os, subprocess, sys, textwrap
     code = textwrap.dedent('''

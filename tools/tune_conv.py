@@ -100,7 +100,13 @@ for name, h, w, cin, cout in layers:
             name, direction, h, w, kin, kout, gf, " ".join("%-7.3f" % r for r in res), bi, gf / best, auto))
     x = torch.randn(n, h, w, (cin + 7) // 8 * 8, device="cuda")
     dy = torch.randn(n, h, w, cout, device="cuda")
-    ms = timeit(lambda: ops.conv3x3_wgrad(x, dy, cin, cout, dtype=DT), args.reps)
+    if args.xb == 1 and cin % 64 == 0 and cout % 64 == 0:
+        xb16, dyb16 = x.bfloat16(), dy.bfloat16()
+        ms32 = timeit(lambda: ops.conv3x3_wgrad(x, dy, cin, cout, dtype=DT), args.reps)
+        ms = timeit(lambda: ops.conv3x3_wgrad_bf16act(xb16, dyb16, cin, cout), args.reps)
+        print("%-16s wgrad fp32-in %.3f ms -> bf16-in:" % (name, ms32), end=" ")
+    else:
+        ms = timeit(lambda: ops.conv3x3_wgrad(x, dy, cin, cout, dtype=DT), args.reps)
     tot["wgrad"] += ms
     print("%-16s wgrad %4dx%-4d %4d->%-4d %6.2f | %.3f ms  %.1f TF/s" % (name, h, w, cin, cout, gf, ms, gf / ms))
 print("sum of best: fwd %.3f ms, dgrad %.3f ms, wgrad %.3f ms" % (tot["fwd"], tot["dgrad"], tot["wgrad"]))
