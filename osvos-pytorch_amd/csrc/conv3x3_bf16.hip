@@ -10,6 +10,7 @@
 //   * numerics equal a bf16-activation pipeline: rounding happens right before the MFMA either way
 #include "common.h"
 #include <type_traits>
+#include "kernels.h"
 
 namespace {
 
@@ -574,10 +575,19 @@ int osvos_conv3x3_bf16mfma_io(const void* x, int xb, const void* wpk, const floa
   if (tile < 0) {
     const char* env = getenv("OSVOS_CONV_TILE_BF16");
     tile = env ? atoi(env) : pick_tile_b(N, H, W, a.CoutP);
+    // bf16 activations, deep layers (K = 9 x 512): the LDS-DMA staged 512 px x 128 co kernel wins when it still fills the chip
+    // (conv4_x 0.355 -> 0.331 ms, conv5_x 0.117 -> 0.098 ms at batch 12)
+    if (!env && xb && Cin >= 512 && a.CoutP >= 128 && osvos_conv3x3_bf16_dma_applicable(Cin, Cout, y_cs) &&
+        (long)N * ceil_div(H, 16) * ceil_div(W, 32) * ceil_div(a.CoutP, 128) >= 256)
+      tile = 32;
     if (!env && (double)H * W * Cin * 4 > 9.0 * Cin * a.CoutP * 2) tile += 100;
   }
   a.map = tile >= 100 ? 1 : 0;
   tile %= 100;
+  if (xb && tile >= 30 && tile <= 33) {      // LDS-DMA staged kernel
+    OSVOS_ARG_CHECK(osvos_conv3x3_bf16_dma_applicable(Cin, Cout, y_cs), "conv3x3 bf16: tile %d (DMA staging) needs Cin %% 16 == 0, Cout, y_cs %% 8 == 0", tile);
+    return osvos_conv3x3_bf16_dma(x, wpk, bias, mask, mask_bf16, y, ybf, N, H, W, Cin, Cout, y_cs, relu, tile - 30, a.map, stream);
+  }
   if (xb) {      // bf16 activations: the tiles the network uses
     switch (tile) {
       case 1: return launch_cfg<B1, 1>(a, stream);
@@ -589,7 +599,7 @@ int osvos_conv3x3_bf16mfma_io(const void* x, int xb, const void* wpk, const floa
       case 20: return launch_cfg<B20, 1>(a, stream);
       case 22: return launch_cfg<B22, 1>(a, stream);
       case 23: return launch_cfg<B23, 1>(a, stream);
-      default: osvos_set_error("conv3x3 bf16: tile config %d is not built for bf16 activations (1, 3, 5, 6, 7, 11, 20, 22, 23 are)", tile); return -1;
+      default: osvos_set_error("conv3x3 bf16: tile config %d is not built for bf16 activations (1, 3, 5, 6, 7, 11, 20, 22, 23, 30..33 are)", tile); return -1;
     }
   }
   switch (tile) {
@@ -626,7 +636,7 @@ int osvos_conv3x3_bf16mfma_io(const void* x, int xb, const void* wpk, const floa
 }
 
 int osvos_conv3x3_bf16mfma_xb_tiles(int* tiles, int max) {      // tile ids built for bf16 activations
-  static const int t[] = {1, 3, 5, 6, 7, 11, 20, 22, 23};
+  static const int t[] = {1, 3, 5, 6, 7, 11, 20, 22, 23, 30, 31, 32, 33};
   int n = 0;
   for (; n < (int)(sizeof(t) / sizeof(t[0])) && n < max; ++n) tiles[n] = t[n];
   return n;

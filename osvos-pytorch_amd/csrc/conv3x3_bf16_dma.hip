@@ -1,0 +1,316 @@
+// 3x3 convolution on bf16 MFMA operands, bf16 activations in HBM, operands staged by LDS-DMA.
+//
+// Same implicit GEMM as conv3x3_bf16.hip (halo tile of the input in LDS as planes of 16-byte channel groups, a tap =
+// an LDS address offset, weights packed [tap][Cin/8][CoutP][8], cout-major accumulators, 16-byte buffer-store epilogue)
+// but the global -> LDS path never touches a register: every wave issues `buffer_load_dwordx4 ... lds` (lane l of an
+// instruction lands in LDS slot base + l; out-of-range offsets land as zeros -- tests/test_gpu_ops.py::
+// test_lds_dma_layout_probe), three LDS buffers rotate (the DMA of chunk k+2 is in flight while chunk k is multiplied),
+// and there is ONE barrier per 16-channel K chunk.  The register-staged kernel spends 20-40 % of a wave's time issuing
+// loads, converting and writing LDS, two barriers per chunk (profiles/r01_phase_probe_bf16.txt); with its loads removed
+// it runs 1435 TFLOP/s against 883 with them.  Here the wave's instruction stream is MFMA + ds_read + 12 DMA issues.
+//
+// Workgroup: 4 waves, 256 pixels (8 rows x 32) x NB*32 couts; wave (wm, wn) owns 4 rows x NB/2 cout blocks.
+// LDS: 3 x 48 KB (NB = 4) -> one workgroup per CU, one wave per SIMD; latency is hidden by the DMA distance (two chunks)
+// and by software-pipelined fragment reads.  Needs Cin % 16 == 0 (every layer but conv1_1).
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+struct DmaArgs {
+  const bf16_t* x;       // bf16 NHWC, channel stride Cin (multiple of 16)
+  const uint4* wpk;      // bf16 pack [9][CinP/8][CoutP][8]
+  const float* bias;
+  const void* mask;      // NHWC like y: fp32, or bf16 when mask_bf16
+  float* y;              // may be NULL when ybf is given
+  bf16_t* ybf;
+  int N, H, W, Cin, CinP, Cout, CoutP, y_cs;
+  int tiles_x, tiles_y, nct, nsp, map;
+  int relu, mask_bf16;
+};
+
+constexpr int TW = 32, HWD = TW + 2;
+constexpr int KG = 2;                                                               // 16 channels per chunk
+constexpr unsigned OOB = 0x80000000u;
+
+// WGM = 2: 4 waves, 8 rows x 32 px, three rotating LDS buffers, one wave per SIMD
+// WGM = 4: 8 waves, 16 rows x 32 px, two LDS buffers, two waves per SIMD (each covers the other's DMA issue and LDS waits)
+template <int NB, int WGM>
+struct DmaCfg {
+  static constexpr int NW = 2 * WGM, NT = 64 * NW;         // wave grid WGM x 2
+  static constexpr int TH = 4 * WGM, HHT = TH + 2, PLANE = HHT * HWD;
+  static constexpr int A_SLOTS = (KG * PLANE + 63) / 64 * 64;
+  static constexpr int A_INSTR = A_SLOTS / 64;
+  static constexpr int NBUF = WGM == 2 ? 3 : 2;
+  static constexpr int BN = NB * 32;
+  static constexpr int WN = NB / 2;                        // cout blocks per wave
+  static constexpr int WM = 4;                             // rows per wave
+  static constexpr int B_SLOTS = 9 * KG * BN;              // multiple of 64
+  static constexpr int B_INSTR = B_SLOTS / 64;
+  static constexpr int BUF_SLOTS = A_SLOTS + B_SLOTS + 64; // + one spare instruction target (keeps every wave's DMA count equal)
+  static constexpr int NA = (A_INSTR + NW - 1) / NW, NBI = (B_INSTR + NW - 1) / NW;
+  static constexpr int NDMA = NA + NBI;                    // DMA instructions per wave per chunk
+  static constexpr size_t LDS_BYTES = (size_t)NBUF * BUF_SLOTS * 16;
+  static_assert(B_SLOTS % 64 == 0, "weight tile must be whole DMA instructions");
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+};
+
+template <int NB, int WGM>
+__global__ __launch_bounds__(64 * 2 * WGM, WGM == 4 ? 2 : 1) void conv3x3_bf16_dma_kernel(DmaArgs a) {
+  using C = DmaCfg<NB, WGM>;
+  constexpr int TH = C::TH, PLANE = C::PLANE, A_SLOTS = C::A_SLOTS, A_INSTR = C::A_INSTR, NBUF = C::NBUF, NW = C::NW;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const uint4* lds = reinterpret_cast<const uint4*>(smem);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  int sp, ct;
+  if (a.map == 0) {
+    sp = blockIdx.x / a.nct;
+    ct = blockIdx.x % a.nct;
+  } else {
+    const int j = blockIdx.x >> 3;
+    ct = j % a.nct;
+    sp = (j / a.nct) * 8 + (blockIdx.x & 7);
+    if (sp >= a.nsp) return;
+  }
+  const int tx = sp % a.tiles_x;
+  sp /= a.tiles_x;
+  const int ty = sp % a.tiles_y;
+  const int n = sp / a.tiles_y;
+  const int x0 = tx * TW, y0 = ty * TH, co0 = ct * C::BN;
+  const int CG = a.CinP >> 3;
+
+  // The DMA instructions are issued through inline asm: hipcc tracks `__builtin_amdgcn_raw_ptr_buffer_load_lds` as an LDS store
+  // and puts `s_waitcnt vmcnt(0)` in front of the next ds_read -- which would wait for the chunk that was just requested and
+  // serialise the pipeline.  Hidden from the compiler, the ordering is ours to keep: vmcnt(NDMA) + barrier per chunk (below).
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  auto make_rsrc = [](const void* p, int bytes) -> i32x4 {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    return i32x4{(int)(unsigned)v, (int)(unsigned)(v >> 32), bytes, 0x00020000};
+  };
+  const i32x4 xrs = make_rsrc(a.x + (size_t)n * a.H * a.W * a.Cin, (int)((size_t)a.H * a.W * a.Cin * 2));
+  const i32x4 wrs = make_rsrc(a.wpk, (int)((size_t)9 * CG * a.CoutP * 16));
+  const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem;     // LDS byte address of the dynamic segment
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+  auto dma16 = [](const i32x4& rs, unsigned lds_addr, unsigned voff, int soff) {
+    asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" : : "s"(lds_addr), "v"(voff), "s"(rs), "s"(soff) : "m0", "memory");
+  };
+#pragma clang diagnostic pop
+
+  // per-lane source offsets of this wave's DMA instructions (chunk 0; the chunk advance rides in the scalar offset)
+  unsigned a_off[C::NA], b_off[C::NBI];
+#pragma unroll
+  for (int i = 0; i < C::NA; ++i) {
+    const int e = 64 * (wave + NW * i) + lane;             // slot inside the A region (instruction wave + NW i)
+    const int g = e / PLANE, rem = e % PLANE;
+    const int hy = rem / HWD, hx = rem % HWD;
+    const int gy = y0 + hy - 1, gx = x0 + hx - 1;
+    a_off[i] = (e < KG * PLANE && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? (unsigned)(((gy * a.W + gx) * a.Cin + 8 * g) * 2) : OOB;
+  }
+#pragma unroll
+  for (int i = 0; i < C::NBI; ++i) {
+    const int e = 64 * (wave + NW * i) + lane;
+    const int tap = e / (KG * C::BN), rem = e % (KG * C::BN);
+    const int g = rem / C::BN, nn = rem % C::BN;
+    b_off[i] = (e < C::B_SLOTS && co0 + nn < a.CoutP) ? (unsigned)(((tap * CG + g) * a.CoutP + co0 + nn) * 16) : OOB;
+  }
+  // LDS target of instruction i of this wave inside a buffer (wave-uniform); instructions past the region go to the spare slots
+  const int wv = __builtin_amdgcn_readfirstlane(wave);        // wave-uniform by construction; make it a scalar for m0
+  // the d-th DMA instruction of this wave for chunk kc into buffer buf (d is a compile-time constant after unrolling)
+  auto dma_one = [&](int d, int kc, int buf, unsigned dead) {
+    const unsigned base = lds0 + (unsigned)(buf * C::BUF_SLOTS * 16);
+    if (d < C::NA) {
+      const int j = wv + NW * d;
+      dma16(xrs, base + (unsigned)(j < A_INSTR ? j * 1024 : (A_SLOTS + C::B_SLOTS) * 16), a_off[d] | dead, kc * (8 * KG * 2));
+    } else {
+      const int i = d - C::NA, j = wv + NW * i;
+      dma16(wrs, base + (unsigned)(j < C::B_INSTR ? (A_SLOTS + 64 * j) * 16 : (A_SLOTS + C::B_SLOTS) * 16), b_off[i] | dead, kc * KG * a.CoutP * 16);
+    }
+  };
+  auto dma_chunk = [&](int kc, int buf, unsigned dead) {
+#pragma unroll
+    for (int d = 0; d < C::NDMA; ++d) dma_one(d, kc, buf, dead);
+  };
+
+  const int a_idx = lh * PLANE + (wm * C::WM) * HWD + li;              // + mi * HWD + r * HWD + s
+  const int b_idx = A_SLOTS + lh * C::BN + wn * C::WN * 32 + li;       // + tap * KG * BN + ni * 32
+
+  f32x16 acc[C::WM][C::WN];
+#pragma unroll
+  for (int mi = 0; mi < C::WM; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < C::WN; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  const int nchunks = a.Cin >> 4;
+  // DIST = how many chunks the DMA runs ahead (NBUF - 1).  s_waitcnt vmcnt((DIST - 1) * NDMA): everything but the newest
+  // DIST - 1 chunks' DMA instructions of THIS wave has landed
+  constexpr int DIST = NBUF - 1;
+  constexpr int VM = (DIST - 1) * C::NDMA;
+  constexpr int WAITCNT = 0x0F70 | (VM & 15) | ((VM >> 4) << 14);
+#pragma unroll
+  for (int c = 0; c < DIST; ++c) dma_chunk(c, c, c < nchunks ? 0u : OOB);
+  __builtin_amdgcn_s_waitcnt(WAITCNT);
+  __syncthreads();
+  int cur = 0;                                                 // chunk k lives in buffer k % NBUF
+  for (int kc = 0; kc < nchunks; ++kc) {
+    // chunk kc + DIST goes to the buffer that was read in iteration kc - 1; every wave left that iteration through the barrier below.
+    // Its DMA instructions are issued one at a time between the MFMAs: back to back they keep the wave off the matrix pipe.
+    const int tgt = cur == 0 ? NBUF - 1 : cur - 1;
+    const unsigned dead = kc + DIST < nchunks ? 0u : OOB;
+    const uint4* As = lds + (size_t)cur * C::BUF_SLOTS;
+    // 9 tap stages, software pipelined: the fragments of tap t+1 are requested before the MFMAs of tap t issue
+    uint4 fa[2][C::WM], fb[2][C::WN];
+    auto ldfrag = [&](int tap, int set) {
+      const int r = tap / 3, s = tap % 3;
+#pragma unroll
+      for (int mi = 0; mi < C::WM; ++mi) fa[set][mi] = As[a_idx + (mi + r) * HWD + s];
+#pragma unroll
+      for (int ni = 0; ni < C::WN; ++ni) fb[set][ni] = As[b_idx + tap * KG * C::BN + ni * 32];
+    };
+    ldfrag(0, 0);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      if (tap + 1 < 9) ldfrag(tap + 1, (tap + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+      constexpr int PER = C::WM * C::WN;                       // MFMAs per tap
+      constexpr int GAP = (9 * PER) / C::NDMA;                 // one DMA issue every GAP MFMAs
+#pragma unroll
+      for (int mi = 0; mi < C::WM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < C::WN; ++ni) {
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fb[tap & 1][ni]),
+                                                                __builtin_bit_cast(bf16x8_t, fa[tap & 1][mi]), acc[mi][ni], 0, 0, 0);
+          const int m = tap * PER + mi * C::WN + ni;           // index of the MFMA just issued
+          if (m % GAP == GAP / 2 && m / GAP < C::NDMA) {
+            dma_one(m / GAP, kc + DIST, tgt, dead);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_s_waitcnt(WAITCNT);                       // chunk kc+1 has landed (this wave's part) ...
+    __syncthreads();                                           // ... everybody's part has, and everybody is done with `cur`
+    cur = cur == NBUF - 1 ? 0 : cur + 1;
+  }
+
+  // ---- epilogue: cout-major accumulators (weights are the first MFMA operand), 16-byte raw buffer stores, no branches ----
+  const size_t img_elems = (size_t)a.H * a.W * a.y_cs;
+  void* const anyp = const_cast<uint4*>(a.wpk);
+  const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(a.y != nullptr ? (void*)(a.y + n * img_elems) : anyp, 0,
+                                                                       a.y != nullptr ? (int)(img_elems * 4) : 0, 0x00020000);
+  const int msz = a.mask_bf16 ? 2 : 4;
+  const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc(
+      a.mask != nullptr ? (void*)(reinterpret_cast<char*>(const_cast<void*>(a.mask)) + n * img_elems * msz) : anyp, 0,
+      a.mask != nullptr ? (int)(img_elems * msz) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(a.bias != nullptr ? (void*)const_cast<float*>(a.bias) : anyp, 0,
+                                                                       a.bias != nullptr ? a.Cout * 4 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(a.ybf != nullptr ? (void*)(a.ybf + n * img_elems) : anyp, 0,
+                                                                       a.ybf != nullptr ? (int)(img_elems * 2) : 0, 0x00020000);
+#pragma unroll
+  for (int ni = 0; ni < C::WN; ++ni) {
+    const int cb = co0 + (wn * C::WN + ni) * 32 + 4 * lh;
+    f32x4 bv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bv[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brs, (cb + 8 * q) * 4, 0, 0));
+#pragma unroll
+    for (int mi = 0; mi < C::WM; ++mi) {
+      const int oy = y0 + wm * C::WM + mi, ox = x0 + li;
+      const unsigned pix = (oy < a.H && ox < a.W) ? (unsigned)((oy * a.W + ox) * a.y_cs) * 4u : OOB;
+      uint2 hb[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int co = cb + 8 * q;
+        const unsigned off = co < a.Cout ? pix + (unsigned)co * 4u : OOB;
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = acc[mi][ni][4 * q + e] + bv[q][e];
+          if (a.relu) v[e] = v[e] > 0.f ? v[e] : 0.f;
+        }
+        if (a.mask != nullptr) {
+          if (a.mask_bf16) {
+            typedef short s16x4 __attribute__((ext_vector_type(4)));
+            const s16x4 m = __builtin_bit_cast(s16x4, __builtin_amdgcn_raw_buffer_load_b64(mrs, off >> 1, 0, 0));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = m[e] > 0 ? v[e] : 0.f;
+          } else {
+            const f32x4 m = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(mrs, off, 0, 0));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = m[e] > 0.f ? v[e] : 0.f;
+          }
+        }
+        if (a.y != nullptr) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, off, 0, 0);
+        bf16x4_t h;
+        h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
+        hb[q] = __builtin_bit_cast(uint2, h);
+      }
+      if (a.ybf != nullptr) {
+#pragma unroll
+        for (int pq = 0; pq < 2; ++pq) {
+          const auto sx = __builtin_amdgcn_permlane32_swap(hb[2 * pq].x, hb[2 * pq + 1].x, false, false);
+          const auto sy = __builtin_amdgcn_permlane32_swap(hb[2 * pq].y, hb[2 * pq + 1].y, false, false);
+          const u32x4 o = {sx[0], sy[0], sx[1], sy[1]};
+          const int co = co0 + (wn * C::WN + ni) * 32 + 16 * pq + 8 * lh;
+          const unsigned off = co < a.Cout ? (pix >> 1) + (unsigned)co * 2u : OOB;
+          __builtin_amdgcn_raw_buffer_store_b128(o, hrs, off, 0, 0);
+        }
+      }
+    }
+  }
+}
+
+template <int NB, int WGM>
+int launch(const DmaArgs& a0, hipStream_t stream) {
+  using C = DmaCfg<NB, WGM>;
+  constexpr int TH = C::TH;
+  static bool attr_set = false;
+  if (!attr_set) {
+    OSVOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16_dma_kernel<NB, WGM>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)C::LDS_BYTES));
+    attr_set = true;
+  }
+  DmaArgs a = a0;
+  a.tiles_x = ceil_div(a.W, TW);
+  a.tiles_y = ceil_div(a.H, TH);
+  a.nct = ceil_div(a.CoutP, C::BN);
+  a.nsp = a.tiles_x * a.tiles_y * a.N;
+  const long blocks = a.map == 0 ? (long)a.nct * a.nsp : (long)a.nct * ((a.nsp + 7) / 8) * 8;
+  OSVOS_ARG_CHECK(blocks > 0 && blocks < (1L << 31), "conv3x3 bf16 dma: grid of %ld blocks", blocks);
+  hipLaunchKernelGGL((conv3x3_bf16_dma_kernel<NB, WGM>), dim3((unsigned)blocks), dim3(C::NT), C::LDS_BYTES, stream, a);
+  OSVOS_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace
+
+bool osvos_conv3x3_bf16_dma_applicable(int Cin, int Cout, int y_cs) { return Cin % 16 == 0 && Cout % 8 == 0 && y_cs % 8 == 0; }
+
+// variant 0: 256 px x 128 couts (4 waves), 1: 256 px x 64 couts (4 waves), 2: 512 px x 128 couts (8 waves), 3: 512 px x 64 couts (8 waves);
+// map = 1: XCD-local spatial block order
+int osvos_conv3x3_bf16_dma(const void* x, const void* wpk, const float* bias, const void* mask, int mask_bf16, float* y, void* ybf,
+                           int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int variant, int map, hipStream_t stream) {
+  OSVOS_ARG_CHECK(x && wpk && (y || ybf), "conv3x3 bf16 dma: null pointer");
+  OSVOS_ARG_CHECK(N > 0 && H > 0 && W > 0 && osvos_conv3x3_bf16_dma_applicable(Cin, Cout, y_cs) && y_cs >= Cout,
+                  "conv3x3 bf16 dma: needs Cin %% 16 == 0, Cout %% 8 == 0, y_cs %% 8 == 0 (got %d, %d, %d)", Cin, Cout, y_cs);
+  OSVOS_ARG_CHECK((long)H * W * Cin < (1L << 29) && (long)H * W * y_cs < (1L << 29), "conv3x3 bf16 dma: image too large for 31-bit byte offsets");
+  DmaArgs a;
+  a.x = reinterpret_cast<const bf16_t*>(x); a.wpk = reinterpret_cast<const uint4*>(wpk); a.bias = bias; a.mask = mask; a.mask_bf16 = mask_bf16 ? 1 : 0;
+  a.y = y; a.ybf = reinterpret_cast<bf16_t*>(ybf);
+  a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.CinP = (Cin + 31) / 32 * 32; a.Cout = Cout; a.CoutP = osvos_cout_pad(Cout); a.y_cs = y_cs;
+  a.relu = relu; a.map = map ? 1 : 0;
+  switch (variant) {
+    case 0: return launch<4, 2>(a, stream);
+    case 1: return launch<2, 2>(a, stream);
+    case 2: return launch<4, 4>(a, stream);
+    case 3: return launch<2, 4>(a, stream);
+    default: osvos_set_error("conv3x3 bf16 dma: unknown variant %d", variant); return -1;
+  }
+}

@@ -61,7 +61,32 @@ __global__ __launch_bounds__(256) void mfma_peak_kernel(float* out, int iters) {
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// LDS-DMA probe (buffer_load_dwordx4 ... lds): 4 waves; wave w issues two DMA instructions, lane l fetching the 16-byte group
+// src[perm] with perm = (l * 7 + 3 * w + i) % nsrc (out-of-range for l == 5: must land as zeros); the LDS image is copied out.
+__global__ __launch_bounds__(256) void lds_dma_probe_kernel(const float* __restrict__ src, int nsrc, float* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) float lds[8 * 64 * 4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, nsrc * 16, 0x00020000);
+  for (int i = threadIdx.x; i < 8 * 64 * 4; i += 256) lds[i] = -1.f;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const unsigned off = lane == 5 ? 0x80000000u : (unsigned)(((lane * 7 + 3 * w + i) % nsrc) * 16);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(lds + (2 * w + i) * 256), 16, off, 0, 0, 0);
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
+  __syncthreads();
+  for (int i = threadIdx.x; i < 8 * 64 * 4; i += 256) out[i] = lds[i];
+}
+
 }  // namespace
+
+extern "C" int osvos_debug_lds_dma(const float* src, int ngroups, float* out, void* stream) {
+  OSVOS_ARG_CHECK(src && out && ngroups > 0, "debug lds dma: bad arguments");
+  hipLaunchKernelGGL(lds_dma_probe_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, src, ngroups, out);
+  OSVOS_LAUNCH_CHECK();
+  return 0;
+}
 
 // runs `blocks` workgroups x 4 waves x iters x 4 MFMAs; FLOPs = blocks*4*iters*4*2*32*32*2
 extern "C" int osvos_debug_mfma_peak(float* out, int blocks, int iters, void* stream) {

@@ -281,12 +281,22 @@ def test_conv3x3_bf16io_bf16_input_and_copy(shape):
     xg = nhwc(x)
     tiles = ops.conv3x3_bf16io_tiles()
     assert 1 in tiles and 20 in tiles
-    for tile in tiles + [-1, 101, 120]:
-        y32, yb32 = ops.conv3x3_bf16io(xg, wpk, b.cuda(), cout, relu=True, mask=nhwc(m), tile=tile)
+    assert all(t in tiles for t in (30, 31, 32, 33))        # the LDS-DMA staged kernel
+    for tile in tiles + [-1, 101, 120, 130, 132]:
+        if tile % 100 in (30, 31, 32, 33) and (cin % 16 != 0 or cout % 8 != 0):
+            with pytest.raises(RuntimeError):
+                ops.conv3x3_bf16io(xg.bfloat16(), wpk, b.cuda(), cout, tile=tile)
+            continue
         y16, yb16 = ops.conv3x3_bf16io(xg.bfloat16(), wpk, b.cuda(), cout, relu=True, mask=nhwc(m), tile=tile)
         assert rel_err(nchw(y16), ref)[0] < 3e-5, (shape, tile)
+        assert torch.equal(yb16, y16.bfloat16()), (shape, tile)
+        if tile % 100 in (30, 31, 32, 33):  # DMA staging exists for bf16 activations only
+            with pytest.raises(RuntimeError):
+                ops.conv3x3_bf16io(xg, wpk, b.cuda(), cout, tile=tile)
+            continue
+        y32, yb32 = ops.conv3x3_bf16io(xg, wpk, b.cuda(), cout, relu=True, mask=nhwc(m), tile=tile)
         assert torch.equal(y16, y32), (shape, tile)                  # identical arithmetic, only the staging differs
-        assert torch.equal(yb16, y16.bfloat16()) and torch.equal(yb32, y32.bfloat16()), (shape, tile)
+        assert torch.equal(yb32, y32.bfloat16()), (shape, tile)
     with pytest.raises(RuntimeError):
         ops.conv3x3_bf16io(xg.bfloat16(), wpk, b.cuda(), cout, tile=0)      # not built for bf16 input
 
@@ -416,3 +426,21 @@ def test_wgrad_bf16act_equals_fp32_input_kernel_on_bf16_values(shape):
     wt = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
     F.conv2d(x.double(), wt, None, padding=1).backward(dy.double())
     assert rel_err(dw16.cpu(), wt.grad)[0] < 3e-5
+
+
+@pytest.mark.gpu
+def test_lds_dma_layout_probe():
+    """buffer_load_dwordx4 ... lds: lane l of a wave instruction lands in LDS slot (M0 base)/16 + l; lanes whose buffer offset
+    is out of range land as zeros -- the two facts the DMA-staged convolution kernel is built on"""
+    import ctypes as C
+    from osvos_pytorch_amd import _lib
+    n = 97
+    src = torch.arange(n * 4, dtype=torch.float32).cuda()
+    out = torch.empty(8 * 64 * 4, device="cuda")
+    _lib.check(_lib.lib().osvos_debug_lds_dma(C.c_void_p(src.data_ptr()), n, C.c_void_p(out.data_ptr()), None), "lds dma")
+    got = out.cpu().view(8, 64, 4)
+    for w in range(4):
+        for i in range(2):
+            for l in range(64):
+                exp = torch.zeros(4) if l == 5 else src.cpu().view(n, 4)[(l * 7 + 3 * w + i) % n]
+                assert torch.equal(got[2 * w + i, l], exp), (w, i, l, got[2 * w + i, l], exp)

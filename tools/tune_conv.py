@@ -79,7 +79,9 @@ for name, h, w, cin, cout in layers:
             yb = torch.empty(n, h, w, ycs, device="cuda", dtype=torch.bfloat16) if (kout % 8 == 0 and not args.noyb) else None
             vp = C.c_void_p
             def run(t):
-                _lib.check(_lib.lib().osvos_conv3x3_bf16io(vp((xb if args.xb == 1 else x).data_ptr()), int(args.xb == 1), vp(wpk.data_ptr()), None, None, 0, vp(yo.data_ptr()),
+                # --xb 1 = what the network does in the bf16 mode: bf16 in, bf16-only out (fp32 out only where no bf16 copy is possible)
+                _lib.check(_lib.lib().osvos_conv3x3_bf16io(vp((xb if args.xb == 1 else x).data_ptr()), int(args.xb == 1), vp(wpk.data_ptr()), None, None, 0,
+                                                          vp(yo.data_ptr()) if (yb is None or args.xb != 1) else None,
                                                           vp(yb.data_ptr()) if yb is not None else None, n, h, w, kin_s, kout, ycs,
                                                           int(direction == "fwd"), t, vp(torch.cuda.current_stream().cuda_stream)), "conv")
         else:
