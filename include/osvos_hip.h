@@ -177,6 +177,14 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
  * OSVOS_F32_BF16MFMA the trunk tensors 0..16 are bf16 unless OSVOS_BF16_STORE=0.) */
 int osvos_net_ws_query(int N, int H, int W, int dtype, int which, size_t* offset, size_t* elems, int* channels, int* h, int* w);
 
+/* ---- result writer / evaluator (train_online.py:181-189) -----------------------------------
+ * osvos_mask_to_bytes: per image p = sigmoid(logit), then scipy<=1.1 imsave's min-max byte scaling
+ *   uint8((p - min) * 255/(max - min) clipped + 0.5); scratch = 2 N unsigned.  The host side writes the PNG.
+ * osvos_mask_iou_counts: per image {|P & G|, |P | G|} with P = logit > logit_threshold, G = gt > 0.5 (DAVIS region measure J);
+ *   counts = 2 N unsigned long long. */
+int osvos_mask_to_bytes(const float* logits, unsigned char* out, void* scratch, long count, int N, void* stream);
+int osvos_mask_iou_counts(const float* logits, const float* gt, void* counts, long count, int N, float logit_threshold, void* stream);
+
 /* ---- fused SGD (torch.optim.SGD semantics, train_online.py:79-88,147) ----------------------
  * for each i: d = g + wd*p; buf = first ? d : momentum*buf + d; p -= lr*buf      (flat tensors) */
 int osvos_sgd_step(float* p, const float* g, float* buf, long count, float lr, float momentum,

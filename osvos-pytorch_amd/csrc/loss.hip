@@ -187,3 +187,98 @@ extern "C" int osvos_sgd_step(float* p, const float* g, float* buf, long count, 
   OSVOS_LAUNCH_CHECK();
   return 0;
 }
+
+// ---- result writer / evaluator (reference train_online.py:181-189: sigmoid -> scipy.misc.imsave, which min-max byte-scales;
+//      the DAVIS region measure J = |P & G| / |P | G|, which the reference leaves to an external toolkit) ----------------------
+namespace {
+
+__device__ inline float sigmoidf_acc(float x) { return 1.f / (1.f + expf(-x)); }
+
+// mm[2 n] / mm[2 n + 1]: bit patterns of min / max sigmoid of image n (positive floats order like unsigned integers)
+__global__ void mask_minmax_kernel(const float* __restrict__ logits, long count, unsigned* __restrict__ mm) {
+  const int n = blockIdx.y;
+  const float* x = logits + (size_t)n * count;
+  float lo = INFINITY, hi = -INFINITY;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
+    const float v = x[i];
+    lo = fminf(lo, v);
+    hi = fmaxf(hi, v);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    lo = fminf(lo, __shfl_xor(lo, o, 64));
+    hi = fmaxf(hi, __shfl_xor(hi, o, 64));
+  }
+  if ((threadIdx.x & 63) == 0 && lo <= hi) {     // sigmoid is monotone: min/max of the probabilities = sigmoid of min/max logit
+    atomicMin(&mm[2 * n], __float_as_uint(sigmoidf_acc(lo)));
+    atomicMax(&mm[2 * n + 1], __float_as_uint(sigmoidf_acc(hi)));
+  }
+}
+
+// scipy<=1.1 bytescale(data, cmin=min, cmax=max): (p - cmin) * (255 / (cmax - cmin)) clipped to [0, 255], + 0.5, truncated
+__global__ void mask_bytescale_kernel(const float* __restrict__ logits, long count, const unsigned* __restrict__ mm, unsigned char* __restrict__ out) {
+  const int n = blockIdx.y;
+  const float cmin = __uint_as_float(mm[2 * n]), cmax = __uint_as_float(mm[2 * n + 1]);
+  float cscale = cmax - cmin;
+  if (cscale == 0.f) cscale = 1.f;
+  const float scale = (float)(255.0 / (double)cscale);
+  const float* x = logits + (size_t)n * count;
+  unsigned char* o = out + (size_t)n * count;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
+    float b = (sigmoidf_acc(x[i]) - cmin) * scale;
+    b = fminf(fmaxf(b, 0.f), 255.f) + 0.5f;
+    o[i] = (unsigned char)b;
+  }
+}
+
+// counts[2 n] = |P & G|, counts[2 n + 1] = |P | G| with P = logit > thr, G = gt > 0.5
+__global__ void mask_iou_kernel(const float* __restrict__ logits, const float* __restrict__ gt, long count, float thr,
+                                unsigned long long* __restrict__ counts) {
+  const int n = blockIdx.y;
+  const float* x = logits + (size_t)n * count;
+  const float* g = gt + (size_t)n * count;
+  unsigned inter = 0, uni = 0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
+    const bool p = x[i] > thr, q = g[i] > 0.5f;
+    inter += (p && q) ? 1u : 0u;
+    uni += (p || q) ? 1u : 0u;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    inter += __shfl_xor(inter, o, 64);
+    uni += __shfl_xor(uni, o, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&counts[2 * n], (unsigned long long)inter);
+    atomicAdd(&counts[2 * n + 1], (unsigned long long)uni);
+  }
+}
+
+}  // namespace
+
+// logits fp32 [N][count] -> out uint8 [N][count]; scratch: 2 N unsigned (device)
+extern "C" int osvos_mask_to_bytes(const float* logits, unsigned char* out, void* scratch, long count, int N, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  OSVOS_ARG_CHECK(logits && out && scratch && count > 0 && N > 0, "mask_to_bytes: bad arguments");
+  unsigned* mm = reinterpret_cast<unsigned*>(scratch);
+  // min slots start at 0xffffffff, max slots at 0 : one memset pattern per half is not available, so two tiny fills
+  OSVOS_HIP_CHECK(hipMemsetAsync(mm, 0, sizeof(unsigned) * 2 * N, stream));
+  for (int n = 0; n < N; ++n) OSVOS_HIP_CHECK(hipMemsetAsync(mm + 2 * n, 0xff, sizeof(unsigned), stream));
+  const dim3 grid((unsigned)grid_for(count, 1024), (unsigned)N);
+  hipLaunchKernelGGL(mask_minmax_kernel, grid, dim3(256), 0, stream, logits, count, mm);
+  OSVOS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(mask_bytescale_kernel, grid, dim3(256), 0, stream, logits, count, mm, out);
+  OSVOS_LAUNCH_CHECK();
+  return 0;
+}
+
+// counts: 2 N unsigned long long (device), overwritten with {intersection, union} pixel counts per image
+extern "C" int osvos_mask_iou_counts(const float* logits, const float* gt, void* counts, long count, int N, float logit_threshold, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  OSVOS_ARG_CHECK(logits && gt && counts && count > 0 && N > 0, "mask_iou_counts: bad arguments");
+  OSVOS_HIP_CHECK(hipMemsetAsync(counts, 0, sizeof(unsigned long long) * 2 * N, stream));
+  hipLaunchKernelGGL(mask_iou_kernel, dim3((unsigned)grid_for(count, 1024), (unsigned)N), dim3(256), 0, stream, logits, gt, count, logit_threshold,
+                     reinterpret_cast<unsigned long long*>(counts));
+  OSVOS_LAUNCH_CHECK();
+  return 0;
+}

@@ -444,3 +444,49 @@ def test_lds_dma_layout_probe():
             for l in range(64):
                 exp = torch.zeros(4) if l == 5 else src.cpu().view(n, 4)[(l * 7 + 3 * w + i) % n]
                 assert torch.equal(got[2 * w + i, l], exp), (w, i, l, got[2 * w + i, l], exp)
+
+
+def _bytescale_scipy11(data):
+    """scipy 1.1 misc.bytescale(data, cmin=None, cmax=None, high=255, low=0) as toimage() calls it for mode 'L' (float32 input)"""
+    cmin, cmax = data.min(), data.max()
+    cscale = cmax - cmin
+    if cscale == 0:
+        cscale = 1
+    scale = np.float32(float(255 - 0) / float(cscale))
+    bytedata = (data - cmin) * scale + np.float32(0)
+    return (bytedata.clip(0, 255) + np.float32(0.5)).astype(np.uint8)
+
+
+@pytest.mark.gpu
+def test_result_writer_bytes_png_and_jaccard(tmp_path):
+    """train_online.py:181-187 restated: sigmoid -> scipy<=1.1 imsave.  Device bytes == numpy restatement except where float32
+    exp differs in the last bit right at a rounding boundary (<= 1 grey level, < 0.1 % of pixels); PNG decodes to the same bytes;
+    J counts are exact integers"""
+    from PIL import Image
+    from osvos_pytorch_amd import results
+    g = torch.Generator().manual_seed(61)
+    logits = (torch.randn(3, 1, 37, 53, generator=g) * 3 - 1)
+    logits[2] = 0.25                                            # constant frame: cscale == 0 branch
+    got = results.mask_bytes(logits.cuda()).cpu().numpy()
+    for n in range(3):
+        pred = np.squeeze(1 / (1 + np.exp(-logits[n].numpy().transpose(1, 2, 0))))       # the reference's float32 numpy sigmoid
+        exp = _bytescale_scipy11(pred)
+        d = np.abs(got[n].astype(np.int32) - exp.astype(np.int32))
+        assert d.max() <= 1 and (d != 0).mean() < 1e-3, (n, d.max(), (d != 0).mean())
+    p = str(tmp_path / "m.png")
+    results.write_png(p, got[0])
+    assert np.array_equal(np.array(Image.open(p)), got[0]) and Image.open(p).mode == "L"
+    results.save_masks(logits.cuda(), [str(tmp_path / ("f%d.png" % i)) for i in range(3)])
+    assert np.array_equal(np.array(Image.open(str(tmp_path / "f1.png"))), got[1])
+    gt = (torch.rand(3, 1, 37, 53, generator=g) > 0.6).float()
+    gt[2] = 0
+    js = results.jaccard(logits.cuda(), gt.cuda())
+    for n in range(3):
+        pm, gm = logits[n].numpy() > 0, gt[n].numpy() > 0.5
+        u = np.logical_or(pm, gm).sum()
+        assert js[n] == (1.0 if u == 0 else np.logical_and(pm, gm).sum() / u)
+    assert results.jaccard(torch.full((1, 1, 4, 4), -5.0).cuda(), torch.zeros(1, 1, 4, 4).cuda()) == [1.0]      # both empty
+    st = results.davis_statistics([0.9, 0.8, 0.7, 0.6, 0.5, 0.4, 0.3, 0.2])
+    assert abs(st["mean"] - 0.55) < 1e-12 and abs(st["recall"] - 0.5) < 1e-12 and abs(st["decay"] - 0.6) < 1e-12
+    with pytest.raises(RuntimeError):
+        results.mask_bytes(logits)

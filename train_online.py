@@ -21,7 +21,8 @@ import numpy as np
 import torch
 
 import networks.vgg_osvos as vo
-from layers.osvos_layers import sigmoid_np
+from layers.osvos_layers import sigmoid_np  # noqa: F401  (kept importable like the reference)
+from osvos_pytorch_amd.results import davis_statistics, jaccard, save_masks
 from mypath import Path
 from osvos_pytorch_amd.parallel import shard_indices
 from osvos_pytorch_amd.train_common import TrainLoop, init_distributed, make_sgd
@@ -48,14 +49,6 @@ def davis_loaders(db_root_dir, seq_name):
     db_train = db.DAVIS2016(train=True, db_root_dir=db_root_dir, transform=composed, seq_name=seq_name)
     db_test = db.DAVIS2016(train=False, db_root_dir=db_root_dir, transform=tr.ToTensor(), seq_name=seq_name)
     return DataLoader(db_train, batch_size=1, shuffle=True, num_workers=1), DataLoader(db_test, batch_size=1, shuffle=False, num_workers=1)
-
-
-def save_png(path, pred):
-    """scipy<=1.1 ``imsave`` semantics: min-max byte scaling (train_online.py:187)."""
-    from PIL import Image
-    lo, hi = float(pred.min()), float(pred.max())
-    scaled = np.zeros_like(pred) if hi <= lo else (pred - lo) / (hi - lo)
-    Image.fromarray((scaled * 255.0 + 0.5).astype(np.uint8)).save(path)
 
 
 def main():
@@ -114,14 +107,18 @@ def main():
         save_dir_res = os.path.join(save_dir, 'Results', seq_name)
         os.makedirs(save_dir_res, exist_ok=True)
         print('Testing Network')
+        js = []
         with torch.no_grad():
             for sample in testloader:
                 img, fname = sample['image'], sample['fname']
                 outputs = net.forward(img.to(device))
-                for jj in range(int(img.size()[0])):
-                    pred = np.transpose(outputs[-1].cpu().data.numpy()[jj, :, :, :], (1, 2, 0))
-                    pred = np.squeeze(sigmoid_np(pred))
-                    save_png(os.path.join(save_dir_res, os.path.basename(fname[jj]) + '.png'), pred)
+                # sigmoid + scipy<=1.1 imsave byte scaling on the device, PNG written by osvos_pytorch_amd.results (reference :181-187)
+                save_masks(outputs[-1], [os.path.join(save_dir_res, os.path.basename(fname[jj]) + '.png') for jj in range(int(img.size()[0]))])
+                if 'gt' in sample:
+                    js.extend(jaccard(outputs[-1], sample['gt'].to(device)))
+        if js:
+            st = davis_statistics(js)
+            print('J (region similarity) on %s: mean %.4f recall %.4f decay %.4f over %d frames' % (seq_name, st['mean'], st['recall'], st['decay'], len(js)))
 
 
 if __name__ == '__main__':
