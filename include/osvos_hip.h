@@ -177,6 +177,14 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
  * OSVOS_F32_BF16MFMA the trunk tensors 0..16 are bf16 unless OSVOS_BF16_STORE=0.) */
 int osvos_net_ws_query(int N, int H, int W, int dtype, int which, size_t* offset, size_t* elems, int* channels, int* h, int* w);
 
+/* ---- training-time input pipeline (dataloaders/davis_2016.py:99-106 + custom_transforms.py: flip, ScaleNRotate, ToTensor) ------
+ * One frame: uint8 BGR [H][W][3] (+ uint8 label [H][W] or NULL) -> float32 image [3][H][W] = (flipped, warped) frame minus mean3,
+ * float32 gt [1][H][W] = label / max(label.max(), 1e-8) (nearest warp for 0/1 masks, bicubic for soft ones, decided on the device).
+ * Minv: HOST pointer to the dst->src affine cv::warpAffine derives from getRotationMatrix2D (6 doubles), NULL = no warp.
+ * scratch: 2 unsigned on the device.  OpenCV's fixed-point coordinate / 5-bit cubic table algorithm, border value 0. */
+int osvos_augment_frame(const unsigned char* img_bgr, const unsigned char* label, const float* mean3, int flip, const double* Minv,
+                        float* out_img, float* out_gt, void* scratch, int H, int W, void* stream);
+
 /* ---- result writer / evaluator (train_online.py:181-189) -----------------------------------
  * osvos_mask_to_bytes: per image p = sigmoid(logit), then scipy<=1.1 imsave's min-max byte scaling
  *   uint8((p - min) * 255/(max - min) clipped + 0.5); scratch = 2 N unsigned.  The host side writes the PNG.

@@ -58,6 +58,7 @@ PROTOTYPES = {
     "osvos_net_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "osvos_net_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "osvos_net_ws_query": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "osvos_augment_frame": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "osvos_mask_to_bytes": (_i, [_vp, _vp, _vp, _l, _i, _vp]),
     "osvos_mask_iou_counts": (_i, [_vp, _vp, _vp, _l, _i, _f, _vp]),
     "osvos_sgd_step": (_i, [_vp, _vp, _vp, _l, _f, _f, _f, _i, _vp]),

@@ -1,0 +1,78 @@
+"""Input pipeline: numpy restatement of the reference transforms (oracle/augment_ref.py) and the device kernel."""
+import os
+import random
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import augment_ref as A
+
+
+def _frame(h, w, seed, soft=False):
+    rng = np.random.default_rng(seed)
+    img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    if soft:
+        lab = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    else:
+        yy, xx = np.mgrid[0:h, 0:w]
+        lab = ((((yy - h / 2) / (h / 3)) ** 2 + ((xx - w / 2) / (w / 4)) ** 2) < 1).astype(np.uint8) * 255
+    return img, lab
+
+
+def test_oracle_invariants_identity_flip_and_integer_shift():
+    """what can be pinned without OpenCV: rot 0 / scale 1 is the identity bit for bit (cubic taps collapse to 0,1,0,0), the flip
+    commutes with it, an integer translation moves pixels exactly and fills the border with 0"""
+    img, lab = _frame(11, 15, 1)
+    i0, g0 = A.augment(img, lab, False, None, None)
+    i1, g1 = A.augment(img, lab, False, 0.0, 1.0)
+    assert np.array_equal(i0, i1) and np.array_equal(g0, g1)
+    assert i0.dtype == np.float32 and i0.shape == (3, 11, 15) and g0.shape == (1, 11, 15)
+    assert np.allclose(i0[:, 2, 3], img[2, 3].astype(np.float32) - np.array(A.MEANVAL, dtype=np.float32))
+    assert set(np.unique(g0)) <= {0.0, 1.0}
+    f0, _ = A.augment(img, lab, True, None, None)
+    assert np.array_equal(f0, i0[:, :, ::-1])
+    src = i0.transpose(1, 2, 0).copy()
+    M = np.array([[1.0, 0.0, 2.0], [0.0, 1.0, -1.0]])
+    sh = A.warp_affine(src, M, cubic=True)
+    exp = np.zeros_like(src)
+    exp[:-1, 2:] = src[1:, :-2]
+    assert np.array_equal(sh, exp)
+    assert np.array_equal(A.warp_affine(src[:, :, 0], M, cubic=False), exp[:, :, 0])
+    c = A._cubic_coeffs(16)
+    assert abs(float(c.sum()) - 1.0) < 1e-6 and abs(float(c[0]) + 0.09375) < 1e-6          # A = -0.75 half-sample taps
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(13, 17, False, None, None, False), (13, 17, True, None, None, False), (24, 31, False, 0.0, 1.0, False),
+                                  (24, 31, True, 17.0, 1.1, False), (33, 40, False, -29.5, 0.77, False), (20, 27, True, 8.25, 1.24, True),
+                                  (9, 6, False, 45.0, 0.8, False)])
+def test_device_pipeline_matches_the_restatement_bit_for_bit(case):
+    from osvos_pytorch_amd.augment import augment_frame
+    h, w, flip, rot, sc, soft = case
+    img, lab = _frame(h, w, 7 + h, soft)
+    ei, eg = A.augment(img, lab, flip, rot, sc)
+    gi, gg = augment_frame(torch.from_numpy(img).cuda(), torch.from_numpy(lab).cuda(), flip, rot, sc)
+    assert np.array_equal(gi.cpu().numpy(), ei), (case, np.abs(gi.cpu().numpy() - ei).max())
+    assert np.array_equal(gg.cpu().numpy(), eg), case
+    gi2, gg2 = augment_frame(torch.from_numpy(img).cuda(), None, flip, rot, sc)
+    assert np.array_equal(gi2.cpu().numpy(), ei) and float(gg2.abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+def test_device_augment_draws_like_the_reference_chain():
+    from osvos_pytorch_amd.augment import DeviceAugment
+    img, lab = _frame(26, 38, 3)
+    random.seed(1234)
+    out = DeviceAugment()(torch.from_numpy(img).cuda(), torch.from_numpy(lab).cuda())
+    random.seed(1234)                      # RandomHorizontalFlip, then ScaleNRotate's two draws (custom_transforms.py:92,25-29)
+    flip = random.random() < 0.5
+    rot = 60 * random.random() - 30
+    sc = 0.5 * random.random() - 0.25 + 1
+    ei, eg = A.augment(img, lab, flip, rot, sc)
+    assert np.array_equal(out['image'].cpu().numpy(), ei) and np.array_equal(out['gt'].cpu().numpy(), eg)
+    assert out['image'].dtype == torch.float32 and tuple(out['gt'].shape) == (1, 26, 38)
+    with pytest.raises(RuntimeError):
+        DeviceAugment()(torch.from_numpy(img), torch.from_numpy(lab))
