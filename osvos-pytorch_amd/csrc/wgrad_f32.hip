@@ -61,36 +61,50 @@ __global__ __launch_bounds__(256, OCC) void wgrad_f32_kernel(WgArgs a) {
   const int p_begin = split * a.per_split;
   const int p_end = min(p_begin + a.per_split, a.npatches);
 
-  f32x4 rdy[NDY], rx[NX];
+  // Staging through raw buffer loads (as in conv3x3_f32.hip): per lane the byte offset of every item RELATIVE to the patch origin
+  // is computed once; per patch only the scalar origin offset, an x-range compare and a select are left.  Rows above / below the
+  // image fall out of the per-image buffer range by themselves (offset < 0 wraps, offset >= H*W*C*4), columns need the compare.
+  constexpr unsigned OOB = 0x80000000u;
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  unsigned dy_rel[NDY], x_rel[NX];
+  int dy_dx[NDY], x_dx[NX];                                   // column of the item inside the patch / halo (-1: no such item)
+#pragma unroll
+  for (int i = 0; i < NDY; ++i) {
+    const int e = tid + i * 256;
+    const int pix = e / (BCO / 4), q = e % (BCO / 4);
+    const bool ok = e < DY_F4 && co0 + 4 * q < a.Cout;
+    dy_rel[i] = (unsigned)((((pix / PW) * a.W + pix % PW) * a.Cout_s + co0 + 4 * q) * 4);
+    dy_dx[i] = ok ? pix % PW : -1;
+  }
+#pragma unroll
+  for (int i = 0; i < NX; ++i) {
+    const int e = tid + i * 256;
+    const int pix = e / (BCI / 4), q = e % (BCI / 4);
+    const bool ok = e < X_F4 && ci0 + 4 * q < a.Cin_s;
+    x_rel[i] = (unsigned)((((pix / XW) * a.W + pix % XW) * a.Cin_s + ci0 + 4 * q) * 4);
+    x_dx[i] = ok ? pix % XW : -1;
+  }
+  const int img_dy_bytes = a.H * a.W * a.Cout_s * 4, img_x_bytes = a.H * a.W * a.Cin_s * 4;
+  u32x4 rdy[NDY], rx[NX];
   auto load_patch = [&](int p) {
     const int px = p % a.npx;
     int t = p / a.npx;
     const int py = t % a.npy;
     const int n = t / a.npy;
     const int x0 = px * PW, y0 = py * PH;
+    const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy) + (size_t)n * a.H * a.W * a.Cout_s, 0, img_dy_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x) + (size_t)n * a.H * a.W * a.Cin_s, 0, img_x_bytes, 0x00020000);
+    const unsigned dy_base = (unsigned)((y0 * a.W + x0) * a.Cout_s * 4);
+    const unsigned x_base = (unsigned)(((y0 - 1) * a.W + (x0 - 1)) * a.Cin_s * 4);     // may be "negative": wraps out of range
 #pragma unroll
     for (int i = 0; i < NDY; ++i) {
-      const int e = tid + i * 256;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (e < DY_F4) {
-        const int pix = e / (BCO / 4), q = e % (BCO / 4);
-        const int gy = y0 + pix / PW, gx = x0 + pix % PW, co = co0 + 4 * q;
-        if (gy < a.H && gx < a.W && co < a.Cout)
-          v = *reinterpret_cast<const f32x4*>(a.dy + ((size_t)(n * a.H + gy) * a.W + gx) * a.Cout_s + co);
-      }
-      rdy[i] = v;
+      const unsigned off = (dy_dx[i] >= 0 && x0 + dy_dx[i] < a.W) ? dy_rel[i] + dy_base : OOB;
+      rdy[i] = __builtin_amdgcn_raw_buffer_load_b128(drs, off, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
-      const int e = tid + i * 256;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (e < X_F4) {
-        const int pix = e / (BCI / 4), q = e % (BCI / 4);
-        const int gy = y0 + pix / XW - 1, gx = x0 + pix % XW - 1, ci = ci0 + 4 * q;
-        if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && ci < a.Cin_s)
-          v = *reinterpret_cast<const f32x4*>(a.x + ((size_t)(n * a.H + gy) * a.W + gx) * a.Cin_s + ci);
-      }
-      rx[i] = v;
+      const unsigned off = (x_dx[i] >= 0 && (unsigned)(x0 - 1 + x_dx[i]) < (unsigned)a.W) ? x_rel[i] + x_base : OOB;
+      rx[i] = __builtin_amdgcn_raw_buffer_load_b128(xrs, off, 0, 0);
     }
   };
   auto store_patch = [&](int buf) {
@@ -98,12 +112,12 @@ __global__ __launch_bounds__(256, OCC) void wgrad_f32_kernel(WgArgs a) {
 #pragma unroll
     for (int i = 0; i < NDY; ++i) {
       const int e = tid + i * 256;
-      if (e < DY_F4) d[e] = rdy[i];
+      if (e < DY_F4) d[e] = __builtin_bit_cast(f32x4, rdy[i]);
     }
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
       const int e = tid + i * 256;
-      if (e < X_F4) d[DY_F4 + e] = rx[i];
+      if (e < X_F4) d[DY_F4 + e] = __builtin_bit_cast(f32x4, rx[i]);
     }
   };
 
@@ -373,6 +387,7 @@ int osvos_conv3x3_wgrad_f32(const float* x, const float* dy, void* ws, float* dw
                             int accumulate, hipStream_t stream) {
   OSVOS_ARG_CHECK(x && dy && ws && dw, "wgrad: null pointer");
   OSVOS_ARG_CHECK(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "wgrad: bad shape");
+  OSVOS_ARG_CHECK((long)H * W * Cin_s < (1L << 29) && (long)H * W * Cout_s < (1L << 29), "wgrad: image too large for 31-bit byte offsets");
   OSVOS_ARG_CHECK(Cin_s % 4 == 0 && Cout_s % 4 == 0 && Cout % 4 == 0 && Cin <= Cin_s && Cout <= Cout_s,
                   "wgrad f32: channel strides must be multiples of 4 (Cin %d/%d Cout %d/%d)", Cin, Cin_s, Cout, Cout_s);
   {
