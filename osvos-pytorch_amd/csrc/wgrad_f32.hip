@@ -288,10 +288,24 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
       }
     }
   }
-  if (db != nullptr && blockIdx.x == 0) {
-    for (int co = threadIdx.x; co < Cout; co += 256) {
-      float b = 0.f;
-      for (int sp = 0; sp < nsplit; ++sp) b += bslab[(size_t)sp * Cout + co];
+  // bias gradient: the workgroups past the weight columns take 32 couts x 8 split lanes each (the first version let ONE
+  // workgroup walk all splits serially: 256 dependent-latency loads that set the kernel's duration on the small layers)
+  const int nblk_dw = (total / 4 + 31) / 32;
+  if (db != nullptr && (int)blockIdx.x >= nblk_dw) {
+    const int co = ((int)blockIdx.x - nblk_dw) * 32 + e;
+    float b = 0.f;
+    if (co < Cout) {
+      int sp = sl;
+      for (; sp + 24 < nsplit; sp += 32)
+        b += (bslab[(size_t)sp * Cout + co] + bslab[(size_t)(sp + 8) * Cout + co]) + (bslab[(size_t)(sp + 16) * Cout + co] + bslab[(size_t)(sp + 24) * Cout + co]);
+      for (; sp < nsplit; sp += 8) b += bslab[(size_t)sp * Cout + co];
+    }
+    __syncthreads();                       // (red[] above is only written by weight-column workgroups; this one reuses it)
+    red[threadIdx.x][0] = b;
+    __syncthreads();
+    if (sl == 0 && co < Cout) {
+#pragma unroll
+      for (int k = 1; k < 8; ++k) b += red[k * 32 + e][0];
       db[co] = accumulate ? (db[co] + b) : b;
     }
   }
@@ -317,7 +331,7 @@ WgPlan make_plan(int N, int H, int W, int Cin_s, int Cout) {
   int want = ceil_div(target_blocks, p.nco_t * p.nci_t);
   int max_split = p.npatches / 4 > 0 ? p.npatches / 4 : 1;
   p.nsplit = want < max_split ? want : max_split;
-  if (p.nsplit > 256) p.nsplit = 256;
+  if (p.nsplit > 256) p.nsplit = 256;       // (512 splits for the one-tile conv1_2: partial kernel -23 us, slab reduce +37 us)
   if (p.nsplit < 1) p.nsplit = 1;
   p.per_split = ceil_div(p.npatches, p.nsplit);
   p.nsplit = ceil_div(p.npatches, p.per_split);
@@ -369,7 +383,7 @@ int osvos_conv3x3_wgrad_small_f32(const void* x, const void* dy, int wide_bf16, 
 int osvos_wgrad_reduce_launch(const float* slab, const float* bslab, float* dw, float* db, int nsplit, int Cout, int Cin,
                               int Cin_s, int accumulate, hipStream_t stream) {
   const int total = Cout * Cin_s * 9;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(total, 128)), dim3(256), 0, stream,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(total, 128) + (db ? ceil_div(Cout, 32) : 0)), dim3(256), 0, stream,
                      slab, bslab, dw, db, nsplit, Cout, Cin, Cin_s, accumulate, 0);
   OSVOS_LAUNCH_CHECK();
   return 0;
@@ -414,7 +428,7 @@ int osvos_conv3x3_wgrad_f32(const float* x, const float* dy, void* ws, float* dw
   }
   if (phase == 1) return 0;
   const int total = Cout * Cin_s * 9;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(total, 128)), dim3(256), 0, stream,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(total, 128) + (db ? ceil_div(Cout, 32) : 0)), dim3(256), 0, stream,
                      a.slab, a.bslab, dw, db, p.nsplit, Cout, Cin, Cin_s, accumulate, a.oihw);
   OSVOS_LAUNCH_CHECK();
   return 0;
