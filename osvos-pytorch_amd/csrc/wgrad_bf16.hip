@@ -20,7 +20,7 @@ namespace {
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 
-constexpr int PW = 32, PH = 4, PPIX = PW * PH;
+constexpr int PW = 32, PH = 8, PPIX = PW * PH;      // 256-pixel patches: one staging round + two barriers per 144 MFMAs of every wave
 constexpr int BCO = 64, BCI = 64;
 constexpr int XROWS = PH + 2, XPITCH = 40;                 // halo rows; 40 px (80 B) per row: 5 groups of 8
 constexpr int DY_CSTRIDE = PH * PW * 2 + 16;               // bytes per cout row (+16 B pad -> conflict-free b128 columns)
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WbArgs a) {
 #pragma unroll
     for (int u = 0; u < NX; ++u) {
       const int grp = sg + 16 * u;                         // 0..29 used: halo row = grp / 5, x group = grp % 5
-      const int it = grp < 30 ? 0 : X_ITEMS;               // groups 30, 31 do not exist
+      const int it = grp < XROWS * 5 ? 0 : X_ITEMS;        // halo rows x 5 groups of 8 pixels exist
       const int hy = grp / 5, hg = grp % 5;
       const int gy = y0 + hy - 1, gx0 = x0 + hg * 8 - 1, ci = ci0 + 4 * xq;
       const bool ok = it < X_ITEMS && gy >= 0 && gy < a.H && ci < a.Cin_s;
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WbArgs a) {
 #pragma unroll
     for (int u = 0; u < NX; ++u) {
       const int grp = sg + 16 * u;
-      if (grp < 30) {
+      if (grp < XROWS * 5) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           uint4 v;
