@@ -379,3 +379,28 @@ def test_bf16_store_mode_within_the_bf16_bars(tmp_path):
     rel = float(np.linalg.norm(b["dx"] - a["dx"]) / np.linalg.norm(a["dx"]))
     print("input gradient, store vs default bf16 mode: rel-L2 %.2e" % rel)
     assert np.isfinite(b["dx"]).all() and rel <= 0.5
+
+
+@pytest.mark.parametrize("shape", [(2, 37, 53), (1, 30, 85), (1, 9, 7), (1, 16, 16)])
+def test_bf16_store_mode_odd_sizes_stay_close_to_fp32(shape):
+    """ceil-mode pooling / partial windows / 1x1 frames through the bf16 kernels (bf16 pooling, bf16 masks, bf16-input weight
+    gradients): logits within 0.25 std of the fp32 mode (tiny frames are noisy), every gradient finite and within 0.5 rel-L2 of the fp32 mode"""
+    from layers.osvos_layers import class_balanced_cross_entropy_loss as cbce
+    from oracle import synth
+    n, h, w = shape
+    wts, x, m = synth.calibrated_problem(n, h, w, seed=33)
+    res = {}
+    for prec in ("fp32", "bf16"):
+        net = build_net(wts).set_precision(prec)
+        outs = net.forward(torch.from_numpy(x).cuda())
+        gt = torch.from_numpy(m).cuda()
+        (0.5 * sum(cbce(o, gt, size_average=False) for o in outs[:-1]) + cbce(outs[-1], gt, size_average=False)).backward()
+        res[prec] = ([o.detach().cpu() for o in outs], {k: v.grad.cpu() for k, v in net.named_parameters() if v.grad is not None})
+    for a, b in zip(*[res[p][0] for p in ("fp32", "bf16")]):
+        tol = max(0.25 * max(float(a.std()) if a.numel() > 1 else 0.0, 3.0), 0.05 * float(a.abs().max()))      # (the 1x1 problem calibrates to huge logits)
+        assert torch.isfinite(b).all() and float((a - b).abs().max()) <= tol
+    for k, ga in res["fp32"][1].items():
+        gb = res["bf16"][1][k]
+        assert torch.isfinite(gb).all(), k
+        if float(ga.norm()) > 0:
+            assert float((ga - gb).norm() / ga.norm()) <= 0.5, (k, float((ga - gb).norm() / ga.norm()))
