@@ -98,7 +98,7 @@ int osvos_conv3x3_wgrad(const void* x, const void* dy, void* ws, float* dw, floa
   NEED_F32(dtype, "conv3x3_wgrad");
   // the wide trunk layers go through the bf16 MFMA kernel; conv1_1 (Cin 3) and side_prep (Cout 16) keep
   // their exact-fp32 skinny kernels (5 % of the weight-gradient FLOPs)
-  if (dtype == OSVOS_F32_BF16MFMA && Cin == Cin_s && osvos_wgrad_bf16_applicable(Cin_s, Cout))
+  if (dtype == OSVOS_F32_BF16MFMA && Cin == Cin_s && Cout % 64 == 0 && osvos_wgrad_bf16_applicable(Cin_s, Cout))
     return osvos_conv3x3_wgrad_bf16mfma((const float*)x, (const float*)dy, ws, dw, db, N, H, W, Cin, Cin_s, Cout, Cout_s,
                                         accumulate, (hipStream_t)stream);
   return osvos_conv3x3_wgrad_f32((const float*)x, (const float*)dy, ws, dw, db, N, H, W, Cin, Cin_s, Cout, Cout_s,
@@ -132,7 +132,7 @@ int osvos_head_bwd(const void* prep, const float* dside, const float* dfused,
                    void* dprep, double* acc, int N, int H, int W, int h, int w, int scale_idx,
                    int dtype, void* stream) {
   NEED_F32(dtype, "head_bwd");
-  return osvos_head_bwd_f32((const float*)prep, dside, dfused, f1, f16, wd, wf, (float*)dprep, acc, N, H, W, h, w,
+  return osvos_head_bwd_f32((const float*)prep, dside, dfused, f1, f16, wd, wf, (float*)dprep, nullptr, acc, N, H, W, h, w,
                             scale_idx, (hipStream_t)stream);
 }
 

@@ -96,6 +96,7 @@ struct HbArgs {
   const float* wd;
   const float* wf;
   f32x4* dprep;
+  uint2* dprep_b;   // optional bf16 copy of dprep (operand of the bf16 side_prep weight gradient)
   double* acc;   // per-workgroup partials [gridDim.x][34]: [0..15] dwf, [16..31] dwd, [32] dbd, [33] spare
   int N, H, W, h, w, s;
 };
@@ -154,6 +155,12 @@ __global__ __launch_bounds__(256) void head_bwd_f32_kernel(HbArgs a) {
           pwd[c] += p[e] * ds;
         }
         a.dprep[pix * 4 + q] = o;
+        if (a.dprep_b != nullptr) {
+          typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+          bf16x4_t hb;
+          hb[0] = (__bf16)o[0]; hb[1] = (__bf16)o[1]; hb[2] = (__bf16)o[2]; hb[3] = (__bf16)o[3];
+          a.dprep_b[pix * 4 + q] = __builtin_bit_cast(uint2, hb);
+        }
       }
       pbd += ds;
     }
@@ -252,7 +259,7 @@ int osvos_head_bwd_blocks(int N, int h, int w, int scale_idx) {
 }
 
 int osvos_head_bwd_f32(const float* prep, const float* dside, const float* dfused, const float* f1, const float* f16,
-                       const float* wd, const float* wf, float* dprep, double* acc, int N, int H, int W, int h, int w,
+                       const float* wd, const float* wf, float* dprep, void* dprep_bf16, double* acc, int N, int H, int W, int h, int w,
                        int scale_idx, hipStream_t stream) {
   OSVOS_ARG_CHECK(prep && f1 && f16 && wd && wf && dprep && acc, "head_bwd: null pointer");
   OSVOS_ARG_CHECK(scale_idx >= 0 && scale_idx < 4 && N > 0 && H > 0 && W > 0 && h > 0 && w > 0, "head_bwd: bad shape");
@@ -260,6 +267,7 @@ int osvos_head_bwd_f32(const float* prep, const float* dside, const float* dfuse
   a.prep = reinterpret_cast<const f32x4*>(prep);
   a.dside = dside; a.dfused = dfused; a.f1 = f1; a.f16 = f16; a.wd = wd; a.wf = wf;
   a.dprep = reinterpret_cast<f32x4*>(dprep);
+  a.dprep_b = reinterpret_cast<uint2*>(dprep_bf16);
   a.acc = acc;
   a.N = N; a.H = H; a.W = W; a.h = h; a.w = w; a.s = 2 << scale_idx;
   const int g = osvos_head_bwd_blocks(N, h, w, scale_idx);

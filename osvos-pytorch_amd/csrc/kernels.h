@@ -24,7 +24,7 @@ int osvos_maxpool2x2_bwd_bf16(const void* x, const void* dy, const void* dside, 
 int osvos_head_lowres_f32(const float* prep, const float* wd, const float* bd, const float* wf,
                           float* score, float* fpart, int N, int h, int w, hipStream_t stream);
 int osvos_head_bwd_f32(const float* prep, const float* dside, const float* dfused, const float* f1, const float* f16,
-                       const float* wd, const float* wf, float* dprep, double* acc, int N, int H, int W, int h, int w,
+                       const float* wd, const float* wf, float* dprep, void* dprep_bf16, double* acc, int N, int H, int W, int h, int w,
                        int scale_idx, hipStream_t stream);
 int osvos_head_bwd_blocks(int N, int h, int w, int scale_idx);   // workgroups (= partial rows of 34 doubles) head_bwd launches
 int osvos_sum_partials(const float* x, long count, double* part, int* nblocks, hipStream_t stream);

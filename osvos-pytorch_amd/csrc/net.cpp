@@ -86,7 +86,7 @@ struct WsLayout {
   size_t dy[kNumTrunk], dpool[5], dside[4], dprep[4], wgrad[kNumConv], acc, dxin;
   // bf16 copies of the conv operands (dtype OSVOS_F32_BF16MFMA only): written by the producer's epilogue, read by the
   // consuming convolution instead of the fp32 tensor (half the bytes, no conversion while staging)
-  size_t xin_b, act_b[kNumTrunk], pooled_b[5], dy_b[kNumTrunk], dpool_b[5], dside_b[4];
+  size_t xin_b, act_b[kNumTrunk], pooled_b[5], dy_b[kNumTrunk], dpool_b[5], dside_b[4], dprep_b[4];
   size_t fwd_total, total;
 };
 
@@ -134,6 +134,7 @@ WsLayout ws_layout(int N, int H, int W, int dtype) {
   for (int i = 0; i < 4; ++i) {
     const size_t npix = (size_t)N * L.hs[i + 1] * L.ws[i + 1];
     L.dprep[i] = take(es * npix * 16);
+    L.dprep_b[i] = store ? take((size_t)2 * npix * 16) : 0;
     L.dside[i] = take(te * npix * kStageC[i + 1]);
     L.dside_b[i] = store ? L.dside[i] : 0;
   }
@@ -430,10 +431,11 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
   // ---- head: upstream full-resolution gradients -> dprep[i] (+ score_dsn / fuse gradients) ----
   for (int i = 0; i < 4; ++i) {
     const int si = i + 1;
-    rc = osvos_head_bwd(at(ws, L.prep[i]), douts[i], dfused, reinterpret_cast<const float*>(at(wbuf, P.f1[i])),
+    rc = osvos_head_bwd_f32(reinterpret_cast<const float*>(at(ws, L.prep[i])), douts[i], dfused, reinterpret_cast<const float*>(at(wbuf, P.f1[i])),
                         reinterpret_cast<const float*>(at(wbuf, P.f16[i])), reinterpret_cast<const float*>(at(wbuf, P.wd[i])),
-                        reinterpret_cast<const float*>(at(wbuf, P.wf)) + 16 * i, at(ws, L.dprep[i]), acc + (size_t)i * OSVOS_HEAD_MAX_BLOCKS * 34,
-                        N, H, W, L.hs[si], L.ws[si], i, dtype, stream);
+                        reinterpret_cast<const float*>(at(wbuf, P.wf)) + 16 * i, reinterpret_cast<float*>(at(ws, L.dprep[i])),
+                        store ? at(ws, L.dprep_b[i]) : nullptr, acc + (size_t)i * OSVOS_HEAD_MAX_BLOCKS * 34,
+                        N, H, W, L.hs[si], L.ws[si], i, stream);
     if (rc) return rc;
     part[i] = acc + (size_t)i * OSVOS_HEAD_MAX_BLOCKS * 34;
     nblk[i] = osvos_head_bwd_blocks(N, L.hs[si], L.ws[si], i);
@@ -465,7 +467,7 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
     const int si = i + 1, sl = kNumTrunk + i, h = L.hs[si], w = L.ws[si];
     const int lx = last_of_stage(si);
     if (grads[d[sl].w_param] != nullptr) {
-      rc = wgrad(at(ws, L.act[lx]), at(ws, L.dprep[i]), sl, h, w);
+      rc = wgrad(at(ws, L.act[lx]), store ? at(ws, L.dprep_b[i]) : at(ws, L.dprep[i]), sl, h, w);      // (store mode: bf16 x and bf16 dprep)
       if (rc) return rc;
     }
   }
