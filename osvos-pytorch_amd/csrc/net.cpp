@@ -478,7 +478,7 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
     // upstream gradient of conv5_3; stages 1-3 are merged in maxpool2x2_bwd below
     void* dst = (i == 3) ? f32(L.dy[lx]) : f32(L.dside[i]);
     void* dst_b = (i == 3) ? sh(L.dy_b[lx]) : (store ? at(ws, L.dside_b[i]) : nullptr);
-    rc = conv_main(at(ws, L.dprep[i]), nullptr, at(wbuf, P.dgrad[sl]), nullptr, (i == 3) ? mk32(L.act[lx]) : nullptr,
+    rc = conv_main(at(ws, L.dprep[i]), store ? at(ws, L.dprep_b[i]) : nullptr, at(wbuf, P.dgrad[sl]), nullptr, (i == 3) ? mk32(L.act[lx]) : nullptr,
                    (i == 3) ? mk16(L.act_b[lx]) : nullptr, dst, dst_b, N, h, w, 16, d[sl].cin, d[sl].cin, 0, dtype, nullptr, stream);
     if (rc) return rc;
   }
