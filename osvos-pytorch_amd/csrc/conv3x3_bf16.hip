@@ -470,12 +470,14 @@ using B24 = CfgB<32, 1, 16, 4, 4, 2, 0, 0, 2, 0, 2>;  // 512 px x 128 co, 8 wave
 using B25 = CfgB<32, 1, 16, 4, 4, 2, 0, 0, 2, 1, 2>;  // + loads interleaved with the MFMAs
 using B26 = CfgB<32, 1, 16, 4, 4, 2, 0, 1, 2, 1, 2>;  // + row re-use
 using B27 = CfgB<32, 1, 16, 4, 4, 2, 1, 0, 2, 1, 2>;  // + fragment double buffering
-constexpr int kNumTilesB = 28;
+using B28 = CfgB<16, 1, 8, 4, 2, 2, 0, 0, 2, 0, 2>;  // B20 as a 16 x 16 pixel tile: 107- and 54-pixel wide maps lose 5 % to padding instead of 20 %
+using B29 = CfgB<16, 1, 8, 2, 2, 2, 1, 0, 1, 0, 4>;  // B1 as a 16 x 16 pixel tile
+constexpr int kNumTilesB = 30;
 template <class C>
 constexpr TileInfoB infoB() { return TileInfoB{C::TW, C::TH, C::BN, C::WM, C::WN, C::LDS_BYTES}; }
 const TileInfoB kTilesB[kNumTilesB] = {infoB<B0>(), infoB<B1>(), infoB<B2>(), infoB<B3>(), infoB<B4>(), infoB<B5>(), infoB<B6>(), infoB<B7>(),
                                        infoB<B8>(), infoB<B9>(),
-                                       infoB<B10>(), infoB<B11>(), infoB<B12>(), infoB<B13>(), infoB<B14>(), infoB<B15>(), infoB<B16>(), infoB<B17>(), infoB<B18>(), infoB<B19>(), infoB<B20>(), infoB<B21>(), infoB<B22>(), infoB<B23>(), infoB<B24>(), infoB<B25>(), infoB<B26>(), infoB<B27>()};
+                                       infoB<B10>(), infoB<B11>(), infoB<B12>(), infoB<B13>(), infoB<B14>(), infoB<B15>(), infoB<B16>(), infoB<B17>(), infoB<B18>(), infoB<B19>(), infoB<B20>(), infoB<B21>(), infoB<B22>(), infoB<B23>(), infoB<B24>(), infoB<B25>(), infoB<B26>(), infoB<B27>(), infoB<B28>(), infoB<B29>()};
 
 // Measured (profiles/r01_tune_bf16_*.txt): with >= 128 couts the 256 px x 128 co tile on 16-channel chunks (B20: 4x2
 // accumulators per wave, two workgroups per CU) moves the fewest bytes per MFMA and wins whenever it yields enough
@@ -488,7 +490,13 @@ int pick_tile_b(int N, int H, int W, int CoutP) {
     const TileInfoB& t = kTilesB[order[k]];
     if (t.bn > CoutP) continue;
     const long tiles = (long)N * ceil_div(H, t.th) * ceil_div(W, t.tw) * ceil_div(CoutP, t.bn);
-    if (tiles >= 400 || k == 3) return order[k];
+    if (tiles >= 400 || k == 3) {
+      if (order[k] == 20) {      // same tile as 16 x 16 pixels when that pads the frame less (107-pixel wide conv4_x: 12 % vs 28 %)
+        const long p20 = (long)ceil_div(H, 8) * 8 * ceil_div(W, 32) * 32, p28 = (long)ceil_div(H, 16) * 16 * ceil_div(W, 16) * 16;
+        if (p28 * 100 < p20 * 92) return 28;
+      }
+      return order[k];
+    }
   }
   return 7;
 }
@@ -584,7 +592,7 @@ int osvos_conv3x3_bf16mfma_io(const void* x, int xb, const void* wpk, const floa
   }
   a.map = tile >= 100 ? 1 : 0;
   tile %= 100;
-  if (xb && tile >= 30 && tile <= 33) {      // LDS-DMA staged kernel
+  if (xb && tile >= 30 && tile <= 35) {      // LDS-DMA staged kernel
     OSVOS_ARG_CHECK(osvos_conv3x3_bf16_dma_applicable(Cin, Cout, y_cs), "conv3x3 bf16: tile %d (DMA staging) needs Cin %% 16 == 0, Cout, y_cs %% 8 == 0", tile);
     return osvos_conv3x3_bf16_dma(x, wpk, bias, mask, mask_bf16, y, ybf, N, H, W, Cin, Cout, y_cs, relu, tile - 30, a.map, stream);
   }
@@ -599,7 +607,9 @@ int osvos_conv3x3_bf16mfma_io(const void* x, int xb, const void* wpk, const floa
       case 20: return launch_cfg<B20, 1>(a, stream);
       case 22: return launch_cfg<B22, 1>(a, stream);
       case 23: return launch_cfg<B23, 1>(a, stream);
-      default: osvos_set_error("conv3x3 bf16: tile config %d is not built for bf16 activations (1, 3, 5, 6, 7, 11, 20, 22, 23, 30..33 are)", tile); return -1;
+      case 28: return launch_cfg<B28, 1>(a, stream);
+      case 29: return launch_cfg<B29, 1>(a, stream);
+      default: osvos_set_error("conv3x3 bf16: tile config %d is not built for bf16 activations (1, 3, 5, 6, 7, 11, 20, 22, 23, 28..35 are)", tile); return -1;
     }
   }
   switch (tile) {
@@ -631,12 +641,14 @@ int osvos_conv3x3_bf16mfma_io(const void* x, int xb, const void* wpk, const floa
     case 25: return launch_cfg<B25>(a, stream);
     case 26: return launch_cfg<B26>(a, stream);
     case 27: return launch_cfg<B27>(a, stream);
+    case 28: return launch_cfg<B28>(a, stream);
+    case 29: return launch_cfg<B29>(a, stream);
     default: osvos_set_error("conv3x3 bf16: unknown tile config %d", tile); return -1;
   }
 }
 
 int osvos_conv3x3_bf16mfma_xb_tiles(int* tiles, int max) {      // tile ids built for bf16 activations
-  static const int t[] = {1, 3, 5, 6, 7, 11, 20, 22, 23, 30, 31, 32, 33};
+  static const int t[] = {1, 3, 5, 6, 7, 11, 20, 22, 23, 28, 29, 30, 31, 32, 33, 34, 35};
   int n = 0;
   for (; n < (int)(sizeof(t) / sizeof(t[0])) && n < max; ++n) tiles[n] = t[n];
   return n;

@@ -28,7 +28,7 @@ struct DmaArgs {
   float* y;              // may be NULL when ybf is given
   bf16_t* ybf;
   int N, H, W, Cin, CinP, Cout, CoutP, y_cs;
-  int tiles_x, tiles_y, nct, nsp, map;
+  int tiles_x, tiles_y, nct, nsp, map, ntiles;
   int relu, mask_bf16;
 };
 
@@ -68,22 +68,34 @@ __global__ __launch_bounds__(64 * 2 * WGM, WGM == 4 ? 2 : 1) void conv3x3_bf16_d
   const int li = lane & 31, lh = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
 
-  int sp, ct;
-  if (a.map == 0) {
-    sp = blockIdx.x / a.nct;
-    ct = blockIdx.x % a.nct;
-  } else {
-    const int j = blockIdx.x >> 3;
-    ct = j % a.nct;
-    sp = (j / a.nct) * 8 + (blockIdx.x & 7);
-    if (sp >= a.nsp) return;
-  }
-  const int tx = sp % a.tiles_x;
-  sp /= a.tiles_x;
-  const int ty = sp % a.tiles_y;
-  const int n = sp / a.tiles_y;
-  const int x0 = tx * TW, y0 = ty * TH, co0 = ct * C::BN;
+  // Tile index -> (image, tile row, tile column, cout tile).  map 0: cout tile in the low bits; map 1: eight consecutive indices
+  // are eight spatial tiles (one per XCD: block b runs on XCD b % 8) and the cout tiles of a spatial tile follow on the SAME XCD.
+  // A persistent workgroup walks t = blockIdx.x, blockIdx.x + gridDim.x, ... (gridDim.x a multiple of 8 keeps it on its XCD).
+  struct Tile { int n, x0, y0, co0; bool live; };
+  auto decode = [&](int t) -> Tile {
+    int sp, ct;
+    if (a.map == 0) {
+      sp = t / a.nct;
+      ct = t % a.nct;
+    } else {
+      const int j = t >> 3;
+      ct = j % a.nct;
+      sp = (j / a.nct) * 8 + (t & 7);
+    }
+    Tile r;
+    r.live = sp < a.nsp;
+    const int tx = sp % a.tiles_x;
+    sp /= a.tiles_x;
+    r.x0 = tx * TW;
+    r.y0 = (sp % a.tiles_y) * TH;
+    r.n = sp / a.tiles_y;
+    r.co0 = ct * C::BN;
+    return r;
+  };
   const int CG = a.CinP >> 3;
+  const int ntiles = a.ntiles;
+  int my_tiles = 0;
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) ++my_tiles;      // (scalar loop; a handful of iterations)
 
   // The DMA instructions are issued through inline asm: hipcc tracks `__builtin_amdgcn_raw_ptr_buffer_load_lds` as an LDS store
   // and puts `s_waitcnt vmcnt(0)` in front of the next ds_read -- which would wait for the chunk that was just requested and
@@ -93,7 +105,7 @@ __global__ __launch_bounds__(64 * 2 * WGM, WGM == 4 ? 2 : 1) void conv3x3_bf16_d
     const unsigned long long v = reinterpret_cast<unsigned long long>(p);
     return i32x4{(int)(unsigned)v, (int)(unsigned)(v >> 32), bytes, 0x00020000};
   };
-  const i32x4 xrs = make_rsrc(a.x + (size_t)n * a.H * a.W * a.Cin, (int)((size_t)a.H * a.W * a.Cin * 2));
+  const size_t ximg_elems = (size_t)a.H * a.W * a.Cin;
   const i32x4 wrs = make_rsrc(a.wpk, (int)((size_t)9 * CG * a.CoutP * 16));
   const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem;     // LDS byte address of the dynamic segment
 #pragma clang diagnostic push
@@ -103,23 +115,28 @@ __global__ __launch_bounds__(64 * 2 * WGM, WGM == 4 ? 2 : 1) void conv3x3_bf16_d
   };
 #pragma clang diagnostic pop
 
-  // per-lane source offsets of this wave's DMA instructions (chunk 0; the chunk advance rides in the scalar offset)
+  // per-lane source offsets of this wave's DMA instructions for the tile being ISSUED (chunk 0; the chunk advance rides in the
+  // scalar offset).  The issue side runs DIST chunks ahead of the multiply side and crosses tile boundaries on its own.
   unsigned a_off[C::NA], b_off[C::NBI];
+  i32x4 xrs = make_rsrc(a.x, 0);
+  auto set_issue_tile = [&](const Tile& T) {
+    xrs = make_rsrc(a.x + (size_t)T.n * ximg_elems, (int)(ximg_elems * 2));
 #pragma unroll
-  for (int i = 0; i < C::NA; ++i) {
-    const int e = 64 * (wave + NW * i) + lane;             // slot inside the A region (instruction wave + NW i)
-    const int g = e / PLANE, rem = e % PLANE;
-    const int hy = rem / HWD, hx = rem % HWD;
-    const int gy = y0 + hy - 1, gx = x0 + hx - 1;
-    a_off[i] = (e < KG * PLANE && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? (unsigned)(((gy * a.W + gx) * a.Cin + 8 * g) * 2) : OOB;
-  }
+    for (int i = 0; i < C::NA; ++i) {
+      const int e = 64 * (wave + NW * i) + lane;             // slot inside the A region (instruction wave + NW i)
+      const int g = e / PLANE, rem = e % PLANE;
+      const int hy = rem / HWD, hx = rem % HWD;
+      const int gy = T.y0 + hy - 1, gx = T.x0 + hx - 1;
+      a_off[i] = (T.live && e < KG * PLANE && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? (unsigned)(((gy * a.W + gx) * a.Cin + 8 * g) * 2) : OOB;
+    }
 #pragma unroll
-  for (int i = 0; i < C::NBI; ++i) {
-    const int e = 64 * (wave + NW * i) + lane;
-    const int tap = e / (KG * C::BN), rem = e % (KG * C::BN);
-    const int g = rem / C::BN, nn = rem % C::BN;
-    b_off[i] = (e < C::B_SLOTS && co0 + nn < a.CoutP) ? (unsigned)(((tap * CG + g) * a.CoutP + co0 + nn) * 16) : OOB;
-  }
+    for (int i = 0; i < C::NBI; ++i) {
+      const int e = 64 * (wave + NW * i) + lane;
+      const int tap = e / (KG * C::BN), rem = e % (KG * C::BN);
+      const int g = rem / C::BN, nn = rem % C::BN;
+      b_off[i] = (T.live && e < C::B_SLOTS && T.co0 + nn < a.CoutP) ? (unsigned)(((tap * CG + g) * a.CoutP + T.co0 + nn) * 16) : OOB;
+    }
+  };
   // LDS target of instruction i of this wave inside a buffer (wave-uniform); instructions past the region go to the spare slots
   const int wv = __builtin_amdgcn_readfirstlane(wave);        // wave-uniform by construction; make it a scalar for m0
   // the d-th DMA instruction of this wave for chunk kc into buffer buf (d is a compile-time constant after unrolling)
@@ -142,29 +159,49 @@ __global__ __launch_bounds__(64 * 2 * WGM, WGM == 4 ? 2 : 1) void conv3x3_bf16_d
   const int b_idx = A_SLOTS + lh * C::BN + wn * C::WN * 32 + li;       // + tap * KG * BN + ni * 32
 
   f32x16 acc[C::WM][C::WN];
+  auto zero_acc = [&]() {
 #pragma unroll
-  for (int mi = 0; mi < C::WM; ++mi)
+    for (int mi = 0; mi < C::WM; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < C::WN; ++ni)
+      for (int ni = 0; ni < C::WN; ++ni)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+  };
+  zero_acc();
 
   const int nchunks = a.Cin >> 4;
+  const int total = my_tiles * nchunks;                       // the chunk stream of this workgroup, across its tiles
   // DIST = how many chunks the DMA runs ahead (NBUF - 1).  s_waitcnt vmcnt((DIST - 1) * NDMA): everything but the newest
-  // DIST - 1 chunks' DMA instructions of THIS wave has landed
+  // DIST - 1 chunks' DMA instructions of THIS wave has landed (epilogue loads / stores in between only make the wait stricter)
   constexpr int DIST = NBUF - 1;
   constexpr int VM = (DIST - 1) * C::NDMA;
   constexpr int WAITCNT = 0x0F70 | (VM & 15) | ((VM >> 4) << 14);
+  // issue side: chunk stream position gi = (tile it_, chunk ikc)
+  int it_ = blockIdx.x, ikc = 0, gi = 0;
+  set_issue_tile(decode(it_));
+  auto issue_advance = [&]() {                               // after all DMA instructions of stream chunk gi have been issued
+    ++gi;
+    if (++ikc == nchunks) {
+      ikc = 0;
+      it_ += gridDim.x;
+      if (gi < total) set_issue_tile(decode(it_));
+    }
+  };
 #pragma unroll
-  for (int c = 0; c < DIST; ++c) dma_chunk(c, c, c < nchunks ? 0u : OOB);
+  for (int c = 0; c < DIST; ++c) {
+    dma_chunk(ikc, c, gi < total ? 0u : OOB);
+    issue_advance();
+  }
   __builtin_amdgcn_s_waitcnt(WAITCNT);
   __syncthreads();
-  int cur = 0;                                                 // chunk k lives in buffer k % NBUF
-  for (int kc = 0; kc < nchunks; ++kc) {
-    // chunk kc + DIST goes to the buffer that was read in iteration kc - 1; every wave left that iteration through the barrier below.
-    // Its DMA instructions are issued one at a time between the MFMAs: back to back they keep the wave off the matrix pipe.
+  int cur = 0;                                                 // stream chunk g lives in buffer g % NBUF
+  int tcur = blockIdx.x, kc = 0;                               // multiply side: tile, chunk
+  for (int g = 0; g < total; ++g) {
+    // stream chunk g + DIST goes to the buffer that was read in iteration g - 1; every wave left that iteration through the barrier
+    // below.  Its DMA instructions are issued one at a time between the MFMAs: back to back they keep the wave off the matrix pipe.
     const int tgt = cur == 0 ? NBUF - 1 : cur - 1;
-    const unsigned dead = kc + DIST < nchunks ? 0u : OOB;
+    const unsigned dead = gi < total ? 0u : OOB;
+    const int dkc = ikc;
     const uint4* As = lds + (size_t)cur * C::BUF_SLOTS;
     // 9 tap stages, software pipelined: the fragments of tap t+1 are requested before the MFMAs of tap t issue
     uint4 fa[2][C::WM], fb[2][C::WN];
@@ -190,85 +227,95 @@ __global__ __launch_bounds__(64 * 2 * WGM, WGM == 4 ? 2 : 1) void conv3x3_bf16_d
                                                                 __builtin_bit_cast(bf16x8_t, fa[tap & 1][mi]), acc[mi][ni], 0, 0, 0);
           const int m = tap * PER + mi * C::WN + ni;           // index of the MFMA just issued
           if (m % GAP == GAP / 2 && m / GAP < C::NDMA) {
-            dma_one(m / GAP, kc + DIST, tgt, dead);
+            dma_one(m / GAP, dkc, tgt, dead);
             __builtin_amdgcn_sched_barrier(0);
           }
         }
       __builtin_amdgcn_sched_barrier(0);
     }
-    __builtin_amdgcn_s_waitcnt(WAITCNT);                       // chunk kc+1 has landed (this wave's part) ...
+    issue_advance();
+    __builtin_amdgcn_s_waitcnt(WAITCNT);                       // stream chunk g+1 has landed (this wave's part) ...
     __syncthreads();                                           // ... everybody's part has, and everybody is done with `cur`
     cur = cur == NBUF - 1 ? 0 : cur + 1;
-  }
-
-  // ---- epilogue: cout-major accumulators (weights are the first MFMA operand), 16-byte raw buffer stores, no branches ----
-  const size_t img_elems = (size_t)a.H * a.W * a.y_cs;
-  void* const anyp = const_cast<uint4*>(a.wpk);
-  const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(a.y != nullptr ? (void*)(a.y + n * img_elems) : anyp, 0,
-                                                                       a.y != nullptr ? (int)(img_elems * 4) : 0, 0x00020000);
-  const int msz = a.mask_bf16 ? 2 : 4;
-  const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc(
-      a.mask != nullptr ? (void*)(reinterpret_cast<char*>(const_cast<void*>(a.mask)) + n * img_elems * msz) : anyp, 0,
-      a.mask != nullptr ? (int)(img_elems * msz) : 0, 0x00020000);
-  const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(a.bias != nullptr ? (void*)const_cast<float*>(a.bias) : anyp, 0,
-                                                                       a.bias != nullptr ? a.Cout * 4 : 0, 0x00020000);
-  const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(a.ybf != nullptr ? (void*)(a.ybf + n * img_elems) : anyp, 0,
-                                                                       a.ybf != nullptr ? (int)(img_elems * 2) : 0, 0x00020000);
+    if (++kc < nchunks) continue;
+    kc = 0;
+    // ---- this tile is complete: epilogue (the DMA of the next tile's first chunks is already in flight) ----
+    const Tile T = decode(tcur);
+    tcur += gridDim.x;
+    const int n = T.n, x0 = T.x0, y0 = T.y0, co0 = T.co0;
+    if (T.live) {
+    // ---- epilogue: cout-major accumulators (weights are the first MFMA operand), 16-byte raw buffer stores, no branches ----
+    const size_t img_elems = (size_t)a.H * a.W * a.y_cs;
+    void* const anyp = const_cast<uint4*>(a.wpk);
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(a.y != nullptr ? (void*)(a.y + n * img_elems) : anyp, 0,
+                                                                         a.y != nullptr ? (int)(img_elems * 4) : 0, 0x00020000);
+    const int msz = a.mask_bf16 ? 2 : 4;
+    const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc(
+        a.mask != nullptr ? (void*)(reinterpret_cast<char*>(const_cast<void*>(a.mask)) + n * img_elems * msz) : anyp, 0,
+        a.mask != nullptr ? (int)(img_elems * msz) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(a.bias != nullptr ? (void*)const_cast<float*>(a.bias) : anyp, 0,
+                                                                         a.bias != nullptr ? a.Cout * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(a.ybf != nullptr ? (void*)(a.ybf + n * img_elems) : anyp, 0,
+                                                                         a.ybf != nullptr ? (int)(img_elems * 2) : 0, 0x00020000);
 #pragma unroll
-  for (int ni = 0; ni < C::WN; ++ni) {
-    const int cb = co0 + (wn * C::WN + ni) * 32 + 4 * lh;
-    f32x4 bv[4];
+    for (int ni = 0; ni < C::WN; ++ni) {
+      const int cb = co0 + (wn * C::WN + ni) * 32 + 4 * lh;
+      f32x4 bv[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) bv[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brs, (cb + 8 * q) * 4, 0, 0));
+      for (int q = 0; q < 4; ++q) bv[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brs, (cb + 8 * q) * 4, 0, 0));
 #pragma unroll
-    for (int mi = 0; mi < C::WM; ++mi) {
-      const int oy = y0 + wm * C::WM + mi, ox = x0 + li;
-      const unsigned pix = (oy < a.H && ox < a.W) ? (unsigned)((oy * a.W + ox) * a.y_cs) * 4u : OOB;
-      uint2 hb[4];
+      for (int mi = 0; mi < C::WM; ++mi) {
+        const int oy = y0 + wm * C::WM + mi, ox = x0 + li;
+        const unsigned pix = (oy < a.H && ox < a.W) ? (unsigned)((oy * a.W + ox) * a.y_cs) * 4u : OOB;
+        uint2 hb[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int co = cb + 8 * q;
-        const unsigned off = co < a.Cout ? pix + (unsigned)co * 4u : OOB;
-        f32x4 v;
+        for (int q = 0; q < 4; ++q) {
+          const int co = cb + 8 * q;
+          const unsigned off = co < a.Cout ? pix + (unsigned)co * 4u : OOB;
+          f32x4 v;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          v[e] = acc[mi][ni][4 * q + e] + bv[q][e];
-          if (a.relu) v[e] = v[e] > 0.f ? v[e] : 0.f;
-        }
-        if (a.mask != nullptr) {
-          if (a.mask_bf16) {
-            typedef short s16x4 __attribute__((ext_vector_type(4)));
-            const s16x4 m = __builtin_bit_cast(s16x4, __builtin_amdgcn_raw_buffer_load_b64(mrs, off >> 1, 0, 0));
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = m[e] > 0 ? v[e] : 0.f;
-          } else {
-            const f32x4 m = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(mrs, off, 0, 0));
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = m[e] > 0.f ? v[e] : 0.f;
+          for (int e = 0; e < 4; ++e) {
+            v[e] = acc[mi][ni][4 * q + e] + bv[q][e];
+            if (a.relu) v[e] = v[e] > 0.f ? v[e] : 0.f;
           }
-        }
-        if (a.y != nullptr) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, off, 0, 0);
-        bf16x4_t h;
-        h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
-        hb[q] = __builtin_bit_cast(uint2, h);
-      }
-      if (a.ybf != nullptr) {
+          if (a.mask != nullptr) {
+            if (a.mask_bf16) {
+              typedef short s16x4 __attribute__((ext_vector_type(4)));
+              const s16x4 m = __builtin_bit_cast(s16x4, __builtin_amdgcn_raw_buffer_load_b64(mrs, off >> 1, 0, 0));
 #pragma unroll
-        for (int pq = 0; pq < 2; ++pq) {
-          const auto sx = __builtin_amdgcn_permlane32_swap(hb[2 * pq].x, hb[2 * pq + 1].x, false, false);
-          const auto sy = __builtin_amdgcn_permlane32_swap(hb[2 * pq].y, hb[2 * pq + 1].y, false, false);
-          const u32x4 o = {sx[0], sy[0], sx[1], sy[1]};
-          const int co = co0 + (wn * C::WN + ni) * 32 + 16 * pq + 8 * lh;
-          const unsigned off = co < a.Cout ? (pix >> 1) + (unsigned)co * 2u : OOB;
-          __builtin_amdgcn_raw_buffer_store_b128(o, hrs, off, 0, 0);
+              for (int e = 0; e < 4; ++e) v[e] = m[e] > 0 ? v[e] : 0.f;
+            } else {
+              const f32x4 m = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(mrs, off, 0, 0));
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = m[e] > 0.f ? v[e] : 0.f;
+            }
+          }
+          if (a.y != nullptr) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, off, 0, 0);
+          bf16x4_t h;
+          h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
+          hb[q] = __builtin_bit_cast(uint2, h);
+        }
+        if (a.ybf != nullptr) {
+#pragma unroll
+          for (int pq = 0; pq < 2; ++pq) {
+            const auto sx = __builtin_amdgcn_permlane32_swap(hb[2 * pq].x, hb[2 * pq + 1].x, false, false);
+            const auto sy = __builtin_amdgcn_permlane32_swap(hb[2 * pq].y, hb[2 * pq + 1].y, false, false);
+            const u32x4 o = {sx[0], sy[0], sx[1], sy[1]};
+            const int co = co0 + (wn * C::WN + ni) * 32 + 16 * pq + 8 * lh;
+            const unsigned off = co < a.Cout ? (pix >> 1) + (unsigned)co * 2u : OOB;
+            __builtin_amdgcn_raw_buffer_store_b128(o, hrs, off, 0, 0);
+          }
         }
       }
     }
+
+    }
+    zero_acc();
   }
 }
 
 template <int NB, int WGM>
-int launch(const DmaArgs& a0, hipStream_t stream) {
+int launch(const DmaArgs& a0, int persist, hipStream_t stream) {
   using C = DmaCfg<NB, WGM>;
   constexpr int TH = C::TH;
   static bool attr_set = false;
@@ -284,7 +331,19 @@ int launch(const DmaArgs& a0, hipStream_t stream) {
   a.nsp = a.tiles_x * a.tiles_y * a.N;
   const long blocks = a.map == 0 ? (long)a.nct * a.nsp : (long)a.nct * ((a.nsp + 7) / 8) * 8;
   OSVOS_ARG_CHECK(blocks > 0 && blocks < (1L << 31), "conv3x3 bf16 dma: grid of %ld blocks", blocks);
-  hipLaunchKernelGGL((conv3x3_bf16_dma_kernel<NB, WGM>), dim3((unsigned)blocks), dim3(C::NT), C::LDS_BYTES, stream, a);
+  a.ntiles = (int)blocks;
+  // persistent: one workgroup per CU (the LDS footprint allows no more) walks tiles b, b + G, ...; the DMA of a tile's first chunks
+  // overlaps the previous tile's epilogue.  G is a multiple of 8 so that a workgroup's tiles stay on its XCD's L2.
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    OSVOS_HIP_CHECK(hipGetDevice(&dev));
+    OSVOS_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    n_cu = n_cu / 8 * 8;
+    if (n_cu < 8) n_cu = 8;
+  }
+  const long grid = persist && blocks > n_cu ? n_cu : blocks;
+  hipLaunchKernelGGL((conv3x3_bf16_dma_kernel<NB, WGM>), dim3((unsigned)grid), dim3(C::NT), C::LDS_BYTES, stream, a);
   OSVOS_LAUNCH_CHECK();
   return 0;
 }
@@ -293,7 +352,8 @@ int launch(const DmaArgs& a0, hipStream_t stream) {
 
 bool osvos_conv3x3_bf16_dma_applicable(int Cin, int Cout, int y_cs) { return Cin % 16 == 0 && Cout % 8 == 0 && y_cs % 8 == 0; }
 
-// variant 0: 256 px x 128 couts (4 waves), 1: 256 px x 64 couts (4 waves), 2: 512 px x 128 couts (8 waves), 3: 512 px x 64 couts (8 waves);
+// variant 0: 256 px x 128 couts (4 waves), 1: 256 px x 64 couts (4 waves), 2: 512 px x 128 couts (8 waves), 3: 512 px x 64 couts (8 waves),
+// 4 / 5: variants 0 / 2 as persistent workgroups (one per CU, tiles pipelined back to back);
 // map = 1: XCD-local spatial block order
 int osvos_conv3x3_bf16_dma(const void* x, const void* wpk, const float* bias, const void* mask, int mask_bf16, float* y, void* ybf,
                            int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int variant, int map, hipStream_t stream) {
@@ -307,10 +367,12 @@ int osvos_conv3x3_bf16_dma(const void* x, const void* wpk, const float* bias, co
   a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.CinP = (Cin + 31) / 32 * 32; a.Cout = Cout; a.CoutP = osvos_cout_pad(Cout); a.y_cs = y_cs;
   a.relu = relu; a.map = map ? 1 : 0;
   switch (variant) {
-    case 0: return launch<4, 2>(a, stream);
-    case 1: return launch<2, 2>(a, stream);
-    case 2: return launch<4, 4>(a, stream);
-    case 3: return launch<2, 4>(a, stream);
+    case 0: return launch<4, 2>(a, 0, stream);
+    case 1: return launch<2, 2>(a, 0, stream);
+    case 2: return launch<4, 4>(a, 0, stream);
+    case 3: return launch<2, 4>(a, 0, stream);
+    case 4: return launch<4, 2>(a, 1, stream);      // persistent forms of 0 and 2
+    case 5: return launch<4, 4>(a, 1, stream);
     default: osvos_set_error("conv3x3 bf16 dma: unknown variant %d", variant); return -1;
   }
 }

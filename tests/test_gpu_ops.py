@@ -187,7 +187,7 @@ BF16_SHAPES = [(1, 9, 11, 8, 32), (2, 17, 35, 16, 64), (1, 33, 70, 64, 128), (1,
 
 
 @pytest.mark.parametrize("shape", BF16_SHAPES)
-@pytest.mark.parametrize("tile", list(range(28)) + [100, 106, 109, 120, -1])
+@pytest.mark.parametrize("tile", list(range(30)) + [100, 106, 109, 120, 128, -1])
 def test_conv3x3_bf16_mfma_forward_all_tiles(shape, tile):
     """bf16-operand path: with inputs that are already bf16-representable the only difference to a float64
     convolution is the fp32 accumulation order -> tight tolerance; this pins layout/indexing, not precision"""
@@ -281,16 +281,16 @@ def test_conv3x3_bf16io_bf16_input_and_copy(shape):
     xg = nhwc(x)
     tiles = ops.conv3x3_bf16io_tiles()
     assert 1 in tiles and 20 in tiles
-    assert all(t in tiles for t in (30, 31, 32, 33))        # the LDS-DMA staged kernel
-    for tile in tiles + [-1, 101, 120, 130, 132]:
-        if tile % 100 in (30, 31, 32, 33) and (cin % 16 != 0 or cout % 8 != 0):
+    assert all(t in tiles for t in (30, 31, 32, 33, 34, 35))      # the LDS-DMA staged kernel
+    for tile in tiles + [-1, 101, 120, 130, 132, 135]:
+        if tile % 100 in (30, 31, 32, 33, 34, 35) and (cin % 16 != 0 or cout % 8 != 0):
             with pytest.raises(RuntimeError):
                 ops.conv3x3_bf16io(xg.bfloat16(), wpk, b.cuda(), cout, tile=tile)
             continue
         y16, yb16 = ops.conv3x3_bf16io(xg.bfloat16(), wpk, b.cuda(), cout, relu=True, mask=nhwc(m), tile=tile)
         assert rel_err(nchw(y16), ref)[0] < 3e-5, (shape, tile)
         assert torch.equal(yb16, y16.bfloat16()), (shape, tile)
-        if tile % 100 in (30, 31, 32, 33):  # DMA staging exists for bf16 activations only
+        if tile % 100 in (30, 31, 32, 33, 34, 35):  # DMA staging exists for bf16 activations only
             with pytest.raises(RuntimeError):
                 ops.conv3x3_bf16io(xg, wpk, b.cuda(), cout, tile=tile)
             continue
