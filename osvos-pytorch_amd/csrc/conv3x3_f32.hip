@@ -338,13 +338,14 @@ using T10 = Cfg<8, 2, 4, 1, 4, 1>;   // 16x16 px x 32 co
 using T11 = Cfg<8, 1, 4, 1, 4, 1>;   //  8x16 px x 32 co
 using T12 = Cfg<16, 1, 8, 1, 4, 1>;  // 16x16 px x 32 co (16x2 row blocks)
 using T13 = Cfg<8, 2, 3, 2, 2, 2>;   // 16x12 px x 64 co
-constexpr int kNumTiles = 14;
+using T14 = Cfg<32, 1, 4, 1, 4, 1>;  // 32x4 px x 32 co: T9's shape with 32-wide row blocks (conflict-free LDS reads)
+constexpr int kNumTiles = 15;
 
 template <class C>
 constexpr TileInfo info() { return TileInfo{C::TW, C::TH, C::BN, C::WM, C::WN, C::LDS_BYTES}; }
 const TileInfo kTiles[kNumTiles] = {info<T0>(), info<T1>(), info<T2>(), info<T3>(), info<T4>(),
                                     info<T5>(), info<T6>(), info<T7>(), info<T8>(), info<T9>(),
-                                    info<T10>(), info<T11>(), info<T12>(), info<T13>()};
+                                    info<T10>(), info<T11>(), info<T12>(), info<T13>(), info<T14>()};
 
 // Measured on MI355X (tools/tune_conv.py, profiles/r01_tune_conv_tiles.txt): the 128-pixel x 32-cout tile T9 -- one
 // accumulator per wave, 5-7 workgroups per CU -- is the fastest or within 2 % of the fastest on every layer of the
@@ -458,6 +459,7 @@ int osvos_conv3x3_f32_ws(const float* x, const float* wpk, const float* bias, co
     case 11: rc = launch_cfg<T11>(a, stream); break;
     case 12: rc = launch_cfg<T12>(a, stream); break;
     case 13: rc = launch_cfg<T13>(a, stream); break;
+    case 14: rc = launch_cfg<T14>(a, stream); break;
     default: osvos_set_error("conv3x3: unknown tile config %d", tile); return -1;
   }
   if (rc || a.ksplit == 1) return rc;

@@ -30,7 +30,7 @@ def test_size_queries():
     assert l.osvos_wpack_dgrad_bytes(64, 3, 0) == 9 * 64 * 32 * 4
     assert l.osvos_net_ws_bytes(1, 480, 854, 0) > 443e6              # at least the saved activations
     assert l.osvos_net_wbuf_bytes(0) > 2 * 14.7e6 * 4
-    assert l.osvos_conv3x3_num_tiles() == 14
+    assert l.osvos_conv3x3_num_tiles() == 15
 
 
 def test_argument_errors_are_reported_not_crashed():

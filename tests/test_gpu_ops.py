@@ -51,7 +51,7 @@ CONV_SHAPES = [
 
 
 @pytest.mark.parametrize("shape", CONV_SHAPES)
-@pytest.mark.parametrize("tile", list(range(14)) + [100, 103, 109, 113, -1])
+@pytest.mark.parametrize("tile", list(range(15)) + [100, 103, 109, 113, 114, -1])
 def test_conv3x3_forward_all_tiles(shape, tile):
     ops = _ops()
     n, h, w, cin, cout = shape
