@@ -37,16 +37,13 @@ constexpr int pitch_for(int rbw, int hw) {
 }
 
 
-template <int RBW_, int TBX_, int TBY_, int NB_, int WGM_, int WGN_, int PIPE_ = 1, int RR_ = 0, int OCC_ = 1, int ILV_ = 0, int KG_ = 4>
+template <int RBW_, int TBX_, int TBY_, int NB_, int WGM_, int WGN_, int PIPE_ = 1, int OCC_ = 1, int KG_ = 4>
 struct CfgB {
   static constexpr int KG = KG_;                       // 16-byte groups (8 bf16 channels each) per K chunk: 4 = 32 channels, 2 = 16
   static constexpr int KS = KG_ / 2;                   // MFMA k-steps (16 channels) per tap and chunk
   static_assert(KG_ == 2 || KG_ == 4, "chunk of 16 or 32 channels");
-  static constexpr int ILV = ILV_;                     // 1: next chunk's global loads are issued one per MFMA inside the stage loop
   static constexpr int OCC = OCC_;                     // waves per SIMD the register allocation must allow
   static constexpr int RBW = RBW_, TBX = TBX_, TBY = TBY_, NB = NB_, WGM = WGM_, WGN = WGN_, PIPE = PIPE_;
-  static constexpr int RR = RR_;                       // row re-use loop (needs one image row per M block)
-  static_assert(RR_ == 0 || (RBW_ == 32 && TBX_ == 1), "row re-use needs RBW = 32, TBX = 1");
   static constexpr int RBH = 32 / RBW;
   static constexpr int TW = TBX * RBW, TH = TBY * RBH;
   static constexpr int HWD = TW + 2, HHT = TH + 2;
@@ -157,19 +154,6 @@ __global__ __launch_bounds__(C::NT, C::OCC) void conv3x3_bf16_kernel(ConvArgsB a
 #pragma unroll
     for (int i = 0; i < C::NBL; ++i) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(wrs, b_off[i], kc * C::KG * a.CoutP * 16, 0);
   };
-  constexpr int NLA = (XB ? 1 : 2) * C::NA;        // activation load instructions per chunk
-  constexpr int NL = NLA + C::NBL;                 // all load instructions per chunk
-  // (past the last chunk `dead` = OOB pushes every offset out of range: the loads return zeros without touching memory)
-  auto load_op = [&](int op, int kc, unsigned dead) {      // op is a compile-time constant after unrolling
-    if (op < NLA) {
-      const int i = XB ? op : op >> 1, h = XB ? 0 : op & 1;
-      const unsigned off = ((kc * C::KG + a_grp >= cin_groups) ? OOB : a_off[i]) | dead;
-      ra[i][h] = __builtin_amdgcn_raw_buffer_load_b128(xrs, off + 16 * h, kc * (8 * C::KG * XE), 0);
-    } else {
-      const int i = op - NLA;
-      rb[i] = __builtin_amdgcn_raw_buffer_load_b128(wrs, b_off[i] | dead, kc * C::KG * a.CoutP * 16, 0);
-    }
-  };
   auto store_chunk = [&]() {
 #pragma unroll
     for (int i = 0; i < C::NA; ++i)
@@ -218,95 +202,38 @@ __global__ __launch_bounds__(C::NT, C::OCC) void conv3x3_bf16_kernel(ConvArgsB a
     PROF_MARK(3);
     __syncthreads();
     PROF_MARK(4);
-    const bool more = kc + 1 < nchunks;
-    if (!C::ILV && more) load_chunk(kc + 1);       // in flight during the MFMAs below
+    if (kc + 1 < nchunks) load_chunk(kc + 1);      // in flight during the MFMAs below
     PROF_MARK(5);
-    // ILV: the next chunk's loads are issued INSIDE the stage loop, one after each MFMA -- the matrix pipe executes
-    // (32 cycles per MFMA) while the wave spends its issue slots on the memory pipe; as a separate phase the 21 loads
-    // of the 256 px x 64 co tile cost 1900 cycles per chunk against 2304 cycles of MFMA (tools/conv_phase_probe.py)
-    auto stages = [&](auto more_c) {
-      constexpr bool ISSUE = decltype(more_c)::value && C::ILV;
-      auto fill = [&](int op) {      // op = index of the MFMA just issued
-        if (ISSUE && op < NL) {
-          load_op(op, kc + 1, more ? 0u : OOB);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      };
-      if constexpr (C::RR) {
-        // Row re-use: an M block is one image row of 32 pixels, so tap row r of output row m reads halo row m + r --
-        // the SAME fragment that tap row r-1 of output row m+1 reads.  Per (tap column s, k-step) stage a wave
-        // fetches WM + 2 halo-row fragments and 3 weight fragments per cout block and issues 3*WM*WN MFMAs:
-        // (WM + 2 + 3 WN) LDS reads per 3 WM WN MFMAs instead of 3 (WM + WN) -- 9 vs 15 for the 4x1 wave tile.
-        constexpr int NR = C::WM + 2;
-        uint4 fa[1 + C::PIPE][NR], fb[1 + C::PIPE][3][C::WN];
-        const int a_row0 = lh * C::PLANE + (wm * C::WM) * C::PITCH + li;
-        auto ldfrag = [&](int st, int set) {
-          const int s = st / C::KS, ks = st % C::KS;
+    // 9 x KS (tap, k-step) stages, software pipelined: operands of stage s+1 are requested before the MFMAs of stage s issue;
+    // sched_barrier pins that order.  (Measured and removed, see DESIGN.md 3.4: re-using A fragments across tap rows -- 40 % fewer
+    // LDS reads -- and issuing the next chunk's loads one per MFMA inside this loop were both no faster.)
+    uint4 fa[1 + C::PIPE][C::WM], fb[1 + C::PIPE][C::WN];
+    auto ldfrag = [&](int st, int set) {
+      const int tap = st / C::KS, ks = st % C::KS;
+      const int r = tap / 3, s = tap % 3;
 #pragma unroll
-          for (int q = 0; q < NR; ++q) fa[set][q] = As[a_row0 + 2 * ks * C::PLANE + q * C::PITCH + s];
+      for (int mi = 0; mi < C::WM; ++mi) fa[set][mi] = As[a_idx[mi] + 2 * ks * C::PLANE + r * C::PITCH + s];
 #pragma unroll
-          for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int ni = 0; ni < C::WN; ++ni) fb[set][r][ni] = Bs[b_idx + ((r * 3 + s) * C::KG + 2 * ks) * C::BN + ni * 32];
-        };
-        if (C::PIPE) ldfrag(0, 0);
-#pragma unroll
-        for (int st = 0; st < 3 * C::KS; ++st) {
-          const int cur = C::PIPE ? (st & 1) : 0;
-          if (C::PIPE) {
-            if (st + 1 < 3 * C::KS) ldfrag(st + 1, (st + 1) & 1);
-            __builtin_amdgcn_sched_barrier(0);
-          } else {
-            ldfrag(st, 0);
-          }
-#pragma unroll
-          for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int mi = 0; mi < C::WM; ++mi)
-#pragma unroll
-              for (int ni = 0; ni < C::WN; ++ni) {
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fb[cur][r][ni]),
-                                                                      __builtin_bit_cast(bf16x8_t, fa[cur][mi + r]), acc[mi][ni], 0, 0, 0);
-                fill(((st * 3 + r) * C::WM + mi) * C::WN + ni);
-              }
-          if (C::PIPE) __builtin_amdgcn_sched_barrier(0);
-        }
-      } else {
-        // 18 (tap, k-step) stages, software pipelined: operands of stage s+1 are requested before the
-        // MFMAs of stage s issue; sched_barrier pins that order
-        uint4 fa[1 + C::PIPE][C::WM], fb[1 + C::PIPE][C::WN];
-        auto ldfrag = [&](int st, int set) {
-          const int tap = st / C::KS, ks = st % C::KS;
-          const int r = tap / 3, s = tap % 3;
-#pragma unroll
-          for (int mi = 0; mi < C::WM; ++mi) fa[set][mi] = As[a_idx[mi] + 2 * ks * C::PLANE + r * C::PITCH + s];
-#pragma unroll
-          for (int ni = 0; ni < C::WN; ++ni) fb[set][ni] = Bs[b_idx + (tap * C::KG + 2 * ks) * C::BN + ni * 32];
-        };
-        if (C::PIPE) ldfrag(0, 0);
-#pragma unroll
-        for (int st = 0; st < 9 * C::KS; ++st) {
-          const int cur = C::PIPE ? (st & 1) : 0;
-          if (C::PIPE) {
-            if (st + 1 < 9 * C::KS) ldfrag(st + 1, (st + 1) & 1);
-            __builtin_amdgcn_sched_barrier(0);
-          } else {
-            ldfrag(st, 0);     // 8-wave tiles: two waves per SIMD cover each other's LDS latency, registers are the scarce resource
-          }
-#pragma unroll
-          for (int mi = 0; mi < C::WM; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < C::WN; ++ni) {
-              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fb[cur][ni]),
-                                                                    __builtin_bit_cast(bf16x8_t, fa[cur][mi]), acc[mi][ni], 0, 0, 0);
-              fill((st * C::WM + mi) * C::WN + ni);
-            }
-          if (C::PIPE) __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-      static_assert(!C::ILV || NL <= 9 * C::KS * C::WM * C::WN, "more loads than MFMAs in a chunk");
+      for (int ni = 0; ni < C::WN; ++ni) fb[set][ni] = Bs[b_idx + (tap * C::KG + 2 * ks) * C::BN + ni * 32];
     };
-    if constexpr (C::ILV) stages(std::true_type{}); else stages(std::false_type{});
+    if (C::PIPE) ldfrag(0, 0);
+#pragma unroll
+    for (int st = 0; st < 9 * C::KS; ++st) {
+      const int cur = C::PIPE ? (st & 1) : 0;
+      if (C::PIPE) {
+        if (st + 1 < 9 * C::KS) ldfrag(st + 1, (st + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+      } else {
+        ldfrag(st, 0);     // two waves per SIMD cover each other's LDS latency, registers are the scarce resource
+      }
+#pragma unroll
+      for (int mi = 0; mi < C::WM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < C::WN; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fb[cur][ni]),
+                                                                __builtin_bit_cast(bf16x8_t, fa[cur][mi]), acc[mi][ni], 0, 0, 0);
+      if (C::PIPE) __builtin_amdgcn_sched_barrier(0);
+    }
     PROF_MARK(6);
   }
 
@@ -448,52 +375,34 @@ using B4 = CfgB<16, 1, 4, 4, 2, 2>;   // 16x8 px x 128 co, 2x2
 using B5 = CfgB<16, 1, 4, 2, 2, 2>;   // 16x8 px x  64 co, 2x1
 using B6 = CfgB<32, 1, 8, 1, 4, 1>;   // 256 px x  32 co, 2x1
 using B7 = CfgB<8, 1, 2, 2, 2, 2>;    //  8x8 px x  64 co, 1x1
-// (a 512 px x 128 co, 4x2-accumulator 8-wave tile would need > 256 registers per lane: it spills)
-using B8 = CfgB<32, 1, 16, 2, 4, 2>;  // 512 px x  64 co, 8 waves, 4x1
-using B9 = CfgB<32, 1, 8, 4, 4, 2>;   // 256 px x 128 co, 8 waves, 2x2
-// row re-use loop (RR = 1)
-using B10 = CfgB<32, 1, 8, 2, 2, 2, 1, 1, 2>;   // B1 shape
-using B11 = CfgB<32, 1, 8, 2, 2, 2, 0, 1, 2>;   // B1 shape, no register double buffering
-using B12 = CfgB<32, 1, 8, 4, 2, 2, 0, 1>;   // B0 shape (4x2 accumulators)
-using B13 = CfgB<32, 1, 8, 4, 2, 2, 1, 1>;
-using B14 = CfgB<32, 1, 4, 4, 2, 2, 1, 1>;   // B2 shape (2x2)
-using B15 = CfgB<32, 1, 8, 4, 1, 4, 0, 1>;   // 256 px x 128 co, every wave all 8 rows x 1 cout block (8x1)
-using B16 = CfgB<32, 1, 8, 2, 2, 2, 1, 0, 2, 1>;   // B1 + interleaved loads
-using B17 = CfgB<32, 1, 8, 2, 2, 2, 0, 1, 2, 1>;   // B11 + interleaved loads
-using B18 = CfgB<32, 1, 4, 2, 2, 2, 1, 0, 1, 1>;   // B3 + interleaved loads
-using B19 = CfgB<16, 1, 4, 2, 2, 2, 1, 0, 1, 1>;   // B5 + interleaved loads
-using B20 = CfgB<32, 1, 8, 4, 2, 2, 0, 0, 2, 0, 2>;  // 256 px x 128 co, 4x2 accumulators, 16-channel chunks, 2 workgroups per CU
-using B21 = CfgB<32, 1, 8, 4, 2, 2, 1, 0, 2, 0, 2>;
-using B22 = CfgB<32, 1, 8, 4, 2, 2, 0, 1, 2, 0, 2>;  // + row re-use
-using B23 = CfgB<32, 1, 8, 2, 2, 2, 1, 0, 3, 0, 2>;  // B1 with 16-channel chunks (3 workgroups per CU)
-using B24 = CfgB<32, 1, 16, 4, 4, 2, 0, 0, 2, 0, 2>;  // 512 px x 128 co, 8 waves (4x2 accumulators each), 16-channel chunks: one workgroup per CU
-using B25 = CfgB<32, 1, 16, 4, 4, 2, 0, 0, 2, 1, 2>;  // + loads interleaved with the MFMAs
-using B26 = CfgB<32, 1, 16, 4, 4, 2, 0, 1, 2, 1, 2>;  // + row re-use
-using B27 = CfgB<32, 1, 16, 4, 4, 2, 1, 0, 2, 1, 2>;  // + fragment double buffering
-using B28 = CfgB<16, 1, 8, 4, 2, 2, 0, 0, 2, 0, 2>;  // B20 as a 16 x 16 pixel tile: 107- and 54-pixel wide maps lose 5 % to padding instead of 20 %
-using B29 = CfgB<16, 1, 8, 2, 2, 2, 1, 0, 1, 0, 4>;  // B1 as a 16 x 16 pixel tile
-constexpr int kNumTilesB = 30;
+//                  RBW TBX TBY NB WGM WGN PIPE OCC KG
+using B8 = CfgB<32, 1, 8, 4, 2, 2, 0, 2, 2>;   // 256 px x 128 co, 4x2 accumulators, 16-channel chunks -> two workgroups per CU (the workhorse)
+using B9 = CfgB<32, 1, 8, 2, 2, 2, 1, 3, 2>;   // 256 px x  64 co, 16-channel chunks, three workgroups per CU (conv1_x)
+using B10 = CfgB<16, 1, 8, 4, 2, 2, 0, 2, 2>;  // B8 as a 16 x 16 pixel tile: 107- and 54-pixel wide maps lose 12 % to padding instead of 28 %
+using B11 = CfgB<16, 1, 8, 2, 2, 2, 1, 1, 4>;  // B1 as a 16 x 16 pixel tile
+// (tile ids in the round-1 profile files predate a clean-up: 20 -> 8, 23 -> 9, 28 -> 10, 29 -> 11; the 8-wave, row-re-use and
+//  interleaved-load variants 8-19 / 21-22 / 24-27 of those files were measured, lost, and are gone)
+constexpr int kNumTilesB = 12;
 template <class C>
 constexpr TileInfoB infoB() { return TileInfoB{C::TW, C::TH, C::BN, C::WM, C::WN, C::LDS_BYTES}; }
 const TileInfoB kTilesB[kNumTilesB] = {infoB<B0>(), infoB<B1>(), infoB<B2>(), infoB<B3>(), infoB<B4>(), infoB<B5>(), infoB<B6>(), infoB<B7>(),
-                                       infoB<B8>(), infoB<B9>(),
-                                       infoB<B10>(), infoB<B11>(), infoB<B12>(), infoB<B13>(), infoB<B14>(), infoB<B15>(), infoB<B16>(), infoB<B17>(), infoB<B18>(), infoB<B19>(), infoB<B20>(), infoB<B21>(), infoB<B22>(), infoB<B23>(), infoB<B24>(), infoB<B25>(), infoB<B26>(), infoB<B27>(), infoB<B28>(), infoB<B29>()};
+                                       infoB<B8>(), infoB<B9>(), infoB<B10>(), infoB<B11>()};
 
-// Measured (profiles/r01_tune_bf16_*.txt): with >= 128 couts the 256 px x 128 co tile on 16-channel chunks (B20: 4x2
+// Measured (profiles/r01_tune_bf16_*.txt): with >= 128 couts the 256 px x 128 co tile on 16-channel chunks (B8: 4x2
 // accumulators per wave, two workgroups per CU) moves the fewest bytes per MFMA and wins whenever it yields enough
 // workgroups (up to 990 TFLOP/s on conv3_x/conv4_x at batch 12); B1 (256 px x 64 co, 4 accumulators) covers the
-// 64-cout layers and the frames that are too small for B20; tiny frames fall back to 128- and 64-pixel tiles.
+// 64-cout layers and the frames that are too small for B8; tiny frames fall back to 128- and 64-pixel tiles.
 int pick_tile_b(int N, int H, int W, int CoutP) {
   if (CoutP <= 32) return 6;
-  const int order[] = {20, 1, 5, 7};
+  const int order[] = {8, 1, 5, 7};
   for (int k = 0; k < 4; ++k) {
     const TileInfoB& t = kTilesB[order[k]];
     if (t.bn > CoutP) continue;
     const long tiles = (long)N * ceil_div(H, t.th) * ceil_div(W, t.tw) * ceil_div(CoutP, t.bn);
     if (tiles >= 400 || k == 3) {
-      if (order[k] == 20) {      // same tile as 16 x 16 pixels when that pads the frame less (107-pixel wide conv4_x: 12 % vs 28 %)
+      if (order[k] == 8) {      // same tile as 16 x 16 pixels when that pads the frame less (107-pixel wide conv4_x: 12 % vs 28 %)
         const long p20 = (long)ceil_div(H, 8) * 8 * ceil_div(W, 32) * 32, p28 = (long)ceil_div(H, 16) * 16 * ceil_div(W, 16) * 16;
-        if (p28 * 100 < p20 * 92) return 28;
+        if (p28 * 100 < p20 * 92) return 10;
       }
       return order[k];
     }
@@ -583,6 +492,7 @@ int osvos_conv3x3_bf16mfma_io(const void* x, int xb, const void* wpk, const floa
   if (tile < 0) {
     const char* env = getenv("OSVOS_CONV_TILE_BF16");
     tile = env ? atoi(env) : pick_tile_b(N, H, W, a.CoutP);
+    if (!env && !xb && tile == 10) tile = 8;     // (the 16 x 16 form spills with fp32 staging registers)
     // bf16 activations, deep layers (K = 9 x 512): the LDS-DMA staged 512 px x 128 co kernel wins when it still fills the chip
     // (conv4_x 0.355 -> 0.331 ms, conv5_x 0.117 -> 0.098 ms at batch 12)
     if (!env && xb && Cin >= 512 && a.CoutP >= 128 && osvos_conv3x3_bf16_dma_applicable(Cin, Cout, y_cs) &&
@@ -596,20 +506,21 @@ int osvos_conv3x3_bf16mfma_io(const void* x, int xb, const void* wpk, const floa
     OSVOS_ARG_CHECK(osvos_conv3x3_bf16_dma_applicable(Cin, Cout, y_cs), "conv3x3 bf16: tile %d (DMA staging) needs Cin %% 16 == 0, Cout, y_cs %% 8 == 0", tile);
     return osvos_conv3x3_bf16_dma(x, wpk, bias, mask, mask_bf16, y, ybf, N, H, W, Cin, Cout, y_cs, relu, tile - 30, a.map, stream);
   }
-  if (xb) {      // bf16 activations: the tiles the network uses
+  if (xb) {
     switch (tile) {
+      case 0: return launch_cfg<B0, 1>(a, stream);
       case 1: return launch_cfg<B1, 1>(a, stream);
+      case 2: return launch_cfg<B2, 1>(a, stream);
       case 3: return launch_cfg<B3, 1>(a, stream);
+      case 4: return launch_cfg<B4, 1>(a, stream);
       case 5: return launch_cfg<B5, 1>(a, stream);
       case 6: return launch_cfg<B6, 1>(a, stream);
       case 7: return launch_cfg<B7, 1>(a, stream);
+      case 8: return launch_cfg<B8, 1>(a, stream);
+      case 9: return launch_cfg<B9, 1>(a, stream);
+      case 10: return launch_cfg<B10, 1>(a, stream);
       case 11: return launch_cfg<B11, 1>(a, stream);
-      case 20: return launch_cfg<B20, 1>(a, stream);
-      case 22: return launch_cfg<B22, 1>(a, stream);
-      case 23: return launch_cfg<B23, 1>(a, stream);
-      case 28: return launch_cfg<B28, 1>(a, stream);
-      case 29: return launch_cfg<B29, 1>(a, stream);
-      default: osvos_set_error("conv3x3 bf16: tile config %d is not built for bf16 activations (1, 3, 5, 6, 7, 11, 20, 22, 23, 28..35 are)", tile); return -1;
+      default: osvos_set_error("conv3x3 bf16: unknown tile config %d", tile); return -1;
     }
   }
   switch (tile) {
@@ -625,30 +536,12 @@ int osvos_conv3x3_bf16mfma_io(const void* x, int xb, const void* wpk, const floa
     case 9: return launch_cfg<B9>(a, stream);
     case 10: return launch_cfg<B10>(a, stream);
     case 11: return launch_cfg<B11>(a, stream);
-    case 12: return launch_cfg<B12>(a, stream);
-    case 13: return launch_cfg<B13>(a, stream);
-    case 14: return launch_cfg<B14>(a, stream);
-    case 15: return launch_cfg<B15>(a, stream);
-    case 16: return launch_cfg<B16>(a, stream);
-    case 17: return launch_cfg<B17>(a, stream);
-    case 18: return launch_cfg<B18>(a, stream);
-    case 19: return launch_cfg<B19>(a, stream);
-    case 20: return launch_cfg<B20>(a, stream);
-    case 21: return launch_cfg<B21>(a, stream);
-    case 22: return launch_cfg<B22>(a, stream);
-    case 23: return launch_cfg<B23>(a, stream);
-    case 24: return launch_cfg<B24>(a, stream);
-    case 25: return launch_cfg<B25>(a, stream);
-    case 26: return launch_cfg<B26>(a, stream);
-    case 27: return launch_cfg<B27>(a, stream);
-    case 28: return launch_cfg<B28>(a, stream);
-    case 29: return launch_cfg<B29>(a, stream);
     default: osvos_set_error("conv3x3 bf16: unknown tile config %d", tile); return -1;
   }
 }
 
 int osvos_conv3x3_bf16mfma_xb_tiles(int* tiles, int max) {      // tile ids built for bf16 activations
-  static const int t[] = {1, 3, 5, 6, 7, 11, 20, 22, 23, 28, 29, 30, 31, 32, 33, 34, 35};
+  static const int t[] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 30, 31, 32, 33, 34, 35};
   int n = 0;
   for (; n < (int)(sizeof(t) / sizeof(t[0])) && n < max; ++n) tiles[n] = t[n];
   return n;

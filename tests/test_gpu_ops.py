@@ -187,7 +187,7 @@ BF16_SHAPES = [(1, 9, 11, 8, 32), (2, 17, 35, 16, 64), (1, 33, 70, 64, 128), (1,
 
 
 @pytest.mark.parametrize("shape", BF16_SHAPES)
-@pytest.mark.parametrize("tile", list(range(30)) + [100, 106, 109, 120, 128, -1])
+@pytest.mark.parametrize("tile", list(range(12)) + [100, 106, 108, 110, -1])
 def test_conv3x3_bf16_mfma_forward_all_tiles(shape, tile):
     """bf16-operand path: with inputs that are already bf16-representable the only difference to a float64
     convolution is the fp32 accumulation order -> tight tolerance; this pins layout/indexing, not precision"""
@@ -280,9 +280,9 @@ def test_conv3x3_bf16io_bf16_input_and_copy(shape):
     wpk = ops.pack_fwd(wt.cuda(), F32_BF16MFMA)
     xg = nhwc(x)
     tiles = ops.conv3x3_bf16io_tiles()
-    assert 1 in tiles and 20 in tiles
+    assert 1 in tiles and 8 in tiles
     assert all(t in tiles for t in (30, 31, 32, 33, 34, 35))      # the LDS-DMA staged kernel
-    for tile in tiles + [-1, 101, 120, 130, 132, 135]:
+    for tile in tiles + [-1, 101, 108, 130, 132, 135]:
         if tile % 100 in (30, 31, 32, 33, 34, 35) and (cin % 16 != 0 or cout % 8 != 0):
             with pytest.raises(RuntimeError):
                 ops.conv3x3_bf16io(xg.bfloat16(), wpk, b.cuda(), cout, tile=tile)
@@ -298,7 +298,7 @@ def test_conv3x3_bf16io_bf16_input_and_copy(shape):
         assert torch.equal(y16, y32), (shape, tile)                  # identical arithmetic, only the staging differs
         assert torch.equal(yb32, y32.bfloat16()), (shape, tile)
     with pytest.raises(RuntimeError):
-        ops.conv3x3_bf16io(xg.bfloat16(), wpk, b.cuda(), cout, tile=0)      # not built for bf16 input
+        ops.conv3x3_bf16io(xg.bfloat16(), wpk, b.cuda(), cout, tile=12)     # no such tile
 
 
 @pytest.mark.gpu
@@ -395,7 +395,7 @@ def test_conv3x3_bf16io_bf16_mask_and_bf16_only_output():
     m = F.relu(torch.randn(n, cout, h, w, generator=g)).bfloat16()           # a post-ReLU activation as the mask
     wpk = ops.pack_dgrad(wt.cuda(), F32_BF16MFMA) if False else ops.pack_fwd(wt.cuda(), F32_BF16MFMA)
     xg, mg = nhwc(x.float()).bfloat16(), nhwc(m.float()).bfloat16()
-    for tile in (-1, 1, 20):
+    for tile in (-1, 1, 8):
         y_ref, yb_ref = ops.conv3x3_bf16io(xg, wpk, None, cout, mask=mg.float(), tile=tile)   # (accumulation order differs between tiles)
         y, yb = ops.conv3x3_bf16io(xg, wpk, None, cout, mask=mg, tile=tile)                   # bf16 mask
         assert torch.equal(y, y_ref) and torch.equal(yb, yb_ref)

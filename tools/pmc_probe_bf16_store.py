@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """rocprofv3 --pmc workload: bf16 in / bf16 out convolutions (the network's bf16 mode) at batch 12, conv3_2 and conv4_2 shapes,
-register-staged tile 20 and the persistent LDS-DMA kernel (tile 35), plus the bf16-input weight gradient."""
+register-staged tile 8 and the persistent LDS-DMA kernel (tile 35), plus the bf16-input weight gradient."""
 import ctypes as C
 import os
 import sys
@@ -19,7 +19,7 @@ for (h, w, c) in ((120, 214, 256), (60, 107, 512)):
     wt = torch.randn(c, c, 3, 3, device="cuda") * 0.05
     wf = ops.pack_fwd(wt, DT)
     yb = torch.empty(n, h, w, c, device="cuda", dtype=torch.bfloat16)
-    for tile in (20, 35):
+    for tile in (8, 35):
         for _ in range(3):
             _lib.check(_lib.lib().osvos_conv3x3_bf16io(vp(x.data_ptr()), 1, vp(wf.data_ptr()), None, None, 0, None, vp(yb.data_ptr()), n, h, w, c, c, c, 1,
                                                       tile, vp(torch.cuda.current_stream().cuda_stream)), "conv")

@@ -57,7 +57,7 @@ def _peak():
 ms = timeit(_peak, 3)
 print("fp32 MFMA-only probe: %.1f TFLOP/s (2048 WGs x 4 waves x %d x 4 MFMA 32x32x2)" % (2048 * 4 * _it * 4 * 2 * 32 * 32 * 2 / ms / 1e9, _it))
 DT = _lib.F32 if args.dtype == "fp32" else _lib.F32_BF16MFMA
-default_tiles = [2, 3, 5, 6, 9, 102, 103, 105, 106, 109] if args.dtype == "fp32" else [1, 3, 5, 7, 8, 9, 101, 105, 108, 109]
+default_tiles = [2, 3, 5, 6, 9, 102, 103, 105, 106, 109] if args.dtype == "fp32" else [1, 3, 5, 8, 9, 10, 32, 35, 108, 110]
 tiles = [int(t) for t in args.tiles.split(",")] if args.tiles else default_tiles
 n = args.batch
 print("layer            dir   HxW       Cin->Cout  GF    | " + " ".join("t%-6d" % t for t in tiles) + " | best  TF/s  auto")
