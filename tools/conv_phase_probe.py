@@ -22,7 +22,9 @@ out = args.lib or "/tmp/libconvprof.so"
 if not args.lib:
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DOSVOS_CONV_PROF"]
                           + ["-D" + d for d in args.defs.split(",") if d]
-                          + [os.path.join(src, "conv3x3_bf16.hip" if args.dtype == "bf16" else "conv3x3_f32.hip"), "-x", "hip", os.path.join(src, "errors.cpp"), "-o", out])
+                          + ([os.path.join(src, "conv3x3_bf16.hip"), os.path.join(src, "conv3x3_bf16_dma.hip")] if args.dtype == "bf16"
+                             else [os.path.join(src, "conv3x3_f32.hip")])
+                          + ["-x", "hip", os.path.join(src, "errors.cpp"), "-o", out])
 lib = C.CDLL(out)
 vp = C.c_void_p
 dev = "cuda"
