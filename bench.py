@@ -28,6 +28,12 @@ import os
 import sys
 import time
 
+# ROCm maps HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  The backward uses three streams (data gradients /
+# weight gradients / slab reduces); once torch.distributed's RCCL communicator adds its own streams two of ours end up on the same
+# hardware queue and serialise -- measured -7 % (128 -> 119 frames/s) from init_process_group alone.  Eight queues restore it.
+# Must be set before the HIP runtime initialises, i.e. before the first CUDA call of the process.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 import torch
 
@@ -235,7 +241,10 @@ def main():
             if reducer is not None:
                 reducer.all_reduce()
             opt.step()
-            opt.zero_grad()
+            if reducer is not None:
+                reducer.zero_grads()
+            else:
+                opt.zero_grad()
             state["ave"] = 0
 
     if args.mode == "infer":

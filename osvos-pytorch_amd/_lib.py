@@ -8,6 +8,10 @@ import shutil
 import subprocess
 import threading
 
+# see bench.py: three backward streams + RCCL's need more than ROCm's default 4 hardware queues (effective only if this module is
+# imported before the process touches the GPU)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "libosvos_hip.so")
 CSRC = os.path.join(_HERE, "csrc")

@@ -19,32 +19,66 @@ import torch.distributed as dist
 
 
 class GradientAllReducer:
+    """Gradients live in ONE flat buffer: after the first backward every ``p.grad`` is re-pointed to a view into it
+    (``attach``), the network's backward accumulates into those views in place, the collective runs on the flat buffer
+    itself and ``zero_grads`` is one memset -- no flatten / unflatten copies (2 x 61 MB per optimizer step before) and no
+    per-tensor allocations.  If somebody replaces a ``.grad`` (``optimizer.zero_grad()`` with set_to_none) the next call
+    copies it back in and re-attaches."""
+
     def __init__(self, module, average=False, process_group=None, always=False):
         self.params = [p for p in module.parameters() if p.requires_grad]
         self.average = average
         self.group = process_group
         self.always = always          # run the collective even in a 1-rank group (exercises RCCL on one GPU)
         self._flat = None
+        self._views = {}              # id(param) -> view into _flat
+
+    def attach(self):
+        """Point the .grad of every parameter that has one at its slice of the flat buffer.  Returns the flat buffer
+        (None when no parameter has a gradient yet)."""
+        have = [p for p in self.params if p.grad is not None]
+        if not have:
+            return None
+        total = sum(p.grad.numel() for p in have)
+        layout_ok = (self._flat is not None and self._flat.numel() == total and self._flat.device == have[0].grad.device
+                     and len(self._views) == len(have) and all(id(p) in self._views for p in have))
+        if not layout_ok:
+            self._flat = torch.empty(total, device=have[0].grad.device, dtype=have[0].grad.dtype)
+            self._views, off = {}, 0
+            for p in have:
+                n = p.grad.numel()
+                self._views[id(p)] = self._flat[off:off + n].view_as(p.grad)
+                off += n
+        stale = [p for p in have if p.grad.data_ptr() != self._views[id(p)].data_ptr()]
+        if stale:
+            torch._foreach_copy_([self._views[id(p)] for p in stale], [p.grad for p in stale])
+            for p in stale:
+                p.grad = self._views[id(p)]
+        return self._flat
+
+    def zero_grads(self):
+        """Replacement for ``optimizer.zero_grad()``: keeps the views alive, one memset.  Falls back to setting the
+        gradients to None before the first ``attach``."""
+        if self._flat is None:
+            for p in self.params:
+                p.grad = None
+            return
+        self._flat.zero_()
+        for p in self.params:
+            v = self._views.get(id(p))
+            if v is not None:
+                p.grad = v
 
     def all_reduce(self):
         """Sum (or average) the .grad of every parameter that has one across all ranks."""
+        flat = self.attach()
+        if flat is None:
+            return
         if not dist.is_initialized() or (dist.get_world_size(self.group) == 1 and not self.always):
             return
-        grads = [p.grad for p in self.params if p.grad is not None]
-        if not grads:
-            return
-        total = sum(g.numel() for g in grads)
-        if self._flat is None or self._flat.numel() != total or self._flat.device != grads[0].device:
-            self._flat = torch.empty(total, device=grads[0].device, dtype=grads[0].dtype)
-        views, off = [], 0
-        for g in grads:
-            views.append(self._flat[off:off + g.numel()].view_as(g))
-            off += g.numel()
-        torch._foreach_copy_(views, grads)
-        dist.all_reduce(self._flat, op=dist.ReduceOp.SUM, group=self.group)
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
         if self.average:
-            self._flat.div_(dist.get_world_size(self.group))
-        torch._foreach_copy_(grads, views)
+            flat.div_(dist.get_world_size(self.group))
 
     def broadcast_parameters(self, src=0):
         """Make every rank start from rank `src`'s weights."""

@@ -76,7 +76,10 @@ class TrainLoop(object):
             if self.reducer is not None:
                 self.reducer.all_reduce()
             self.opt.step()
-            self.opt.zero_grad()
+            if self.reducer is not None:
+                self.reducer.zero_grads()          # the flat gradient arena stays attached: one memset
+            else:
+                self.opt.zero_grad()
             self.ave = 0
             stepped = True
         return loss, stepped

@@ -53,3 +53,38 @@ def test_shard_indices_partition():
     for n, w in [(20, 8), (5, 2), (3, 4)]:
         parts = [shard_indices(n, r, w) for r in range(w)]
         assert sorted(sum(parts, [])) == list(range(n))
+
+
+def test_flat_gradient_arena_views_zero_and_reattach():
+    """the reducer keeps every .grad as a view into one flat buffer: accumulation lands in it, zero_grads is one memset that
+    keeps the views, a foreign optimizer.zero_grad() (set_to_none) is repaired at the next call, parameters without a
+    gradient stay out of the buffer"""
+    sys.path.insert(0, REPO)
+    from osvos_pytorch_amd.parallel import GradientAllReducer
+    torch.manual_seed(1)
+    model = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(4, 1, 1))
+    model.register_parameter("frozen", torch.nn.Parameter(torch.ones(3)))
+    red = GradientAllReducer(model)
+    assert red.attach() is None
+    red.zero_grads()                                   # before the first backward: plain None
+    x = torch.randn(2, 3, 8, 8)
+    model(x).sum().backward()
+    ref = [p.grad.clone() for p in model.parameters() if p.grad is not None]
+    flat = red.attach()
+    live = [p for p in model.parameters() if p.grad is not None]
+    assert flat.numel() == sum(p.numel() for p in live) and model.frozen.grad is None
+    assert all(p.grad.data_ptr() >= flat.data_ptr() and p.grad.data_ptr() < flat.data_ptr() + flat.numel() * 4 for p in live)
+    assert all(torch.equal(p.grad, r) for p, r in zip(live, ref))
+    model(x).sum().backward()                          # autograd accumulates INTO the views
+    assert torch.allclose(flat, torch.cat([2 * r.flatten() for r in ref]))
+    ptrs = [p.grad.data_ptr() for p in live]
+    red.zero_grads()
+    assert float(flat.abs().max()) == 0.0 and [p.grad.data_ptr() for p in live] == ptrs
+    opt = torch.optim.SGD(model.parameters(), lr=0.1)
+    model(x).sum().backward()
+    opt.zero_grad()                                    # drops the views (set_to_none)
+    model(x).sum().backward()
+    assert red.attach() is flat and [p.grad.data_ptr() for p in live] == ptrs
+    assert torch.allclose(flat, torch.cat([r.flatten() for r in ref]))
+    red.all_reduce()                                   # no process group: a no-op that leaves the arena attached
+    assert [p.grad.data_ptr() for p in live] == ptrs
