@@ -85,3 +85,29 @@ def test_layer_helpers_match_reference_golden():
         interp_surgery(torch.nn.ConvTranspose2d(2, 2, (4, 6), bias=False))
     with pytest.raises(RuntimeError):
         class_balanced_cross_entropy_loss(torch.zeros(1, 1, 4, 4), torch.zeros(1, 1, 4, 4))
+
+
+def test_missing_library_fails_loudly_no_fallback(tmp_path):
+    """no extension, no automatic build -> RuntimeError at the first use; there is no CPU / torch fallback path to fall into.
+    (Run in a subprocess: the library handle is cached per process.)"""
+    import subprocess
+    import sys
+    code = ("import os, sys\n"
+            "sys.path.insert(0, %r)\n"
+            "os.environ['OSVOS_AUTOBUILD'] = '0'\n"
+            "import osvos_pytorch_amd._lib as L\n"
+            "L.SO_PATH = %r\n"
+            "try:\n"
+            "    L.lib()\n"
+            "except RuntimeError as e:\n"
+            "    print('RAISED', e)\n"
+            "else:\n"
+            "    print('LOADED')\n") % (REPO, str(tmp_path / "nope" / "libosvos_hip.so"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300).stdout
+    assert "RAISED" in out and "cannot load" in out, out
+    # and the module refuses CPU tensors instead of computing on them
+    import torch
+    import networks.vgg_osvos as vo
+    net = vo.OSVOS(pretrained=0)
+    with pytest.raises(RuntimeError):
+        net.forward(torch.zeros(1, 3, 16, 16))
