@@ -32,6 +32,8 @@ class NetRuntime:
         self.dtype = F32_BF16MFMA if os.environ.get("OSVOS_PRECISION", "fp32").lower() == "bf16" else F32
         self.aux_stream = None        # second HIP stream: wgrad kernels overlap the dgrad kernels
         self.aux2_stream = None       # third: the slab reduces of the weight gradients
+        self.auxf_stream = None       # forward side branches (own stream: a forward pipelined under the previous backward must not queue
+                                      # behind that backward's weight-gradient kernels)
         self.two_streams = os.environ.get("OSVOS_TWO_STREAMS", "1") != "0"
         self.inplace_accumulate = os.environ.get("OSVOS_INPLACE_GRAD", "1") != "0"
 
@@ -41,6 +43,13 @@ class NetRuntime:
         if self.aux_stream is None or self.aux_stream.device != device:
             self.aux_stream = torch.cuda.Stream(device=device)
         return C.c_void_p(self.aux_stream.cuda_stream)
+
+    def auxf(self, device):
+        if not self.two_streams:
+            return None
+        if self.auxf_stream is None or self.auxf_stream.device != device:
+            self.auxf_stream = torch.cuda.Stream(device=device)
+        return C.c_void_p(self.auxf_stream.cuda_stream)
 
     def aux2(self, device):
         if not self.two_streams or os.environ.get("OSVOS_THREE_STREAMS", "1") == "0":
@@ -114,7 +123,7 @@ class OSVOSNetFunction(torch.autograd.Function):
         ws = torch.empty(nbytes, device=xin.device, dtype=torch.uint8)
         outs = [torch.empty((n, 1, h, w), device=xin.device, dtype=torch.float32) for _ in range(5)]
         check(l.osvos_net_forward(C.c_void_p(xin.data_ptr()), C.c_void_p(rt.wbuf.data_ptr()), C.c_void_p(ws.data_ptr()),
-                                  ptr_array([o.data_ptr() for o in outs]), n, h, w, rt.dtype, _stream(), rt.aux(xin.device)), "net_forward")
+                                  ptr_array([o.data_ptr() for o in outs]), n, h, w, rt.dtype, _stream(), rt.auxf(xin.device)), "net_forward")
         ctx.rt, ctx.ws, ctx.shape = rt, ws, (n, h, w)
         ctx.param_meta = [(tuple(p.shape), p.device) for p in ps]
         ctx.params = params          # for in-place gradient accumulation in backward
