@@ -1,0 +1,60 @@
+"""CPU: host-side pieces of the section-8f components (no kernel runs): PNG writer, J statistics, affine-matrix host math,
+optimizer argument checks."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+
+def test_png_writer_round_trips_through_pil(tmp_path):
+    from PIL import Image
+    from osvos_pytorch_amd.results import write_png
+    rng = np.random.default_rng(0)
+    for shape in [(1, 1), (7, 13), (480, 854)]:
+        img = rng.integers(0, 256, shape, dtype=np.uint8)
+        p = str(tmp_path / ("a%dx%d.png" % shape))
+        write_png(p, img)
+        back = Image.open(p)
+        assert back.mode == "L" and back.size == (shape[1], shape[0]) and np.array_equal(np.array(back), img)
+    with pytest.raises(ValueError):
+        write_png(str(tmp_path / "bad.png"), np.zeros((2, 2, 3), dtype=np.uint8))
+
+
+def test_davis_statistics():
+    from osvos_pytorch_amd.results import davis_statistics
+    st = davis_statistics([1.0, 0.0])
+    assert st["mean"] == 0.5 and st["recall"] == 0.5
+    st = davis_statistics([0.9] * 4 + [0.5] * 4 + [0.5] * 4 + [0.1] * 4)
+    assert abs(st["decay"] - 0.8) < 1e-12 and abs(st["mean"] - 0.5) < 1e-12 and st["recall"] == 0.25
+    with pytest.raises(ValueError):
+        davis_statistics([])
+
+
+def test_rotation_matrix_inverse_matches_the_oracle_and_inverts():
+    from oracle import augment_ref as A
+    from osvos_pytorch_amd.augment import rotation_matrix_inverse
+    for (w, h, rot, sc) in [(854, 480, 17.5, 1.1), (31, 24, -30.0, 0.75), (10, 10, 0.0, 1.0)]:
+        m = rotation_matrix_inverse(w, h, rot, sc)
+        fwd = A.get_rotation_matrix_2d((w / 2, h / 2), rot, sc)
+        assert np.array_equal(np.array(m), A.invert_affine(fwd))            # same operations, same order: bit-equal doubles
+        full = np.vstack([fwd, [0, 0, 1]]) @ np.vstack([np.array(m).reshape(2, 3), [0, 0, 1]])
+        assert np.allclose(full, np.eye(3), atol=1e-9)
+
+
+def test_fused_sgd_argument_checks_and_cpu_refusal():
+    from osvos_pytorch_amd.optim import FusedSGD
+    p = [torch.zeros(3, requires_grad=True)]
+    for kw in ({"nesterov": True}, {"dampening": 0.1}, {"lr": -1.0}, {"momentum": -0.1}, {"weight_decay": -1.0}):
+        with pytest.raises(ValueError):
+            FusedSGD(p, **kw)
+    o = FusedSGD(p, lr=0.1, momentum=0.9)
+    o.step()                                   # no gradients: nothing to do, nothing touched
+    p[0].grad = torch.ones(3)
+    with pytest.raises(RuntimeError):
+        o.step()                               # CPU parameter: refused, no fallback
+    assert torch.equal(p[0].detach(), torch.zeros(3))
