@@ -77,48 +77,65 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WbArgs a) {
   stage_t rdy[NDY][8], rx[NX][8];
   f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
   const bool want_bias = a.bslab != nullptr && cit == 0;
-  auto ldg = [&](const void* base, size_t elem) -> stage_t {
-    if constexpr (XB != 0) return *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(base) + elem);
-    else return *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(base) + elem);
+  // Staging through raw buffer loads (as in the convolution kernels): the byte offset of every item relative to the patch origin is
+  // computed once; per patch a scalar origin offset is added, columns outside the image are pushed out of range by a compare +
+  // select, rows above / below fall out of the per-image buffer range by themselves.  No branch per load (48 of them per patch).
+  constexpr unsigned OOB = 0x80000000u;
+  constexpr int ES = XB ? 2 : 4;                             // bytes per element
+  unsigned dy_rel[NDY], x_rel[NX];
+  int dy_c0[NDY], x_c0[NX];                                  // first column of the item inside the patch / halo, -1 = no such item
+#pragma unroll
+  for (int u = 0; u < NDY; ++u) {
+    const int grp = sg + 16 * u;                             // row = grp / 4, x group = grp % 4
+    const int co = co0 + 4 * dq;
+    dy_rel[u] = (unsigned)((((grp >> 2) * a.W + (grp & 3) * 8) * a.Cout_s + co) * ES);
+    dy_c0[u] = co < a.Cout ? (grp & 3) * 8 : -1;
+  }
+#pragma unroll
+  for (int u = 0; u < NX; ++u) {
+    const int grp = sg + 16 * u;                             // halo row = grp / 5, x group = grp % 5
+    const int hy = grp / 5, hg = grp % 5, ci = ci0 + 4 * xq;
+    x_rel[u] = (unsigned)(((hy * a.W + hg * 8) * a.Cin_s + ci) * ES);
+    x_c0[u] = (grp < XROWS * 5 && ci < a.Cin_s) ? hg * 8 : -1;
+  }
+  auto ldb = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned off) -> stage_t {
+    if constexpr (XB != 0) {
+      typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+      const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, off, 0, 0);
+      return uint2{v[0], v[1]};
+    } else {
+      typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+      return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+    }
   };
-  auto zero = [&]() -> stage_t {
-    if constexpr (XB != 0) return uint2{0u, 0u};
-    else return f32x4{0.f, 0.f, 0.f, 0.f};
-  };
+  const int img_dy_bytes = a.H * a.W * a.Cout_s * ES, img_x_bytes = a.H * a.W * a.Cin_s * ES;
   auto load_patch = [&](int p) {
     const int px = p % a.npx;
     int t = p / a.npx;
     const int py = t % a.npy;
     const int n = t / a.npy;
     const int x0 = px * PW, y0 = py * PH;
+    const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(a.dy)) + (size_t)n * img_dy_bytes, 0, img_dy_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(a.x)) + (size_t)n * img_x_bytes, 0, img_x_bytes, 0x00020000);
+    const unsigned dy_base = (unsigned)((y0 * a.W + x0) * a.Cout_s * ES);
+    const unsigned x_base = (unsigned)(((y0 - 1) * a.W + (x0 - 1)) * a.Cin_s * ES);      // may be "negative": wraps out of range
 #pragma unroll
-    for (int u = 0; u < NDY; ++u) {
-      const int grp = sg + 16 * u;                         // 0..15: row = grp / 4, x group = grp % 4
-      const int gy = y0 + (grp >> 2), gx0 = x0 + (grp & 3) * 8, co = co0 + 4 * dq;
-      const bool ok = gy < a.H && co < a.Cout;
-      const size_t src = ((size_t)(n * a.H + gy) * a.W + gx0) * a.Cout_s + co;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        stage_t v = zero();
-        if (ok && gx0 + j < a.W) v = ldg(a.dy, src + (size_t)j * a.Cout_s);
-        rdy[u][j] = v;
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < NX; ++u) {
-      const int grp = sg + 16 * u;                         // 0..29 used: halo row = grp / 5, x group = grp % 5
-      const int it = grp < XROWS * 5 ? 0 : X_ITEMS;        // halo rows x 5 groups of 8 pixels exist
-      const int hy = grp / 5, hg = grp % 5;
-      const int gy = y0 + hy - 1, gx0 = x0 + hg * 8 - 1, ci = ci0 + 4 * xq;
-      const bool ok = it < X_ITEMS && gy >= 0 && gy < a.H && ci < a.Cin_s;
-      const ptrdiff_t src = ((ptrdiff_t)(n * a.H + gy) * a.W + gx0) * a.Cin_s + ci;
+    for (int u = 0; u < NDY; ++u)
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        stage_t v = zero();
-        if (ok && gx0 + j >= 0 && gx0 + j < a.W && hg * 8 + j < PW + 2) v = ldg(a.x, (size_t)(src + (ptrdiff_t)j * a.Cin_s));
-        rx[u][j] = v;
+        const unsigned off = (dy_c0[u] >= 0 && x0 + dy_c0[u] + j < a.W) ? dy_rel[u] + dy_base + (unsigned)(j * a.Cout_s * ES) : OOB;
+        rdy[u][j] = ldb(drs, off);
       }
-    }
+#pragma unroll
+    for (int u = 0; u < NX; ++u)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const bool ok = x_c0[u] >= 0 && x_c0[u] + j < PW + 2 && (unsigned)(x0 - 1 + x_c0[u] + j) < (unsigned)a.W;
+        const unsigned off = ok ? x_rel[u] + x_base + (unsigned)(j * a.Cin_s * ES) : OOB;
+        rx[u][j] = ldb(xrs, off);
+      }
   };
   // channel c of the pixel pair (j, j+1) -> one dword of two bf16: cvt_pk from fp32, v_perm_b32 byte select from bf16
   auto pair = [&](const stage_t& lo, const stage_t& hi, int c) -> unsigned {
@@ -314,6 +331,7 @@ int osvos_conv3x3_wgrad_bf16mfma_io(const void* x, const void* dy, int xb, void*
                                     int accumulate, hipStream_t stream) {
   OSVOS_ARG_CHECK(x && dy && ws && dw, "wgrad bf16: null pointer");
   OSVOS_ARG_CHECK(osvos_wgrad_bf16_applicable(Cin_s, Cout) && Cin == Cin_s && Cout_s % 4 == 0, "wgrad bf16: unsupported shape");
+  OSVOS_ARG_CHECK((long)H * W * Cin_s < (1L << 29) && (long)H * W * Cout_s < (1L << 29), "wgrad bf16: image too large for 31-bit byte offsets");
   WbPlan p = make_plan(N, H, W, Cin_s, Cout);
   WbArgs a;
   a.x = x; a.dy = dy;
