@@ -20,10 +20,12 @@
 
 namespace {
 
-constexpr int PW = 32, PH = 2;                 // pixel patch
-constexpr int PPIX = PW * PH;                  // 64 output pixels per patch
-constexpr int XW = PW + 2, XH = PH + 2;        // halo
-constexpr int XPIX = XW * XH;                  // 136
+// pixel patch of 64 output pixels: 32 x 2 by default, 16 x 4 (PWT = 16) where that pads the frame less (107-pixel wide conv4_x:
+// 112 instead of 128 columns are multiplied); halo = patch + 1 pixel on every side
+constexpr int PPIX = 64;
+template <int PWT> struct Geo {
+  static constexpr int PW = PWT, PH = PPIX / PWT, XW = PWT + 2, XH = PH + 2, XPIX = XW * XH;
+};
 
 struct WgArgs {
   const float* x;
@@ -38,8 +40,9 @@ struct WgArgs {
 
 // PIPE: pinned software pipeline of the operand fetch; DBUF: two LDS patch buffers (one barrier per
 // patch) instead of one (two barriers, half the LDS); OCC: __launch_bounds__ waves/SIMD
-template <int CB, int IB, int PIPE, int DBUF, int OCC>
+template <int CB, int IB, int PIPE, int DBUF, int OCC, int PWT = 32>
 __global__ __launch_bounds__(256, OCC) void wgrad_f32_kernel(WgArgs a) {
+  constexpr int PW = Geo<PWT>::PW, PH = Geo<PWT>::PH, XW = Geo<PWT>::XW, XPIX = Geo<PWT>::XPIX;
   constexpr int BCO = CB * 32, BCI = IB * 32;
   constexpr int DY_F4 = PPIX * BCO / 4, X_F4 = XPIX * BCI / 4;
   constexpr int BUF_F4 = DY_F4 + X_F4;
@@ -312,7 +315,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 }
 
 struct WgPlan {
-  int cb, ib, nco_t, nci_t, npx, npy, npatches, nsplit, per_split;
+  int cb, ib, pw, nco_t, nci_t, npx, npy, npatches, nsplit, per_split;
   size_t slab_floats, bslab_floats;
 };
 
@@ -321,12 +324,20 @@ WgPlan make_plan(int N, int H, int W, int Cin_s, int Cout) {
   if (Cout <= 32) { p.cb = 1; p.ib = 4; } else { p.cb = 2; p.ib = 2; }
   p.nco_t = ceil_div(Cout, p.cb * 32);
   p.nci_t = ceil_div(Cin_s, p.ib * 32);
+  // 16 x 4 patches when they cover the frame with at least 8 % fewer padded pixels (and the generic 64 x 64 kernel is used)
+  p.pw = 32;
+  if (p.cb == 2 && (long)ceil_div(W, 16) * 16 * ceil_div(H, 4) * 4 * 100 < (long)ceil_div(W, 32) * 32 * ceil_div(H, 2) * 2 * 92) p.pw = 16;
+  {
+    const char* e = getenv("OSVOS_WGRAD_PW");
+    if (e && p.cb == 2) p.pw = atoi(e) == 16 ? 16 : 32;
+  }
+  const int PW = p.pw, PH = PPIX / p.pw;
   p.npx = ceil_div(W, PW);
   p.npy = ceil_div(H, PH);
   p.npatches = N * p.npx * p.npy;
   const char* env = getenv("OSVOS_WGRAD_BLOCKS");
   // ~2 workgroups per CU; small frames (conv5 at 480p: 30 patches) prefer fewer, longer splits
-  int target_blocks = env ? atoi(env) : (N * ceil_div(W, PW) * ceil_div(H, PH) >= 100 ? 512 : 256);
+  int target_blocks = env ? atoi(env) : (p.npatches >= 100 ? 512 : 256);
   if (target_blocks < 1) target_blocks = 512;
   int want = ceil_div(target_blocks, p.nco_t * p.nci_t);
   int max_split = p.npatches / 4 > 0 ? p.npatches / 4 : 1;
@@ -340,16 +351,16 @@ WgPlan make_plan(int N, int H, int W, int Cin_s, int Cout) {
   return p;
 }
 
-template <int CB, int IB, int PIPE, int DBUF, int OCC>
+template <int CB, int IB, int PIPE, int DBUF, int OCC, int PWT = 32>
 int launch_wgrad(const WgArgs& a, long blocks, hipStream_t stream) {
-  constexpr size_t lds = (size_t)(DBUF ? 2 : 1) * (PPIX * CB * 32 + XPIX * IB * 32) * 4;
+  constexpr size_t lds = (size_t)(DBUF ? 2 : 1) * (PPIX * CB * 32 + Geo<PWT>::XPIX * IB * 32) * 4;
   static bool attr_set = false;
   if (!attr_set) {
-    OSVOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_f32_kernel<CB, IB, PIPE, DBUF, OCC>),
+    OSVOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_f32_kernel<CB, IB, PIPE, DBUF, OCC, PWT>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL((wgrad_f32_kernel<CB, IB, PIPE, DBUF, OCC>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL((wgrad_f32_kernel<CB, IB, PIPE, DBUF, OCC, PWT>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
   OSVOS_LAUNCH_CHECK();
   return 0;
 }
@@ -423,7 +434,9 @@ int osvos_conv3x3_wgrad_f32(const float* x, const float* dy, void* ws, float* dw
   a.oihw = (wgrad_variant() >> 3) & 1;
   const int phase = osvos_wgrad_phase();
   if (phase != 2) {
-    int rc = (p.cb == 1) ? launch_wgrad_variant<1, 4>(a, blocks, stream) : launch_wgrad_variant<2, 2>(a, blocks, stream);
+    int rc = (p.cb == 1) ? launch_wgrad_variant<1, 4>(a, blocks, stream)
+                         : (p.pw == 16 ? launch_wgrad<2, 2, 1, 0, 2, 16>(a, blocks, stream)      // (the measured-best variant only)
+                                       : launch_wgrad_variant<2, 2>(a, blocks, stream));
     if (rc) return rc;
   }
   if (phase == 1) return 0;
