@@ -386,8 +386,10 @@ int pick_ksplit(const TileInfo& t, int N, int H, int W, int Cin, int Cout, int C
   if (Cout % 4 != 0 || y_cs % 4 != 0 || Cin < 256) return 1;
   const long blocks = (long)N * ceil_div(H, t.th) * ceil_div(W, t.tw) * ceil_div(CoutP, t.bn);
   int ks = 1;
-  // measured (tools/tune_splitk.py): only grids of about one workgroup per CU gain (conv5_x at batch 1, 0.099 -> 0.090 ms);
-  // 6420-pixel and larger layers are MFMA-issue bound, not fill bound, and lose the finalize pass
+  // measured (tools/tune_splitk.py, end-of-round kernels): grids of about one workgroup per CU gain (conv5_x at batch 1, 0.090 -> 0.088
+  // ms).  conv4_x (896 workgroups, 3.5 per CU) would gain too (0.288 -> 0.269 ms, +1.7 % on the step) but is left un-split on purpose:
+  // the changed summation order moves the stage-0 gradients of the un-trained test net by ~1e-3 (ReLU / arg-max flips at near-ties),
+  // past the parity bar of tests/test_gpu_net.py::test_full_size_against_cpu_oracle.  OSVOS_CONV_KSPLIT=2 forces it.
   while (ks < 8 && blocks * ks < 512 && (Cin / 8) / (ks * 2) >= 8) ks *= 2;
   return ks;
 }
