@@ -13,6 +13,35 @@ for n, c, tot, avg, pct in rows:
     n = n.replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")
     out.append("%-96s %7d %12.1f %10.1f %6.2f" % (n[:96], c, tot / steps, avg, pct))
 out.append("total kernel time per step: %.1f us" % (sum(r[2] for r in rows) / steps))
+
+# forward / backward split of the convolution launches (the same kernel runs both passes): a step's forward is everything between
+# its NCHW->NHWC conversion and its first loss kernel.  This is the row to hold against bench.py's roofline.families.conv_fwd
+# (hipEvent-timed, un-profiled): ms_per_step / launches there = the average forward launch duration here.
+try:
+    tabs = [r[0] for r in db.execute("select name from sqlite_master where type in ('table','view')")]
+    ks = [t for t in tabs if "kernel_symbol" in t.lower()][-1]
+    cols = [r[1] for r in db.execute("pragma table_info(%s)" % ks)]
+    namecol = "kernel_name" if "kernel_name" in cols else cols[-1]
+    disp = list(db.execute("select s.%s, d.start, d.end, d.stream_id from rocpd_kernel_dispatch d join %s s on d.kernel_id = s.id order by d.start" % (namecol, ks)))
+    phase, acc, main = None, {"fwd": [], "bwd": []}, {"fwd": [], "bwd": []}
+    main_stream = None
+    for name, t0, t1, stream in disp:
+        if "nchw_to_nhwc" in name:
+            phase, main_stream = "fwd", stream
+        elif "cbce_count" in name:
+            phase = "bwd"
+        elif phase and ("conv3x3_f32_kernel" in name or "conv3x3_bf16_kernel" in name or "conv3x3_bf16_dma_kernel" in name):
+            acc[phase].append((t1 - t0) / 1e3)
+            if stream == main_stream:
+                main[phase].append((t1 - t0) / 1e3)
+    for ph, label in (("fwd", "forward"), ("bwd", "backward (data gradient, overlapped with the weight-gradient stream)")):
+        if acc[ph]:
+            out.append("conv3x3 launches in the %s: %d (%.1f per step), average %.1f us, %.1f us per step"
+                       % (label, len(acc[ph]), len(acc[ph]) / steps, sum(acc[ph]) / len(acc[ph]), sum(acc[ph]) / steps))
+            out.append("    of which on the main stream (the side-branch 3x3 convs run beside them on a second stream): %d, average %.1f us, %.1f us per step"
+                       % (len(main[ph]), sum(main[ph]) / max(1, len(main[ph])), sum(main[ph]) / steps))
+except Exception as e:      # older trace layouts: keep the plain table
+    out.append("(forward/backward split unavailable: %s)" % e)
 text = "\n".join(out)
 if len(sys.argv) > 3:
     open(sys.argv[3], "w").write(text + "\n")
