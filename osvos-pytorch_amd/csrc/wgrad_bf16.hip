@@ -14,6 +14,7 @@
 // 9 accumulators, 1 A read + 6 B reads + 12 VALU per 9 MFMAs (a 128-cout tile with 18 accumulators
 // per wave spills: 288 accumulator + 128 staging registers).
 #include "common.h"
+#include <stdlib.h>
 #include <type_traits>
 
 namespace {
@@ -37,6 +38,8 @@ struct WbArgs {
   float* bslab;
   int N, H, W, Cin_s, Cout, Cout_s;
   int npx, npy, npatches, per_split, nco_t, nci_t;
+  int map;               // 1: XCD-local order (the channel tiles of one split share an XCD = one L2)
+  unsigned long long* prof;   // phase counters, read only by builds with -DOSVOS_WGRAD_PROF (tools/native/wgrad_probe.cpp)
 };
 
 __device__ inline unsigned pack2(float lo, float hi) {
@@ -57,7 +60,10 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WbArgs a) {
   const int li = lane & 31, lh = lane >> 5;
   const int wc = wave >> 1, wi = wave & 1;
 
+  // map 1: block b runs on XCD b % 8; give every XCD whole splits, so that the nco_t x nci_t workgroups that stream the same pixels
+  // (one split) sit behind the same L2 and the patch data crosses the fabric once instead of once per XCD
   int id = blockIdx.x;
+  if (a.map == 1) id = (id & 7) * (gridDim.x >> 3) + (id >> 3);
   const int cit = id % a.nci_t;
   id /= a.nci_t;
   const int cot = id % a.nco_t;
@@ -104,7 +110,6 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WbArgs a) {
       const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, off, 0, 0);
       return uint2{v[0], v[1]};
     } else {
-      typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
       return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
     }
   };
@@ -198,12 +203,28 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WbArgs a) {
   const char* a_base = dYs + (wc * 32 + li) * DY_CSTRIDE + lh * 16;
   const char* b_base = Xs + (wi * 32 + li) * X_CSTRIDE + lh * 16;
 
+#ifdef OSVOS_WGRAD_PROF
+  unsigned long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tp = __builtin_amdgcn_s_memtime(), tq;
+  const unsigned long long t_begin = tp;
+#define WPROF(k) do { __builtin_amdgcn_sched_barrier(0); tq = __builtin_amdgcn_s_memtime(); pt[k] += tq - tp; tp = tq; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define WPROF(k) do { } while (0)
+#endif
   if (p_begin < p_end) load_patch(p_begin);
+  WPROF(0);
   for (int p = p_begin; p < p_end; ++p) {
     __syncthreads();
+    WPROF(1);
+#ifdef OSVOS_WGRAD_PROF
+    __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0): the wait for the patch's global loads, separated from the transposing stores
+    WPROF(2);
+#endif
     store_patch();
+    WPROF(3);
     __syncthreads();
+    WPROF(4);
     if (p + 1 < p_end) load_patch(p + 1);
+    WPROF(5);
     // k-step = 16 consecutive pixels of one patch row.  One wave per SIMD (288 registers), so the loop is software
     // pipelined by hand: the 7 LDS reads of k-step ks+1 are requested before the 9 MFMAs of k-step ks issue
     // (two named register sets, sched_barrier pins the order -- hipcc otherwise sinks the reads to their first use)
@@ -248,6 +269,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WbArgs a) {
       mm(f1);
       __builtin_amdgcn_sched_barrier(0);
     }
+    WPROF(6);
   }
   __syncthreads();
 
@@ -271,6 +293,15 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WbArgs a) {
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), srs, off, 0, 0);
       }
   }
+#ifdef OSVOS_WGRAD_PROF
+  WPROF(7);
+  if (a.prof != nullptr && lane == 0) {
+    unsigned long long* q = a.prof + ((size_t)blockIdx.x * 4 + wave) * 10;
+    for (int k = 0; k < 8; ++k) q[k] = pt[k];
+    q[8] = t_begin;
+    q[9] = tp;
+  }
+#endif
   if (a.bslab != nullptr && cit == 0) {
     f32x4* red = reinterpret_cast<f32x4*>(smem);          // [16 pixel groups][16 quads]
     red[sg * 16 + sq] = bsum;
@@ -285,6 +316,246 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WbArgs a) {
     }
   }
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// bf16-in-HBM staging, second form (tools/native/wgrad_probe: the first form spends 34-37 % of a wave's life ISSUING the next patch's
+// 32 buffer_load_b64 -- a wave-level load costs the CU ~32-38 cycles whatever its width or lane pattern, i.e. 13 B/clk/CU with
+// 8-byte lanes -- and the MFMA pipe idles meanwhile: one wave per SIMD, and a wave held in a vmem issue cannot issue MFMAs):
+//   * item = 8 pixels x 8 channels: eight 16-byte loads (one pixel's channel octet each), 24 per thread and patch instead of 32;
+//     eight consecutive lanes hold two octets x four pixel groups, so the transposing ds_write_b128 are 2-way conflicted at worst
+//     (13 issue cycles hide 16 array cycles) and the fragment reads stay conflict-free
+//   * the loads of patch p+1 are issued from inside the (fully unrolled) k-loop of patch p, three per two k-steps, so they drain
+//     behind 18 MFMAs instead of in front of them
+// Measured and dropped (profiles/r01_wgrad_bf16_forms.txt): line-contiguous lanes with skewed channel rows (same time: the address
+// pattern is not what limits the loads); twelve waves with the tap rows cut across waves (3 accumulators per wave, three waves per
+// SIMD), single and double buffered; separate producer and consumer waves over two 6-row tile buffers.  All land within 3 % of
+// this form: what they share is the 76 KB a workgroup streams per 18.9 MFLOP patch, ~8 B/clk/CU sustained -- the tile, not the
+// schedule, is the limit, and 144 accumulator registers per wave leave no room for a bigger one.
+__global__ __launch_bounds__(256) void wgrad_bf16v2_kernel(WbArgs a) {
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* dYs = smem;
+  char* Xs = smem + DY_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wc = wave >> 1, wi = wave & 1;
+
+  int id = blockIdx.x;
+  if (a.map == 1) id = (id & 7) * (gridDim.x >> 3) + (id >> 3);
+  const int cit = id % a.nci_t;
+  id /= a.nci_t;
+  const int cot = id % a.nco_t;
+  const int split = id / a.nco_t;
+  const int co0 = cot * BCO, ci0 = cit * BCI;
+  const int p_begin = split * a.per_split, p_end = min(p_begin + a.per_split, a.npatches);
+
+  // items: (pixel group of 8 along x, channel octet).  dY: 32 groups x 8 octets = one per thread; X halo: 50 x 8 = 400, two slots per thread
+  const int so = (tid & 1) | ((tid >> 2) & 6);
+  const int sg = ((tid >> 1) & 3) | ((tid >> 3) & 0x1c);       // 0..31; the second X item is group sg + 32
+  constexpr unsigned OOB = 0x80000000u;
+  u32x4 rdy[8], rx[2][8];
+  float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const bool want_bias = a.bslab != nullptr && cit == 0;
+  const int dy_c0 = (co0 + 8 * so < a.Cout) ? (sg & 3) * 8 : -1000000;              // first column of the item inside the patch
+  const unsigned dy_rel = (unsigned)((((sg >> 2) * a.W + (sg & 3) * 8) * a.Cout_s + co0 + 8 * so) * 2);
+  unsigned x_rel[2];
+  int x_c0[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int g = sg + 32 * u, hy = g / 5, hg = g % 5;
+    x_rel[u] = (unsigned)(((hy * a.W + hg * 8) * a.Cin_s + ci0 + 8 * so) * 2);
+    x_c0[u] = (g < XROWS * 5 && ci0 + 8 * so < a.Cin_s) ? hg * 8 : -1000000;
+  }
+  const int img_dy_bytes = a.H * a.W * a.Cout_s * 2, img_x_bytes = a.H * a.W * a.Cin_s * 2;
+  const unsigned dy_pix = (unsigned)(a.Cout_s * 2), x_pix = (unsigned)(a.Cin_s * 2);
+
+  struct Patch { __amdgpu_buffer_rsrc_t drs, xrs; unsigned dy_base, x_base; int x0; };
+  auto locate = [&](int p, bool live) -> Patch {
+    const int px = p % a.npx;
+    int t = p / a.npx;
+    const int py = t % a.npy;
+    const int n = live ? t / a.npy : 0;
+    Patch q;
+    q.x0 = live ? px * PW : 0x40000000;            // dead patch (past the split's last): every column test fails -> all loads out of range
+    const int y0 = py * PH;
+    q.drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(a.dy)) + (size_t)n * img_dy_bytes, 0, img_dy_bytes, 0x00020000);
+    q.xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(a.x)) + (size_t)n * img_x_bytes, 0, img_x_bytes, 0x00020000);
+    q.dy_base = (unsigned)((y0 * a.W + px * PW) * a.Cout_s * 2);
+    q.x_base = (unsigned)(((y0 - 1) * a.W + (px * PW - 1)) * a.Cin_s * 2);       // may be "negative": wraps out of range
+    return q;
+  };
+  // load number i of a patch: 0-7 dY pixel i; 8-23 X item (i-8)/8 pixel (i-8)%8
+  auto issue = [&](const Patch& q, int i) {
+    if (i < 8) {
+      const unsigned off = (q.x0 + dy_c0 + i < a.W && dy_c0 >= 0) ? dy_rel + q.dy_base + (unsigned)i * dy_pix : OOB;
+      rdy[i] = __builtin_amdgcn_raw_buffer_load_b128(q.drs, off, 0, 0);
+    } else {
+      const int u = (i - 8) >> 3, j = (i - 8) & 7;
+      const bool ok = x_c0[u] >= 0 && x_c0[u] + j < PW + 2 && (unsigned)(q.x0 - 1 + x_c0[u] + j) < (unsigned)a.W;
+      const unsigned off = ok ? x_rel[u] + q.x_base + (unsigned)j * x_pix : OOB;
+      rx[u][j] = __builtin_amdgcn_raw_buffer_load_b128(q.xrs, off, 0, 0);
+    }
+  };
+  // 8 pixels x 8 channels in registers -> per channel one 16-byte row piece of 8 pixels (v_perm_b32 picks the two bf16 of a pixel pair)
+  auto transpose_store = [&](const u32x4 (&r)[8], char* row0, int row_stride) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const unsigned sel = (c & 1) ? 0x07060302u : 0x05040100u;
+      uint4 v;
+      v.x = __builtin_amdgcn_perm(r[1][c >> 1], r[0][c >> 1], sel);
+      v.y = __builtin_amdgcn_perm(r[3][c >> 1], r[2][c >> 1], sel);
+      v.z = __builtin_amdgcn_perm(r[5][c >> 1], r[4][c >> 1], sel);
+      v.w = __builtin_amdgcn_perm(r[7][c >> 1], r[6][c >> 1], sel);
+      *reinterpret_cast<uint4*>(row0 + c * row_stride) = v;
+    }
+  };
+  char* const dy_dst = dYs + (8 * so) * DY_CSTRIDE + sg * 16;
+  char* const x_dst = Xs + (8 * so) * X_CSTRIDE + sg * 16;
+  auto store_patch = [&]() {
+    if (want_bias) {                                  // bias gradient: fp32 column sums of the (bf16) dY
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          bsum[2 * d] += __uint_as_float(rdy[j][d] << 16);
+          bsum[2 * d + 1] += __uint_as_float(rdy[j][d] & 0xffff0000u);
+        }
+    }
+    transpose_store(rdy, dy_dst, DY_CSTRIDE);
+    transpose_store(rx[0], x_dst, X_CSTRIDE);
+    if (sg + 32 < XROWS * 5) transpose_store(rx[1], x_dst + 32 * 16, X_CSTRIDE);
+  };
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  const int ca = wc * 32 + li, cb = wi * 32 + li;
+  const char* a_base = dYs + ca * DY_CSTRIDE + lh * 16;
+  const char* b_base = Xs + cb * X_CSTRIDE + lh * 16;
+
+#ifdef OSVOS_WGRAD_PROF
+  unsigned long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tp = __builtin_amdgcn_s_memtime(), tq;
+  const unsigned long long t_begin = tp;
+#endif
+  {
+    const Patch q = locate(p_begin, p_begin < p_end);
+#pragma unroll
+    for (int i = 0; i < 24; ++i) issue(q, i);
+  }
+  WPROF(0);
+  for (int p = p_begin; p < p_end; ++p) {
+    __syncthreads();
+    WPROF(1);
+#ifdef OSVOS_WGRAD_PROF
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    WPROF(2);
+#endif
+    store_patch();
+    WPROF(3);
+    __syncthreads();
+    WPROF(4);
+    const Patch nx = locate(p + 1, p + 1 < p_end);
+    WPROF(5);
+    struct Frag { uint4 a0; uint4 w0[3]; unsigned w4[3]; };
+    auto ldk = [&](int ks, Frag& f) {
+      const int row = ks >> 1, kx = ks & 1;
+      f.a0 = *reinterpret_cast<const uint4*>(a_base + (row * PW + kx * 16) * 2);
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const char* src = b_base + ((row + r) * XPITCH + kx * 16) * 2;
+        f.w0[r] = *reinterpret_cast<const uint4*>(src);
+        f.w4[r] = reinterpret_cast<const uint4*>(src + 16)->x;
+      }
+    };
+    // rows of taps; `mid` (a load number or -1) is issued after the first row's three MFMAs
+    auto mm = [&](const Frag& f, int mid) {
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        uint4 b[3];
+        b[0] = f.w0[r];
+        b[1].x = __builtin_amdgcn_alignbit(f.w0[r].y, f.w0[r].x, 16);
+        b[1].y = __builtin_amdgcn_alignbit(f.w0[r].z, f.w0[r].y, 16);
+        b[1].z = __builtin_amdgcn_alignbit(f.w0[r].w, f.w0[r].z, 16);
+        b[1].w = __builtin_amdgcn_alignbit(f.w4[r], f.w0[r].w, 16);
+        b[2].x = f.w0[r].y; b[2].y = f.w0[r].z; b[2].z = f.w0[r].w; b[2].w = f.w4[r];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+          const bf16x8_t bb = __builtin_bit_cast(bf16x8_t, b[s]);
+          acc[r * 3 + s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bb, __builtin_bit_cast(bf16x8_t, f.a0), acc[r * 3 + s], 0, 0, 0);
+        }
+        if (r == 0 && mid >= 0) {
+          __builtin_amdgcn_sched_barrier(0);
+          issue(nx, mid);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    };
+    Frag f0, f1;
+    ldk(0, f0);
+#pragma unroll
+    for (int it = 0; it < PH; ++it) {                     // two k-steps and three loads of the next patch per turn
+      ldk(2 * it + 1, f1);
+      issue(nx, 3 * it);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(f0, 3 * it + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      ldk((2 * it + 2) & (PH * 2 - 1), f0);
+      issue(nx, 3 * it + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(f1, -1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    WPROF(6);
+  }
+  __syncthreads();
+
+  {   // slab epilogue, as in the first form
+    const size_t slab_elems = (size_t)9 * a.Cout * a.Cin_s;
+    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(a.slab + (size_t)split * slab_elems, 0, (int)(slab_elems * 4), 0x00020000);
+    const int co = co0 + wc * 32 + li;
+    const int cib = ci0 + wi * 32 + 4 * lh;
+    const unsigned row = co < a.Cout ? (unsigned)(co * a.Cin_s) * 4u : OOB;
+    const unsigned tap_stride = (unsigned)(a.Cout * a.Cin_s) * 4u;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int ci = cib + 8 * q;
+        const unsigned off = ci < a.Cin_s ? row + (unsigned)t * tap_stride + (unsigned)ci * 4u : OOB;
+        const f32x4 v = {acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), srs, off, 0, 0);
+      }
+  }
+#ifdef OSVOS_WGRAD_PROF
+  WPROF(7);
+  if (a.prof != nullptr && lane == 0) {
+    unsigned long long* q = a.prof + ((size_t)blockIdx.x * 4 + wave) * 10;
+    for (int k = 0; k < 8; ++k) q[k] = pt[k];
+    q[8] = t_begin;
+    q[9] = tp;
+  }
+#endif
+  if (want_bias) {
+    float* red = reinterpret_cast<float*>(smem);          // [32 pixel groups][8 octets][8 channels]
+#pragma unroll
+    for (int c = 0; c < 8; ++c) red[(sg * 8 + so) * 8 + c] = bsum[c];
+    __syncthreads();
+    if (tid < 64) {
+      float sum = 0.f;
+      for (int g = 0; g < 32; ++g) sum += red[g * 64 + tid];
+      if (co0 + tid < a.Cout) a.bslab[(size_t)split * a.Cout + co0 + tid] = sum;
+    }
+  }
+}
+constexpr size_t kLdsV2 = (size_t)DY_BYTES + X_BYTES;
+
+constexpr int kDefaultMap = 1;      // bf16-input form: XCD-local split order (L2 hit rate 38 % -> 77 %, HBM reads / 3; OSVOS_WGRAD_MAP=0 turns it off)
+constexpr int kDefaultForm = 1;     // bf16-input kernel: 1 = second staging form (wgrad_bf16v2_kernel), 0 = first (OSVOS_WGRAD_FORM)
+unsigned long long* g_wgrad_prof = nullptr;
 
 struct WbPlan {
   int nco_t, nci_t, npx, npy, npatches, nsplit, per_split;
@@ -332,6 +603,8 @@ int osvos_conv3x3_wgrad_bf16mfma_io(const void* x, const void* dy, int xb, void*
   OSVOS_ARG_CHECK(x && dy && ws && dw, "wgrad bf16: null pointer");
   OSVOS_ARG_CHECK(osvos_wgrad_bf16_applicable(Cin_s, Cout) && Cin == Cin_s && Cout_s % 4 == 0, "wgrad bf16: unsupported shape");
   OSVOS_ARG_CHECK((long)H * W * Cin_s < (1L << 29) && (long)H * W * Cout_s < (1L << 29), "wgrad bf16: image too large for 31-bit byte offsets");
+  static const int form_env = getenv("OSVOS_WGRAD_FORM") ? atoi(getenv("OSVOS_WGRAD_FORM")) : -1;
+  const int form = xb ? (form_env >= 0 ? form_env : kDefaultForm) : 0;
   WbPlan p = make_plan(N, H, W, Cin_s, Cout);
   WbArgs a;
   a.x = x; a.dy = dy;
@@ -339,6 +612,10 @@ int osvos_conv3x3_wgrad_bf16mfma_io(const void* x, const void* dy, int xb, void*
   a.bslab = db ? a.slab + p.slab_floats : nullptr;
   a.N = N; a.H = H; a.W = W; a.Cin_s = Cin_s; a.Cout = Cout; a.Cout_s = Cout_s;
   a.npx = p.npx; a.npy = p.npy; a.npatches = p.npatches; a.per_split = p.per_split; a.nco_t = p.nco_t; a.nci_t = p.nci_t;
+  const long blocks = (long)p.nsplit * p.nco_t * p.nci_t;
+  static const int map_env = getenv("OSVOS_WGRAD_MAP") ? atoi(getenv("OSVOS_WGRAD_MAP")) : -1;
+  a.map = (map_env >= 0 ? map_env : kDefaultMap) == 1 && blocks % 8 == 0 ? 1 : 0;
+  a.prof = g_wgrad_prof;
   constexpr size_t lds = (size_t)DY_BYTES + X_BYTES;
   static bool attr_set = false;
   if (!attr_set) {
@@ -348,9 +625,16 @@ int osvos_conv3x3_wgrad_bf16mfma_io(const void* x, const void* dy, int xb, void*
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  const long blocks = (long)p.nsplit * p.nco_t * p.nci_t;
   const int phase = osvos_wgrad_phase();
-  if (phase != 2) {
+  if (phase != 2 && form != 0) {
+    static bool attr2_set = false;
+    if (!attr2_set) {
+      OSVOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsV2));
+      attr2_set = true;
+    }
+    hipLaunchKernelGGL(wgrad_bf16v2_kernel, dim3((unsigned)blocks), dim3(256), kLdsV2, stream, a);
+    OSVOS_LAUNCH_CHECK();
+  } else if (phase != 2) {
     if (xb) hipLaunchKernelGGL(wgrad_bf16_kernel<1>, dim3((unsigned)blocks), dim3(256), lds, stream, a);
     else hipLaunchKernelGGL(wgrad_bf16_kernel<0>, dim3((unsigned)blocks), dim3(256), lds, stream, a);
     OSVOS_LAUNCH_CHECK();
@@ -358,6 +642,10 @@ int osvos_conv3x3_wgrad_bf16mfma_io(const void* x, const void* dy, int xb, void*
   if (phase == 1) return 0;
   return osvos_wgrad_reduce_launch(a.slab, a.bslab, dw, db, p.nsplit, Cout, Cin, Cin_s, accumulate, stream);
 }
+
+#ifdef OSVOS_WGRAD_PROF
+extern "C" void osvos_debug_set_wgrad_prof_bf16(unsigned long long* p) { g_wgrad_prof = p; }
+#endif
 
 int osvos_conv3x3_wgrad_bf16mfma(const float* x, const float* dy, void* ws, float* dw, float* db,
                                  int N, int H, int W, int Cin, int Cin_s, int Cout, int Cout_s,
