@@ -40,6 +40,7 @@ struct WbArgs {
   int npx, npy, npatches, per_split, nco_t, nci_t;
   int map;               // 1: XCD-local order (the channel tiles of one split share an XCD = one L2)
   unsigned long long* prof;   // phase counters, read only by builds with -DOSVOS_WGRAD_PROF (tools/native/wgrad_probe.cpp)
+  int dbg;               // PROF builds: 1 = skip the X loads, 2 = skip all loads (wrong results; how much do the streamed bytes cost?)
 };
 
 __device__ inline unsigned pack2(float lo, float hi) {
@@ -332,11 +333,16 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WbArgs a) {
 // SIMD), single and double buffered; separate producer and consumer waves over two 6-row tile buffers.  All land within 3 % of
 // this form: what they share is the 76 KB a workgroup streams per 18.9 MFLOP patch, ~8 B/clk/CU sustained -- the tile, not the
 // schedule, is the limit, and 144 accumulator registers per wave leave no room for a bigger one.
-__global__ __launch_bounds__(256) void wgrad_bf16v2_kernel(WbArgs a) {
+// WAVES = 4: 64 couts x 64 cins per workgroup, one wave per SIMD.  WAVES = 8: 128 couts x 64 cins -- the register budget of two waves
+// per SIMD (256) holds 144 accumulators + ONE dY and ONE X item of staging: a wave stuck in a vmem issue or in the transposing stores
+// leaves the matrix pipe to its neighbour, and a patch costs 16 loads per 144 MFMAs instead of 24
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void wgrad_bf16v2_kernel(WbArgs a) {
+  constexpr int BCOT = 16 * WAVES, OCT = BCOT / 8, NXI = WAVES == 4 ? 2 : 1, NLD = 8 + 8 * NXI, DYT_BYTES = BCOT * DY_CSTRIDE;
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* dYs = smem;
-  char* Xs = smem + DY_BYTES;
+  char* Xs = smem + DYT_BYTES;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int wc = wave >> 1, wi = wave & 1;
@@ -347,25 +353,34 @@ __global__ __launch_bounds__(256) void wgrad_bf16v2_kernel(WbArgs a) {
   id /= a.nci_t;
   const int cot = id % a.nco_t;
   const int split = id / a.nco_t;
-  const int co0 = cot * BCO, ci0 = cit * BCI;
+  const int co0 = cot * BCOT, ci0 = cit * BCI;
   const int p_begin = split * a.per_split, p_end = min(p_begin + a.per_split, a.npatches);
 
   // items: (pixel group of 8 along x, channel octet).  dY: 32 groups x 8 octets = one per thread; X halo: 50 x 8 = 400, two slots per thread
-  const int so = (tid & 1) | ((tid >> 2) & 6);
-  const int sg = ((tid >> 1) & 3) | ((tid >> 3) & 0x1c);       // 0..31; the second X item is group sg + 32
+  // (tid bits, low to high: octet bit 0, group bits 0-1, the other octet bits, the other group bits)
+  const int so = WAVES == 4 ? (tid & 1) | ((tid >> 2) & 6) : (tid & 1) | ((tid >> 2) & 0xe);                 // dY item: octet 0..OCT-1
+  const int sg = WAVES == 4 ? ((tid >> 1) & 3) | ((tid >> 3) & 0x1c) : ((tid >> 1) & 3) | ((tid >> 4) & 0x1c);   // and pixel group 0..31
+  const int xo = (tid & 1) | ((tid >> 2) & 6);                                                               // X item(s): octet 0..7
+  const int xg = ((tid >> 1) & 3) | ((tid >> 3) & (WAVES == 4 ? 0x1c : 0x3c));       // group 0..31 (a second item is group + 32) / 0..63
   constexpr unsigned OOB = 0x80000000u;
-  u32x4 rdy[8], rx[2][8];
+  u32x4 rdy[8], rx[NXI][8];
   float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const bool want_bias = a.bslab != nullptr && cit == 0;
-  const int dy_c0 = (co0 + 8 * so < a.Cout) ? (sg & 3) * 8 : -1000000;              // first column of the item inside the patch
+  int dy_c0 = (co0 + 8 * so < a.Cout) ? (sg & 3) * 8 : -1000000;              // first column of the item inside the patch
+#ifdef OSVOS_WGRAD_PROF
+  if (a.dbg >= 2) dy_c0 = -1000000;
+#endif
   const unsigned dy_rel = (unsigned)((((sg >> 2) * a.W + (sg & 3) * 8) * a.Cout_s + co0 + 8 * so) * 2);
-  unsigned x_rel[2];
-  int x_c0[2];
+  unsigned x_rel[NXI];
+  int x_c0[NXI];
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int g = sg + 32 * u, hy = g / 5, hg = g % 5;
-    x_rel[u] = (unsigned)(((hy * a.W + hg * 8) * a.Cin_s + ci0 + 8 * so) * 2);
-    x_c0[u] = (g < XROWS * 5 && ci0 + 8 * so < a.Cin_s) ? hg * 8 : -1000000;
+  for (int u = 0; u < NXI; ++u) {
+    const int g = xg + 32 * u, hy = g / 5, hg = g % 5;
+    x_rel[u] = (unsigned)(((hy * a.W + hg * 8) * a.Cin_s + ci0 + 8 * xo) * 2);
+    x_c0[u] = (g < XROWS * 5 && ci0 + 8 * xo < a.Cin_s) ? hg * 8 : -1000000;
+#ifdef OSVOS_WGRAD_PROF
+    if (a.dbg >= 1) x_c0[u] = -1000000;
+#endif
   }
   const int img_dy_bytes = a.H * a.W * a.Cout_s * 2, img_x_bytes = a.H * a.W * a.Cin_s * 2;
   const unsigned dy_pix = (unsigned)(a.Cout_s * 2), x_pix = (unsigned)(a.Cin_s * 2);
@@ -385,8 +400,9 @@ __global__ __launch_bounds__(256) void wgrad_bf16v2_kernel(WbArgs a) {
     q.x_base = (unsigned)(((y0 - 1) * a.W + (px * PW - 1)) * a.Cin_s * 2);       // may be "negative": wraps out of range
     return q;
   };
-  // load number i of a patch: 0-7 dY pixel i; 8-23 X item (i-8)/8 pixel (i-8)%8
+  // load number i of a patch: 0-7 dY pixel i; 8.. X item (i-8)/8 pixel (i-8)%8; past the last: nothing
   auto issue = [&](const Patch& q, int i) {
+    if (i >= NLD) return;
     if (i < 8) {
       const unsigned off = (q.x0 + dy_c0 + i < a.W && dy_c0 >= 0) ? dy_rel + q.dy_base + (unsigned)i * dy_pix : OOB;
       rdy[i] = __builtin_amdgcn_raw_buffer_load_b128(q.drs, off, 0, 0);
@@ -411,7 +427,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16v2_kernel(WbArgs a) {
     }
   };
   char* const dy_dst = dYs + (8 * so) * DY_CSTRIDE + sg * 16;
-  char* const x_dst = Xs + (8 * so) * X_CSTRIDE + sg * 16;
+  char* const x_dst = Xs + (8 * xo) * X_CSTRIDE + xg * 16;
   auto store_patch = [&]() {
     if (want_bias) {                                  // bias gradient: fp32 column sums of the (bf16) dY
 #pragma unroll
@@ -423,8 +439,10 @@ __global__ __launch_bounds__(256) void wgrad_bf16v2_kernel(WbArgs a) {
         }
     }
     transpose_store(rdy, dy_dst, DY_CSTRIDE);
-    transpose_store(rx[0], x_dst, X_CSTRIDE);
-    if (sg + 32 < XROWS * 5) transpose_store(rx[1], x_dst + 32 * 16, X_CSTRIDE);
+    if (xg < XROWS * 5) transpose_store(rx[0], x_dst, X_CSTRIDE);
+    if constexpr (NXI == 2) {
+      if (xg + 32 < XROWS * 5) transpose_store(rx[NXI - 1], x_dst + 32 * 16, X_CSTRIDE);
+    }
   };
 
   f32x16 acc[9];
@@ -444,7 +462,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16v2_kernel(WbArgs a) {
   {
     const Patch q = locate(p_begin, p_begin < p_end);
 #pragma unroll
-    for (int i = 0; i < 24; ++i) issue(q, i);
+    for (int i = 0; i < NLD; ++i) issue(q, i);
   }
   WPROF(0);
   for (int p = p_begin; p < p_end; ++p) {
@@ -462,6 +480,9 @@ __global__ __launch_bounds__(256) void wgrad_bf16v2_kernel(WbArgs a) {
     WPROF(5);
     struct Frag { uint4 a0; uint4 w0[3]; unsigned w4[3]; };
     auto ldk = [&](int ks, Frag& f) {
+#if defined(OSVOS_WGRAD_ABL) && OSVOS_WGRAD_ABL == 2
+      if (ks > 1) return;                                  // ablation: no LDS fragment reads after the first two k-steps
+#endif
       const int row = ks >> 1, kx = ks & 1;
       f.a0 = *reinterpret_cast<const uint4*>(a_base + (row * PW + kx * 16) * 2);
 #pragma unroll
@@ -484,30 +505,58 @@ __global__ __launch_bounds__(256) void wgrad_bf16v2_kernel(WbArgs a) {
         b[2].x = f.w0[r].y; b[2].y = f.w0[r].z; b[2].z = f.w0[r].w; b[2].w = f.w4[r];
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
+#if defined(OSVOS_WGRAD_ABL) && OSVOS_WGRAD_ABL == 1
+          acc[r * 3 + s][0] += __uint_as_float(b[s].x ^ b[s].y ^ b[s].z ^ b[s].w ^ f.a0.x ^ f.a0.w);      // ablation: no MFMA
+#else
           const bf16x8_t bb = __builtin_bit_cast(bf16x8_t, b[s]);
           acc[r * 3 + s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bb, __builtin_bit_cast(bf16x8_t, f.a0), acc[r * 3 + s], 0, 0, 0);
+#endif
         }
         if (r == 0 && mid >= 0) {
           __builtin_amdgcn_sched_barrier(0);
+#if !(defined(OSVOS_WGRAD_ABL) && OSVOS_WGRAD_ABL == 3)
           issue(nx, mid);
+#endif
           __builtin_amdgcn_sched_barrier(0);
         }
       }
     };
-    Frag f0, f1;
-    ldk(0, f0);
+    if constexpr (WAVES == 8) {
+      // two waves per SIMD cover each other's LDS latency: ONE fragment set (19 registers less than the ping-pong below -- the
+      // difference between fitting 256 registers and spilling the staging registers to scratch, whose in-order vmcnt waits would
+      // then wait for the next patch's global loads as well)
+      Frag f;
 #pragma unroll
-    for (int it = 0; it < PH; ++it) {                     // two k-steps and three loads of the next patch per turn
-      ldk(2 * it + 1, f1);
-      issue(nx, 3 * it);
-      __builtin_amdgcn_sched_barrier(0);
-      mm(f0, 3 * it + 1);
-      __builtin_amdgcn_sched_barrier(0);
-      ldk((2 * it + 2) & (PH * 2 - 1), f0);
-      issue(nx, 3 * it + 2);
-      __builtin_amdgcn_sched_barrier(0);
-      mm(f1, -1);
-      __builtin_amdgcn_sched_barrier(0);
+      for (int ks = 0; ks < PH * 2; ++ks) {
+        ldk(ks, f);
+#if !(defined(OSVOS_WGRAD_ABL) && OSVOS_WGRAD_ABL == 3)
+        issue(nx, ks);
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        mm(f, -1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+    Frag f0, f1;
+      ldk(0, f0);
+  #pragma unroll
+      for (int it = 0; it < PH; ++it) {                     // two k-steps and NLD / 8 (three or two) loads of the next patch per turn
+        constexpr int LPT = NLD / PH;
+        ldk(2 * it + 1, f1);
+  #if !(defined(OSVOS_WGRAD_ABL) && OSVOS_WGRAD_ABL == 3)
+        issue(nx, LPT * it);
+  #endif
+        __builtin_amdgcn_sched_barrier(0);
+        mm(f0, LPT == 3 ? LPT * it + 2 : -1);
+        __builtin_amdgcn_sched_barrier(0);
+        ldk((2 * it + 2) & (PH * 2 - 1), f0);
+  #if !(defined(OSVOS_WGRAD_ABL) && OSVOS_WGRAD_ABL == 3)                // ablation 3: no vmem instruction inside the k-loop
+        issue(nx, LPT * it + 1);
+  #endif
+        __builtin_amdgcn_sched_barrier(0);
+        mm(f1, -1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     WPROF(6);
   }
@@ -533,28 +582,29 @@ __global__ __launch_bounds__(256) void wgrad_bf16v2_kernel(WbArgs a) {
 #ifdef OSVOS_WGRAD_PROF
   WPROF(7);
   if (a.prof != nullptr && lane == 0) {
-    unsigned long long* q = a.prof + ((size_t)blockIdx.x * 4 + wave) * 10;
+    unsigned long long* q = a.prof + ((size_t)blockIdx.x * WAVES + wave) * 10;
     for (int k = 0; k < 8; ++k) q[k] = pt[k];
     q[8] = t_begin;
     q[9] = tp;
   }
 #endif
   if (want_bias) {
-    float* red = reinterpret_cast<float*>(smem);          // [32 pixel groups][8 octets][8 channels]
+    float* red = reinterpret_cast<float*>(smem);          // [32 pixel groups][OCT octets][8 channels]
 #pragma unroll
-    for (int c = 0; c < 8; ++c) red[(sg * 8 + so) * 8 + c] = bsum[c];
+    for (int c = 0; c < 8; ++c) red[(sg * OCT + so) * 8 + c] = bsum[c];
     __syncthreads();
-    if (tid < 64) {
+    if (tid < BCOT) {
       float sum = 0.f;
-      for (int g = 0; g < 32; ++g) sum += red[g * 64 + tid];
+      for (int g = 0; g < 32; ++g) sum += red[g * BCOT + tid];
       if (co0 + tid < a.Cout) a.bslab[(size_t)split * a.Cout + co0 + tid] = sum;
     }
   }
 }
-constexpr size_t kLdsV2 = (size_t)DY_BYTES + X_BYTES;
+constexpr size_t kLdsV2 = (size_t)DY_BYTES + X_BYTES, kLdsV2w = (size_t)2 * DY_BYTES + X_BYTES;
 
 constexpr int kDefaultMap = 1;      // bf16-input form: XCD-local split order (L2 hit rate 38 % -> 77 %, HBM reads / 3; OSVOS_WGRAD_MAP=0 turns it off)
-constexpr int kDefaultForm = 1;     // bf16-input kernel: 1 = second staging form (wgrad_bf16v2_kernel), 0 = first (OSVOS_WGRAD_FORM)
+constexpr int kDefaultForm = 2;     // bf16-input kernel: 0 = first staging form, 1 = second (wgrad_bf16v2_kernel<4>), 2 = second with eight waves / 128-cout
+constexpr int kWideForm = 2;        // tiles where Cout allows (OSVOS_WGRAD_FORM)
 unsigned long long* g_wgrad_prof = nullptr;
 
 struct WbPlan {
@@ -562,14 +612,15 @@ struct WbPlan {
   size_t slab_floats, bslab_floats;
 };
 
-WbPlan make_plan(int N, int H, int W, int Cin_s, int Cout) {
+// bco = 128: the eight-wave form (one workgroup per CU: aim at one round of 256 workgroups)
+WbPlan make_plan(int N, int H, int W, int Cin_s, int Cout, int bco = BCO) {
   WbPlan p;
-  p.nco_t = ceil_div(Cout, BCO);
+  p.nco_t = ceil_div(Cout, bco);
   p.nci_t = ceil_div(Cin_s, BCI);
   p.npx = ceil_div(W, PW);
   p.npy = ceil_div(H, PH);
   p.npatches = N * p.npx * p.npy;
-  int want = ceil_div(512, p.nco_t * p.nci_t);
+  int want = ceil_div(bco == BCO ? 512 : 256, p.nco_t * p.nci_t);
   const int max_split = p.npatches / 2 > 0 ? p.npatches / 2 : 1;
   if (want > max_split) want = max_split;
   if (want > 256) want = 256;
@@ -592,8 +643,9 @@ bool osvos_wgrad_bf16_applicable(int Cin_s, int Cout) { return Cin_s % 64 == 0 &
 
 size_t osvos_wgrad_bf16_ws_bytes(int N, int H, int W, int Cin_s, int Cout) {
   if (!osvos_wgrad_bf16_applicable(Cin_s, Cout)) return 0;
-  WbPlan p = make_plan(N, H, W, Cin_s, Cout);
-  return align_up((p.slab_floats + p.bslab_floats) * sizeof(float), 256);
+  const WbPlan p = make_plan(N, H, W, Cin_s, Cout), pw = make_plan(N, H, W, Cin_s, Cout, 128);      // whichever form runs
+  const size_t f = p.slab_floats + p.bslab_floats, fw = pw.slab_floats + pw.bslab_floats;
+  return align_up((f > fw ? f : fw) * sizeof(float), 256);
 }
 
 // xb = 0: x and dy fp32; xb = 1: both bf16
@@ -605,7 +657,8 @@ int osvos_conv3x3_wgrad_bf16mfma_io(const void* x, const void* dy, int xb, void*
   OSVOS_ARG_CHECK((long)H * W * Cin_s < (1L << 29) && (long)H * W * Cout_s < (1L << 29), "wgrad bf16: image too large for 31-bit byte offsets");
   static const int form_env = getenv("OSVOS_WGRAD_FORM") ? atoi(getenv("OSVOS_WGRAD_FORM")) : -1;
   const int form = xb ? (form_env >= 0 ? form_env : kDefaultForm) : 0;
-  WbPlan p = make_plan(N, H, W, Cin_s, Cout);
+  const bool wide = form >= kWideForm && Cout % 128 == 0;        // eight-wave form: 128-cout tiles
+  WbPlan p = make_plan(N, H, W, Cin_s, Cout, wide ? 128 : BCO);
   WbArgs a;
   a.x = x; a.dy = dy;
   a.slab = reinterpret_cast<float*>(ws);
@@ -616,6 +669,7 @@ int osvos_conv3x3_wgrad_bf16mfma_io(const void* x, const void* dy, int xb, void*
   static const int map_env = getenv("OSVOS_WGRAD_MAP") ? atoi(getenv("OSVOS_WGRAD_MAP")) : -1;
   a.map = (map_env >= 0 ? map_env : kDefaultMap) == 1 && blocks % 8 == 0 ? 1 : 0;
   a.prof = g_wgrad_prof;
+  a.dbg = getenv("OSVOS_WGRAD_DBG") ? atoi(getenv("OSVOS_WGRAD_DBG")) : 0;
   constexpr size_t lds = (size_t)DY_BYTES + X_BYTES;
   static bool attr_set = false;
   if (!attr_set) {
@@ -629,10 +683,12 @@ int osvos_conv3x3_wgrad_bf16mfma_io(const void* x, const void* dy, int xb, void*
   if (phase != 2 && form != 0) {
     static bool attr2_set = false;
     if (!attr2_set) {
-      OSVOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsV2));
+      OSVOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16v2_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsV2));
+      OSVOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16v2_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsV2w));
       attr2_set = true;
     }
-    hipLaunchKernelGGL(wgrad_bf16v2_kernel, dim3((unsigned)blocks), dim3(256), kLdsV2, stream, a);
+    if (wide) hipLaunchKernelGGL(wgrad_bf16v2_kernel<8>, dim3((unsigned)blocks), dim3(512), kLdsV2w, stream, a);
+    else hipLaunchKernelGGL(wgrad_bf16v2_kernel<4>, dim3((unsigned)blocks), dim3(256), kLdsV2, stream, a);
     OSVOS_LAUNCH_CHECK();
   } else if (phase != 2) {
     if (xb) hipLaunchKernelGGL(wgrad_bf16_kernel<1>, dim3((unsigned)blocks), dim3(256), lds, stream, a);

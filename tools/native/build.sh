@@ -1,8 +1,11 @@
 #!/bin/bash
 # native probes (tools/native/bin/, git-ignored, travels with the gpurun snapshot)
+# usage: build.sh [ABL]   ABL = 1 no MFMA, 2 no LDS fragment reads, 3 no vmem inside the k-loop (timing ablations, wrong results)
 set -e
 cd "$(dirname "$0")"
 mkdir -p bin
 C=../../osvos-pytorch_amd/csrc
-/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -Wno-unused-function -DOSVOS_WGRAD_PROF \
-  $C/wgrad_bf16.hip $C/wgrad_f32.hip $C/wgrad_small_f32.hip -x hip $C/errors.cpp wgrad_probe.cpp -o bin/wgrad_probe
+ABL=${1:-0}
+OUT=bin/wgrad_probe; [ "$ABL" != "0" ] && OUT=bin/wgrad_probe_abl$ABL
+/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -Wno-unused-function -DOSVOS_WGRAD_PROF -DOSVOS_WGRAD_ABL=$ABL \
+  $C/wgrad_bf16.hip $C/wgrad_f32.hip $C/wgrad_small_f32.hip -x hip $C/errors.cpp wgrad_probe.cpp -o $OUT
