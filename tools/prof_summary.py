@@ -1,13 +1,14 @@
 #!/usr/bin/env python3
 """Turn a rocprofv3 (ROCm 7.2, rocpd sqlite) kernel trace into the text summary kept under profiles/.
-usage: prof_summary.py <results.db> <steps> [out.txt]"""
+usage: prof_summary.py <results.db> <steps> [out.txt] [command text]"""
 import sqlite3
 import sys
 
 db = sqlite3.connect(sys.argv[1])
 steps = float(sys.argv[2])
 rows = list(db.execute("select name,total_calls,total_duration,average,percentage from top_kernels"))
-out = ["rocprofv3 --kernel-trace --stats  (command: python bench.py --steps 20 --warmup 5 --no-cpu-baseline; %d profiled steps incl. warm-up)" % steps,
+cmd = sys.argv[4] if len(sys.argv) > 4 else "python bench.py --steps 20 --warmup 5 --no-cpu-baseline"
+out = ["rocprofv3 --kernel-trace --stats  (command: %s; %d profiled steps incl. warm-up)" % (cmd, steps),
        "%-96s %7s %12s %10s %6s" % ("kernel", "calls", "us/step", "avg_us", "%")]
 for n, c, tot, avg, pct in rows:
     n = n.replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")
