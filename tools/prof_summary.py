@@ -24,6 +24,8 @@ try:
     cols = [r[1] for r in db.execute("pragma table_info(%s)" % ks)]
     namecol = "kernel_name" if "kernel_name" in cols else cols[-1]
     disp = list(db.execute("select s.%s, d.start, d.end, d.stream_id from rocpd_kernel_dispatch d join %s s on d.kernel_id = s.id order by d.start" % (namecol, ks)))
+    bf16_run = any("conv3x3_bf16" in d[0] for d in disp)       # a bf16 run's fp32 conv launches are bench.py's calibration forward
+    conv_names = ("conv3x3_bf16_kernel", "conv3x3_bf16_dma_kernel") if bf16_run else ("conv3x3_f32_kernel",)
     phase, acc, main = None, {"fwd": [], "bwd": []}, {"fwd": [], "bwd": []}
     main_stream = None
     for name, t0, t1, stream in disp:
@@ -31,7 +33,7 @@ try:
             phase, main_stream = "fwd", stream
         elif "cbce_count" in name:
             phase = "bwd"
-        elif phase and ("conv3x3_f32_kernel" in name or "conv3x3_bf16_kernel" in name or "conv3x3_bf16_dma_kernel" in name):
+        elif phase and any(c in name for c in conv_names):
             acc[phase].append((t1 - t0) / 1e3)
             if stream == main_stream:
                 main[phase].append((t1 - t0) / 1e3)
