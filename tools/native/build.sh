@@ -9,3 +9,6 @@ ABL=${1:-0}
 OUT=bin/wgrad_probe; [ "$ABL" != "0" ] && OUT=bin/wgrad_probe_abl$ABL
 /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -Wno-unused-function -DOSVOS_WGRAD_PROF -DOSVOS_WGRAD_ABL=$ABL \
   $C/wgrad_bf16.hip $C/wgrad_f32.hip $C/wgrad_small_f32.hip -x hip $C/errors.cpp wgrad_probe.cpp -o $OUT
+# convolution probe (production kernels, no instrumentation)
+/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -Wno-unused-function \
+  $C/conv3x3_f32.hip $C/conv3x3_bf16.hip $C/conv3x3_bf16_dma.hip $C/pack.hip -x hip $C/errors.cpp conv_probe.cpp -o bin/conv_probe
