@@ -392,6 +392,8 @@ const TileInfoB kTilesB[kNumTilesB] = {infoB<B0>(), infoB<B1>(), infoB<B2>(), in
 // accumulators per wave, two workgroups per CU) moves the fewest bytes per MFMA and wins whenever it yields enough
 // workgroups (up to 990 TFLOP/s on conv3_x/conv4_x at batch 12); B1 (256 px x 64 co, 4 accumulators) covers the
 // 64-cout layers and the frames that are too small for B8; tiny frames fall back to 128- and 64-pixel tiles.
+constexpr int kDmaMinCin = 512, kDmaTile = 32;      // auto rule for the LDS-DMA kernel (OSVOS_DMA_MIN_CIN / OSVOS_DMA_TILE override)
+
 int pick_tile_b(int N, int H, int W, int CoutP) {
   if (CoutP <= 32) return 6;
   const int order[] = {8, 1, 5, 7};
@@ -495,9 +497,11 @@ int osvos_conv3x3_bf16mfma_io(const void* x, int xb, const void* wpk, const floa
     if (!env && !xb && tile == 10) tile = 8;     // (the 16 x 16 form spills with fp32 staging registers)
     // bf16 activations, deep layers (K = 9 x 512): the LDS-DMA staged 512 px x 128 co kernel wins when it still fills the chip
     // (conv4_x 0.355 -> 0.331 ms, conv5_x 0.117 -> 0.098 ms at batch 12)
-    if (!env && xb && Cin >= 512 && a.CoutP >= 128 && osvos_conv3x3_bf16_dma_applicable(Cin, Cout, y_cs) &&
+    static const int dma_min_cin = getenv("OSVOS_DMA_MIN_CIN") ? atoi(getenv("OSVOS_DMA_MIN_CIN")) : kDmaMinCin;
+    static const int dma_tile = getenv("OSVOS_DMA_TILE") ? atoi(getenv("OSVOS_DMA_TILE")) : kDmaTile;
+    if (!env && xb && Cin >= dma_min_cin && a.CoutP >= 128 && osvos_conv3x3_bf16_dma_applicable(Cin, Cout, y_cs) &&
         (long)N * ceil_div(H, 16) * ceil_div(W, 32) * ceil_div(a.CoutP, 128) >= 256)
-      tile = 32;
+      tile = dma_tile;
     if (!env && (double)H * W * Cin * 4 > 9.0 * Cin * a.CoutP * 2) tile += 100;
   }
   a.map = tile >= 100 ? 1 : 0;
