@@ -16,7 +16,7 @@ from collections import OrderedDict
 
 import numpy as np
 
-from .torch_ref import N_SCALES, SIDE_CH, bilinear_filter, state_dict_spec
+from .torch_ref import N_SCALES, bilinear_filter, state_dict_spec
 
 
 def make_frame(n, h, w, seed=0):

@@ -22,7 +22,6 @@ checked against them in tests/test_oracle_golden.py.
 """
 from __future__ import annotations
 
-import math
 from collections import OrderedDict
 
 import numpy as np

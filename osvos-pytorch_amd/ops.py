@@ -9,8 +9,7 @@ import ctypes as C
 
 import torch
 
-from . import _lib
-from ._lib import F32, F32_BF16MFMA, check, lib, ptr_array
+from ._lib import F32, F32_BF16MFMA, check, lib
 
 
 def _stream():

@@ -1,7 +1,7 @@
 """Where do a conv workgroup's cycles go?  Builds conv3x3_bf16.hip with -DOSVOS_CONV_PROF (s_memtime marks around every
 phase of the K loop) into a scratch library, runs one layer and prints the per-wave averages.  GPU box only.
 usage: python tools/conv_phase_probe.py [--tile 1] [--batch 12] [--layer conv3_2]"""
-import argparse, ctypes as C, os, subprocess, sys
+import argparse, ctypes as C, os, subprocess
 import numpy as np
 import torch
 
