@@ -12,3 +12,4 @@ OUT=bin/wgrad_probe; [ "$ABL" != "0" ] && OUT=bin/wgrad_probe_abl$ABL
 # convolution probe (production kernels, no instrumentation)
 /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -Wno-unused-function \
   $C/conv3x3_f32.hip $C/conv3x3_bf16.hip $C/conv3x3_bf16_dma.hip $C/pack.hip -x hip $C/errors.cpp conv_probe.cpp -o bin/conv_probe
+/opt/rocm/bin/hipcc -O2 -std=c++17 --offload-arch=gfx950 tr_probe.cpp -o bin/tr_probe
