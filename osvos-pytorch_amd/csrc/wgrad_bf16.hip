@@ -600,6 +600,219 @@ __global__ __launch_bounds__(64 * WAVES) void wgrad_bf16v2_kernel(WbArgs a) {
     }
   }
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// EXPERIMENTAL (OSVOS_WGRAD_FORM=3, not the default): pixel-major tiles.  The tiles stay the way they lie in HBM -- [pixel][channel], one
+// 16-byte piece per lane in, one ds_write_b128 out, no register transposition -- and the MFMA k-fragments (8 consecutive PIXELS of one
+// channel per lane) are gathered by the LDS itself: ds_read_b64_tr_b16 hands lane i of a 16-lane group column i of the 4 x 16 element
+// block its lanes address (tools/native/tr_probe; lane (i, g) points at pixel i/4, channels 4 (i%4) + 16 g).  A tap shift is then a plain
+// address offset: no 20-byte window, no v_alignbit, no register copies -- the k-loop is 20 LDS reads + 9 MFMAs per k-step and nothing
+// else.  Pixel pitch = channel bytes + 64 so that the four pixel rows of one read fall on disjoint quarters of the 64 banks.
+// Same k-order as the other forms (k = pixel 8 (lane>>5) + element): bit-identical results.
+template <int WAVES>
+struct PM {
+  static constexpr int BCOT = 16 * WAVES, OCT = BCOT / 8, NT = 64 * WAVES;
+  static constexpr int DYP = BCOT * 2 + 64, XP = BCI * 2 + 64;            // pixel pitches in bytes: 192 / 320 and 192
+  static constexpr int HW_ = PW + 2, XPIX = (PH + 2) * HW_;                 // 34-pixel halo rows, 340 halo pixels
+  static constexpr int DY_B = PPIX * DYP, X_B = XPIX * XP;
+  static constexpr int NDYL = PH, NXL = (XPIX * 8 + NT - 1) / NT, NLD = NDYL + NXL;      // 16-byte loads per thread and patch: 8 + 11 / 8 + 6
+  static constexpr size_t LDS = (size_t)DY_B + X_B;
+};
+
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void wgrad_bf16pm_kernel(WbArgs a) {
+  using G = PM<WAVES>;
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* dYs = smem;
+  char* Xs = smem + G::DY_B;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wc = wave >> 1, wi = wave & 1;
+  constexpr unsigned OOB = 0x80000000u;
+
+  int id = blockIdx.x;
+  if (a.map == 1) id = (id & 7) * (gridDim.x >> 3) + (id >> 3);
+  const int cit = id % a.nci_t;
+  id /= a.nci_t;
+  const int cot = id % a.nco_t;
+  const int split = id / a.nco_t;
+  const int co0 = cot * G::BCOT, ci0 = cit * BCI;
+  const int p_begin = split * a.per_split, p_end = min(p_begin + a.per_split, a.npatches);
+
+  // staging pieces (16 bytes = 8 channels of one pixel).  dY piece j of this thread: patch row j, column dx, channel octet doct;
+  // X piece j: halo pixel xh0 + (NT / 8) j (row-major over the 10 x 34 halo), channel octet xoct
+  const int doct = tid % G::OCT, dx = tid / G::OCT;
+  const int xoct = tid & 7, xh0 = tid >> 3;
+  const bool dy_ch_ok = co0 + 8 * doct < a.Cout, x_ch_ok = ci0 + 8 * xoct < a.Cin_s;
+  u32x4 rdy[G::NDYL], rx[G::NXL];
+  float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const bool want_bias = a.bslab != nullptr && cit == 0;
+  const int img_dy_bytes = a.H * a.W * a.Cout_s * 2, img_x_bytes = a.H * a.W * a.Cin_s * 2;
+  const unsigned dy_row = (unsigned)(a.W * a.Cout_s * 2);
+  const unsigned dy_rel = (unsigned)((dx * a.Cout_s + co0 + 8 * doct) * 2);
+
+  struct Patch { __amdgpu_buffer_rsrc_t drs, xrs; unsigned dy_base, x_base; int x0; };
+  auto locate = [&](int p, bool live) -> Patch {
+    const int px = p % a.npx;
+    int t = p / a.npx;
+    const int py = t % a.npy;
+    const int n = live ? t / a.npy : 0;
+    Patch q;
+    q.x0 = live ? px * PW : 0x40000000;            // dead patch: every column test fails -> all loads out of range
+    const int y0 = py * PH;
+    q.drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(a.dy)) + (size_t)n * img_dy_bytes, 0, img_dy_bytes, 0x00020000);
+    q.xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(a.x)) + (size_t)n * img_x_bytes, 0, img_x_bytes, 0x00020000);
+    q.dy_base = (unsigned)((y0 * a.W + px * PW) * a.Cout_s * 2);
+    q.x_base = (unsigned)(((y0 - 1) * a.W + (px * PW - 1)) * a.Cin_s * 2);       // may be "negative": wraps out of range
+    return q;
+  };
+  auto issue = [&](const Patch& q, int i) {
+    if (i >= G::NLD) return;
+    if (i < G::NDYL) {
+      const unsigned off = (dy_ch_ok && q.x0 + dx < a.W) ? dy_rel + q.dy_base + (unsigned)i * dy_row : OOB;
+      rdy[i] = __builtin_amdgcn_raw_buffer_load_b128(q.drs, off, 0, 0);
+    } else {
+      const int j = i - G::NDYL;
+      const int hp = xh0 + (G::NT / 8) * j, hy = hp / G::HW_, hx = hp - hy * G::HW_;
+      const bool ok = x_ch_ok && hp < G::XPIX && (unsigned)(q.x0 - 1 + hx) < (unsigned)a.W;
+      const unsigned off = ok ? q.x_base + (unsigned)(((hy * a.W + hx) * a.Cin_s + ci0 + 8 * xoct) * 2) : OOB;
+      rx[j] = __builtin_amdgcn_raw_buffer_load_b128(q.xrs, off, 0, 0);
+    }
+  };
+  auto store_patch = [&]() {
+    if (want_bias) {                                  // bias gradient: fp32 column sums of the (bf16) dY
+#pragma unroll
+      for (int j = 0; j < G::NDYL; ++j)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          bsum[2 * d] += __uint_as_float(rdy[j][d] << 16);
+          bsum[2 * d + 1] += __uint_as_float(rdy[j][d] & 0xffff0000u);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < G::NDYL; ++j)
+      *reinterpret_cast<u32x4*>(dYs + (j * PW + dx) * G::DYP + doct * 16) = rdy[j];
+#pragma unroll
+    for (int j = 0; j < G::NXL; ++j) {
+      const int hp = xh0 + (G::NT / 8) * j;
+      if (hp < G::XPIX) *reinterpret_cast<u32x4*>(Xs + hp * G::XP + xoct * 16) = rx[j];
+    }
+  };
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  // fragment gather: lane (i = lane & 15, g = (lane >> 4) & 1, lh = lane >> 5) addresses pixel 8 lh + i / 4 (+4 for the second read),
+  // channels 16 g + 4 (i % 4) .. +3 of its wave's 32-channel block, and receives channel 16 g + i of pixels 8 lh .. 8 lh + 7
+  const int fi = lane & 15, fg = (lane >> 4) & 1, lh = lane >> 5;
+  const char* a_base = dYs + (8 * lh + (fi >> 2)) * G::DYP + (32 * wc + 16 * fg + 4 * (fi & 3)) * 2;
+  const char* b_base = Xs + (8 * lh + (fi >> 2)) * G::XP + (32 * wi + 16 * fg + 4 * (fi & 3)) * 2;
+  auto tr8 = [&](const char* p, int pitch) -> s16x8 {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 4 * pitch));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  };
+
+#ifdef OSVOS_WGRAD_PROF
+  unsigned long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tp = __builtin_amdgcn_s_memtime(), tq;
+  const unsigned long long t_begin = tp;
+#endif
+  {
+    const Patch q = locate(p_begin, p_begin < p_end);
+#pragma unroll
+    for (int i = 0; i < G::NLD; ++i) issue(q, i);
+  }
+  WPROF(0);
+  for (int p = p_begin; p < p_end; ++p) {
+    __syncthreads();
+    WPROF(1);
+#ifdef OSVOS_WGRAD_PROF
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    WPROF(2);
+#endif
+    store_patch();
+    WPROF(3);
+    __syncthreads();
+    WPROF(4);
+    const Patch nx = locate(p + 1, p + 1 < p_end);
+    WPROF(5);
+    // 48 stages = 16 k-steps x 3 tap rows; stage st multiplies tap row r = st % 3 of k-step ks = st / 3 while the three B fragments
+    // of stage st + 1 (and, every third stage, the A fragment of the next k-step) are being gathered
+    s16x8 af[2], bfr[2][3];
+    auto lda = [&](int ks) { af[ks & 1] = tr8(a_base + ((ks >> 1) * PW + (ks & 1) * 16) * G::DYP, G::DYP); };
+    auto ldb = [&](int st) {
+      const int ks = st / 3, r = st % 3;
+#pragma unroll
+      for (int s2 = 0; s2 < 3; ++s2)
+        bfr[st & 1][s2] = tr8(b_base + (((ks >> 1) + r) * G::HW_ + (ks & 1) * 16 + s2) * G::XP, G::XP);
+    };
+    lda(0);
+    ldb(0);
+#pragma unroll
+    for (int st = 0; st < PH * 2 * 3; ++st) {
+      const int ks = st / 3, r = st % 3;
+      if (st + 1 < PH * 2 * 3) {
+        if (r == 2) lda(ks + 1);
+        ldb(st + 1);
+      }
+      if ((st * G::NLD) / (PH * 6) != ((st + 1) * G::NLD) / (PH * 6)) issue(nx, (st * G::NLD) / (PH * 6));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s2 = 0; s2 < 3; ++s2)
+        acc[r * 3 + s2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, bfr[st & 1][s2]), __builtin_bit_cast(bf16x8_t, af[ks & 1]),
+                                                                acc[r * 3 + s2], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    WPROF(6);
+  }
+  __syncthreads();
+
+  {   // slab epilogue, as in the other forms
+    const int li = lane & 31;
+    const size_t slab_elems = (size_t)9 * a.Cout * a.Cin_s;
+    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(a.slab + (size_t)split * slab_elems, 0, (int)(slab_elems * 4), 0x00020000);
+    const int co = co0 + wc * 32 + li;
+    const int cib = ci0 + wi * 32 + 4 * lh;
+    const unsigned row = co < a.Cout ? (unsigned)(co * a.Cin_s) * 4u : OOB;
+    const unsigned tap_stride = (unsigned)(a.Cout * a.Cin_s) * 4u;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int ci = cib + 8 * q;
+        const unsigned off = ci < a.Cin_s ? row + (unsigned)t * tap_stride + (unsigned)ci * 4u : OOB;
+        const f32x4 v = {acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), srs, off, 0, 0);
+      }
+  }
+#ifdef OSVOS_WGRAD_PROF
+  WPROF(7);
+  if (a.prof != nullptr && lane == 0) {
+    unsigned long long* q = a.prof + ((size_t)blockIdx.x * WAVES + wave) * 10;
+    for (int k = 0; k < 8; ++k) q[k] = pt[k];
+    q[8] = t_begin;
+    q[9] = tp;
+  }
+#endif
+  if (want_bias) {
+    float* red = reinterpret_cast<float*>(smem);          // [32 columns][OCT octets][8 channels]
+#pragma unroll
+    for (int c = 0; c < 8; ++c) red[(dx * G::OCT + doct) * 8 + c] = bsum[c];
+    __syncthreads();
+    if (tid < G::BCOT) {
+      float sum = 0.f;
+      for (int g = 0; g < 32; ++g) sum += red[g * G::BCOT + tid];
+      if (co0 + tid < a.Cout) a.bslab[(size_t)split * a.Cout + co0 + tid] = sum;
+    }
+  }
+}
+
 constexpr size_t kLdsV2 = (size_t)DY_BYTES + X_BYTES, kLdsV2w = (size_t)2 * DY_BYTES + X_BYTES;
 
 constexpr int kDefaultMap = 1;      // bf16-input form: XCD-local split order (L2 hit rate 38 % -> 77 %, HBM reads / 3; OSVOS_WGRAD_MAP=0 turns it off)
@@ -680,7 +893,18 @@ int osvos_conv3x3_wgrad_bf16mfma_io(const void* x, const void* dy, int xb, void*
     attr_set = true;
   }
   const int phase = osvos_wgrad_phase();
-  if (phase != 2 && form != 0) {
+  if (phase != 2 && form == 3) {
+    static bool attr3_set = false;
+    constexpr size_t lds4 = PM<4>::LDS, lds8 = PM<8>::LDS;
+    if (!attr3_set) {
+      OSVOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16pm_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
+      OSVOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16pm_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
+      attr3_set = true;
+    }
+    if (wide) hipLaunchKernelGGL(wgrad_bf16pm_kernel<8>, dim3((unsigned)blocks), dim3(512), lds8, stream, a);
+    else hipLaunchKernelGGL(wgrad_bf16pm_kernel<4>, dim3((unsigned)blocks), dim3(256), lds4, stream, a);
+    OSVOS_LAUNCH_CHECK();
+  } else if (phase != 2 && form != 0) {
     static bool attr2_set = false;
     if (!attr2_set) {
       OSVOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16v2_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsV2));
