@@ -744,29 +744,37 @@ __global__ __launch_bounds__(64 * WAVES) void wgrad_bf16pm_kernel(WbArgs a) {
     WPROF(5);
     // 48 stages = 16 k-steps x 3 tap rows; stage st multiplies tap row r = st % 3 of k-step ks = st / 3 while the three B fragments
     // of stage st + 1 (and, every third stage, the A fragment of the next k-step) are being gathered
-    s16x8 af[2], bfr[2][3];
-    auto lda = [&](int ks) { af[ks & 1] = tr8(a_base + ((ks >> 1) * PW + (ks & 1) * 16) * G::DYP, G::DYP); };
+    constexpr int NB = WAVES == 8 ? 1 : 2;      // fragment sets: two waves per SIMD cover each other's LDS latency, and 256 registers leave no room for two
+    s16x8 af[NB], bfr[NB][3];
+    auto lda = [&](int ks) { af[ks & (NB - 1)] = tr8(a_base + ((ks >> 1) * PW + (ks & 1) * 16) * G::DYP, G::DYP); };
     auto ldb = [&](int st) {
       const int ks = st / 3, r = st % 3;
 #pragma unroll
       for (int s2 = 0; s2 < 3; ++s2)
-        bfr[st & 1][s2] = tr8(b_base + (((ks >> 1) + r) * G::HW_ + (ks & 1) * 16 + s2) * G::XP, G::XP);
+        bfr[st & (NB - 1)][s2] = tr8(b_base + (((ks >> 1) + r) * G::HW_ + (ks & 1) * 16 + s2) * G::XP, G::XP);
     };
-    lda(0);
-    ldb(0);
+    if constexpr (NB == 2) {
+      lda(0);
+      ldb(0);
+    }
 #pragma unroll
     for (int st = 0; st < PH * 2 * 3; ++st) {
       const int ks = st / 3, r = st % 3;
-      if (st + 1 < PH * 2 * 3) {
-        if (r == 2) lda(ks + 1);
-        ldb(st + 1);
+      if constexpr (NB == 2) {
+        if (st + 1 < PH * 2 * 3) {
+          if (r == 2) lda(ks + 1);
+          ldb(st + 1);
+        }
+      } else {
+        if (r == 0) lda(ks);
+        ldb(st);
       }
       if ((st * G::NLD) / (PH * 6) != ((st + 1) * G::NLD) / (PH * 6)) issue(nx, (st * G::NLD) / (PH * 6));
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int s2 = 0; s2 < 3; ++s2)
-        acc[r * 3 + s2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, bfr[st & 1][s2]), __builtin_bit_cast(bf16x8_t, af[ks & 1]),
-                                                                acc[r * 3 + s2], 0, 0, 0);
+        acc[r * 3 + s2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, bfr[st & (NB - 1)][s2]),
+                                                                __builtin_bit_cast(bf16x8_t, af[ks & (NB - 1)]), acc[r * 3 + s2], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
     WPROF(6);
