@@ -890,7 +890,8 @@ int osvos_conv3x3_wgrad_bf16mfma_io(const void* x, const void* dy, int xb, void*
   static const int map_env = getenv("OSVOS_WGRAD_MAP") ? atoi(getenv("OSVOS_WGRAD_MAP")) : -1;
   a.map = (map_env >= 0 ? map_env : kDefaultMap) == 1 && blocks % 8 == 0 ? 1 : 0;
   a.prof = g_wgrad_prof;
-  a.dbg = getenv("OSVOS_WGRAD_DBG") ? atoi(getenv("OSVOS_WGRAD_DBG")) : 0;
+  static const int dbg_env = getenv("OSVOS_WGRAD_DBG") ? atoi(getenv("OSVOS_WGRAD_DBG")) : 0;
+  a.dbg = dbg_env;
   constexpr size_t lds = (size_t)DY_BYTES + X_BYTES;
   static bool attr_set = false;
   if (!attr_set) {
