@@ -1,18 +1,19 @@
-// 3x3 convolution weight gradient with bf16 MFMA operands (dtype OSVOS_F32_BF16MFMA): fp32 NHWC
-// tensors in HBM, operands rounded to bf16 (RNE) and TRANSPOSED while they are staged into LDS, fp32
-// accumulation in v_mfma_f32_32x32x16_bf16, fp32 slabs + the shared deterministic reduce.
+// 3x3 convolution weight gradient with bf16 MFMA operands (dtype OSVOS_F32_BF16MFMA): operands rounded to bf16 (RNE), fp32
+// accumulation in v_mfma_f32_32x32x16_bf16, fp32 slabs + the shared deterministic reduce (wgrad_f32.hip).
 //
-// The reduction index k of D[co][ci] += sum_k dY[k][co] * X[k + tap][ci] is the PIXEL axis, and a bf16
-// MFMA wants 8 consecutive k per lane, so both tiles live in LDS channel-major: [channel][row][x] with
-// x contiguous (one lane = one ds_read_b128 = 8 pixels of one channel).  The transposition happens in
-// registers on the way in: a thread loads 8 pixels x 4 channels (8 coalesced float4 loads) and stores
-// 4 x 16 bytes.  Channel rows are padded by 16 B so the 32 channels a wave reads hit distinct slots.
-// The horizontal tap shift (s = 0,1,2 pixels = 0,2,4 bytes) would misalign a 16-byte read; instead ONE
-// aligned 20-byte window is read per (row, k-step) and the three shifted operands are formed in
-// registers (s = 1: four v_alignbit, s = 0 / 2: plain register selection).
-// Workgroup tile: 64 couts x 64 cins x 9 taps; wave (wc, wi) owns couts 32*wc..+31, cins 32*wi..+31:
-// 9 accumulators, 1 A read + 6 B reads + 12 VALU per 9 MFMAs (a 128-cout tile with 18 accumulators
-// per wave spills: 288 accumulator + 128 staging registers).
+// The reduction index k of D[co][ci] += sum_k dY[k][co] * X[k + tap][ci] is the PIXEL axis, and a bf16 MFMA wants 8 consecutive k per
+// lane, while the tensors lie [pixel][channel] in HBM.  Kernels in this file, in the order they were written:
+//   wgrad_bf16_kernel<XB>     first form.  XB = 0: fp32 tensors in HBM (the bf16 mode without bf16 storage), XB = 1: bf16 tensors.
+//                             Tiles are TRANSPOSED in registers on the way into LDS ([channel][row][x], x contiguous: one lane = one
+//                             ds_read_b128 = 8 pixels of one channel; channel rows padded by 16 B).  The horizontal tap shift
+//                             (0 / 2 / 4 bytes) would misalign a 16-byte read: ONE aligned 20-byte window is read per (row, k-step) and
+//                             the three shifted operands are formed in registers (s = 1: four v_alignbit, s = 0 / 2: selection).
+//                             64 couts x 64 cins x 9 taps per workgroup, wave (wc, wi) owns a 32 x 32 x 9 block = 9 accumulators.
+//   wgrad_bf16v2_kernel<W>    what runs for bf16 tensors (OSVOS_WGRAD_FORM 1 / 2): 16-byte item loads issued from inside the k-loop,
+//                             W = 8 waves on 128-cout tiles where Cout allows.  Same LDS image and k-loop as the first form.
+//   wgrad_bf16pm_kernel<W>    experimental (OSVOS_WGRAD_FORM=3): pixel-major LDS tiles gathered with ds_read_b64_tr_b16.
+// All forms produce bit-identical weight gradients (same patches, splits and k-order).  Probe builds (-DOSVOS_WGRAD_PROF, -DOSVOS_WGRAD_ABL=n:
+// tools/native/) add s_memtime phase marks and timing ablations; the shipped library compiles none of that.
 #include "common.h"
 #include <stdlib.h>
 #include <type_traits>
