@@ -490,3 +490,39 @@ def test_result_writer_bytes_png_and_jaccard(tmp_path):
     assert abs(st["mean"] - 0.55) < 1e-12 and abs(st["recall"] - 0.5) < 1e-12 and abs(st["decay"] - 0.6) < 1e-12
     with pytest.raises(RuntimeError):
         results.mask_bytes(logits)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(__import__("os").environ.get("OSVOS_TEST_EXPERIMENTAL") != "1",
+                    reason="kernel forms that are not the default: OSVOS_TEST_EXPERIMENTAL=1 python -m pytest -m gpu -k wgrad_bf16_forms")
+def test_wgrad_bf16_forms_are_bit_identical(tmp_path):
+    """OSVOS_WGRAD_FORM 0 / 1 / 3 (first staging form, four-wave item form, experimental pixel-major tiles read with
+    ds_read_b64_tr_b16) against the default form: same patches, same splits, same k-order -> the weight gradient must be
+    bit-identical, the bias gradient equal up to fp32 summation order.  Shapes cover ragged right / bottom edges, one and two
+    128-cout tiles, 64-cout tiles and several images.  The switch is read once per process: every form runs in a subprocess."""
+    import os, subprocess, sys, textwrap
+    code = textwrap.dedent('''
+        import sys, numpy as np, torch
+        sys.path.insert(0, %r)
+        import osvos_pytorch_amd.ops as ops
+        res = {}
+        for n, h, w, cin, cout in [(1, 9, 11, 64, 64), (2, 17, 35, 64, 128), (1, 33, 70, 128, 64), (3, 8, 40, 64, 64), (2, 30, 54, 256, 256), (1, 60, 107, 128, 256)]:
+            g = torch.Generator().manual_seed(1000 + h)
+            x = torch.randn(n, h, w, cin, generator=g).bfloat16().cuda()
+            dy = torch.randn(n, h, w, cout, generator=g).bfloat16().cuda()
+            dw, db = ops.conv3x3_wgrad_bf16act(x, dy, cin, cout)
+            res["dw_%%dx%%dx%%d_%%d_%%d" %% (n, h, w, cin, cout)] = dw.cpu().numpy()
+            res["db_%%dx%%dx%%d_%%d_%%d" %% (n, h, w, cin, cout)] = db.cpu().numpy()
+        np.savez(sys.argv[1], **res)
+    ''') % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),)
+    got = {}
+    for form in ("2", "0", "1", "3"):
+        out = str(tmp_path / ("f%s.npz" % form))
+        subprocess.run([sys.executable, "-c", code, out], check=True, env=dict(os.environ, OSVOS_WGRAD_FORM=form), timeout=600)
+        got[form] = dict(np.load(out))
+    for form in ("0", "1", "3"):
+        for k, ref in got["2"].items():
+            if k.startswith("dw_"):
+                assert np.array_equal(got[form][k], ref), (form, k)
+            else:
+                assert np.allclose(got[form][k], ref, rtol=1e-5, atol=1e-4), (form, k)
