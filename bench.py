@@ -19,6 +19,14 @@ Prints ONE JSON line on rank 0 with the contract fields plus `roofline` (dominan
 the conv3x3 implicit-GEMM MFMA kernel; achieved = algorithmic FLOPs / summed launch durations
 measured with HIP events on the launch stream inside the timed region) and `cpu_baseline` (the
 torch-CPU restatement of the reference loop from oracle/torch_ref.py on this node's host cores).
+
+The headline `value` times EXACTLY --steps steps (driver contract).  Because that region is only
+~0.16 s at the driver's --steps 20, the same loop is then run again for at least --min-seconds
+(default 2 s) and reported as `sustained` next to it.  With the default workload on one GPU the line
+also carries, under `extra_configs`, the other two single-GPU configurations of BASELINE.json --
+configs[2] (854x480 batch 12 parent loop, bf16 MFMA) and configs[4] (1920x1080 batch 4 inference from
+a captured hipGraph) -- and `with_loss_item_sync`, the headline loop with the reference's
+`loss.item()` every iteration (train_online.py:128) left in.  `--no-extra` skips them.
 """
 import argparse
 import ctypes as C
@@ -170,6 +178,169 @@ def cpu_baseline(h, w, mode, n_ave, budget_s=20.0):
                       "(oneDNN), median after 1 warm-up" % (len(timed), mode, w, h, torch.__version__)}
 
 
+class Workload(object):
+    """One benchmark configuration: builds the net + synthetic batch, exposes step()."""
+
+    def __init__(self, mode, precision, height, width, batch, graph, n_ave, item_sync, device, rank, dist, force_dist):
+        from layers.osvos_layers import class_balanced_cross_entropy_loss as cbce
+        from osvos_pytorch_amd.parallel import GradientAllReducer
+        self.mode, self.precision, self.h, self.w, self.batch, self.graph = mode, precision, height, width, batch, graph
+        self.n_ave = n_ave or (5 if mode == "online" else 10)
+        self.item_sync = item_sync
+        self.cbce = cbce
+        self.net, self.x, self.gt = synth_problem(batch, height, width, device, seed=rank)
+        self.net.set_precision(precision)
+        self.net.set_inplace_grad_accumulation(True)      # what osvos_pytorch_amd.train_common.TrainLoop (the scripts' loop) does
+        self.opt = make_optimizer(self.net, "online" if mode == "infer" else mode)
+        self.reducer = GradientAllReducer(self.net, average=True, always=force_dist) if dist is not None else None
+        self.running = torch.zeros((), device=device)
+        self.ave, self.epoch, self.nsteps = 0, 0, 0
+        self.keep = {}
+        self.step = self._train_step
+        if mode == "infer":
+            self.step = self._infer_eager
+            if graph:
+                for _ in range(3):
+                    self._infer_eager()            # packs weights, creates the aux stream/events, sets kernel attributes
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._infer_eager()
+                self.step = g.replay
+                self.keep["graph"] = g
+
+    def _infer_eager(self):
+        with torch.no_grad():
+            self.keep["outs"] = self.net.forward(self.x)      # train_online.py:172-181 (sigmoid/PNG writing is host I/O)
+
+    def _train_step(self):
+        # body of train_online.py:116-149 (train_parent.py:132-172 for --mode parent)
+        inputs = self.x.detach().requires_grad_()         # train_online.py:121: the input gradient is computed
+        outputs = self.net.forward(inputs)
+        if self.mode == "online":
+            loss = self.cbce(outputs[-1], self.gt, size_average=False)
+        else:
+            losses = [self.cbce(o, self.gt, size_average=False) for o in outputs]
+            loss = (1 - self.epoch / 240) * sum(losses[:-1]) + losses[-1]
+        if self.item_sync:
+            self.running.add_(loss.item())                # train_online.py:128: D2H sync every iteration
+        else:
+            self.running.add_(loss.detach())
+        loss /= self.n_ave
+        loss.backward()
+        self.ave += 1
+        self.nsteps += 1
+        if self.ave % self.n_ave == 0:
+            if self.reducer is not None:
+                self.reducer.all_reduce()
+            self.opt.step()
+            if self.reducer is not None:
+                self.reducer.zero_grads()
+            else:
+                self.opt.zero_grad()
+            self.ave = 0
+
+    def describe(self):
+        if self.mode == "infer":
+            return ("%dx%d batch=%d inference forward (train_online.py:172-181), no_grad, %s, %s, frames resident in HBM"
+                    % (self.w, self.h, self.batch, "hipGraph replay" if self.graph else "eager launches", self.precision))
+        return ("%dx%d batch=%d %s fine-tune loop (train_%s.py), fused-head%s loss, nAveGrad=%d, SGD %d-group, %s, frame resident in HBM"
+                % (self.w, self.h, self.batch, self.mode, self.mode, "" if self.mode == "online" else "+4 side", self.n_ave,
+                   8 if self.mode == "online" else 10, self.precision))
+
+
+def load_traffic():
+    """HBM-side bytes per launch of the dominant kernel from the rocprofv3 --pmc passes (FETCH_SIZE x 2 on gfx950 +
+    WRITE_SIZE, MI355X_MICROARCH.md section HBM), as written by tools/pmc_traffic.py into profiles/ together with the
+    commit it was measured at.  None when that file is absent -- bench.py itself cannot read PMC counters."""
+    path = os.path.join(REPO, "profiles", "r02_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        t["source"] = "profiles/r02_pmc_traffic.json"
+        return t
+    except Exception:
+        return None
+
+
+def timed_region(wl, steps, dist, device, prof_lib=None):
+    """barrier + synchronize, `steps` x step(), synchronize + barrier; returns (seconds [max over ranks], prof tuple)."""
+    from osvos_pytorch_amd import _lib
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    if prof_lib is not None:
+        _lib.check(prof_lib.osvos_prof_start(steps * 64 + 64), "prof_start")
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        wl.step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    ms = (C.c_double * 4)()
+    fl = (C.c_double * 4)()
+    cnt = (C.c_long * 4)()
+    if prof_lib is not None:
+        _lib.check(prof_lib.osvos_prof_stop(ms, fl, cnt), "prof_stop")
+    if dist is not None:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed, (list(ms), list(fl), list(cnt))
+
+
+def measure(wl, steps, warmup, min_seconds, world, dist, device, use_prof=True):
+    """W warm-up steps, EXACTLY `steps` timed steps (headline), then a sustained region of >= min_seconds."""
+    from osvos_pytorch_amd import _lib
+    lib = _lib.lib()
+    for _ in range(warmup):
+        wl.step()
+    prof = use_prof and not (wl.mode == "infer" and wl.graph)
+    elapsed, (ms, fl, cnt) = timed_region(wl, steps, dist, device, lib if prof else None)
+    frames = steps * wl.batch * world
+    res = {"value": frames / elapsed, "ms_per_step": elapsed / steps * 1e3, "elapsed": elapsed}
+    if min_seconds > 0:
+        n2 = max(steps, int(math.ceil(min_seconds / max(elapsed / steps, 1e-6))))
+        n2 = -(-n2 // wl.n_ave) * wl.n_ave if wl.mode != "infer" else n2     # whole optimizer steps
+        e2, _ = timed_region(wl, n2, dist, device, None)
+        res["sustained"] = {"seconds": round(e2, 3), "steps": n2, "value": round(n2 * wl.batch * world / e2, 3),
+                            "ms_per_step": round(e2 / n2 * 1e3, 4)}
+    gf_fwd = conv_gflop_forward(wl.h, wl.w) * wl.batch
+    passes = 1 if wl.mode == "infer" else 3
+    peak = FP32_MFMA_PEAK_TFLOPS if wl.precision == "fp32" else BF16_MFMA_PEAK_TFLOPS
+    kname = ("conv3x3_f32_kernel", "wgrad_f32_kernel") if wl.precision == "fp32" else ("conv3x3_bf16_kernel", "wgrad_bf16_kernel")
+    roof = None
+    step_frac = round(passes * gf_fwd / 1e3 / (elapsed / steps) / peak, 4)
+    if wl.mode == "infer" and wl.graph:
+        # one captured graph per step: the family is the whole forward (17 conv launches + glue)
+        ach = gf_fwd / 1e3 / (elapsed / steps)
+        act_gb = 0.904 * (wl.h * wl.w) / (480.0 * 854.0) * wl.batch * (1.0 if wl.precision == "fp32" else 0.5)   # SURVEY 8d: min conv tensor traffic
+        roof = {"bound": "mfma", "kernel": "hipGraph replay of osvos_net_forward (%s x17 + pool/head glue)" % kname[0],
+                "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                "traffic": None, "algorithmic_hbm_GBps": round(act_gb / (elapsed / steps), 1), "hbm_peak_GBps": 8000}
+    elif prof and cnt[0] + cnt[1] > 0:
+        # dominant kernel family: the MFMA conv kernels.  Family 0 = conv3x3 forward launches (one event pair per
+        # launch); family 1 = backward regions, i.e. the data-gradient launch of a layer running concurrently with its
+        # weight-gradient launch (+ slab reduce) on the second stream, timed fork -> join.  FLOPs are algorithmic.
+        conv_ms, conv_fl = ms[0] + ms[1], fl[0] + fl[1]
+        ach = conv_fl / (conv_ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": "%s fwd launches + (%s dgrad || %s) backward regions" % (kname[0], kname[0], kname[1]),
+                "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                "launches": int(cnt[0] + cnt[1]), "avg_launch_ms": round(conv_ms / (cnt[0] + cnt[1]), 4),
+                "algorithmic_gflop_per_launch": round(conv_fl / (cnt[0] + cnt[1]) / 1e9, 3),
+                "families": {"conv_fwd": {"ms_per_step": round(ms[0] / steps, 3), "tflops": round(fl[0] / (ms[0] * 1e-3) / 1e12, 2) if ms[0] else None},
+                             "conv_bwd_dgrad+wgrad": {"ms_per_step": round(ms[1] / steps, 3), "tflops": round(fl[1] / (ms[1] * 1e-3) / 1e12, 2) if ms[1] else None}},
+                "step_conv_fraction_of_mfma_roofline": step_frac,
+                "traffic": load_traffic() if wl.precision == "fp32" else None}
+    res["roofline"] = roof
+    res["step_conv_fraction_of_mfma_roofline"] = step_frac
+    return res
+
+
+DTYPE_NAME = {"fp32": "f32", "bf16": "bf16 MFMA operands and bf16 trunk tensors (fwd+dgrad+wgrad), f32 accumulate; head/loss/skinny wgrads/parameters f32"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -187,10 +358,12 @@ def main():
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--n-ave-grad", type=int, default=0, help="0 = reference value (5 online, 10 parent)")
     ap.add_argument("--item-sync", type=int, default=0, help="1 = loss.item() every iteration like the reference's logging")
+    ap.add_argument("--min-seconds", type=float, default=2.0, help="length of the additional `sustained` timed region (0 = skip)")
     ap.add_argument("--force-dist", action="store_true", help="initialise the nccl (RCCL) process group and run the gradient "
                     "all-reduce even with one rank (single-GPU check of the multi-GPU path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip extra_configs (configs[2], configs[4]) and the item-sync figure")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -209,144 +382,72 @@ def main():
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
-    from layers.osvos_layers import class_balanced_cross_entropy_loss as cbce
-    from osvos_pytorch_amd import _lib
-    from osvos_pytorch_amd.parallel import GradientAllReducer
-
-    n_ave = args.n_ave_grad or (5 if args.mode == "online" else 10)
-    net, x, gt = synth_problem(args.batch, args.height, args.width, device, seed=rank)
-    net.set_precision(args.precision)
-    opt = make_optimizer(net, "online" if args.mode == "infer" else args.mode)
-    reducer = GradientAllReducer(net, average=True, always=args.force_dist) if dist is not None else None
-    running = torch.zeros((), device=device)
-    state = {"ave": 0, "epoch": 0}
-
-    def step():
-        # body of train_online.py:116-149 (train_parent.py:132-172 for --mode parent)
-        inputs = x.detach().requires_grad_()         # train_online.py:121: the input gradient is computed
-        outputs = net.forward(inputs)
-        if args.mode == "online":
-            loss = cbce(outputs[-1], gt, size_average=False)
-        else:
-            losses = [cbce(o, gt, size_average=False) for o in outputs]
-            loss = (1 - state["epoch"] / 240) * sum(losses[:-1]) + losses[-1]
-        if args.item_sync:
-            running.add_(loss.item())
-        else:
-            running.add_(loss.detach())
-        loss /= n_ave
-        loss.backward()
-        state["ave"] += 1
-        if state["ave"] % n_ave == 0:
-            if reducer is not None:
-                reducer.all_reduce()
-            opt.step()
-            if reducer is not None:
-                reducer.zero_grads()
-            else:
-                opt.zero_grad()
-            state["ave"] = 0
-
-    if args.mode == "infer":
-        keep = {}
-
-        def infer_eager():
-            with torch.no_grad():
-                keep["outs"] = net.forward(x)      # train_online.py:172-181 (sigmoid/PNG writing is host I/O)
-        step = infer_eager
-        if args.graph:
-            for _ in range(3):
-                infer_eager()                      # packs weights, creates the aux stream/events, sets kernel attributes
-            torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                infer_eager()
-            step = graph.replay
-    for _ in range(args.warmup):
-        step()
-    lib = _lib.lib()
-    prof = (not args.no_prof) and not (args.mode == "infer" and args.graph)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    if prof:
-        _lib.check(lib.osvos_prof_start(args.steps * 64 + 64), "prof_start")
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    ms = (C.c_double * 4)()
-    fl = (C.c_double * 4)()
-    cnt = (C.c_long * 4)()
-    if prof:
-        _lib.check(lib.osvos_prof_stop(ms, fl, cnt), "prof_stop")
-    if dist is not None:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    frames = args.steps * args.batch * world
-    value = frames / elapsed
+    wl = Workload(args.mode, args.precision, args.height, args.width, args.batch, args.graph, args.n_ave_grad, args.item_sync,
+                  device, rank, dist, args.force_dist)
+    res = measure(wl, args.steps, args.warmup, args.min_seconds, world, dist, device, use_prof=not args.no_prof)
+    default_workload = (args.mode, args.precision, args.height, args.width, args.batch, args.item_sync) == ("online", "fp32", 480, 854, 1, 0)
+    extras, item_line = None, None
+    if world == 1 and dist is None and default_workload and not args.no_extra:
+        # the headline loop with the reference's per-iteration loss.item() left in (train_online.py:128)
+        wl.item_sync = 1
+        r = measure(wl, args.steps, 2, 0.0, 1, None, device, use_prof=False)
+        item_line = {"value": round(r["value"], 3), "ms_per_step": round(r["ms_per_step"], 4), "unit": "frames/s",
+                     "note": "same loop with running_loss += loss.item() every iteration (D2H sync), as the reference logs"}
+        wl.item_sync = 0
+        running_loss = float(wl.running.item()) / max(1, wl.nsteps)
+        del wl
+        torch.cuda.empty_cache()
+        extras = []
+        for (name, mode, prec, h, w, b, graph) in [
+                ("configs[2]: 854x480 batch=12 parent training bf16 (MFMA path)", "parent", "bf16", 480, 854, 12, 0),
+                ("configs[4]: 1920x1080 inference-only forward, batch=4, hipGraph-captured", "infer", "fp32", 1080, 1920, 4, 1)]:
+            try:
+                w2 = Workload(mode, prec, h, w, b, graph, 0, 0, device, rank, None, False)
+                r = measure(w2, max(10, min(args.steps, 30)), max(3, min(args.warmup, 5)), args.min_seconds, 1, None, device, use_prof=True)
+                extras.append({"config": name, "workload": w2.describe(), "value": round(r["value"], 3), "unit": "frames/s",
+                               "steps": max(10, min(args.steps, 30)), "ms_per_step": round(r["ms_per_step"], 4), "dtype": DTYPE_NAME[prec],
+                               "sustained": r.get("sustained"), "roofline": r["roofline"]})
+                del w2
+            except Exception as e:  # the headline must still be reported
+                extras.append({"config": name, "error": repr(e)})
+            torch.cuda.empty_cache()
+        wl = None
+    else:
+        running_loss = float(wl.running.item()) / max(1, wl.nsteps) if wl.nsteps else 0.0
 
     if rank == 0:
-        gf_fwd = conv_gflop_forward(args.height, args.width) * args.batch
-        passes = 1 if args.mode == "infer" else 3
-        peak = FP32_MFMA_PEAK_TFLOPS if args.precision == "fp32" else BF16_MFMA_PEAK_TFLOPS
-        kname = ("conv3x3_f32_kernel", "wgrad_f32_kernel") if args.precision == "fp32" else ("conv3x3_bf16_kernel", "wgrad_bf16_kernel")
-        roof = None
-        if args.mode == "infer" and args.graph:
-            # one captured graph per step: the family is the whole forward (17 conv launches + glue)
-            ach = gf_fwd / 1e3 / (elapsed / args.steps)
-            act_gb = 0.904 * (args.height * args.width) / (480.0 * 854.0) * args.batch     # min conv tensor traffic, fp32
-            roof = {"bound": "mfma", "kernel": "hipGraph replay of osvos_net_forward (%s x17 + pool/head glue)" % kname[0],
-                    "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                    "traffic": None, "algorithmic_hbm_GBps": round(act_gb / (elapsed / args.steps), 1), "hbm_peak_GBps": 8000}
-        if prof and cnt[0] + cnt[1] > 0:
-            # dominant kernel family: the MFMA conv kernels.  Family 0 = conv3x3_f32_kernel forward
-            # launches (one event pair per launch); family 1 = backward regions, i.e. the data-gradient
-            # launch of a layer running concurrently with its weight-gradient launch (+ slab reduce) on
-            # the second stream, timed fork -> join.  FLOPs are algorithmic (2*N*H*W*Cout*9*Cin each).
-            conv_ms = ms[0] + ms[1]
-            conv_fl = fl[0] + fl[1]
-            ach = conv_fl / (conv_ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": "%s fwd launches + (%s dgrad || %s) backward regions" % (kname[0], kname[0], kname[1]),
-                    "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(ach / peak, 4),
-                    "launches": int(cnt[0] + cnt[1]), "avg_launch_ms": round(conv_ms / (cnt[0] + cnt[1]), 4),
-                    "algorithmic_gflop_per_launch": round(conv_fl / (cnt[0] + cnt[1]) / 1e9, 3),
-                    "families": {"conv_fwd": {"ms_per_step": round(ms[0] / args.steps, 3), "tflops": round(fl[0] / (ms[0] * 1e-3) / 1e12, 2) if ms[0] else None},
-                                 "conv_bwd_dgrad+wgrad": {"ms_per_step": round(ms[1] / args.steps, 3), "tflops": round(fl[1] / (ms[1] * 1e-3) / 1e12, 2) if ms[1] else None}},
-                    "step_conv_fraction_of_mfma_roofline": round(passes * gf_fwd / 1e3 / (elapsed / args.steps) / peak, 4),
-                    # HBM-side bytes per launch from rocprofv3 --pmc (profiles/r01_pmc_conv3_2_conv1_2.txt), conv3_2 forward
-                    # launch: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE; algorithmic 55.0 MB
-                    "traffic": {"conv3_2_fwd_launch_MB": 94.1, "algorithmic_MB": 55.0, "source": "profiles/r01_pmc_conv3_2_conv1_2.txt"}}
+        n_ave = args.n_ave_grad or (5 if args.mode == "online" else 10)
         base = None
         if not args.no_cpu_baseline and world == 1 and args.mode != "infer":
             try:
                 base = cpu_baseline(args.height, args.width, args.mode, n_ave)
             except Exception as e:  # the GPU result must still be reported
                 base = {"error": repr(e)}
+        if args.mode == "infer":
+            workload = ("%dx%d batch=%d inference forward (train_online.py:172-181), no_grad, %s, %s, frames resident in HBM"
+                        % (args.width, args.height, args.batch, "hipGraph replay" if args.graph else "eager launches", args.precision))
+        else:
+            workload = ("%dx%d batch=%d %s fine-tune loop (train_%s.py), fused-head%s loss, nAveGrad=%d, SGD %d-group, %s, "
+                        "frame resident in HBM" % (args.width, args.height, args.batch, args.mode, args.mode,
+                                                   "" if args.mode == "online" else "+4 side", n_ave, 8 if args.mode == "online" else 10,
+                                                   args.precision))
         line = {
             "metric": ("frames/sec (fwd+bwd) OSVOS-VGG16 854x480 per GPU" if (args.height, args.width) == (480, 854) else
                        "frames/sec (fwd+bwd) OSVOS-VGG16 %dx%d" % (args.width, args.height)) if args.mode != "infer" else
                       "frames/sec (forward only) OSVOS-VGG16 %dx%d" % (args.width, args.height),
-            "value": round(value, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "bf16 MFMA operands and bf16 trunk tensors (fwd+dgrad+wgrad), f32 accumulate; head/loss/skinny wgrads/parameters f32",
+            "value": round(res["value"], 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(res["ms_per_step"], 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": DTYPE_NAME[args.precision],
             "data": "synthetic",
-            "config": {"workload": ("%dx%d batch=%d inference forward (train_online.py:172-181), no_grad, %s, fp32, frames resident in HBM"
-                                    % (args.width, args.height, args.batch, "hipGraph replay" if args.graph else "eager launches"))
-                       if args.mode == "infer" else
-                       "%dx%d batch=%d %s fine-tune loop (train_%s.py), fused-head%s loss, nAveGrad=%d, SGD 8-group, "
-                       "fp32, frame resident in HBM" % (args.width, args.height, args.batch, args.mode, args.mode,
-                                                        "" if args.mode == "online" else "+4 side", n_ave),
+            "config": {"workload": workload,
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                        "grad_allreduce": "per optimizer step (RCCL)" if dist is not None else "none",
                        "loss_item_sync_each_iter": bool(args.item_sync)},
-            "roofline": roof, "cpu_baseline": base,
-            "running_loss": float(running.item()) / max(1, args.steps + args.warmup),
+            "roofline": res["roofline"], "cpu_baseline": base,
+            "sustained": res.get("sustained"),
+            "with_loss_item_sync": item_line,
+            "extra_configs": extras,
+            "running_loss": running_loss,
         }
         print(json.dumps(line))
     if dist is not None:

@@ -3,18 +3,18 @@
 environment variable so the entry scripts can be pointed at data without editing this file."""
 import os
 
-from util.path_abstract import GETTERS, PathAbstract
-
-_LOCATIONS = {
-    "db_root_dir": ("OSVOS_DB_ROOT", "/path/to/DAVIS-2016"),
-    "save_root_dir": ("OSVOS_SAVE_ROOT", "./models"),
-    "models_dir": ("OSVOS_MODELS_DIR", "./models"),
-}
-assert set(_LOCATIONS) == set(GETTERS)
+from util.path_abstract import PathAbstract
 
 
-def _lookup(env, default):
-    return staticmethod(lambda: os.environ.get(env, default))
+class Path(PathAbstract):
+    @staticmethod
+    def db_root_dir():
+        return os.environ.get("OSVOS_DB_ROOT", "/path/to/DAVIS-2016")
 
+    @staticmethod
+    def save_root_dir():
+        return os.environ.get("OSVOS_SAVE_ROOT", "./models")
 
-Path = type("Path", (PathAbstract,), {name: _lookup(*spec) for name, spec in _LOCATIONS.items()})
+    @staticmethod
+    def models_dir():
+        return os.environ.get("OSVOS_MODELS_DIR", "./models")

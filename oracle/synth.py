@@ -114,3 +114,53 @@ def calibrated_problem(n, h, w, seed=0, wseed=1):
     m = make_mask(n, h, w, seed)
     wts = calibrate_heads(make_weights(wseed), torch_forward_fn(), x)
     return wts, x, m
+
+
+# ---- synthetic stand-ins for the two pretrained-weight files the reference can start from (both absent offline) ----
+# vgg_osvos.py:92-109 loads models/vgg_pytorch.pth (a torchvision VGG-16 state_dict) through its VGG shell;
+# vgg_osvos.py:110-125 loads models/vgg_caffe.mat (Caffe export: weights[0][i] stored [kw,kh,cin,cout], biases[0][i] [cout,1]).
+# The generators below write files of exactly those layouts from a seed, so the reference (tests/golden/make_golden.py) and
+# the drop-in (tests/test_host_utils_cpu.py) can load the SAME bytes.
+VGG16_FEATURE_CONVS = [0, 2, 5, 7, 10, 12, 14, 17, 19, 21, 24, 26, 28]      # conv indices inside torchvision's vgg16.features
+
+
+def vgg_trunk_arrays(seed):
+    """13 (weight [cout,cin,3,3], bias [cout]) float32 pairs, He-scaled, seeded."""
+    from .torch_ref import STAGE_CHANNELS, STAGE_IN
+    rng = np.random.default_rng(4000 + seed)
+    out = []
+    for si, chans in enumerate(STAGE_CHANNELS):
+        cin = STAGE_IN[si]
+        for cout in chans:
+            w = (rng.standard_normal((cout, cin, 3, 3)) * np.sqrt(2.0 / (9 * cout))).astype(np.float32)
+            b = (rng.standard_normal((cout,)) * 0.1).astype(np.float32)
+            out.append((w, b))
+            cin = cout
+    return out
+
+
+def write_vgg_pytorch_pth(path, seed):
+    """torchvision-layout VGG-16 state_dict: features.<i>.weight/bias for the 13 convs + the three classifier Linear
+    layers (zeros; the reference's strict load_state_dict needs them present with the right shapes, ~550 MB on disk)."""
+    import torch
+    sd = OrderedDict()
+    for fi, (w, b) in zip(VGG16_FEATURE_CONVS, vgg_trunk_arrays(seed)):
+        sd["features.%d.weight" % fi] = torch.from_numpy(w)
+        sd["features.%d.bias" % fi] = torch.from_numpy(b)
+    for ci, (o, i) in zip((0, 3, 6), ((4096, 512 * 7 * 7), (4096, 4096), (1000, 4096))):
+        sd["classifier.%d.weight" % ci] = torch.zeros(o, i)
+        sd["classifier.%d.bias" % ci] = torch.zeros(o)
+    torch.save(sd, path)
+
+
+def write_vgg_caffe_mat(path, seed):
+    """Caffe-export layout: 'weights' / 'biases' are 1 x 13 object arrays; weights[0][i] is the OIHW tensor transposed
+    (all axes reversed -> [kw, kh, cin, cout]), biases[0][i] is [cout, 1]."""
+    import scipy.io
+    arrs = vgg_trunk_arrays(seed)
+    ws = np.empty((1, len(arrs)), dtype=object)
+    bs = np.empty((1, len(arrs)), dtype=object)
+    for i, (w, b) in enumerate(arrs):
+        ws[0, i] = np.ascontiguousarray(w.transpose())
+        bs[0, i] = b[:, None].copy()
+    scipy.io.savemat(path, {"weights": ws, "biases": bs})

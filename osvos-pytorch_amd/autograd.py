@@ -35,7 +35,8 @@ class NetRuntime:
         self.auxf_stream = None       # forward side branches (own stream: a forward pipelined under the previous backward must not queue
                                       # behind that backward's weight-gradient kernels)
         self.two_streams = os.environ.get("OSVOS_TWO_STREAMS", "1") != "0"
-        self.inplace_accumulate = os.environ.get("OSVOS_INPLACE_GRAD", "1") != "0"
+        # in-place accumulation into existing .grad tensors inside backward (see OSVOSNetFunction.backward): explicit opt-in
+        self.inplace_accumulate = os.environ.get("OSVOS_INPLACE_GRAD", "0") == "1"
 
     def aux(self, device):
         if not self.two_streams:
@@ -133,6 +134,9 @@ class OSVOSNetFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *douts):
         rt, ws = ctx.rt, ctx.ws
+        if ws is None:
+            raise RuntimeError("OSVOS backward called a second time on the same graph: the activation workspace was released after "
+                               "the first backward (retain_graph=True is not supported by the MI355X path; run forward again)")
         n, h, w = ctx.shape
         if rt.key != ctx.pack_key:
             raise RuntimeError("parameters changed between forward and backward of the same graph")
@@ -145,19 +149,30 @@ class OSVOSNetFunction(torch.autograd.Function):
             if need and 42 <= i < 50 and all(g is None for g in d[:4]):
                 need = False       # score_dsn gets no gradient when only the fused head is used
             wanted.append(need)
+        # The weight-gradient kernels produce a layer's weight AND bias gradient in one launch, and the C side launches them
+        # when the layer's weight target is non-NULL: a layer with exactly one of (weight, bias) trainable still needs both
+        # targets.  The unwanted half goes to a scratch tensor that autograd never sees.
+        launch = list(wanted)
+        for wi in range(8, 42, 2):                       # (weight, bias) pairs of the 13 trunk + 4 side_prep convs
+            launch[wi] = launch[wi + 1] = wanted[wi] or wanted[wi + 1]
         # Gradient accumulation (loss /= nAveGrad; backward; ... step every nAveGrad): when every wanted
         # parameter already holds a dense .grad, the slab-reduce kernels add into it directly and autograd
-        # is handed None (no 52 extra add kernels, no 61 MB of temporaries per micro-batch)
+        # is handed None (no 52 extra add kernels, no 61 MB of temporaries per micro-batch).  OPT-IN
+        # (OSVOS.set_inplace_grad_accumulation(True); TrainLoop and bench.py do it): a custom Function cannot tell
+        # loss.backward() from torch.autograd.grad(...), and under the latter .grad must stay untouched and the gradients
+        # must be RETURNED -- so the default is the plain autograd contract.
         inplace = rt.inplace_accumulate and all(
             (not w) or (p.grad is not None and p.grad.is_contiguous() and p.grad.dtype == torch.float32 and p.grad.device == dev)
             for w, p in zip(wanted, ctx.params))
+
+        def scratch(i):
+            return torch.empty(ctx.param_meta[i][0], device=dev, dtype=torch.float32)
         if inplace:
-            targets = [p.grad if w else None for w, p in zip(wanted, ctx.params)]
+            targets = [(p.grad if w else scratch(i)) if l else None for i, (l, w, p) in enumerate(zip(launch, wanted, ctx.params))]
             grads = [None] * len(wanted)
         else:
-            targets = [torch.empty(shape, device=dev, dtype=torch.float32) if w else None
-                       for w, (shape, _) in zip(wanted, ctx.param_meta)]
-            grads = targets
+            targets = [scratch(i) if l else None for i, l in enumerate(launch)]
+            grads = [t if w else None for t, w in zip(targets, wanted)]
         dx = torch.empty((n, 3, h, w), device=dev, dtype=torch.float32) if ctx.needs_input_grad[1] else None
         check(l.osvos_net_backward(C.c_void_p(rt.wbuf.data_ptr()), C.c_void_p(ws.data_ptr()),
                                    ptr_array([None if g is None else g.data_ptr() for g in d]),

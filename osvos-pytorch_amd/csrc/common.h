@@ -4,6 +4,7 @@
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "../../include/osvos_hip.h"
 
@@ -35,6 +36,16 @@ void osvos_wgrad_set_phase(int p);
   } while (0)
 
 #define OSVOS_LAUNCH_CHECK() OSVOS_HIP_CHECK(hipGetLastError())
+
+// per-device one-time state (kernel attributes): a process may drive more than one GPU
+#define OSVOS_MAX_DEVICES 64
+static inline int osvos_current_device() {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= OSVOS_MAX_DEVICES) d = 0;
+  return d;
+}
+// integer environment knob, read once per process (tuning / test switches must not cost a getenv per launch)
+#define OSVOS_ENV_INT(var, name, dflt) static const int var = [] { const char* e_ = getenv(name); return e_ ? atoi(e_) : (dflt); }()
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }

@@ -346,7 +346,8 @@ __global__ __launch_bounds__(C::NT, C::OCC) void conv3x3_bf16_kernel(ConvArgsB a
 
 template <class C, int XB = 0>
 int launch_cfg(const ConvArgsB& a0, hipStream_t stream) {
-  static bool attr_set = false;
+  static bool attr_set_dev[OSVOS_MAX_DEVICES] = {};      // hipFuncSetAttribute is per device
+  bool& attr_set = attr_set_dev[osvos_current_device()];
   if (!attr_set) {
     OSVOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16_kernel<C, XB>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
@@ -492,8 +493,9 @@ int osvos_conv3x3_bf16mfma_io(const void* x, int xb, const void* wpk, const floa
   a.relu = relu;
   a.prof = g_conv_prof;
   if (tile < 0) {
-    const char* env = getenv("OSVOS_CONV_TILE_BF16");
-    tile = env ? atoi(env) : pick_tile_b(N, H, W, a.CoutP);
+    OSVOS_ENV_INT(env_tile, "OSVOS_CONV_TILE_BF16", -1);
+    const bool env = env_tile >= 0;
+    tile = env ? env_tile : pick_tile_b(N, H, W, a.CoutP);
     if (!env && !xb && tile == 10) tile = 8;     // (the 16 x 16 form spills with fp32 staging registers)
     // bf16 activations, deep layers (K = 9 x 512): the LDS-DMA staged 512 px x 128 co kernel wins when it still fills the chip
     // (conv4_x 0.355 -> 0.331 ms, conv5_x 0.117 -> 0.098 ms at batch 12)

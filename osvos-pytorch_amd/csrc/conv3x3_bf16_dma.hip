@@ -318,7 +318,8 @@ template <int NB, int WGM>
 int launch(const DmaArgs& a0, int persist, hipStream_t stream) {
   using C = DmaCfg<NB, WGM>;
   constexpr int TH = C::TH;
-  static bool attr_set = false;
+  static bool attr_set_dev[OSVOS_MAX_DEVICES] = {};      // hipFuncSetAttribute is per device
+  bool& attr_set = attr_set_dev[osvos_current_device()];
   if (!attr_set) {
     OSVOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16_dma_kernel<NB, WGM>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)C::LDS_BYTES));

@@ -299,7 +299,8 @@ __global__ __launch_bounds__(256) void conv3x3_f32_kernel(ConvArgs a) {
 
 template <class C>
 int launch_cfg(const ConvArgs& a0, hipStream_t stream) {
-  static bool attr_set = false;
+  static bool attr_set_dev[OSVOS_MAX_DEVICES] = {};      // hipFuncSetAttribute is per device
+  bool& attr_set = attr_set_dev[osvos_current_device()];
   if (!attr_set) {
     OSVOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f32_kernel<C>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
@@ -428,21 +429,23 @@ int osvos_conv3x3_f32_ws(const float* x, const float* wpk, const float* bias, co
   a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.CoutP = osvos_cout_pad(Cout); a.y_cs = y_cs;
   a.relu = relu;
   if (tile < 0) {
-    const char* env = getenv("OSVOS_CONV_TILE");
-    tile = env ? atoi(env) : pick_tile(N, H, W, Cin, a.CoutP);
+    OSVOS_ENV_INT(env_tile, "OSVOS_CONV_TILE", -1);
+    tile = env_tile >= 0 ? env_tile : pick_tile(N, H, W, Cin, a.CoutP);
     // activations larger than the weights -> keep the halo tile XCD-local
-    if (!env && (double)H * W * Cin > 9.0 * Cin * a.CoutP) tile += 100;
+    if (env_tile < 0 && (double)H * W * Cin > 9.0 * Cin * a.CoutP) tile += 100;
   }
   a.map = tile >= 100 ? 1 : 0;
   tile %= 100;
   OSVOS_ARG_CHECK(tile >= 0 && tile < kNumTiles, "conv3x3: unknown tile config %d", tile);
   a.ksplit = 1;
   a.prof = g_conv_prof_f32;
-  a.prof = g_conv_prof_f32;
   a.part = reinterpret_cast<float*>(part_ws);
   if (part_ws != nullptr) {
-    const char* env = getenv("OSVOS_CONV_KSPLIT");
-    a.ksplit = g_force_ksplit > 0 ? g_force_ksplit : (env ? atoi(env) : pick_ksplit(kTiles[tile], N, H, W, Cin, Cout, a.CoutP, y_cs));
+    // OSVOS_CONV_KSPLIT overrides the automatic choice, but only where the automatic choice could split as well (Cin >= 256):
+    // the caller sizes `part_ws` for those layers only (net.cpp ws_layout), a forced split of a shallow layer would overrun it
+    OSVOS_ENV_INT(env_ks, "OSVOS_CONV_KSPLIT", 0);
+    a.ksplit = g_force_ksplit > 0 ? g_force_ksplit
+                                  : ((env_ks > 0 && Cin >= 256) ? env_ks : pick_ksplit(kTiles[tile], N, H, W, Cin, Cout, a.CoutP, y_cs));
     if (a.ksplit < 1 || a.ksplit > 8 || Cout % 4 != 0 || y_cs % 4 != 0 || a.ksplit > (Cin >> 3)) a.ksplit = 1;
   }
   int rc;

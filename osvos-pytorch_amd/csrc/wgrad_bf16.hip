@@ -894,7 +894,8 @@ int osvos_conv3x3_wgrad_bf16mfma_io(const void* x, const void* dy, int xb, void*
   static const int dbg_env = getenv("OSVOS_WGRAD_DBG") ? atoi(getenv("OSVOS_WGRAD_DBG")) : 0;
   a.dbg = dbg_env;
   constexpr size_t lds = (size_t)DY_BYTES + X_BYTES;
-  static bool attr_set = false;
+  static bool attr_set_dev[OSVOS_MAX_DEVICES] = {};      // hipFuncSetAttribute is per device
+  bool& attr_set = attr_set_dev[osvos_current_device()];
   if (!attr_set) {
     OSVOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16_kernel<0>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

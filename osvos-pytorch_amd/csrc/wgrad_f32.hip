@@ -328,16 +328,16 @@ WgPlan make_plan(int N, int H, int W, int Cin_s, int Cout) {
   p.pw = 32;
   if (p.cb == 2 && (long)ceil_div(W, 16) * 16 * ceil_div(H, 4) * 4 * 100 < (long)ceil_div(W, 32) * 32 * ceil_div(H, 2) * 2 * 92) p.pw = 16;
   {
-    const char* e = getenv("OSVOS_WGRAD_PW");
-    if (e && p.cb == 2) p.pw = atoi(e) == 16 ? 16 : 32;
+    OSVOS_ENV_INT(env_pw, "OSVOS_WGRAD_PW", 0);
+    if (env_pw > 0 && p.cb == 2) p.pw = env_pw == 16 ? 16 : 32;
   }
   const int PW = p.pw, PH = PPIX / p.pw;
   p.npx = ceil_div(W, PW);
   p.npy = ceil_div(H, PH);
   p.npatches = N * p.npx * p.npy;
-  const char* env = getenv("OSVOS_WGRAD_BLOCKS");
+  OSVOS_ENV_INT(env_blocks, "OSVOS_WGRAD_BLOCKS", 0);
   // ~2 workgroups per CU; small frames (conv5 at 480p: 30 patches) prefer fewer, longer splits
-  int target_blocks = env ? atoi(env) : (p.npatches >= 100 ? 512 : 256);
+  int target_blocks = env_blocks > 0 ? env_blocks : (p.npatches >= 100 ? 512 : 256);
   if (target_blocks < 1) target_blocks = 512;
   int want = ceil_div(target_blocks, p.nco_t * p.nci_t);
   int max_split = p.npatches / 4 > 0 ? p.npatches / 4 : 1;
@@ -354,7 +354,8 @@ WgPlan make_plan(int N, int H, int W, int Cin_s, int Cout) {
 template <int CB, int IB, int PIPE, int DBUF, int OCC, int PWT = 32>
 int launch_wgrad(const WgArgs& a, long blocks, hipStream_t stream) {
   constexpr size_t lds = (size_t)(DBUF ? 2 : 1) * (PPIX * CB * 32 + Geo<PWT>::XPIX * IB * 32) * 4;
-  static bool attr_set = false;
+  static bool attr_set_dev[OSVOS_MAX_DEVICES] = {};      // hipFuncSetAttribute is per device
+  bool& attr_set = attr_set_dev[osvos_current_device()];
   if (!attr_set) {
     OSVOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_f32_kernel<CB, IB, PIPE, DBUF, OCC, PWT>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -367,8 +368,8 @@ int launch_wgrad(const WgArgs& a, long blocks, hipStream_t stream) {
 
 // tuning knob (tools/tune_conv.py): bit0 PIPE, bit1 DBUF, bit2 OCC=2, bit3 reference-order slabs
 int wgrad_variant() {
-  const char* env = getenv("OSVOS_WGRAD_VARIANT");
-  return env ? atoi(env) : 5;     // measured best (tools/tune_wgrad.py): pipelined fetch, one LDS buffer, 2 WGs/CU
+  OSVOS_ENV_INT(env_variant, "OSVOS_WGRAD_VARIANT", 5);
+  return env_variant;     // measured best (tools/tune_wgrad.py): pipelined fetch, one LDS buffer, 2 WGs/CU
 }
 
 template <int CB, int IB>
@@ -416,8 +417,8 @@ int osvos_conv3x3_wgrad_f32(const float* x, const float* dy, void* ws, float* dw
   OSVOS_ARG_CHECK(Cin_s % 4 == 0 && Cout_s % 4 == 0 && Cout % 4 == 0 && Cin <= Cin_s && Cout <= Cout_s,
                   "wgrad f32: channel strides must be multiples of 4 (Cin %d/%d Cout %d/%d)", Cin, Cin_s, Cout, Cout_s);
   {
-    const char* env = getenv("OSVOS_WGRAD_GENERIC");     // tuning / tests: force the generic kernel
-    if (!(env && atoi(env))) {
+    OSVOS_ENV_INT(env_generic, "OSVOS_WGRAD_GENERIC", 0);     // tuning / tests: force the generic kernel
+    if (!env_generic) {
       const int rc = osvos_conv3x3_wgrad_small_f32(x, dy, 0, ws, dw, db, N, H, W, Cin, Cin_s, Cout, Cout_s, accumulate, stream);
       if (rc <= 0) return rc;
     }

@@ -356,7 +356,8 @@ int osvos_conv3x3_wgrad_small_f32(const void* x, const void* dy, int wide_bf16, 
     a.N = N; a.H = H; a.W = W; a.Cout = Cout; a.Cout_s = Cout_s;
     a.npx = p.npx; a.npy = p.npy; a.npatches = p.npatches; a.per_split = p.per_split;
     constexpr size_t lds = (size_t)(C3_PPIX * 64 + C3_XPIX * 4) * 4;
-    static bool attr_set = false;
+    static bool attr_set_dev[OSVOS_MAX_DEVICES] = {};      // hipFuncSetAttribute is per device
+  bool& attr_set = attr_set_dev[osvos_current_device()];
     if (!attr_set) {
       OSVOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_c3_f32_kernel),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -29,12 +29,22 @@ def class_balanced_cross_entropy_loss(output, label, size_average=True, batch_av
 
 
 def center_crop(x, height, width):
-    """Keep the central ``height x width`` window: floor(excess/2) rows/cols are dropped at the
-    top/left and ceil(excess/2) at the bottom/right -- the pixels the reference keeps with its
-    negative F.pad (osvos_layers.py:52-56).  (The network itself fuses this into the head kernel.)"""
-    eh, ew = int(x.size(2)) - int(height), int(x.size(3)) - int(width)
-    t, l = eh // 2, ew // 2
-    return x[:, :, t:t + int(height), l:l + int(width)].clone()
+    """Central ``height x width`` window of ``x`` with the reference's rounding (osvos_layers.py:51-56): with
+    ``c = (size_in - target) / -2`` the left/top side moves by ``ceil(c)`` and the right/bottom side by ``floor(c)``.
+    Negative amounts crop (input larger than the target: floor(excess/2) rows/cols dropped at the top/left,
+    ceil(excess/2) at the bottom/right); positive amounts zero-pad (input smaller than the target), exactly like the
+    reference's ``F.pad`` with mixed-sign pads.  Returns a new tensor.  (The network itself fuses the crop into the
+    head kernel; this helper exists for callers of the reference's ``layers.osvos_layers`` API.)"""
+    height, width = int(height), int(width)
+    eh, ew = int(x.size(2)) - height, int(x.size(3)) - width
+    top, left = -(eh // 2), -(ew // 2)                 # ceil(c): > 0 pads, < 0 crops
+    out = x.new_zeros((x.size(0), x.size(1), height, width))
+    sy, sx = max(0, -top), max(0, -left)               # first source row / column kept
+    dy, dx = max(0, top), max(0, left)                 # where it lands in the result
+    nh, nw = min(int(x.size(2)) - sy, height - dy), min(int(x.size(3)) - sx, width - dx)
+    if nh > 0 and nw > 0:
+        out[:, :, dy:dy + nh, dx:dx + nw] = x[:, :, sy:sy + nh, sx:sx + nw]
+    return out
 
 
 def upsample_filt(size):

@@ -79,6 +79,19 @@ class OSVOS(nn.Module):
         self._runtime.set_precision(name)
         return self
 
+    def set_inplace_grad_accumulation(self, on=True):
+        """Opt in to accumulating parameter gradients straight into existing ``.grad`` tensors inside the backward kernels
+        (gradient-accumulation loops: no temporaries, no per-tensor add kernels).  Only valid when every backward through
+        this module is a ``loss.backward()`` -- under ``torch.autograd.grad`` leave it off.  Not part of the reference's API."""
+        self._runtime.inplace_accumulate = bool(on)
+        return self
+
+    def invalidate_packed_weights(self):
+        """Force a re-pack of the parameters on the next forward.  Needed only after writing parameters through ``.data``
+        (``p.data.copy_(...)``, ``dist.broadcast(p.data)``): such writes do not bump ``p._version``, which keys the cache."""
+        self._runtime.key = None
+        return self
+
     def _initialize_weights(self, pretrained):
         for m in self.modules():
             if isinstance(m, nn.Conv2d):

@@ -55,6 +55,8 @@ class TrainLoop(object):
         self.n_ave_grad, self.n_epochs = n_ave_grad, n_epochs
         self.reducer = reducer
         self.ave = 0
+        if hasattr(net, 'set_inplace_grad_accumulation'):
+            net.set_inplace_grad_accumulation(True)      # every backward of this loop is loss.backward()
         dev = next(net.parameters()).device
         self.running = [torch.zeros((), device=dev) for _ in range(5 if mode == 'parent' else 1)]
 

@@ -153,6 +153,7 @@ def helpers_fixture():
         t = torch.arange(hin * win, dtype=torch.float32).reshape(1, 1, hin, win)
         c = ref_layers.center_crop(t, ht, wt)
         out["crop|%d_%d_%d_%d" % (hin, win, ht, wt)] = np.array([c[0, 0, 0, 0].item() // win, c[0, 0, 0, 0].item() % win, c.shape[2], c.shape[3]], np.int64)
+    crops_fixture(out)
     rng = np.random.default_rng(7)
     logits = (rng.standard_normal((2, 1, 9, 11)) * 4).astype(np.float32)
     lab = (rng.random((2, 1, 9, 11)) > 0.7).astype(np.float32)
@@ -177,9 +178,54 @@ def helpers_fixture():
     print("wrote helpers")
 
 
+def adapters_fixture():
+    """The reference's two weight-import paths (vgg_osvos.py:92-125) run on seeded synthetic files of the right layout
+    (the real vgg_pytorch.pth / vgg_caffe.mat are absent offline): checksums of the 26 trunk tensors the reference ends up
+    with, their contiguity, plus what a reference-saved state_dict of the Caffe-initialised net looks like."""
+    import tempfile
+    out = {"meta": np.array([5, 6], np.int64)}         # seeds of the .pth and the .mat
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.makedirs(os.path.join(tmp, "models"))
+        synth.write_vgg_pytorch_pth(os.path.join(tmp, "models", "vgg_pytorch.pth"), 5)
+        synth.write_vgg_caffe_mat(os.path.join(tmp, "models", "vgg_caffe.mat"), 6)
+        os.chdir(tmp)                                   # the reference's Path.models_dir() is "./models"
+        try:
+            for pretrained, tag in ((1, "pth"), (2, "mat")):
+                torch.manual_seed(0)
+                net = ref_vo.OSVOS(pretrained=pretrained)
+                named = [(k, v) for k, v in net.state_dict().items() if k.startswith("stages.")]
+                assert len(named) == 26
+                grads_summary(named, out, tag + "|")
+                out[tag + "|contiguous"] = np.array([bool(v.is_contiguous()) for _, v in named])
+                # the heads keep the default init (normal(0, 0.001) / bilinear): pin two of them as well
+                grads_summary([(k, v) for k, v in net.state_dict().items() if k in ("upscale.2.weight", "fuse.bias")], out, tag + "|")
+                if pretrained == 2:
+                    # a checkpoint the reference writes from this net (train_parent.py:175-176) keeps the transposed strides
+                    torch.save(net.state_dict(), os.path.join(tmp, "ref_saved.pth"))
+                    back = torch.load(os.path.join(tmp, "ref_saved.pth"))
+                    out["mat|saved_contiguous"] = np.array([bool(back[k].is_contiguous()) for k, _ in named])
+        finally:
+            os.chdir(cwd)
+    np.savez_compressed(os.path.join(HERE, "adapters.npz"), **out)
+    print("wrote adapters", {k: out[k].tolist() for k in out if k.endswith("contiguous")})
+
+
+def crops_fixture(out):
+    """center_crop with target > input (zero padding) and mixed crop/pad (osvos_layers.py:51-56): full result arrays."""
+    for (hin, win, ht, wt) in [(5, 8, 10, 13), (5, 13, 10, 8), (7, 7, 12, 2), (4, 4, 9, 9), (9, 6, 4, 11)]:
+        t = torch.arange(1, hin * win + 1, dtype=torch.float32).reshape(1, 1, hin, win)
+        out["cropfull|%d_%d_%d_%d" % (hin, win, ht, wt)] = ref_layers.center_crop(t, ht, wt).numpy()
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
+    if len(sys.argv) > 1:                              # python make_golden.py helpers adapters  -> only those fixtures
+        for what in sys.argv[1:]:
+            {"helpers": helpers_fixture, "adapters": adapters_fixture}[what]()
+        sys.exit(0)
     helpers_fixture()
+    adapters_fixture()
     for c in CASES:
         run_case(*c)
