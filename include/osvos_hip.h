@@ -61,6 +61,16 @@ int osvos_pack_conv3x3_dgrad(const float* w_oihw, void* wpk, int Cout, int Cin, 
 int osvos_conv3x3(const void* x, const void* wpk, const float* bias, const void* mask, void* y,
                   int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int dtype, int tile, void* stream);
 int osvos_conv3x3_num_tiles(void);
+/* f32x3: the SAME fp32 convolution (fp32 tensors, fp32 packs, dtype OSVOS_F32) evaluated on the bf16 matrix pipe with
+ * three-way split operands -- v = hi + mid + lo exactly (three bf16 pieces), a*b ~ six bf16 products accumulated in fp32,
+ * dropped terms <= 2^-24 |a b| each: fp32-grade results at up to 2.67x the fp32-MFMA rate.  Needs Cin % 16 == 0,
+ * Cout % 4 == 0 and >= 32, y_cs % 4 == 0; other shapes (conv1_1, side_prep) stay on the exact kernel.
+ *   tile 200 + k (k < osvos_conv3x3_f32x3_num_tiles(), +100 for the XCD-local map) forces an f32x3 tile config;
+ *   osvos_set_fp32_conv_mode(1) makes tile = -1 choose f32x3 wherever it applies (0 = exact fp32 MFMA; the
+ *   environment variable OSVOS_FP32_CONV=x3|exact sets the initial value); returns the previous mode. */
+int osvos_conv3x3_f32x3_tiles(void);
+int osvos_set_fp32_conv_mode(int mode);
+int osvos_get_fp32_conv_mode(void);
 /* same convolution cut into `ksplit` parts along K = 9*Cin (0 = automatic, 1..8): layers too small to balance over
  * 256 CUs (conv4_x, conv5_x at batch 1) get more, shorter workgroups; partial sums go to part_ws
  * (osvos_conv3x3_splitk_ws_bytes) and a second kernel applies bias / ReLU / mask.  fp32 only. */

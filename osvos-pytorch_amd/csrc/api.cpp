@@ -50,6 +50,8 @@ int osvos_conv3x3(const void* x, const void* wpk, const float* bias, const void*
                            N, H, W, Cin, Cout, y_cs, relu, tile, (hipStream_t)stream);
 }
 
+int osvos_conv3x3_f32x3_tiles(void) { return osvos_conv3x3_f32x3_num_tiles(); }
+
 // bf16-MFMA convolution with explicit operand / result formats: x fp32 (x_is_bf16 = 0) or bf16 NHWC; y fp32 and,
 // when y_bf16 != NULL, a bf16 copy of y with the same channel stride (the operand of the next convolution)
 int osvos_conv3x3_bf16io(const void* x, int x_is_bf16, const void* wpk, const float* bias, const void* mask, int mask_is_bf16, float* y,

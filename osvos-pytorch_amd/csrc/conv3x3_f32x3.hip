@@ -1,0 +1,435 @@
+// 3x3 stride-1 pad-1 convolution, NHWC fp32 in / fp32 out, computed on the bf16 matrix pipe with THREE-WAY SPLIT
+// operands ("f32x3"): the same problem, the same tensors and the same weight packs as conv3x3_f32.hip
+// (reference vgg_osvos.py:41,142-143 forward; with the rotated pack, the data-gradient half of its backward).
+//
+// Why: on gfx950 v_mfma_f32_32x32x2_f32 peaks at 157 TFLOP/s while v_mfma_f32_32x32x16_bf16 peaks at 2.5 PFLOP/s,
+// 16x more.  An fp32 number is the exact sum of three bf16 numbers (8 + 8 + 8 significand bits, each piece the
+// round-to-nearest-even bf16 of what is left: v = h + m + l), so
+//     a * b = ah*bh + ah*bm + am*bh + am*bm + ah*bl + al*bh  (+ am*bl + al*bm + al*bl, each <= 2^-24 |a b|, dropped)
+// i.e. SIX bf16 MFMAs with fp32 accumulation reproduce an fp32 product to fp32 round-off (every bf16 x bf16
+// product is exact in fp32; the accumulator is the same fp32 register an fp32 MFMA would use).  Six passes over a
+// pipe that is 16x faster = 2.67x the fp32-MFMA rate for fp32-grade results.  The split happens while the fp32
+// tiles are staged into LDS (v_cvt_pk_bf16_f32 + two subtractions per piece); HBM and L2 see plain fp32 tensors.
+// tests/test_gpu_ops.py holds this kernel to the SAME float64 bars as the exact fp32 kernel.
+//
+// Structure (implicit GEMM, M = pixels, N = Cout, K = 9 * Cin, 16-channel K chunks = one MFMA k-step):
+//   * halo tile (TH+2) x (TW+2) staged once per chunk as 3 planes x 2 groups of 16-byte slots (8 bf16 channels of one
+//     pixel), re-used by all 9 taps (a tap is an LDS address offset); weights of the chunk (9 taps x 16 ci x BN co)
+//     staged from the fp32 pack [tap][Cin/4][CoutP][4] and split the same way
+//   * one LDS buffer, the NEXT chunk waits in registers (raw fp32, loaded with branch-free buffer loads while the
+//     MFMAs of the current chunk run)
+//   * per (tap, M block): 3 A fragments + (per tap) 3 x WN B fragments -> 6 WN MFMAs; fragment reads are issued one
+//     step ahead and pinned with sched_barrier (hipcc otherwise sinks every ds_read to its first use)
+//   * epilogue identical to conv3x3_f32.hip (cout-major accumulators -> 16-byte buffer stores, bias / ReLU / ReLU-mask
+//     of the producer fused, split-K partial sums)
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+struct ConvArgsX {
+  const float* x;
+  const float* wpk;      // fp32 pack [9][Cin/4][CoutP][4] (osvos_pack_fwd_f32 / osvos_pack_dgrad_f32)
+  const float* bias;
+  const float* mask;
+  float* y;
+  int N, H, W, Cin, Cout, CoutP, y_cs;
+  int tiles_x, tiles_y, nct;
+  int relu, map, nsp;
+  int ksplit;
+  float* part;
+};
+
+constexpr int cdivx(int a, int b) { return (a + b - 1) / b; }
+constexpr int pitch_x(int rbw, int hw) {
+  return rbw == 32 ? hw : (rbw == 16 ? cdivx(hw, 16) * 16 : cdivx(hw - 8, 16) * 16 + 8);
+}
+
+template <int RBW_, int TBX_, int TBY_, int NB_, int WGM_, int WGN_, int OCC_, int ILV_ = 0>
+struct CfgX {
+  static constexpr int RBW = RBW_, TBX = TBX_, TBY = TBY_, NB = NB_, WGM = WGM_, WGN = WGN_, OCC = OCC_;
+  static constexpr int ILV = ILV_;        // 1: the next chunk's global loads are issued one item per (tap, M block) step inside the MFMA loop
+  static constexpr int RBH = 32 / RBW;
+  static constexpr int TW = TBX * RBW, TH = TBY * RBH;
+  static constexpr int HWD = TW + 2, HHT = TH + 2;
+  static constexpr int PITCH = pitch_x(RBW, HWD);
+  static constexpr int PLANE = HHT * PITCH;              // 16-byte slots of one (piece, channel group) plane of the halo tile
+  static constexpr int BN = NB * 32;
+  static constexpr int A_U4 = 6 * PLANE;                 // [piece 3][group 2][PLANE]
+  static constexpr int B_ITEMS = 18 * BN;                // [tap 9][group 2][BN]
+  static constexpr int B_U4 = 3 * B_ITEMS;               // [piece 3][tap 9][group 2][BN]
+  static constexpr int BUF_U4 = A_U4 + B_U4;
+  static constexpr int A_ITEMS = HHT * HWD * 2;
+  static constexpr int NT = 64 * WGM * WGN;
+  static constexpr int NA = cdivx(A_ITEMS, NT);
+  static constexpr int NBL = cdivx(B_ITEMS, NT);
+  static constexpr int MB = TBX * TBY;
+  static constexpr int WM = MB / WGM, WN = NB / WGN;
+  static constexpr size_t LDS_BYTES = (size_t)(BUF_U4 + 1) * 16;
+  static_assert(WGM * WGN == 4 || WGM * WGN == 8, "4 or 8 waves per workgroup");
+  static_assert(MB % WGM == 0 && NB % WGN == 0, "wave grid must divide the tile");
+  static_assert(LDS_BYTES <= 160 * 1024, "tile does not fit the 160 KB LDS of a gfx950 CU");
+};
+
+__device__ inline unsigned cvt2(float a, float b) {
+  bf16x2_t h;
+  h[0] = (__bf16)a;
+  h[1] = (__bf16)b;
+  return __builtin_bit_cast(unsigned, h);
+}
+// v = p0 + p1 + p2 exactly (pieces are round-to-nearest-even bf16 of the running remainder)
+__device__ inline void split2(float a, float b, unsigned& p0, unsigned& p1, unsigned& p2) {
+  p0 = cvt2(a, b);
+  float ra = a - __uint_as_float(p0 << 16), rb = b - __uint_as_float(p0 & 0xffff0000u);
+  p1 = cvt2(ra, rb);
+  ra -= __uint_as_float(p1 << 16);
+  rb -= __uint_as_float(p1 & 0xffff0000u);
+  p2 = cvt2(ra, rb);
+}
+__device__ inline void split8(const u32x4& lo, const u32x4& hi, uint4& p0, uint4& p1, uint4& p2) {
+  const f32x4 a = __builtin_bit_cast(f32x4, lo), b = __builtin_bit_cast(f32x4, hi);
+  split2(a[0], a[1], p0.x, p1.x, p2.x);
+  split2(a[2], a[3], p0.y, p1.y, p2.y);
+  split2(b[0], b[1], p0.z, p1.z, p2.z);
+  split2(b[2], b[3], p0.w, p1.w, p2.w);
+}
+
+template <class C>
+__global__ __launch_bounds__(C::NT, C::OCC) void conv3x3_f32x3_kernel(ConvArgsX a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint4* As = reinterpret_cast<uint4*>(smem);
+  uint4* Bs = As + C::A_U4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm = wave / C::WGN, wn = wave % C::WGN;
+
+  int sp, ct;
+  if (a.map == 0) {          // Cout tile in the low bits: XCD b % 8 keeps one weight slice hot in its L2
+    sp = blockIdx.x / a.nct;
+    ct = blockIdx.x % a.nct;
+  } else {                   // Cout tiles of one spatial tile on the same XCD: the halo is fetched from HBM once per XCD
+    const int j = blockIdx.x >> 3;
+    ct = j % a.nct;
+    sp = (j / a.nct) * 8 + (blockIdx.x & 7);
+    if (sp >= a.nsp) return;
+  }
+  const int tx = sp % a.tiles_x;
+  sp /= a.tiles_x;
+  const int ty = sp % a.tiles_y;
+  const int n = sp / a.tiles_y;
+  const int x0 = tx * C::TW, y0 = ty * C::TH, co0 = ct * C::BN;
+  const int CQ = a.Cin >> 2;
+  const float* ximg = a.x + (size_t)n * a.H * a.W * a.Cin;
+
+  constexpr unsigned OOB = 0x80000000u;      // past num_records: the buffer load returns zeros, no branch in the K loop
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ximg), 0, (int)((size_t)a.H * a.W * a.Cin * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wpk), 0, (int)((size_t)9 * CQ * a.CoutP * 16), 0x00020000);
+  unsigned a_off[C::NA];
+  int a_dst[C::NA];
+#pragma unroll
+  for (int i = 0; i < C::NA; ++i) {
+    const int e = tid + i * C::NT;
+    const int g = e & 1, pix = e >> 1;
+    const int hy = pix / C::HWD, hx = pix % C::HWD;
+    const int gy = y0 + hy - 1, gx = x0 + hx - 1;
+    const bool slot = e < C::A_ITEMS;
+    a_dst[i] = slot ? g * C::PLANE + hy * C::PITCH + hx : -1;
+    a_off[i] = (slot && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? (unsigned)(((gy * a.W + gx) * a.Cin + 8 * g) * 4) : OOB;
+  }
+  unsigned b_off[C::NBL];
+#pragma unroll
+  for (int i = 0; i < C::NBL; ++i) {
+    const int e = tid + i * C::NT;
+    const int tap = e / (2 * C::BN), rem = e % (2 * C::BN);
+    const int g = rem / C::BN, nn = rem % C::BN;
+    b_off[i] = (e < C::B_ITEMS && co0 + nn < a.CoutP) ? (unsigned)(((tap * CQ + 2 * g) * a.CoutP + co0 + nn) * 16) : OOB;
+  }
+  const unsigned b_q1 = (unsigned)a.CoutP * 16u;       // the second channel quad of a group sits one [CoutP][4] row further
+
+  u32x4 ra[C::NA][2], rb[C::NBL][2];
+  auto load_item = [&](int it, int kc) {      // it: compile-time item index (A items first)
+    if (it < C::NA) {
+      ra[it][0] = __builtin_amdgcn_raw_buffer_load_b128(xrs, a_off[it], kc * 64, 0);
+      ra[it][1] = __builtin_amdgcn_raw_buffer_load_b128(xrs, a_off[it] + 16u, kc * 64, 0);
+    } else if (it < C::NA + C::NBL) {
+      const int i = it - C::NA;
+      rb[i][0] = __builtin_amdgcn_raw_buffer_load_b128(wrs, b_off[i], kc * 4 * a.CoutP * 16, 0);
+      rb[i][1] = __builtin_amdgcn_raw_buffer_load_b128(wrs, b_off[i] + b_q1, kc * 4 * a.CoutP * 16, 0);
+    }
+  };
+  auto load_chunk = [&](int kc) {
+#pragma unroll
+    for (int it = 0; it < C::NA + C::NBL; ++it) load_item(it, kc);
+  };
+  static_assert(C::NA + C::NBL <= 9 * C::WM, "interleaved staging: one item per step must cover the chunk");
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int i = 0; i < C::NA; ++i) {
+      uint4 p0, p1, p2;
+      split8(ra[i][0], ra[i][1], p0, p1, p2);
+      if (C::A_ITEMS % C::NT == 0 || a_dst[i] >= 0) {
+        As[a_dst[i]] = p0;
+        As[a_dst[i] + 2 * C::PLANE] = p1;
+        As[a_dst[i] + 4 * C::PLANE] = p2;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < C::NBL; ++i) {
+      uint4 p0, p1, p2;
+      split8(rb[i][0], rb[i][1], p0, p1, p2);
+      const int e = tid + i * C::NT;
+      if (C::B_ITEMS % C::NT == 0 || e < C::B_ITEMS) {
+        Bs[e] = p0;
+        Bs[e + C::B_ITEMS] = p1;
+        Bs[e + 2 * C::B_ITEMS] = p2;
+      }
+    }
+  };
+
+  int a_idx[C::WM];
+#pragma unroll
+  for (int mi = 0; mi < C::WM; ++mi) {
+    const int mb = wm * C::WM + mi;
+    const int mbx = mb % C::TBX, mby = mb / C::TBX;
+    const int dy = li / C::RBW, dx = li % C::RBW;
+    a_idx[mi] = lh * C::PLANE + (mby * C::RBH + dy) * C::PITCH + mbx * C::RBW + dx;
+  }
+  const int b_idx = lh * C::BN + wn * C::WN * 32 + li;
+
+  f32x16 acc[C::WM][C::WN];
+#pragma unroll
+  for (int mi = 0; mi < C::WM; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < C::WN; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  const int nch_all = a.Cin >> 4;
+  const int kc_begin = (int)((long)nch_all * blockIdx.y / a.ksplit);
+  const int kc_end = (int)((long)nch_all * (blockIdx.y + 1) / a.ksplit);
+  load_chunk(kc_begin);
+  for (int kc = kc_begin; kc < kc_end; ++kc) {
+    __syncthreads();                     // every wave is done with the previous chunk's tiles
+    store_chunk();
+    __syncthreads();
+    const bool more = kc + 1 < kc_end;
+    if (!C::ILV && more) load_chunk(kc + 1);      // in flight during the MFMAs below
+    // 9 x WM steps (tap, M block); fragments of step s+1 (and, once per tap, the weights of tap+1) are requested
+    // before the 6 WN MFMAs of step s issue
+    uint4 fb[2][3][C::WN], fa[2][3];
+    auto ldB = [&](int tap, int set) {
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int ni = 0; ni < C::WN; ++ni) fb[set][p][ni] = Bs[b_idx + (p * 9 + tap) * 2 * C::BN + ni * 32];
+    };
+    auto ldA = [&](int tap, int mi, int set) {
+      const int r = tap / 3, s = tap % 3;
+#pragma unroll
+      for (int p = 0; p < 3; ++p) fa[set][p] = As[a_idx[mi] + p * 2 * C::PLANE + r * C::PITCH + s];
+    };
+    ldB(0, 0);
+    ldA(0, 0, 0);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+      for (int mi = 0; mi < C::WM; ++mi) {
+        const int step = tap * C::WM + mi;
+        if (mi + 1 < C::WM) ldA(tap, mi + 1, (step + 1) & 1);
+        else if (tap + 1 < 9) ldA(tap + 1, 0, (step + 1) & 1);
+        if (mi == 0 && tap + 1 < 9) ldB(tap + 1, (tap + 1) & 1);
+        if (C::ILV && more) load_item(step, kc + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const int sa = step & 1, sb = tap & 1;
+        // pieces: 0 = high, 1 = middle, 2 = low.  Small products first, the dominant hi x hi product last.
+        constexpr int PB[6] = {2, 0, 1, 1, 0, 0};
+        constexpr int PA[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+          for (int ni = 0; ni < C::WN; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fb[sb][PB[t]][ni]),
+                                                                  __builtin_bit_cast(bf16x8_t, fa[sa][PA[t]]), acc[mi][ni], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+
+  // ---- epilogue (same as conv3x3_f32.hip): D = [cout rows][pixel columns], lane (li, lh) holds pixel li of its M block
+  // and couts 8 q + 4 lh + (0..3) in registers 4q..4q+3 = one 16-byte store
+  const size_t img_elems = (size_t)a.H * a.W * a.y_cs;
+  const bool split = a.ksplit > 1;       // split-K: raw partial sums, dense [part][n][pixel][Cout]; epilogue in the finalize kernel
+  const int cs = split ? a.Cout : a.y_cs;
+  const size_t out_elems = (size_t)a.H * a.W * cs;
+  float* obase = split ? a.part + ((size_t)blockIdx.y * a.N + n) * out_elems : a.y + n * out_elems;
+  const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(obase, 0, (int)(out_elems * 4), 0x00020000);
+  const bool use_mask = !split && a.mask != nullptr;
+  const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(use_mask ? a.mask + n * img_elems : a.y), 0,
+                                                                       use_mask ? (int)(img_elems * 4) : 0, 0x00020000);
+  const bool use_bias = !split && a.bias != nullptr;
+  const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(use_bias ? a.bias : a.y), 0, use_bias ? a.Cout * 4 : 0, 0x00020000);
+  const bool relu = !split && a.relu;
+#pragma unroll
+  for (int ni = 0; ni < C::WN; ++ni) {
+    const int cb = co0 + (wn * C::WN + ni) * 32 + 4 * lh;
+    f32x4 bv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bv[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brs, (cb + 8 * q) * 4, 0, 0));
+#pragma unroll
+    for (int mi = 0; mi < C::WM; ++mi) {
+      const int mb = wm * C::WM + mi;
+      const int oy = y0 + (mb / C::TBX) * C::RBH + li / C::RBW;
+      const int ox = x0 + (mb % C::TBX) * C::RBW + li % C::RBW;
+      const unsigned pix = (oy < a.H && ox < a.W) ? (unsigned)((oy * a.W + ox) * cs) * 4u : OOB;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int co = cb + 8 * q;
+        const unsigned off = co < a.Cout ? pix + (unsigned)co * 4u : OOB;
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = acc[mi][ni][4 * q + e] + bv[q][e];
+          if (relu) v[e] = v[e] > 0.f ? v[e] : 0.f;
+        }
+        if (use_mask) {
+          const f32x4 m = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(mrs, off, 0, 0));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = m[e] > 0.f ? v[e] : 0.f;
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, off, 0, 0);
+      }
+    }
+  }
+}
+
+template <class C>
+int launch_x(const ConvArgsX& a0, hipStream_t stream) {
+  static bool attr_set_dev[OSVOS_MAX_DEVICES] = {};      // hipFuncSetAttribute is per device
+  bool& attr_set = attr_set_dev[osvos_current_device()];
+  if (!attr_set) {
+    OSVOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f32x3_kernel<C>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
+    attr_set = true;
+  }
+  ConvArgsX a = a0;
+  a.tiles_x = ceil_div(a.W, C::TW);
+  a.tiles_y = ceil_div(a.H, C::TH);
+  a.nct = ceil_div(a.CoutP, C::BN);
+  a.nsp = a.tiles_x * a.tiles_y * a.N;
+  const long blocks = a.map == 0 ? (long)a.nct * a.nsp : (long)a.nct * ((a.nsp + 7) / 8) * 8;
+  OSVOS_ARG_CHECK(blocks > 0 && blocks < (1L << 31), "conv3x3 f32x3: grid of %ld blocks", blocks);
+  hipLaunchKernelGGL(conv3x3_f32x3_kernel<C>, dim3((unsigned)blocks, (unsigned)a.ksplit), dim3(C::NT), C::LDS_BYTES, stream, a);
+  OSVOS_LAUNCH_CHECK();
+  return 0;
+}
+
+struct TileInfoX { int tw, th, bn, nt; size_t lds; };
+
+//                 RBW TBX TBY NB WGM WGN OCC
+using X0 = CfgX<32, 1, 8, 4, 2, 2, 1>;   // 32x8 px x 128 co, 4 waves (4x2 accumulators per wave), 143 KB LDS
+using X1 = CfgX<32, 1, 8, 4, 4, 2, 1>;   // 32x8 px x 128 co, 8 waves (2x2 accumulators per wave): two waves per SIMD
+using X2 = CfgX<32, 1, 4, 4, 2, 2, 1>;   // 32x4 px x 128 co, 4 waves (2x2), 130 KB
+using X3 = CfgX<32, 1, 8, 2, 2, 2, 1>;   // 32x8 px x  64 co, 4 waves (4x1),  88 KB
+using X4 = CfgX<32, 1, 8, 2, 4, 2, 1>;   // 32x8 px x  64 co, 8 waves (2x1)
+using X5 = CfgX<32, 1, 4, 2, 2, 2, 2>;   // 32x4 px x  64 co, 4 waves (2x1),  75 KB: two workgroups per CU
+using X6 = CfgX<16, 1, 4, 2, 2, 2, 1>;   // 16x8 px x  64 co, 4 waves (2x1), 86 KB: narrow maps (107 / 54 pixels wide)
+using X7 = CfgX<16, 1, 8, 2, 2, 2, 1>;   // 16x16 px x 64 co, 4 waves (4x1)
+using X8 = CfgX<16, 1, 8, 2, 4, 2, 1>;   // 16x16 px x 64 co, 8 waves (2x1)
+using X9 = CfgX<16, 1, 4, 4, 2, 2, 1>;   // 16x8 px x 128 co, 4 waves (2x2)
+using X10 = CfgX<32, 1, 8, 4, 4, 2, 1, 1>;  // X1 with the staging loads spread over the MFMA loop
+using X11 = CfgX<32, 1, 8, 4, 2, 2, 1, 1>;  // X0 ...
+using X12 = CfgX<32, 1, 8, 2, 4, 2, 1, 1>;  // X4 ...
+using X13 = CfgX<32, 1, 4, 2, 2, 2, 2, 1>;  // X5 ...
+constexpr int kNumTilesX = 14;
+template <class C>
+constexpr TileInfoX infoX() { return TileInfoX{C::TW, C::TH, C::BN, C::NT, C::LDS_BYTES}; }
+const TileInfoX kTilesX[kNumTilesX] = {infoX<X0>(), infoX<X1>(), infoX<X2>(), infoX<X3>(), infoX<X4>(),
+                                       infoX<X5>(), infoX<X6>(), infoX<X7>(), infoX<X8>(), infoX<X9>(),
+                                       infoX<X10>(), infoX<X11>(), infoX<X12>(), infoX<X13>()};
+
+long tiles_of(const TileInfoX& t, int N, int H, int W, int CoutP) {
+  return (long)N * ceil_div(H, t.th) * ceil_div(W, t.tw) * ceil_div(CoutP, t.bn);
+}
+
+// First-cut choice (to be replaced by the measured table of tools/tune_conv.py --x3): the biggest tile that still yields
+// about one workgroup per CU, narrow 16-wide tiles where 32-wide ones pad the frame by more than 10 %.
+int pick_tile_x(int N, int H, int W, int CoutP) {
+  const bool narrow = (long)ceil_div(W, 32) * 32 * 100 > (long)ceil_div(W, 16) * 16 * 110;
+  if (CoutP >= 128) {
+    if (!narrow && tiles_of(kTilesX[1], N, H, W, CoutP) >= 230) return 1;
+    if (narrow && tiles_of(kTilesX[9], N, H, W, CoutP) >= 230) return 9;
+    if (!narrow && tiles_of(kTilesX[2], N, H, W, CoutP) >= 230) return 2;
+  }
+  if (!narrow && tiles_of(kTilesX[4], N, H, W, CoutP) >= 230) return 4;
+  if (narrow && tiles_of(kTilesX[8], N, H, W, CoutP) >= 230) return 8;
+  return narrow ? 6 : 5;
+}
+
+// K parts so that small layers (conv5_x at batch 1) put about two workgroups on every CU
+int pick_ksplit_x(const TileInfoX& t, int N, int H, int W, int Cin, int Cout, int CoutP) {
+  if (Cin < 256) return 1;
+  const long blocks = tiles_of(t, N, H, W, CoutP);
+  int ks = 1;
+  while (ks < 8 && blocks * ks < 384 && (Cin / 16) / (ks * 2) >= 4) ks *= 2;
+  return ks;
+}
+
+}  // namespace
+
+int osvos_conv3x3_f32x3_num_tiles(void) { return kNumTilesX; }
+
+bool osvos_conv3x3_f32x3_applicable(int Cin, int Cout, int y_cs) { return Cin % 16 == 0 && Cout % 4 == 0 && y_cs % 4 == 0 && Cout >= 32; }
+
+// same contract as osvos_conv3x3_f32_ws (conv3x3_f32.hip); tile: -1 = automatic, 0..kNumTilesX-1 (+100: XCD-local halo map)
+int osvos_conv3x3_f32x3(const float* x, const float* wpk, const float* bias, const float* mask, float* y,
+                        int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int tile, int ksplit, void* part_ws, hipStream_t stream) {
+  OSVOS_ARG_CHECK(x && wpk && y, "conv3x3 f32x3: null pointer");
+  OSVOS_ARG_CHECK(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv3x3 f32x3: bad shape");
+  OSVOS_ARG_CHECK(osvos_conv3x3_f32x3_applicable(Cin, Cout, y_cs), "conv3x3 f32x3: needs Cin %% 16 == 0 (%d), Cout, y_cs %% 4 == 0 (%d, %d), Cout >= 32",
+                  Cin, Cout, y_cs);
+  OSVOS_ARG_CHECK(y_cs >= Cout, "conv3x3 f32x3: y channel stride %d < Cout %d", y_cs, Cout);
+  OSVOS_ARG_CHECK((long)H * W * Cin < (1L << 29) && (long)H * W * y_cs < (1L << 29), "conv3x3 f32x3: image too large for 31-bit byte offsets");
+  ConvArgsX a;
+  a.x = x; a.wpk = wpk; a.bias = bias; a.mask = mask; a.y = y;
+  a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.CoutP = osvos_cout_pad(Cout); a.y_cs = y_cs;
+  a.relu = relu;
+  if (tile < 0) {
+    OSVOS_ENV_INT(env_tile, "OSVOS_X3_TILE", -1);
+    tile = env_tile >= 0 ? env_tile : pick_tile_x(N, H, W, a.CoutP);
+    if (env_tile < 0 && (double)H * W * Cin > 9.0 * Cin * a.CoutP) tile += 100;      // activations larger than the weights
+  }
+  a.map = tile >= 100 ? 1 : 0;
+  tile %= 100;
+  OSVOS_ARG_CHECK(tile >= 0 && tile < kNumTilesX, "conv3x3 f32x3: unknown tile config %d", tile);
+  a.part = reinterpret_cast<float*>(part_ws);
+  a.ksplit = 1;
+  if (part_ws != nullptr) {
+    OSVOS_ENV_INT(env_ks, "OSVOS_X3_KSPLIT", 0);
+    a.ksplit = ksplit > 0 ? ksplit : (env_ks > 0 && Cin >= 256 ? env_ks : pick_ksplit_x(kTilesX[tile], N, H, W, Cin, Cout, a.CoutP));
+    if (a.ksplit < 1 || a.ksplit > 8 || a.ksplit > (Cin >> 4)) a.ksplit = 1;
+  }
+  int rc;
+  switch (tile) {
+    case 0: rc = launch_x<X0>(a, stream); break;
+    case 1: rc = launch_x<X1>(a, stream); break;
+    case 2: rc = launch_x<X2>(a, stream); break;
+    case 3: rc = launch_x<X3>(a, stream); break;
+    case 4: rc = launch_x<X4>(a, stream); break;
+    case 5: rc = launch_x<X5>(a, stream); break;
+    case 6: rc = launch_x<X6>(a, stream); break;
+    case 7: rc = launch_x<X7>(a, stream); break;
+    case 8: rc = launch_x<X8>(a, stream); break;
+    case 9: rc = launch_x<X9>(a, stream); break;
+    case 10: rc = launch_x<X10>(a, stream); break;
+    case 11: rc = launch_x<X11>(a, stream); break;
+    case 12: rc = launch_x<X12>(a, stream); break;
+    case 13: rc = launch_x<X13>(a, stream); break;
+    default: osvos_set_error("conv3x3 f32x3: unknown tile config %d", tile); return -1;
+  }
+  if (rc) return rc;
+  return a.ksplit > 1 ? osvos_conv3x3_splitk_finalize_f32(a.part, bias, mask, y, (long)N * H * W, Cout, y_cs, a.ksplit, relu, stream) : 0;
+}

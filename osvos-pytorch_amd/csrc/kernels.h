@@ -8,6 +8,14 @@ size_t osvos_conv3x3_splitk_ws_bytes_f32(int N, int H, int W, int Cout);
 void osvos_conv3x3_force_ksplit(int k);
 int osvos_conv3x3_f32_ws(const float* x, const float* wpk, const float* bias, const float* mask, float* y,
                          int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int tile, void* part_ws, hipStream_t stream);
+int osvos_conv3x3_splitk_finalize_f32(const float* part, const float* bias, const float* mask, float* y, long npix, int Cout, int y_cs,
+                                      int ksplit, int relu, hipStream_t stream);
+// f32x3 (conv3x3_f32x3.hip): fp32 tensors and fp32 packs, three-way bf16 split operands on the bf16 matrix pipe
+int osvos_fp32_conv_mode();          // 0 exact fp32 MFMA, 1 f32x3
+bool osvos_conv3x3_f32x3_applicable(int Cin, int Cout, int y_cs);
+int osvos_conv3x3_f32x3_num_tiles(void);
+int osvos_conv3x3_f32x3(const float* x, const float* wpk, const float* bias, const float* mask, float* y,
+                        int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int tile, int ksplit, void* part_ws, hipStream_t stream);
 size_t osvos_wgrad_ws_bytes_f32(int N, int H, int W, int Cin_s, int Cout);
 int osvos_conv3x3_wgrad_f32(const float* x, const float* dy, void* ws, float* dw, float* db,
                             int N, int H, int W, int Cin, int Cin_s, int Cout, int Cout_s,
