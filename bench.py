@@ -308,14 +308,15 @@ def measure(wl, steps, warmup, min_seconds, world, dist, device, use_prof=True):
                             "ms_per_step": round(e2 / n2 * 1e3, 4)}
     gf_fwd = conv_gflop_forward(wl.h, wl.w) * wl.batch
     passes = 1 if wl.mode == "infer" else 3
-    peak = FP32_MFMA_PEAK_TFLOPS if wl.precision == "fp32" else BF16_MFMA_PEAK_TFLOPS
-    kname = ("conv3x3_f32_kernel", "wgrad_f32_kernel") if wl.precision == "fp32" else ("conv3x3_bf16_kernel", "wgrad_bf16_kernel")
+    peak = BF16_MFMA_PEAK_TFLOPS if wl.precision == "bf16" else FP32_MFMA_PEAK_TFLOPS
+    kname = {"fp32": ("conv3x3_f32_kernel", "wgrad_f32_kernel"), "fp32x3": ("conv3x3_f32x3_kernel", "wgrad_f32_kernel"),
+             "bf16": ("conv3x3_bf16_kernel", "wgrad_bf16_kernel")}[wl.precision]
     roof = None
     step_frac = round(passes * gf_fwd / 1e3 / (elapsed / steps) / peak, 4)
     if wl.mode == "infer" and wl.graph:
         # one captured graph per step: the family is the whole forward (17 conv launches + glue)
         ach = gf_fwd / 1e3 / (elapsed / steps)
-        act_gb = 0.904 * (wl.h * wl.w) / (480.0 * 854.0) * wl.batch * (1.0 if wl.precision == "fp32" else 0.5)   # min conv tensor traffic
+        act_gb = 0.904 * (wl.h * wl.w) / (480.0 * 854.0) * wl.batch * (0.5 if wl.precision == "bf16" else 1.0)   # min conv tensor traffic
         roof = {"bound": "mfma", "kernel": "hipGraph replay of osvos_net_forward (%s x17 + pool/head glue)" % kname[0],
                 "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                 "traffic": None, "algorithmic_hbm_GBps": round(act_gb / (elapsed / steps), 1), "hbm_peak_GBps": 8000}
@@ -338,7 +339,8 @@ def measure(wl, steps, warmup, min_seconds, world, dist, device, use_prof=True):
     return res
 
 
-DTYPE_NAME = {"fp32": "f32", "bf16": "bf16 MFMA operands and bf16 trunk tensors (fwd+dgrad+wgrad), f32 accumulate; head/loss/skinny wgrads/parameters f32"}
+DTYPE_NAME = {"fp32": "f32",
+              "fp32x3": "f32 tensors and parameters; wide 3x3 convolutions (fwd, dgrad) as three-way bf16 split on the bf16 MFMA pipe (6 bf16 products per f32 product, f32 accumulate: f32-grade results); everything else f32", "bf16": "bf16 MFMA operands and bf16 trunk tensors (fwd+dgrad+wgrad), f32 accumulate; head/loss/skinny wgrads/parameters f32"}
 
 
 def main():
@@ -349,7 +351,7 @@ def main():
     ap.add_argument("--mode", default="online", choices=["online", "parent", "infer"],
                     help="online/parent: restated training loops (fwd+loss+bwd+SGD); infer: forward only under no_grad "
                          "(BASELINE.json configs[4]: use --height 1080 --width 1920 --batch 4 --graph 1)")
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
+    ap.add_argument("--precision", default=os.environ.get("OSVOS_PRECISION", "fp32"), choices=["fp32", "fp32x3", "bf16"],
                     help="bf16: the three conv passes on bf16 MFMA operands, trunk tensors stored as bf16 (fp32 accumulate); "
                          "the headline configs[1] is fp32")
     ap.add_argument("--graph", type=int, default=0, help="infer mode: replay the forward from a captured hipGraph")

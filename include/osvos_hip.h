@@ -28,6 +28,9 @@ extern "C" {
 #define OSVOS_BF16 1          /* bf16 tensors in HBM: reserved, not built */
 #define OSVOS_F32_BF16MFMA 2  /* fp32 tensors in HBM; conv forward/data-gradient operands rounded to bf16 (RNE) while
                                  staged into LDS, v_mfma_f32_32x32x16_bf16 with fp32 accumulate; everything else fp32 */
+#define OSVOS_F32_X3 3        /* fp32 tensors, fp32 parameters and fp32 weight packs exactly as OSVOS_F32; the wide 3x3 convolutions
+                                 (forward, data gradient) run on the bf16 matrix pipe with three-way split operands (six bf16
+                                 products per fp32 product, fp32 accumulate): fp32-grade results, see osvos_conv3x3 below */
 #define OSVOS_NPARAMS 52 /* tensors of OSVOS.state_dict(), reference order */
 
 int osvos_version(void);
@@ -65,7 +68,7 @@ int osvos_conv3x3_num_tiles(void);
  * three-way split operands -- v = hi + mid + lo exactly (three bf16 pieces), a*b ~ six bf16 products accumulated in fp32,
  * dropped terms <= 2^-24 |a b| each: fp32-grade results at up to 2.67x the fp32-MFMA rate.  Needs Cin % 16 == 0,
  * Cout % 4 == 0 and >= 32, y_cs % 4 == 0; other shapes (conv1_1, side_prep) stay on the exact kernel.
- *   tile 200 + k (k < osvos_conv3x3_f32x3_num_tiles(), +100 for the XCD-local map) forces an f32x3 tile config;
+ *   tile 200 + k (k < osvos_conv3x3_f32x3_tiles(), +100 for the XCD-local map) forces an f32x3 tile config;
  *   osvos_set_fp32_conv_mode(1) makes tile = -1 choose f32x3 wherever it applies (0 = exact fp32 MFMA; the
  *   environment variable OSVOS_FP32_CONV=x3|exact sets the initial value); returns the previous mode. */
 int osvos_conv3x3_f32x3_tiles(void);

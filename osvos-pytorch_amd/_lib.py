@@ -18,7 +18,7 @@ CSRC = os.path.join(_HERE, "csrc")
 _lock = threading.Lock()
 _lib = None
 
-F32, BF16, F32_BF16MFMA = 0, 1, 2
+F32, BF16, F32_BF16MFMA, F32_X3 = 0, 1, 2, 3
 NPARAMS = 52
 
 _vp, _i, _l, _sz, _f = C.c_void_p, C.c_int, C.c_long, C.c_size_t, C.c_float

@@ -8,7 +8,7 @@ import os
 
 import torch
 
-from ._lib import F32, F32_BF16MFMA, NPARAMS, check, lib, ptr_array
+from ._lib import F32, F32_BF16MFMA, F32_X3, NPARAMS, check, lib, ptr_array
 
 # indices (state_dict order) of the frozen transposed-conv weights: lr 0 in both reference
 # scripts (train_online.py:84-85, train_parent.py:99-100); their gradients are never formed
@@ -29,7 +29,7 @@ class NetRuntime:
         self.deconv_key = None
         # 'fp32' (exact fp32 MFMA everywhere) or 'bf16' (conv forward / data-gradient operands rounded to bf16,
         # fp32 accumulate and fp32 tensors; weight gradients, head and loss stay fp32)
-        self.dtype = F32_BF16MFMA if os.environ.get("OSVOS_PRECISION", "fp32").lower() == "bf16" else F32
+        self.dtype = {"bf16": F32_BF16MFMA, "fp32x3": F32_X3}.get(os.environ.get("OSVOS_PRECISION", "fp32").lower(), F32)
         self.aux_stream = None        # second HIP stream: wgrad kernels overlap the dgrad kernels
         self.aux2_stream = None       # third: the slab reduces of the weight gradients
         self.auxf_stream = None       # forward side branches (own stream: a forward pipelined under the previous backward must not queue
@@ -60,7 +60,7 @@ class NetRuntime:
         return C.c_void_p(self.aux2_stream.cuda_stream)
 
     def set_precision(self, name):
-        dt = {"fp32": F32, "bf16": F32_BF16MFMA}[name]
+        dt = {"fp32": F32, "bf16": F32_BF16MFMA, "fp32x3": F32_X3}[name]
         if dt != self.dtype:
             self.dtype, self.wbuf, self.key = dt, None, None
 

@@ -46,6 +46,9 @@ int osvos_conv3x3(const void* x, const void* wpk, const float* bias, const void*
   if (dtype == OSVOS_F32_BF16MFMA)
     return osvos_conv3x3_bf16mfma((const float*)x, wpk, bias, (const float*)mask, (float*)y, N, H, W, Cin, Cout, y_cs, relu, tile,
                                   (hipStream_t)stream);
+  if (dtype == OSVOS_F32_X3 && tile < 0 && osvos_conv3x3_f32x3_applicable(Cin, Cout, y_cs))
+    return osvos_conv3x3_f32x3((const float*)x, (const float*)wpk, bias, (const float*)mask, (float*)y, N, H, W, Cin, Cout, y_cs, relu, -1, 0,
+                               nullptr, (hipStream_t)stream);
   return osvos_conv3x3_f32((const float*)x, (const float*)wpk, bias, (const float*)mask, (float*)y,
                            N, H, W, Cin, Cout, y_cs, relu, tile, (hipStream_t)stream);
 }
@@ -80,7 +83,7 @@ size_t osvos_conv3x3_splitk_ws_bytes(int N, int H, int W, int Cout, int dtype) {
 int osvos_conv3x3_splitk(const void* x, const void* wpk, const float* bias, const void* mask, void* y,
                          int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int dtype, int tile, int ksplit,
                          void* part_ws, void* stream) {
-  OSVOS_ARG_CHECK(dtype == OSVOS_F32, "conv3x3_splitk: fp32 only (dtype %d)", dtype);
+  OSVOS_ARG_CHECK(dtype == OSVOS_F32 || dtype == OSVOS_F32_X3, "conv3x3_splitk: fp32 only (dtype %d)", dtype);
   OSVOS_ARG_CHECK(part_ws != nullptr && ksplit >= 0 && ksplit <= 8, "conv3x3_splitk: bad ksplit / workspace");
   osvos_conv3x3_force_ksplit(ksplit);
   const int rc = osvos_conv3x3_f32_ws((const float*)x, (const float*)wpk, bias, (const float*)mask, (float*)y, N, H, W, Cin, Cout,

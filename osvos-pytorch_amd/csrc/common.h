@@ -81,4 +81,4 @@ static inline int osvos_group(int dtype) { return dtype == OSVOS_BF16 ? 8 : 4; }
 static inline int osvos_cin_pad(int cin, int dtype) { int g2 = 2 * osvos_group(dtype); return (cin + g2 - 1) / g2 * g2; }
 static inline int osvos_cout_pad(int cout) { return (cout + 31) / 32 * 32; }
 static inline size_t osvos_elem(int dtype) { return dtype == OSVOS_BF16 ? 2 : 4; }   // activation element size
-static inline bool osvos_dtype_built(int dtype) { return dtype == OSVOS_F32 || dtype == OSVOS_F32_BF16MFMA; }
+static inline bool osvos_dtype_built(int dtype) { return dtype == OSVOS_F32 || dtype == OSVOS_F32_BF16MFMA || dtype == OSVOS_F32_X3; }

@@ -192,7 +192,10 @@ EventPool& event_pool() {
 // (mask_b: bf16 mask, takes precedence over the fp32 `mask`; y may be NULL in the bf16 modes when y_b is given)
 inline int conv_main(const void* x, const void* x_b, const void* wpk, const float* bias, const void* mask, const void* mask_b, void* y, void* y_b,
                      int N, int h, int w, int cin, int cout, int y_cs, int relu, int dtype, void* part, hipStream_t stream) {
-  if (dtype == OSVOS_F32)
+  if (dtype == OSVOS_F32_X3 && osvos_conv3x3_f32x3_applicable(cin, cout, y_cs))      // three-way bf16 split on the bf16 matrix pipe
+    return osvos_conv3x3_f32x3((const float*)x, (const float*)wpk, bias, (const float*)mask, (float*)y, N, h, w, cin, cout, y_cs, relu, -1, 0,
+                               part, stream);
+  if (dtype == OSVOS_F32 || dtype == OSVOS_F32_X3)
     return osvos_conv3x3_f32_ws((const float*)x, (const float*)wpk, bias, (const float*)mask, (float*)y, N, h, w, cin, cout, y_cs,
                                 relu, -1, part, stream);
   return osvos_conv3x3_bf16mfma_io(x_b ? x_b : x, x_b ? 1 : 0, wpk, bias, mask_b ? mask_b : mask, mask_b ? 1 : 0, (float*)y, y_b, N, h, w, cin,

@@ -74,7 +74,8 @@ class OSVOS(nn.Module):
         return list(outs)
 
     def set_precision(self, name):
-        """'fp32' (default, reference-exact arithmetic) or 'bf16' (bf16 MFMA operands for the conv forward and
+        """'fp32' (default, exact fp32 MFMA), 'fp32x3' (fp32 tensors and fp32-grade results, the wide convolutions on the bf16 matrix pipe with
+        three-way split operands) or 'bf16' (bf16 MFMA operands for the conv forward and
         data-gradient kernels, fp32 accumulate, fp32 tensors).  Not part of the reference's API."""
         self._runtime.set_precision(name)
         return self

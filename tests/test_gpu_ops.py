@@ -65,6 +65,94 @@ def test_conv3x3_forward_all_tiles(shape, tile):
     assert emax < 2e-5 and el2 < 1e-5, (shape, tile, emax, el2)
 
 
+X3_SHAPES = [
+    # N, H, W, Cin, Cout  (f32x3 needs Cin % 16 == 0, Cout % 4 == 0 and >= 32)
+    (2, 17, 35, 16, 64),
+    (1, 33, 70, 64, 128),
+    (1, 40, 45, 32, 96),
+    (1, 30, 54, 512, 64),
+    (2, 9, 11, 48, 32),
+]
+
+
+@pytest.mark.parametrize("shape", X3_SHAPES)
+@pytest.mark.parametrize("tile", [200 + k for k in range(14)] + [301, 305, 310])
+def test_conv3x3_f32x3_all_tiles(shape, tile):
+    """f32x3 (three-way bf16 split on the bf16 matrix pipe) is held to the SAME float64 bars as the exact fp32 MFMA kernel."""
+    ops = _ops()
+    assert ops.lib().osvos_conv3x3_f32x3_tiles() == 14
+    n, h, w, cin, cout = shape
+    g = torch.Generator().manual_seed(hash(shape) % 1000 + 3)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)
+    b = torch.randn(cout, generator=g)
+    ref = F.relu(F.conv2d(x.double(), wt.double(), b.double(), padding=1))
+    y = ops.conv3x3(nhwc(x), ops.pack_fwd(wt.cuda()), b.cuda(), cout, relu=True, tile=tile)
+    emax, el2 = rel_err(nchw(y), ref)
+    assert emax < 2e-5 and el2 < 1e-5, (shape, tile, emax, el2)
+
+
+def test_conv3x3_f32x3_is_fp32_grade_and_covers_mask_stride_dgrad_splitk():
+    """(1) error against float64 no worse than 2x the exact fp32 kernel's on a K = 9 x 512 reduction with wide-range data;
+    (2) mask / channel stride / no bias; (3) the data-gradient pack; (4) split-K; (5) dtype OSVOS_F32_X3 and the process-wide mode."""
+    ops = _ops()
+    from osvos_pytorch_amd._lib import F32_X3
+    g = torch.Generator().manual_seed(77)
+    n, h, w, cin, cout = 1, 30, 54, 512, 128
+    # activations spread over 6 decades (post-ReLU like: half of them zero), weights He-scaled
+    x = torch.randn(n, cin, h, w, generator=g) * torch.exp(torch.randn(n, cin, h, w, generator=g) * 2.0)
+    x = x * (torch.rand(n, cin, h, w, generator=g) > 0.5)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (9 * cout)) ** 0.5
+    ref = F.conv2d(x.double(), wt.double(), None, padding=1)
+    pk = ops.pack_fwd(wt.cuda())
+    e_exact = rel_err(nchw(ops.conv3x3(nhwc(x), pk, None, cout, tile=9)), ref)
+    e_x3 = rel_err(nchw(ops.conv3x3(nhwc(x), pk, None, cout, tile=201)), ref)
+    print("K=4608 conv vs float64: exact fp32 MFMA max %.2e l2 %.2e | f32x3 max %.2e l2 %.2e" % (e_exact + e_x3))
+    assert e_x3[1] <= 2.0 * e_exact[1] + 1e-8 and e_x3[0] <= 3.0 * e_exact[0] + 1e-8, (e_exact, e_x3)
+    # (2)
+    n, h, w, cin, cout = 2, 21, 37, 32, 40
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / 17
+    b = torch.randn(cout, generator=g)
+    ref = F.conv2d(x.double(), wt.double(), b.double(), padding=1)
+    xg, pk = nhwc(x), ops.pack_fwd(wt.cuda())
+    y = ops.conv3x3(xg, pk, b.cuda(), cout, relu=False, y_cs=48, tile=205)
+    assert rel_err(nchw(y[..., :cout]), ref)[0] < 2e-5
+    assert float(y[..., cout:].abs().max()) == 0.0
+    m = torch.randn(n, cout, h, w, generator=g)
+    ym = ops.conv3x3(xg, pk, b.cuda(), cout, relu=False, mask=nhwc(m), tile=203)
+    assert rel_err(nchw(ym), ref * (m > 0))[0] < 2e-5
+    # (3) data gradient = conv of dy with the rotated pack: 40 -> 32 channels needs Cin(=cout here) % 16: use 48 -> 32
+    cin, cout = 32, 48
+    x = torch.randn(n, cin, h, w, generator=g, dtype=torch.float64, requires_grad=True)
+    wt = torch.randn(cout, cin, 3, 3, generator=g, dtype=torch.float64) / 17
+    dy = torch.randn(n, cout, h, w, generator=g, dtype=torch.float64)
+    F.conv2d(x, wt, None, padding=1).backward(dy)
+    dx = ops.conv3x3(nhwc(dy), ops.pack_dgrad(wt.float().cuda()), None, cin, relu=False, tile=205)
+    assert rel_err(nchw(dx), x.grad)[0] < 3e-5
+    # (4) split-K through the f32x3 kernel (partial sums + finalize with bias / ReLU)
+    n, h, w, cin, cout = 1, 15, 27, 256, 64
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / 48
+    b = torch.randn(cout, generator=g)
+    ref = F.relu(F.conv2d(x.double(), wt.double(), b.double(), padding=1))
+    for ks in (2, 4, 8):
+        y = ops.conv3x3_splitk(nhwc(x), ops.pack_fwd(wt.cuda()), b.cuda(), cout, ks, relu=True, tile=205)
+        assert rel_err(nchw(y), ref)[0] < 2e-5, ks
+    # (5) automatic choice under dtype OSVOS_F32_X3 and under the process-wide switch
+    y3 = ops.conv3x3(nhwc(x), ops.pack_fwd(wt.cuda()), b.cuda(), cout, relu=True, dtype=F32_X3)
+    assert rel_err(nchw(y3), ref)[0] < 2e-5
+    l = ops.lib()
+    prev = l.osvos_set_fp32_conv_mode(1)
+    try:
+        assert l.osvos_get_fp32_conv_mode() == 1
+        ym = ops.conv3x3(nhwc(x), ops.pack_fwd(wt.cuda()), b.cuda(), cout, relu=True)
+    finally:
+        l.osvos_set_fp32_conv_mode(prev)
+    assert torch.equal(ym, y3)      # same kernel, same tile choice
+    assert l.osvos_get_fp32_conv_mode() == prev
+
+
 def test_conv3x3_matches_naive_kernel_and_mask_and_stride():
     ops = _ops()
     g = torch.Generator().manual_seed(5)
