@@ -94,7 +94,7 @@ int osvos_conv3x3_splitk(const void* x, const void* wpk, const float* bias, cons
 
 size_t osvos_wgrad_ws_bytes(int N, int H, int W, int Cin, int Cout, int dtype) {
   const size_t f = osvos_wgrad_ws_bytes_f32(N, H, W, Cin, Cout);
-  const size_t b = dtype == OSVOS_F32_BF16MFMA ? osvos_wgrad_bf16_ws_bytes(N, H, W, Cin, Cout) : 0;
+  const size_t b = dtype == OSVOS_F32_BF16MFMA ? osvos_wgrad_bf16_ws_bytes(N, H, W, Cin, Cout) : osvos_wgrad_f32x3_ws_bytes(N, H, W, Cin, Cout);
   return f > b ? f : b;
 }
 int osvos_conv3x3_wgrad(const void* x, const void* dy, void* ws, float* dw, float* db,
@@ -106,6 +106,11 @@ int osvos_conv3x3_wgrad(const void* x, const void* dy, void* ws, float* dw, floa
   if (dtype == OSVOS_F32_BF16MFMA && Cin == Cin_s && Cout % 64 == 0 && osvos_wgrad_bf16_applicable(Cin_s, Cout))
     return osvos_conv3x3_wgrad_bf16mfma((const float*)x, (const float*)dy, ws, dw, db, N, H, W, Cin, Cin_s, Cout, Cout_s,
                                         accumulate, (hipStream_t)stream);
+  // f32x3 (dtype OSVOS_F32_X3, or OSVOS_F32 under the process-wide f32x3 mode): the wide trunk layers on the bf16 matrix pipe with
+  // three-way split operands; conv1_1 and side_prep keep their exact skinny kernels
+  if ((dtype == OSVOS_F32_X3 || (dtype == OSVOS_F32 && osvos_fp32_conv_mode() == 1)) && osvos_wgrad_f32x3_applicable(Cin, Cin_s, Cout, Cout_s))
+    return osvos_conv3x3_wgrad_f32x3((const float*)x, (const float*)dy, ws, dw, db, N, H, W, Cin, Cin_s, Cout, Cout_s, accumulate,
+                                     (hipStream_t)stream);
   return osvos_conv3x3_wgrad_f32((const float*)x, (const float*)dy, ws, dw, db, N, H, W, Cin, Cin_s, Cout, Cout_s,
                                  accumulate, (hipStream_t)stream);
 }

@@ -393,6 +393,8 @@ int pick_ksplit(const TileInfo& t, int N, int H, int W, int Cin, int Cout, int C
   // the changed summation order moves the stage-0 gradients of the un-trained test net by ~1e-3 (ReLU / arg-max flips at near-ties),
   // past the parity bar of tests/test_gpu_net.py::test_full_size_against_cpu_oracle.  OSVOS_CONV_KSPLIT=2 forces it.
   while (ks < 8 && blocks * ks < 512 && (Cin / 8) / (ks * 2) >= 8) ks *= 2;
+  // skinny Cout (side_prep, CoutP = 32): a few dozen workgroups at most -- cut K as far as 4-chunk parts allow
+  if (CoutP <= 32) while (ks < 8 && blocks * ks < 256 && (Cin / 8) / (ks * 2) >= 2) ks *= 2;
   return ks;
 }
 

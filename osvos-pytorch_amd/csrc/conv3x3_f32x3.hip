@@ -344,37 +344,33 @@ using X10 = CfgX<32, 1, 8, 4, 4, 2, 1, 1>;  // X1 with the staging loads spread 
 using X11 = CfgX<32, 1, 8, 4, 2, 2, 1, 1>;  // X0 ...
 using X12 = CfgX<32, 1, 8, 2, 4, 2, 1, 1>;  // X4 ...
 using X13 = CfgX<32, 1, 4, 2, 2, 2, 2, 1>;  // X5 ...
-constexpr int kNumTilesX = 14;
+using X14 = CfgX<16, 1, 8, 2, 4, 2, 1, 1>;  // X8 ...
+constexpr int kNumTilesX = 15;
 template <class C>
 constexpr TileInfoX infoX() { return TileInfoX{C::TW, C::TH, C::BN, C::NT, C::LDS_BYTES}; }
 const TileInfoX kTilesX[kNumTilesX] = {infoX<X0>(), infoX<X1>(), infoX<X2>(), infoX<X3>(), infoX<X4>(),
                                        infoX<X5>(), infoX<X6>(), infoX<X7>(), infoX<X8>(), infoX<X9>(),
-                                       infoX<X10>(), infoX<X11>(), infoX<X12>(), infoX<X13>()};
+                                       infoX<X10>(), infoX<X11>(), infoX<X12>(), infoX<X13>(), infoX<X14>()};
 
 long tiles_of(const TileInfoX& t, int N, int H, int W, int CoutP) {
   return (long)N * ceil_div(H, t.th) * ceil_div(W, t.tw) * ceil_div(CoutP, t.bn);
 }
 
-// First-cut choice (to be replaced by the measured table of tools/tune_conv.py --x3): the biggest tile that still yields
-// about one workgroup per CU, narrow 16-wide tiles where 32-wide ones pad the frame by more than 10 %.
+// Measured on MI355X (tools/tune_x3.py, profiles/r02_tune_x3.txt; 854x480 batch 1): the eight-wave tiles with the staging loads
+// spread over the MFMA loop win everywhere -- two waves per SIMD cover each other's vmem-issue and LDS stalls.  128-cout tiles
+// (X10: fewest weight bytes per MFMA) when they still give ~one workgroup per CU, else 64-cout tiles; 16 x 16 pixel tiles where
+// 32-wide ones pad the frame by more than 10 % (the 107-pixel wide conv4_x); K splits top small grids up to ~200 workgroups.
 int pick_tile_x(int N, int H, int W, int CoutP) {
   const bool narrow = (long)ceil_div(W, 32) * 32 * 100 > (long)ceil_div(W, 16) * 16 * 110;
-  if (CoutP >= 128) {
-    if (!narrow && tiles_of(kTilesX[1], N, H, W, CoutP) >= 230) return 1;
-    if (narrow && tiles_of(kTilesX[9], N, H, W, CoutP) >= 230) return 9;
-    if (!narrow && tiles_of(kTilesX[2], N, H, W, CoutP) >= 230) return 2;
-  }
-  if (!narrow && tiles_of(kTilesX[4], N, H, W, CoutP) >= 230) return 4;
-  if (narrow && tiles_of(kTilesX[8], N, H, W, CoutP) >= 230) return 8;
-  return narrow ? 6 : 5;
+  if (CoutP >= 128 && !narrow && tiles_of(kTilesX[10], N, H, W, CoutP) >= 200) return 10;
+  return narrow ? 14 : 12;
 }
 
-// K parts so that small layers (conv5_x at batch 1) put about two workgroups on every CU
 int pick_ksplit_x(const TileInfoX& t, int N, int H, int W, int Cin, int Cout, int CoutP) {
   if (Cin < 256) return 1;
   const long blocks = tiles_of(t, N, H, W, CoutP);
   int ks = 1;
-  while (ks < 8 && blocks * ks < 384 && (Cin / 16) / (ks * 2) >= 4) ks *= 2;
+  while (ks < 8 && blocks * ks < 200 && (Cin / 16) / (ks * 2) >= 4) ks *= 2;
   return ks;
 }
 
@@ -428,6 +424,7 @@ int osvos_conv3x3_f32x3(const float* x, const float* wpk, const float* bias, con
     case 11: rc = launch_x<X11>(a, stream); break;
     case 12: rc = launch_x<X12>(a, stream); break;
     case 13: rc = launch_x<X13>(a, stream); break;
+    case 14: rc = launch_x<X14>(a, stream); break;
     default: osvos_set_error("conv3x3 f32x3: unknown tile config %d", tile); return -1;
   }
   if (rc) return rc;

@@ -83,6 +83,7 @@ struct WsLayout {
   int hs[5], ws[5];
   size_t xin, act[kNumTrunk], pooled[5], prep[4], score[4], fpart[4];
   size_t conv_part;          // split-K partial sums of the small deep layers (forward prefix: inference uses it too)
+  size_t side_part[4];       // the same for the side_prep convolutions, which run on the aux stream beside the trunk (own buffers)
   size_t dy[kNumTrunk], dpool[5], dside[4], dprep[4], wgrad[kNumConv], acc, dxin;
   // bf16 copies of the conv operands (dtype OSVOS_F32_BF16MFMA only): written by the producer's epilogue, read by the
   // consuming convolution instead of the fp32 tensor (half the bytes, no conversion while staging)
@@ -129,6 +130,10 @@ WsLayout ws_layout(int N, int H, int W, int dtype) {
         if (b > mx) mx = b;
       }
     L.conv_part = take(mx);
+    // side_prep[i]: Cout = 16 on a small frame is a handful of workgroups walking K = 9 Cin serially (88 us for 0.24 GFLOP at
+    // 30 x 54) -- and the last one sits exposed between conv5_3 and the head.  K splits turn it into a full-chip launch.
+    for (int i = 0; i < 4; ++i)
+      L.side_part[i] = kStageC[i + 1] >= 256 ? take(osvos_conv3x3_splitk_ws_bytes_f32(N, L.hs[i + 1], L.ws[i + 1], 16)) : (size_t)-1;
   }
   L.fwd_total = off;          // everything above is all an inference-only forward touches
   for (int i = 0; i < 4; ++i) {
@@ -328,7 +333,7 @@ int osvos_net_forward(const float* x_nchw, const void* wbuf, void* ws, float* co
       {
         ProfScope ps(OSVOS_PROF_OTHER, conv_flops(N, h, w, d[sl].cin, 16), aux);
         rc = conv_main(cur, cur_b, at(wbuf, P.fwd[sl]), reinterpret_cast<const float*>(at(wbuf, P.bias[sl])), nullptr, nullptr,
-                       at(ws, L.prep[i]), nullptr, N, h, w, d[sl].cin_s, 16, 16, 0, dtype, nullptr, aux);
+                       at(ws, L.prep[i]), nullptr, N, h, w, d[sl].cin_s, 16, 16, 0, dtype, L.side_part[i] != (size_t)-1 ? at(ws, L.side_part[i]) : nullptr, aux);
       }
       if (rc) return rc;
       float* sc = reinterpret_cast<float*>(at(ws, L.score[i]));

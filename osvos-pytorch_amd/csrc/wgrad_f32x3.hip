@@ -1,0 +1,345 @@
+// 3x3 convolution weight gradient, fp32 tensors in / fp32 gradient out, on the bf16 matrix pipe with THREE-WAY SPLIT operands
+// (the weight-gradient third of dtype OSVOS_F32_X3; see conv3x3_f32x3.hip for the arithmetic: v = hi + mid + lo exactly, six bf16
+// products per fp32 product, fp32 accumulation, dropped terms <= 2^-24 relative).  Replaces the weight / bias half of
+// aten::convolution_backward for nn.Conv2d(k=3, p=1) (reference vgg_osvos.py:41,142; autograd of train_online.py:141).
+//
+//   D[tap][co][ci] = sum_pixels dY[p][co] * X[p + tap][ci]          (bias gradient = column sums of dY, exact fp32)
+//
+// The reduction index is the PIXEL axis and a bf16 MFMA wants 8 consecutive k per lane, while the tensors lie [pixel][channel].
+// Tiles stay pixel-major in LDS (one 16-byte slot = 8 bf16 channels of one pixel, three planes = the three pieces) and the k-fragments
+// are gathered by the LDS itself with ds_read_b64_tr_b16 (semantics verified lane by lane: profiles/r01_tr_b16_probe.txt) -- a tap shift
+// is an address offset, nothing is transposed in registers.  Pixel pitch = channel bytes + 64 so the four pixel rows of one gather
+// fall on disjoint quarters of the 64 banks.
+//   * workgroup = 4 waves = 64 couts x 64 cins x 9 taps; wave (wc, wi) owns a 32 x 32 x 9 block = 9 accumulators (144 registers)
+//   * patches of 16 x PH pixels (PH = 6: 480p stage heights 480/240/120/60/30 are multiples of 6); a k-step = one 16-pixel patch row
+//   * per (k-step, tap row): 3 tap columns x 3 pieces of X gathered (18 reads) -> 18 MFMAs; fragment sets double buffered
+//   * the next patch's fp32 pieces are loaded from INSIDE the k-loop (one item per stage) and split / written after the barrier
+//   * deterministic: fixed patch -> split assignment, fp32 slabs [split][tap][co][ci] + the shared slab reduce (wgrad_f32.hip)
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+constexpr int PW = 16, BCO = 64, BCI = 64, NT = 256;
+constexpr int PITCH = BCO * 2 + 64;            // bytes per pixel and plane (64 channels x 2 B + 64 B skew)
+
+template <int PH_>
+struct G3 {
+  static constexpr int PH = PH_;
+  static constexpr int PPIX = PW * PH, HW_ = PW + 2, XPIX = (PH + 2) * HW_;
+  static constexpr int DY_B = PPIX * PITCH, X_B = XPIX * PITCH;        // bytes of one piece plane
+  static constexpr int DY_ITEMS = PPIX * 8, X_ITEMS = XPIX * 8;        // (pixel, channel octet)
+  static constexpr int NDY = (DY_ITEMS + NT - 1) / NT, NX = (X_ITEMS + NT - 1) / NT, NIT = NDY + NX;
+  static constexpr int NST = 3 * PH;                                  // stages (k-step, tap row) per patch
+  static constexpr size_t LDS = (size_t)3 * (DY_B + X_B);
+  static_assert(NIT <= NST, "one staged item per stage must cover the patch");
+  static_assert(LDS <= 160 * 1024, "tiles exceed the LDS of a CU");
+};
+
+struct W3Args {
+  const float* x;
+  const float* dy;
+  float* slab;
+  float* bslab;
+  int N, H, W, Cin_s, Cout, Cout_s;
+  int npx, npy, npatches, per_split, nco_t, nci_t;
+  int map;
+};
+
+__device__ inline unsigned cvt2w(float a, float b) {
+  bf16x2_t h;
+  h[0] = (__bf16)a;
+  h[1] = (__bf16)b;
+  return __builtin_bit_cast(unsigned, h);
+}
+__device__ inline void split2w(float a, float b, unsigned& p0, unsigned& p1, unsigned& p2) {
+  p0 = cvt2w(a, b);
+  float ra = a - __uint_as_float(p0 << 16), rb = b - __uint_as_float(p0 & 0xffff0000u);
+  p1 = cvt2w(ra, rb);
+  ra -= __uint_as_float(p1 << 16);
+  rb -= __uint_as_float(p1 & 0xffff0000u);
+  p2 = cvt2w(ra, rb);
+}
+__device__ inline void split8w(const u32x4& lo, const u32x4& hi, u32x4& p0, u32x4& p1, u32x4& p2) {
+  const f32x4 a = __builtin_bit_cast(f32x4, lo), b = __builtin_bit_cast(f32x4, hi);
+  unsigned q0[4], q1[4], q2[4];
+  split2w(a[0], a[1], q0[0], q1[0], q2[0]);
+  split2w(a[2], a[3], q0[1], q1[1], q2[1]);
+  split2w(b[0], b[1], q0[2], q1[2], q2[2]);
+  split2w(b[2], b[3], q0[3], q1[3], q2[3]);
+  p0 = u32x4{q0[0], q0[1], q0[2], q0[3]};
+  p1 = u32x4{q1[0], q1[1], q1[2], q1[3]};
+  p2 = u32x4{q2[0], q2[1], q2[2], q2[3]};
+}
+
+template <int PH>
+__global__ __launch_bounds__(NT) void wgrad_f32x3_kernel(W3Args a) {
+  using G = G3<PH>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* dYs = smem;                         // [piece 3][PPIX][PITCH]
+  char* Xs = smem + 3 * G::DY_B;            // [piece 3][XPIX][PITCH]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wc = wave >> 1, wi = wave & 1;
+  constexpr unsigned OOB = 0x80000000u;
+
+  int id = blockIdx.x;
+  if (a.map == 1) id = (id & 7) * (gridDim.x >> 3) + (id >> 3);      // XCD-local: the channel tiles of one split share an L2
+  const int cit = id % a.nci_t;
+  id /= a.nci_t;
+  const int cot = id % a.nco_t;
+  const int split = id / a.nco_t;
+  const int co0 = cot * BCO, ci0 = cit * BCI;
+  const int p_begin = split * a.per_split, p_end = min(p_begin + a.per_split, a.npatches);
+
+  // staged items: (pixel, channel octet) = 32 bytes of fp32 in, 3 x 16 bytes of bf16 pieces out.  oct = tid & 7 for every item.
+  const int oct = tid & 7, pg = tid >> 3;
+  const bool dy_ch_ok = co0 + 8 * oct < a.Cout, x_ch_ok = ci0 + 8 * oct < a.Cin_s;
+  u32x4 rdy[G::NDY][2], rx[G::NX][2];
+  float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const bool want_bias = a.bslab != nullptr && cit == 0;
+  const int img_dy_bytes = a.H * a.W * a.Cout_s * 4, img_x_bytes = a.H * a.W * a.Cin_s * 4;
+
+  struct Patch { __amdgpu_buffer_rsrc_t drs, xrs; int x0, y0; };
+  auto locate = [&](int p, bool live) -> Patch {
+    const int px = p % a.npx;
+    int t = p / a.npx;
+    const int py = t % a.npy;
+    const int n = live ? t / a.npy : 0;
+    Patch q;
+    q.x0 = live ? px * PW : 0x40000000;            // dead patch: every column test fails -> all loads out of range
+    q.y0 = py * PH;
+    q.drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(a.dy)) + (size_t)n * img_dy_bytes, 0, img_dy_bytes, 0x00020000);
+    q.xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(a.x)) + (size_t)n * img_x_bytes, 0, img_x_bytes, 0x00020000);
+    return q;
+  };
+  // rows above / below the image fall out of the per-image buffer range by themselves (negative offsets wrap past num_records);
+  // columns outside the image must be pushed out explicitly (they would alias the neighbouring row)
+  auto issue = [&](const Patch& q, int it) {      // it: compile-time item index (dY items first)
+    if (it < G::NDY) {
+      const int p = pg + (NT / 8) * it, py = p / PW, pxx = p - py * PW;
+      const bool ok = dy_ch_ok && (G::DY_ITEMS % NT == 0 || p < G::PPIX) && q.x0 + pxx < a.W;
+      const unsigned off = ok ? (unsigned)((((q.y0 + py) * a.W + q.x0 + pxx) * a.Cout_s + co0 + 8 * oct) * 4) : OOB;
+      rdy[it][0] = __builtin_amdgcn_raw_buffer_load_b128(q.drs, off, 0, 0);
+      rdy[it][1] = __builtin_amdgcn_raw_buffer_load_b128(q.drs, off + 16u, 0, 0);
+    } else if (it < G::NIT) {
+      const int j = it - G::NDY;
+      const int hp = pg + (NT / 8) * j, hy = hp / G::HW_, hx = hp - hy * G::HW_;
+      const bool ok = x_ch_ok && hp < G::XPIX && (unsigned)(q.x0 - 1 + hx) < (unsigned)a.W;
+      const unsigned off = ok ? (unsigned)((((q.y0 - 1 + hy) * a.W + q.x0 - 1 + hx) * a.Cin_s + ci0 + 8 * oct) * 4) : OOB;
+      rx[j][0] = __builtin_amdgcn_raw_buffer_load_b128(q.xrs, off, 0, 0);
+      rx[j][1] = __builtin_amdgcn_raw_buffer_load_b128(q.xrs, off + 16u, 0, 0);
+    }
+  };
+  auto store_patch = [&]() {
+#pragma unroll
+    for (int i = 0; i < G::NDY; ++i) {
+      if (want_bias) {                              // bias gradient: exact fp32 column sums of dY (zeros outside the image)
+        const f32x4 lo = __builtin_bit_cast(f32x4, rdy[i][0]), hi = __builtin_bit_cast(f32x4, rdy[i][1]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { bsum[c] += lo[c]; bsum[4 + c] += hi[c]; }
+      }
+      u32x4 p0, p1, p2;
+      split8w(rdy[i][0], rdy[i][1], p0, p1, p2);
+      const int p = pg + (NT / 8) * i;
+      if (G::DY_ITEMS % NT == 0 || p < G::PPIX) {
+        char* d = dYs + p * PITCH + oct * 16;
+        *reinterpret_cast<u32x4*>(d) = p0;
+        *reinterpret_cast<u32x4*>(d + G::DY_B) = p1;
+        *reinterpret_cast<u32x4*>(d + 2 * G::DY_B) = p2;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < G::NX; ++j) {
+      u32x4 p0, p1, p2;
+      split8w(rx[j][0], rx[j][1], p0, p1, p2);
+      const int hp = pg + (NT / 8) * j;
+      if (G::X_ITEMS % NT == 0 || hp < G::XPIX) {
+        char* d = Xs + hp * PITCH + oct * 16;
+        *reinterpret_cast<u32x4*>(d) = p0;
+        *reinterpret_cast<u32x4*>(d + G::X_B) = p1;
+        *reinterpret_cast<u32x4*>(d + 2 * G::X_B) = p2;
+      }
+    }
+  };
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  // fragment gather: lane (fi = lane & 15, fg = (lane >> 4) & 1, lh = lane >> 5) addresses pixel 8 lh + fi / 4 (+4 for the second read),
+  // channels 16 fg + 4 (fi % 4) .. +3 of its wave's 32-channel block, and receives channel 16 fg + fi of pixels 8 lh .. 8 lh + 7
+  const int fi = lane & 15, fg = (lane >> 4) & 1, lh = lane >> 5;
+  const char* a_base = dYs + (8 * lh + (fi >> 2)) * PITCH + (32 * wc + 16 * fg + 4 * (fi & 3)) * 2;
+  const char* b_base = Xs + (8 * lh + (fi >> 2)) * PITCH + (32 * wi + 16 * fg + 4 * (fi & 3)) * 2;
+  auto tr8 = [&](const char* p) -> s16x8 {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 4 * PITCH));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  };
+
+  {
+    const Patch q = locate(p_begin, p_begin < p_end);
+#pragma unroll
+    for (int it = 0; it < G::NIT; ++it) issue(q, it);
+  }
+  for (int p = p_begin; p < p_end; ++p) {
+    __syncthreads();                   // every wave is done with the previous patch's tiles
+    store_patch();
+    __syncthreads();
+    const Patch nx = locate(p + 1, p + 1 < p_end);
+    s16x8 af[2][3], bfr[2][3][3];      // [set][piece] / [set][piece][tap column]
+    auto lda = [&](int ks) {
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) af[ks & 1][pc] = tr8(a_base + pc * G::DY_B + ks * PW * PITCH);
+    };
+    auto ldb = [&](int st) {
+      const int ks = st / 3, r = st % 3;
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc)
+#pragma unroll
+        for (int s = 0; s < 3; ++s) bfr[st & 1][pc][s] = tr8(b_base + pc * G::X_B + ((ks + r) * G::HW_ + s) * PITCH);
+    };
+    lda(0);
+    ldb(0);
+#pragma unroll
+    for (int st = 0; st < G::NST; ++st) {
+      const int ks = st / 3, r = st % 3;
+      if (st + 1 < G::NST) {
+        if (r == 2) lda(ks + 1);
+        ldb(st + 1);
+      }
+      issue(nx, st);                    // next patch's fp32 pieces: one item (two 16-byte loads) per stage
+      __builtin_amdgcn_sched_barrier(0);
+      // pieces: 0 = high, 1 = middle, 2 = low; small products first.  First operand = X (rows = cin), second = dY (columns = cout)
+      constexpr int PX[6] = {2, 0, 1, 1, 0, 0};
+      constexpr int PD[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+          acc[r * 3 + s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, bfr[st & 1][PX[t]][s]),
+                                                                  __builtin_bit_cast(bf16x8_t, af[ks & 1][PD[t]]), acc[r * 3 + s], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  __syncthreads();
+
+  {   // slab epilogue: D = [cin rows][cout columns]; lane (li, lh) holds cout li and cins 8 q + 4 lh + (0..3) = one 16-byte store
+    const int li = lane & 31;
+    const size_t slab_elems = (size_t)9 * a.Cout * a.Cin_s;
+    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(a.slab + (size_t)split * slab_elems, 0, (int)(slab_elems * 4), 0x00020000);
+    const int co = co0 + wc * 32 + li;
+    const int cib = ci0 + wi * 32 + 4 * lh;
+    const unsigned row = co < a.Cout ? (unsigned)(co * a.Cin_s) * 4u : OOB;
+    const unsigned tap_stride = (unsigned)(a.Cout * a.Cin_s) * 4u;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int ci = cib + 8 * q;
+        const unsigned off = ci < a.Cin_s ? row + (unsigned)t * tap_stride + (unsigned)ci * 4u : OOB;
+        const f32x4 v = {acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), srs, off, 0, 0);
+      }
+  }
+  if (want_bias) {
+    float* red = reinterpret_cast<float*>(smem);          // [32 pixel groups][64 channels]
+#pragma unroll
+    for (int c = 0; c < 8; ++c) red[pg * BCO + oct * 8 + c] = bsum[c];
+    __syncthreads();
+    if (tid < BCO) {
+      float sum = 0.f;
+      for (int g = 0; g < NT / 8; ++g) sum += red[g * BCO + tid];
+      if (co0 + tid < a.Cout) a.bslab[(size_t)split * a.Cout + co0 + tid] = sum;
+    }
+  }
+}
+
+struct W3Plan {
+  int ph, nco_t, nci_t, npx, npy, npatches, nsplit, per_split;
+  size_t slab_floats, bslab_floats;
+};
+
+// one workgroup per CU (135 KB of LDS): aim at one round of ~256 workgroups, each with a long patch range
+W3Plan make_plan3(int N, int H, int W, int Cin_s, int Cout) {
+  W3Plan p;
+  p.ph = (ceil_div(H, 6) * 6 <= ceil_div(H, 4) * 4) ? 6 : 4;
+  p.nco_t = ceil_div(Cout, BCO);
+  p.nci_t = ceil_div(Cin_s, BCI);
+  p.npx = ceil_div(W, PW);
+  p.npy = ceil_div(H, p.ph);
+  p.npatches = N * p.npx * p.npy;
+  int want = ceil_div(256, p.nco_t * p.nci_t);
+  const int max_split = p.npatches / 2 > 0 ? p.npatches / 2 : 1;
+  if (want > max_split) want = max_split;
+  if (want > 256) want = 256;
+  p.per_split = ceil_div(p.npatches, want);
+  p.nsplit = ceil_div(p.npatches, p.per_split);
+  p.slab_floats = (size_t)p.nsplit * 9 * Cout * Cin_s;
+  p.bslab_floats = (size_t)p.nsplit * Cout;
+  return p;
+}
+
+template <int PH>
+int launch3(const W3Args& a, long blocks, hipStream_t stream) {
+  static bool attr_set_dev[OSVOS_MAX_DEVICES] = {};
+  bool& attr_set = attr_set_dev[osvos_current_device()];
+  if (!attr_set) {
+    OSVOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_f32x3_kernel<PH>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)G3<PH>::LDS));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(wgrad_f32x3_kernel<PH>, dim3((unsigned)blocks), dim3(NT), G3<PH>::LDS, stream, a);
+  OSVOS_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace
+
+int osvos_wgrad_reduce_launch(const float* slab, const float* bslab, float* dw, float* db, int nsplit, int Cout, int Cin,
+                              int Cin_s, int accumulate, hipStream_t stream);
+
+// the wide trunk layers (channel counts multiples of 64, no channel padding); conv1_1 and side_prep keep their exact skinny kernels
+bool osvos_wgrad_f32x3_applicable(int Cin, int Cin_s, int Cout, int Cout_s) {
+  return Cin == Cin_s && Cin_s % 64 == 0 && Cout % 64 == 0 && Cout_s % 4 == 0;
+}
+
+size_t osvos_wgrad_f32x3_ws_bytes(int N, int H, int W, int Cin_s, int Cout) {
+  if (Cin_s % 64 != 0 || Cout % 64 != 0) return 0;
+  const W3Plan p = make_plan3(N, H, W, Cin_s, Cout);
+  return align_up((p.slab_floats + p.bslab_floats) * sizeof(float), 256);
+}
+
+int osvos_conv3x3_wgrad_f32x3(const float* x, const float* dy, void* ws, float* dw, float* db,
+                              int N, int H, int W, int Cin, int Cin_s, int Cout, int Cout_s, int accumulate, hipStream_t stream) {
+  OSVOS_ARG_CHECK(x && dy && ws && dw, "wgrad f32x3: null pointer");
+  OSVOS_ARG_CHECK(N > 0 && H > 0 && W > 0, "wgrad f32x3: bad shape");
+  OSVOS_ARG_CHECK(osvos_wgrad_f32x3_applicable(Cin, Cin_s, Cout, Cout_s), "wgrad f32x3: unsupported shape (Cin %d/%d Cout %d/%d)", Cin, Cin_s, Cout, Cout_s);
+  OSVOS_ARG_CHECK((long)H * W * Cin_s < (1L << 29) && (long)H * W * Cout_s < (1L << 29), "wgrad f32x3: image too large for 31-bit byte offsets");
+  const W3Plan p = make_plan3(N, H, W, Cin_s, Cout);
+  W3Args a;
+  a.x = x; a.dy = dy;
+  a.slab = reinterpret_cast<float*>(ws);
+  a.bslab = db ? a.slab + p.slab_floats : nullptr;
+  a.N = N; a.H = H; a.W = W; a.Cin_s = Cin_s; a.Cout = Cout; a.Cout_s = Cout_s;
+  a.npx = p.npx; a.npy = p.npy; a.npatches = p.npatches; a.per_split = p.per_split; a.nco_t = p.nco_t; a.nci_t = p.nci_t;
+  const long blocks = (long)p.nsplit * p.nco_t * p.nci_t;
+  OSVOS_ENV_INT(map_env, "OSVOS_WGRAD_MAP", 1);
+  a.map = (map_env == 1 && blocks % 8 == 0) ? 1 : 0;
+  const int phase = osvos_wgrad_phase();
+  if (phase != 2) {
+    const int rc = p.ph == 6 ? launch3<6>(a, blocks, stream) : launch3<4>(a, blocks, stream);
+    if (rc) return rc;
+  }
+  if (phase == 1) return 0;
+  return osvos_wgrad_reduce_launch(a.slab, a.bslab, dw, db, p.nsplit, Cout, Cin, Cin_s, accumulate, stream);
+}

@@ -50,11 +50,19 @@ class TrainLoop(object):
     is kept on the device and only read back when the caller asks for it (the reference's
     ``loss.item()`` every iteration is a logging artefact that stalls the GPU)."""
 
-    def __init__(self, net, optimizer, mode='online', n_ave_grad=5, n_epochs=240, reducer=None):
+    def __init__(self, net, optimizer, mode='online', n_ave_grad=5, n_epochs=240, reducer=None, local_ave=None, loss_fn=None):
+        """``n_ave_grad``: the loss divisor = micro-batches per optimizer step summed over ALL ranks (the reference's nAveGrad).
+        ``local_ave``: micro-batches THIS rank contributes to a step (default: all of them); the step -- all-reduce, SGD update,
+        one-memset zeroing of the flat gradient arena -- fires after that many local backwards.  The counter persists across
+        epochs like the reference's ``aveGrad`` (train_parent.py:128,163-172).  ``loss_fn``: the class-balanced BCE (default: the
+        HIP kernel; the CPU tests of the data-parallel bookkeeping pass the oracle's)."""
         self.net, self.opt, self.mode = net, optimizer, mode
         self.n_ave_grad, self.n_epochs = n_ave_grad, n_epochs
+        self.local_ave = int(local_ave) if local_ave else n_ave_grad
+        self.loss_fn = loss_fn or class_balanced_cross_entropy_loss
         self.reducer = reducer
         self.ave = 0
+        self.steps = 0
         if hasattr(net, 'set_inplace_grad_accumulation'):
             net.set_inplace_grad_accumulation(True)      # every backward of this loop is loss.backward()
         dev = next(net.parameters()).device
@@ -63,10 +71,10 @@ class TrainLoop(object):
     def micro_batch(self, inputs, gts, epoch=0):
         outputs = self.net.forward(inputs)
         if self.mode == 'online':
-            loss = class_balanced_cross_entropy_loss(outputs[-1], gts, size_average=False)
+            loss = self.loss_fn(outputs[-1], gts, size_average=False)
             self.running[0] += loss.detach()
         else:
-            losses = [class_balanced_cross_entropy_loss(o, gts, size_average=False) for o in outputs]
+            losses = [self.loss_fn(o, gts, size_average=False) for o in outputs]
             for r, l in zip(self.running, losses):
                 r += l.detach()
             loss = (1 - epoch / self.n_epochs) * sum(losses[:-1]) + losses[-1]
@@ -74,7 +82,7 @@ class TrainLoop(object):
         loss.backward()
         self.ave += 1
         stepped = False
-        if self.ave % self.n_ave_grad == 0:
+        if self.ave % self.local_ave == 0:
             if self.reducer is not None:
                 self.reducer.all_reduce()
             self.opt.step()
@@ -83,6 +91,7 @@ class TrainLoop(object):
             else:
                 self.opt.zero_grad()
             self.ave = 0
+            self.steps += 1
             stepped = True
         return loss, stepped
 
@@ -91,6 +100,41 @@ class TrainLoop(object):
         for r in self.running:
             r.zero_()
         return vals
+
+
+def check_world_divides(n_ave_grad, world):
+    """Data-parallel accumulation reproduces the single-process gradient only when every rank contributes the same number
+    of micro-batches to every optimizer step, i.e. when the world size divides nAveGrad.  Anything else would
+    silently train on a different effective batch; refuse it and say what works."""
+    if world < 1 or n_ave_grad % world != 0:
+        up = -(-n_ave_grad // world) * world
+        raise ValueError("nAveGrad = %d is not a multiple of the world size %d: each optimizer step would sum %d micro-batches scaled by "
+                         "1/%d.  Use --n-ave-grad %d (or a world size among %s)."
+                         % (n_ave_grad, world, (n_ave_grad // world) * world, n_ave_grad, up,
+                            [w for w in range(1, n_ave_grad + 1) if n_ave_grad % w == 0]))
+    return n_ave_grad // world
+
+
+def epoch_plan(n_items, epoch, n_ave_grad, rank=0, world=1, seed=0, shuffle=True):
+    """Which frames THIS rank runs in `epoch`, in order: a list of (dataset index, global iteration number).
+
+    Every rank derives the SAME permutation of range(n_items) for an epoch (generator seeded with (seed, epoch)), so across
+    ranks each frame is visited exactly once per epoch and nothing is decoded twice.  The global micro-batch stream
+    g = epoch * n_items + position is cut into optimizer steps of n_ave_grad consecutive iterations -- across epoch
+    boundaries, like the reference's persistent ``aveGrad`` counter (train_parent.py:128,163-172) -- and inside a step rank r
+    takes slots r, r + W, ...: every rank contributes n_ave_grad / W micro-batches to every step, all ranks enter the same
+    number of all-reduces, and W x (n_ave_grad / W) micro-batches of per-frame class-balanced losses sum to the
+    single-process gradient of the same stream (up to summation order)."""
+    check_world_divides(n_ave_grad, world)
+    if shuffle:
+        g = torch.Generator().manual_seed(int(seed) * 1000003 + int(epoch))
+        perm = torch.randperm(n_items, generator=g).tolist()
+    else:
+        perm = list(range(n_items))
+    g0 = epoch * n_items
+    # slot (g mod n_ave_grad) mod W == g mod W because W divides n_ave_grad: a plain round-robin over the global stream, so
+    # ANY n_ave_grad consecutive iterations (also a window that starts at a resume point) hold n_ave_grad / W of every rank
+    return [(idx, g0 + j) for j, idx in enumerate(perm) if (g0 + j) % world == rank]
 
 
 def init_distributed():

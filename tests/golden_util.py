@@ -40,3 +40,19 @@ def check_grad(g, prefix, key, arr, rtol_l2, what=""):
     assert abs(np.sqrt((a * a).sum()) - l2) <= rtol_l2 * l2 + 1e-30, (what, key, "l2", np.sqrt((a * a).sum()), l2)
     err = np.abs(a[idx] - val).max()
     assert err <= 20 * rtol_l2 * scale + rtol_l2 * np.abs(val).max(), (what, key, "samples", err, scale)
+
+
+def check_grad_either(g, mode, key, arr, rtol_l2, what=""):
+    """A gradient must match what the REAL reference produced for it in float32 (its CPU path) OR in float64 (truth) -- both
+    are stored.  On these un-trained nets the reference's own float32 result can sit several 1e-3 from its float64 result on
+    the stage-0 / input gradients (one ReLU or arg-max flip at a near-tie; its NCHW and channels_last code paths disagree by
+    the same amount), so an implementation whose round-off lands on the float64 side of such a flip is right, not wrong."""
+    try:
+        check_grad(g, "f32|%s|grad|" % mode, key, arr, rtol_l2, what=what)
+    except AssertionError as e32:
+        if "f64|%s|grad|%s|l2" % (mode, key) not in g.files:
+            raise
+        try:
+            check_grad(g, "f64|%s|grad|" % mode, key, arr, rtol_l2, what=what + " (float64 reference)")
+        except AssertionError as e64:
+            raise AssertionError("matches neither the reference's float32 nor its float64 gradient: %s ; %s" % (e32, e64))

@@ -76,11 +76,11 @@ X3_SHAPES = [
 
 
 @pytest.mark.parametrize("shape", X3_SHAPES)
-@pytest.mark.parametrize("tile", [200 + k for k in range(14)] + [301, 305, 310])
+@pytest.mark.parametrize("tile", [200 + k for k in range(15)] + [301, 305, 310])
 def test_conv3x3_f32x3_all_tiles(shape, tile):
     """f32x3 (three-way bf16 split on the bf16 matrix pipe) is held to the SAME float64 bars as the exact fp32 MFMA kernel."""
     ops = _ops()
-    assert ops.lib().osvos_conv3x3_f32x3_tiles() == 14
+    assert ops.lib().osvos_conv3x3_f32x3_tiles() == 15
     n, h, w, cin, cout = shape
     g = torch.Generator().manual_seed(hash(shape) % 1000 + 3)
     x = torch.randn(n, cin, h, w, generator=g)
@@ -151,6 +151,39 @@ def test_conv3x3_f32x3_is_fp32_grade_and_covers_mask_stride_dgrad_splitk():
         l.osvos_set_fp32_conv_mode(prev)
     assert torch.equal(ym, y3)      # same kernel, same tile choice
     assert l.osvos_get_fp32_conv_mode() == prev
+
+
+@pytest.mark.parametrize("shape", [(1, 13, 21, 64, 64), (2, 30, 54, 128, 64), (1, 60, 107, 64, 128), (1, 25, 37, 64, 64),
+                                   (3, 6, 16, 64, 64), (1, 121, 215, 64, 64)])
+def test_wgrad_f32x3(shape):
+    """f32x3 weight gradient (three-way bf16 split, pixel-major tiles gathered with ds_read_b64_tr_b16): the SAME float64 bars as the
+    exact fp32 kernel (test_conv3x3_dgrad_and_wgrad); odd sizes, batch > 1, accumulation, and the error next to the exact kernel's."""
+    ops = _ops()
+    from osvos_pytorch_amd._lib import F32_X3
+    n, h, w, cin, cout = shape
+    g = torch.Generator().manual_seed(19 + h)
+    x = torch.randn(n, cin, h, w, generator=g) * torch.exp(torch.randn(n, cin, h, w, generator=g))
+    x = x * (torch.rand(n, cin, h, w, generator=g) > 0.4)          # post-ReLU like operand
+    dy = torch.randn(n, cout, h, w, generator=g) * torch.exp(torch.randn(n, cout, h, w, generator=g))
+    wt = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    b = torch.zeros(cout, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), wt, b, padding=1).backward(dy.double())
+    xg, dyg = nhwc(x), nhwc(dy)
+    dw, db = ops.conv3x3_wgrad(xg, dyg, cin, cout, dtype=F32_X3)
+    dwe, dbe = ops.conv3x3_wgrad(xg, dyg, cin, cout)
+    e3, ee = rel_err(dw.cpu(), wt.grad), rel_err(dwe.cpu(), wt.grad)
+    print("wgrad %s vs float64: exact fp32 max %.2e l2 %.2e | f32x3 max %.2e l2 %.2e" % ((shape,) + ee + e3))
+    assert e3[0] < 3e-5 and e3[1] < 1e-5, (shape, e3)
+    assert e3[1] <= 2.0 * ee[1] + 1e-7, (shape, e3, ee)
+    assert rel_err(db.cpu(), b.grad)[0] < 3e-5, shape
+    dw2, db2 = ops.conv3x3_wgrad(xg, dyg, cin, cout, accumulate_into=(dw.clone(), db.clone()), dtype=F32_X3)
+    assert rel_err(dw2.cpu(), 2 * wt.grad)[0] < 3e-5 and rel_err(db2.cpu(), 2 * b.grad)[0] < 3e-5
+    # shapes it does not take fall back to the exact kernels under the same dtype (conv1_1: Cin 3 padded to 8; side_prep: Cout 16)
+    x8 = torch.randn(1, 9, 11, 8, device="cuda")
+    dy64 = torch.randn(1, 9, 11, 64, device="cuda")
+    a1, _ = ops.conv3x3_wgrad(x8, dy64, 3, 64, dtype=F32_X3)
+    a0, _ = ops.conv3x3_wgrad(x8, dy64, 3, 64)
+    assert torch.equal(a1, a0)
 
 
 def test_conv3x3_matches_naive_kernel_and_mask_and_stride():

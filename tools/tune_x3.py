@@ -88,3 +88,19 @@ for name, h, w, cin, cout in layers:
               % (name, direction, h, w, kin, kout, gf, exact, gf / exact, auto, bt[0], bt[1], best, gf / best, exact / best))
         print("    [k1 map0/map1%s] " % ("/k2../k4.." if kin >= 256 else "") + "  ".join(cells))
 print("sum over the listed layers: exact %.3f ms, f32x3 best %.3f ms" % (tot_e, tot_x))
+print("weight gradient (fp32 x, dy -> fp32 dW, db; slabs + reduce included):")
+tw_e, tw_x = 0.0, 0.0
+for name, h, w, cin, cout in layers:
+    if args.layers and name not in args.layers.split(","):
+        continue
+    if cin % 64 or cout % 64:
+        continue
+    gf = 2.0 * n * h * w * cout * 9 * cin / 1e9
+    x = torch.randn(n, h, w, cin, device="cuda")
+    dy = torch.randn(n, h, w, cout, device="cuda")
+    e = timeit(lambda: ops.conv3x3_wgrad(x, dy, cin, cout), args.reps)
+    t3 = timeit(lambda: ops.conv3x3_wgrad(x, dy, cin, cout, dtype=_lib.F32_X3), args.reps)
+    tw_e += e
+    tw_x += t3
+    print("%-8s wgrad %4dx%-4d %4d->%-4d %6.2f GF | exact %.3f ms %6.1f TF/s | f32x3 %.3f ms %6.1f TF/s (%.2fx)" % (name, h, w, cin, cout, gf, e, gf / e, t3, gf / t3, e / t3))
+print("weight gradient sum over the listed layers: exact %.3f ms, f32x3 %.3f ms" % (tw_e, tw_x))

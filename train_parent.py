@@ -2,11 +2,18 @@
 the reference's train_parent.py (240 epochs, nAveGrad 10, snapshot every 40 epochs to
 ``<save_dir>/parent_epoch-<e>.pth``), on the MI355X-native OSVOS path.
 
-Data parallel: launch with ``python -m torch.distributed.run --nproc-per-node N train_parent.py``;
-rank r takes micro-batches r, r+N, ... of every optimizer step, accumulates locally and the flat
-gradient buffer is all-reduced (RCCL over xGMI) once per step.  With the reference's batch-1,
-per-frame class weights this reproduces the single-process gradient exactly (up to summation
-order) whenever N divides nAveGrad (N in {1, 2, 5, 10}); for N in {4, 8} use --n-ave-grad 8 / 16.
+Data parallel: launch with ``python -m torch.distributed.run --nproc-per-node N train_parent.py``.
+Every rank derives the same per-epoch permutation of the frames (``--seed``) and runs the iterations
+g = rank (mod N) of that global stream -- indices are sharded BEFORE anything is decoded; the stream is
+cut into optimizer steps of nAveGrad consecutive iterations (across epoch boundaries, like the
+reference's persistent ``aveGrad`` counter), each rank accumulates its nAveGrad / N micro-batches
+locally and the flat gradient buffer is all-reduced (RCCL over xGMI) once per step.  With the
+reference's batch-1, per-frame class weights this reproduces the single-process gradient of the same
+stream exactly (up to summation order).  N must divide nAveGrad (N in {1, 2, 5, 10} for the
+reference's 10); for N in {4, 8} pass --n-ave-grad 8 / 16 -- anything else is refused, not approximated.
+
+``--device-augment`` replaces the reference's cv2 transform chain (train_parent.py:106-110) by Pillow
+decode -> pinned uint8 staging -> one HIP kernel (osvos_pytorch_amd.augment), prefetched on a copy stream.
 """
 from __future__ import division
 
@@ -25,7 +32,7 @@ import torch
 
 import networks.vgg_osvos as vo
 from mypath import Path
-from osvos_pytorch_amd.train_common import TrainLoop, init_distributed, make_reducer, make_sgd
+from osvos_pytorch_amd.train_common import TrainLoop, check_world_divides, epoch_plan, init_distributed, make_reducer, make_sgd
 
 
 def synthetic_dataset(n, h, w):
@@ -40,19 +47,48 @@ def synthetic_dataset(n, h, w):
     return out
 
 
-def davis_loaders(db_root_dir):
+def synthetic_raw_frames(n, h, w):
+    """uint8 BGR frames + 0/255 labels for --device-augment --synthetic (what cv2.imread would hand the reference)."""
+    from osvos_pytorch_amd.davis_io import ArrayFrames
+    frames = []
+    for s in synthetic_dataset(n, h, w):
+        img = (s['image'][0].permute(1, 2, 0) + 116.0).clamp(0, 255).to(torch.uint8).numpy()
+        frames.append((img, (s['gt'][0, 0] * 255).to(torch.uint8).numpy()))
+    return ArrayFrames(frames)
+
+
+def davis_datasets(db_root_dir):
+    """The reference's datasets (train_parent.py:106-113), indexable: the data-parallel plan shards INDICES before anything is
+    decoded, so no rank ever loads a frame it does not train on."""
     try:
         from torchvision import transforms
-        from torch.utils.data import DataLoader
         from dataloaders import davis_2016 as db
         from dataloaders import custom_transforms as tr
     except ImportError as e:
-        raise SystemExit("DAVIS loading needs the reference's dataloaders package + cv2 + torchvision (%s); "
-                         "use --synthetic to run without data" % e)
+        raise SystemExit("DAVIS loading through the reference's transforms needs its dataloaders package + cv2 + torchvision (%s); "
+                         "use --device-augment (Pillow decode + HIP augmentation) or --synthetic N" % e)
     composed = transforms.Compose([tr.RandomHorizontalFlip(), tr.ScaleNRotate(rots=(-30, 30), scales=(.75, 1.25)), tr.ToTensor()])
     db_train = db.DAVIS2016(train=True, inputRes=None, db_root_dir=db_root_dir, transform=composed)
     db_test = db.DAVIS2016(train=False, db_root_dir=db_root_dir, transform=tr.ToTensor())
-    return DataLoader(db_train, batch_size=1, shuffle=True, num_workers=2), DataLoader(db_test, batch_size=1, shuffle=False, num_workers=2)
+    return db_train, db_test
+
+
+def epoch_samples(args, trainset, plan, device, augment):
+    """Yield {'image': [1,3,H,W], 'gt': [1,1,H,W]} for this rank's frames of one epoch, in plan order."""
+    indices = [idx for idx, _ in plan]
+    if augment is not None:
+        # decode on the host -> pinned uint8 -> GPU (copy stream, a few frames ahead) -> one HIP kernel: mean / flip / warp / CHW
+        from osvos_pytorch_amd.davis_io import DevicePrefetcher
+        for _, img, lab in DevicePrefetcher(trainset, indices, device, depth=args.prefetch):
+            s = augment(img, lab)
+            yield {'image': s['image'][None], 'gt': s['gt'][None]}
+    elif isinstance(trainset, list):
+        for idx in indices:
+            yield trainset[idx]
+    else:
+        from torch.utils.data import DataLoader
+        for s in DataLoader(trainset, batch_size=1, sampler=indices, num_workers=2):
+            yield s
 
 
 def main():
@@ -63,10 +99,16 @@ def main():
     ap.add_argument('--resume-epoch', type=int, default=0)
     ap.add_argument('--height', type=int, default=480)
     ap.add_argument('--width', type=int, default=854)
+    ap.add_argument('--seed', type=int, default=0, help='seed of the per-epoch frame permutation (identical on every rank)')
+    ap.add_argument('--device-augment', action='store_true',
+                    help='input pipeline on the GPU: Pillow decode -> pinned uint8 -> osvos_augment_frame (flip, scale+rotate, mean, CHW)')
+    ap.add_argument('--prefetch', type=int, default=3, help='--device-augment: frames decoded / copied ahead of the training step')
+    ap.add_argument('--precision', default=os.environ.get('OSVOS_PRECISION', 'fp32'), choices=['fp32', 'fp32x3', 'bf16'])
     args = ap.parse_args()
 
     rank, world, device = init_distributed()
     nEpochs, nAveGrad, resume_epoch = args.epochs, args.n_ave_grad, args.resume_epoch
+    local_ave = check_world_divides(nAveGrad, world)      # raises when the world size does not divide nAveGrad
     snapshot, nTestInterval = 40, 5
     save_dir = Path.save_root_dir()
     os.makedirs(save_dir, exist_ok=True)
@@ -82,61 +124,67 @@ def main():
         print("Updating weights from: {}".format(ckpt))
         net.load_state_dict(torch.load(ckpt, map_location=lambda storage, loc: storage))
     net.to(device)
+    net.set_precision(args.precision)
     optimizer = make_sgd(net, 'parent')
     reducer = make_reducer(net, world, average=False)
     if reducer is not None:
         reducer.broadcast_parameters(0)
-    if args.synthetic:
+        net.invalidate_packed_weights()      # broadcast writes through .data: the packed-weight cache cannot see it
+    augment = None
+    if args.device_augment:
+        import random
+        from osvos_pytorch_amd.augment import DeviceAugment
+        from osvos_pytorch_amd.davis_io import DavisFrames
+        random.seed(args.seed * 7919 + rank)                 # augmentation draws: independent per rank, reproducible
+        augment = DeviceAugment(rots=(-30, 30), scales=(.75, 1.25))
+        trainset = synthetic_raw_frames(args.synthetic, args.height, args.width) if args.synthetic else DavisFrames(True, Path.db_root_dir())
+        testset = synthetic_dataset(2, args.height, args.width) if args.synthetic else None
+    elif args.synthetic:
         trainset, testset = synthetic_dataset(args.synthetic, args.height, args.width), synthetic_dataset(2, args.height, args.width)
     else:
-        trainset, testset = davis_loaders(Path.db_root_dir())
-    # every rank walks the same order and keeps the micro-batches r, r+W, ... of each group of nAveGrad
-    local_ave = max(1, nAveGrad // world)
-    loop = TrainLoop(net, optimizer, mode='parent', n_ave_grad=nAveGrad, n_epochs=nEpochs, reducer=reducer)
-    loop.n_ave_grad = nAveGrad          # loss divisor stays the global nAveGrad (sum over all ranks)
+        trainset, testset = davis_datasets(Path.db_root_dir())
+    # loss divisor = the global nAveGrad (sum over all ranks); this rank contributes nAveGrad / world micro-batches per step
+    loop = TrainLoop(net, optimizer, mode='parent', n_ave_grad=nAveGrad, n_epochs=nEpochs, reducer=reducer, local_ave=local_ave)
     print("Training Network")
     for epoch in range(resume_epoch, nEpochs):
         start_time = timeit.default_timer()
+        # one permutation per epoch, the same on every rank; rank r runs the iterations g = r (mod world) of the global stream
+        plan = epoch_plan(len(trainset), epoch, nAveGrad, rank, world, seed=args.seed)
         count = 0
-        for ii, sample in enumerate(trainset):
-            if ii % world != rank:
-                continue
+        for sample in epoch_samples(args, trainset, plan, device, augment):
             inputs, gts = sample['image'], sample['gt']
-            inputs.requires_grad_()
+            inputs.requires_grad_()                         # train_parent.py:136: the input gradient is computed
             inputs, gts = inputs.to(device), gts.to(device)
-            outputs = net.forward(inputs)
-            from layers.osvos_layers import class_balanced_cross_entropy_loss as cbce
-            losses = [cbce(o, gts, size_average=False) for o in outputs]
-            for r, l in zip(loop.running, losses):
-                r += l.detach()
-            loss = (1 - epoch / nEpochs) * sum(losses[:-1]) + losses[-1]
-            loss /= nAveGrad
-            loss.backward()
+            loop.micro_batch(inputs, gts, epoch=epoch)      # forward, 5 losses, /= nAveGrad, backward, step every local_ave
             count += 1
-            if count % local_ave == 0:
-                if reducer is not None:
-                    reducer.all_reduce()
-                optimizer.step()
-                optimizer.zero_grad()
-        running = [v / max(1, count) for v in loop.pop_running()]
+        running = loop.pop_running()
+        if reducer is not None:                             # epoch statistics over ALL ranks' frames (one tiny collective per epoch)
+            import torch.distributed as dist
+            t = torch.tensor(running + [float(count)], device=device, dtype=torch.float64)
+            dist.all_reduce(t)
+            running, count_all = t[:-1].tolist(), int(t[-1].item())
+        else:
+            count_all = count
         if rank == 0:
-            print('[Epoch: %d, numImages: %5d]' % (epoch, count * world))
+            print('[Epoch: %d, numImages: %5d]' % (epoch, count_all))
             for l, v in enumerate(running):
-                print('Loss %d: %f' % (l, v))
+                print('Loss %d: %f' % (l, v / max(1, count_all)))
             print("Execution time: " + str(timeit.default_timer() - start_time))
         if (epoch % snapshot) == snapshot - 1 and epoch != 0 and rank == 0:
             torch.save(net.state_dict(), os.path.join(save_dir, modelName + '_epoch-' + str(epoch) + '.pth'))
-        if epoch % nTestInterval == (nTestInterval - 1):
+        if testset is not None and epoch % nTestInterval == (nTestInterval - 1):
+            from layers.osvos_layers import class_balanced_cross_entropy_loss as cbce
             with torch.no_grad():
                 tot = [0.0] * 5
                 for sample in testset:
                     outputs = net.forward(sample['image'].to(device))
-                    from layers.osvos_layers import class_balanced_cross_entropy_loss as cbce
                     for i, o in enumerate(outputs):
                         tot[i] += cbce(o, sample['gt'].to(device), size_average=False).item()
                 if rank == 0:
                     for l, v in enumerate(tot):
                         print('***Testing *** Loss %d: %f' % (l, v / max(1, len(testset))))
+    if rank == 0:
+        print("optimizer steps taken: %d" % loop.steps)
 
 
 if __name__ == '__main__':
