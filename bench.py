@@ -181,7 +181,7 @@ def cpu_baseline(h, w, mode, n_ave, budget_s=20.0):
 class Workload(object):
     """One benchmark configuration: builds the net + synthetic batch, exposes step()."""
 
-    def __init__(self, mode, precision, height, width, batch, graph, n_ave, item_sync, device, rank, dist, force_dist):
+    def __init__(self, mode, precision, height, width, batch, graph, n_ave, item_sync, device, rank, dist, force_dist, graph_train=0):
         from layers.osvos_layers import class_balanced_cross_entropy_loss as cbce
         from osvos_pytorch_amd.parallel import GradientAllReducer
         self.mode, self.precision, self.h, self.w, self.batch, self.graph = mode, precision, height, width, batch, graph
@@ -197,6 +197,10 @@ class Workload(object):
         self.ave, self.epoch, self.nsteps = 0, 0, 0
         self.keep = {}
         self.step = self._train_step
+        self.graph_train = bool(graph_train) and mode != "infer"
+        if self.graph_train:
+            self._capture_micro_step()
+            self.step = self._train_step_graph
         if mode == "infer":
             self.step = self._infer_eager
             if graph:
@@ -212,6 +216,57 @@ class Workload(object):
     def _infer_eager(self):
         with torch.no_grad():
             self.keep["outs"] = self.net.forward(self.x)      # train_online.py:172-181 (sigmoid/PNG writing is host I/O)
+
+    def _micro(self):
+        """forward + loss(es) + running-loss update + backward of ONE micro-batch (train_online.py:116-141): the capturable part."""
+        inputs = self.x.detach().requires_grad_()
+        outputs = self.net.forward(inputs)
+        if self.mode == "online":
+            loss = self.cbce(outputs[-1], self.gt, size_average=False)
+        else:
+            losses = [self.cbce(o, self.gt, size_average=False) for o in outputs]
+            loss = self.side_w * sum(losses[:-1]) + losses[-1]
+        self.running.add_(loss.detach())
+        loss /= self.n_ave
+        loss.backward()
+
+    def _capture_micro_step(self):
+        """hipGraph of one micro-batch (about 110 kernel launches on four streams: forward + side branches, loss, data-gradient chain,
+        weight gradients, slab reduces).  What stays outside the graph is what changes between replays: the weight re-pack after an
+        optimizer step and the optimizer step itself.  Gradients accumulate in place into persistent .grad tensors."""
+        self.side_w = torch.ones((), device=self.x.device)          # (1 - epoch / nEpochs) as a device scalar (epoch 0 here)
+        for _ in range(2 * self.n_ave):                              # two full optimizer cycles: momentum buffers, streams, events, packs
+            self._micro()
+            self.ave += 1
+            if self.ave % self.n_ave == 0:
+                self.opt.step()
+                self.opt.zero_grad(set_to_none=False)
+                self.ave = 0
+        self._repack()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._micro()
+        self.keep["train_graph"] = g
+        self.opt.zero_grad(set_to_none=False)                        # the capture pass accumulated one micro-batch: start the cycle clean
+        self.running.zero_()
+        torch.cuda.synchronize()
+
+    def _repack(self):
+        self.net._runtime.ensure_packed([p.detach() for p in self.net.parameters()])
+
+    def _train_step_graph(self):
+        if self.ave == 0:
+            self._repack()                                            # weights changed at the last optimizer step
+        self.keep["train_graph"].replay()
+        self.ave += 1
+        self.nsteps += 1
+        if self.ave % self.n_ave == 0:
+            if self.reducer is not None:
+                self.reducer.all_reduce()
+            self.opt.step()
+            self.opt.zero_grad(set_to_none=False)
+            self.ave = 0
 
     def _train_step(self):
         # body of train_online.py:116-149 (train_parent.py:132-172 for --mode parent)
@@ -244,9 +299,10 @@ class Workload(object):
         if self.mode == "infer":
             return ("%dx%d batch=%d inference forward (train_online.py:172-181), no_grad, %s, %s, frames resident in HBM"
                     % (self.w, self.h, self.batch, "hipGraph replay" if self.graph else "eager launches", self.precision))
-        return ("%dx%d batch=%d %s fine-tune loop (train_%s.py), fused-head%s loss, nAveGrad=%d, SGD %d-group, %s, frame resident in HBM"
+        return ("%dx%d batch=%d %s fine-tune loop (train_%s.py), fused-head%s loss, nAveGrad=%d, SGD %d-group, %s, frame resident in HBM%s"
                 % (self.w, self.h, self.batch, self.mode, self.mode, "" if self.mode == "online" else "+4 side", self.n_ave,
-                   8 if self.mode == "online" else 10, self.precision))
+                   8 if self.mode == "online" else 10, self.precision,
+                   ", micro-batch (fwd+loss+bwd) replayed from a captured hipGraph" if self.graph_train else ""))
 
 
 def load_traffic():
@@ -296,7 +352,7 @@ def measure(wl, steps, warmup, min_seconds, world, dist, device, use_prof=True):
     lib = _lib.lib()
     for _ in range(warmup):
         wl.step()
-    prof = use_prof and not (wl.mode == "infer" and wl.graph)
+    prof = use_prof and not (wl.mode == "infer" and wl.graph) and not getattr(wl, "graph_train", False)
     elapsed, (ms, fl, cnt) = timed_region(wl, steps, dist, device, lib if prof else None)
     frames = steps * wl.batch * world
     res = {"value": frames / elapsed, "ms_per_step": elapsed / steps * 1e3, "elapsed": elapsed}
@@ -308,32 +364,54 @@ def measure(wl, steps, warmup, min_seconds, world, dist, device, use_prof=True):
                             "ms_per_step": round(e2 / n2 * 1e3, 4)}
     gf_fwd = conv_gflop_forward(wl.h, wl.w) * wl.batch
     passes = 1 if wl.mode == "infer" else 3
-    peak = BF16_MFMA_PEAK_TFLOPS if wl.precision == "bf16" else FP32_MFMA_PEAK_TFLOPS
-    kname = {"fp32": ("conv3x3_f32_kernel", "wgrad_f32_kernel"), "fp32x3": ("conv3x3_f32x3_kernel", "wgrad_f32_kernel"),
+    # f32x3: fp32 results from the bf16 matrix pipe -- every algorithmic FLOP is executed as SIX bf16 MFMA FLOPs.  The roofline that
+    # bounds those kernels is the bf16 dense peak; `achieved` counts the EXECUTED bf16 FLOPs (6 x algorithmic), the algorithmic rate
+    # and its ratio to the fp32-MFMA peak (the roofline of the exact kernels, which this mode is free to exceed) are given next to it.
+    x3 = wl.precision == "fp32x3"
+    mult = 6.0 if x3 else 1.0
+    peak = FP32_MFMA_PEAK_TFLOPS if wl.precision == "fp32" else BF16_MFMA_PEAK_TFLOPS
+    kname = {"fp32": ("conv3x3_f32_kernel", "wgrad_f32_kernel"), "fp32x3": ("conv3x3_f32x3_kernel", "wgrad_f32x3_kernel"),
              "bf16": ("conv3x3_bf16_kernel", "wgrad_bf16_kernel")}[wl.precision]
     roof = None
-    step_frac = round(passes * gf_fwd / 1e3 / (elapsed / steps) / peak, 4)
+    step_alg = passes * gf_fwd / 1e3 / (elapsed / steps)
+    step_frac = round(mult * step_alg / peak, 4)
+
+    def x3_extra(alg_tflops):
+        if not x3:
+            return {}
+        return {"executed_over_algorithmic": 6, "algorithmic_tflops": round(alg_tflops, 2),
+                "algorithmic_over_fp32_mfma_peak": round(alg_tflops / FP32_MFMA_PEAK_TFLOPS, 4),
+                "note": "f32x3: 6 bf16 MFMA products per fp32 product; conv1_1 and the Cout=16 side_prep passes (3 % of the FLOPs) "
+                        "run on the exact fp32 kernels and are counted at 6x as well"}
     if wl.mode == "infer" and wl.graph:
         # one captured graph per step: the family is the whole forward (17 conv launches + glue)
-        ach = gf_fwd / 1e3 / (elapsed / steps)
+        ach = mult * gf_fwd / 1e3 / (elapsed / steps)
         act_gb = 0.904 * (wl.h * wl.w) / (480.0 * 854.0) * wl.batch * (0.5 if wl.precision == "bf16" else 1.0)   # min conv tensor traffic
         roof = {"bound": "mfma", "kernel": "hipGraph replay of osvos_net_forward (%s x17 + pool/head glue)" % kname[0],
                 "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                 "traffic": None, "algorithmic_hbm_GBps": round(act_gb / (elapsed / steps), 1), "hbm_peak_GBps": 8000}
+        roof.update(x3_extra(ach / mult))
+    elif getattr(wl, "graph_train", False):
+        # the micro-batch is ONE graph launch: no per-launch events inside; the family is the step's conv work over the step time
+        ach = mult * step_alg
+        roof = {"bound": "mfma", "kernel": "hipGraph replay of one micro-batch: %s fwd + (%s dgrad || %s) + pool/head/loss glue" % (kname[0], kname[0], kname[1]),
+                "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None}
+        roof.update(x3_extra(step_alg))
     elif prof and cnt[0] + cnt[1] > 0:
         # dominant kernel family: the MFMA conv kernels.  Family 0 = conv3x3 forward launches (one event pair per
         # launch); family 1 = backward regions, i.e. the data-gradient launch of a layer running concurrently with its
         # weight-gradient launch (+ slab reduce) on the second stream, timed fork -> join.  FLOPs are algorithmic.
-        conv_ms, conv_fl = ms[0] + ms[1], fl[0] + fl[1]
+        conv_ms, conv_fl = ms[0] + ms[1], mult * (fl[0] + fl[1])
         ach = conv_fl / (conv_ms * 1e-3) / 1e12
         roof = {"bound": "mfma", "kernel": "%s fwd launches + (%s dgrad || %s) backward regions" % (kname[0], kname[0], kname[1]),
                 "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                 "launches": int(cnt[0] + cnt[1]), "avg_launch_ms": round(conv_ms / (cnt[0] + cnt[1]), 4),
                 "algorithmic_gflop_per_launch": round(conv_fl / (cnt[0] + cnt[1]) / 1e9, 3),
-                "families": {"conv_fwd": {"ms_per_step": round(ms[0] / steps, 3), "tflops": round(fl[0] / (ms[0] * 1e-3) / 1e12, 2) if ms[0] else None},
-                             "conv_bwd_dgrad+wgrad": {"ms_per_step": round(ms[1] / steps, 3), "tflops": round(fl[1] / (ms[1] * 1e-3) / 1e12, 2) if ms[1] else None}},
+                "families": {"conv_fwd": {"ms_per_step": round(ms[0] / steps, 3), "tflops": round(mult * fl[0] / (ms[0] * 1e-3) / 1e12, 2) if ms[0] else None},
+                             "conv_bwd_dgrad+wgrad": {"ms_per_step": round(ms[1] / steps, 3), "tflops": round(mult * fl[1] / (ms[1] * 1e-3) / 1e12, 2) if ms[1] else None}},
                 "step_conv_fraction_of_mfma_roofline": step_frac,
                 "traffic": load_traffic() if wl.precision == "fp32" else None}
+        roof.update(x3_extra(ach / mult))
     res["roofline"] = roof
     res["step_conv_fraction_of_mfma_roofline"] = step_frac
     return res
@@ -351,10 +429,13 @@ def main():
     ap.add_argument("--mode", default="online", choices=["online", "parent", "infer"],
                     help="online/parent: restated training loops (fwd+loss+bwd+SGD); infer: forward only under no_grad "
                          "(BASELINE.json configs[4]: use --height 1080 --width 1920 --batch 4 --graph 1)")
-    ap.add_argument("--precision", default=os.environ.get("OSVOS_PRECISION", "fp32"), choices=["fp32", "fp32x3", "bf16"],
-                    help="bf16: the three conv passes on bf16 MFMA operands, trunk tensors stored as bf16 (fp32 accumulate); "
-                         "the headline configs[1] is fp32")
+    ap.add_argument("--precision", default=os.environ.get("OSVOS_PRECISION", "fp32x3"), choices=["fp32", "fp32x3", "bf16"],
+                    help="fp32x3 (default, the module's default): fp32 tensors, fp32-grade results, the wide 3x3 convolutions (fwd, dgrad, wgrad) on the "
+                         "bf16 matrix pipe with three-way split operands; fp32: the same on the exact fp32 MFMA kernels; bf16: bf16 MFMA operands "
+                         "and bf16 trunk tensors (configs[2])")
     ap.add_argument("--graph", type=int, default=0, help="infer mode: replay the forward from a captured hipGraph")
+    ap.add_argument("--graph-train", type=int, default=0, help="training modes: capture one micro-batch (forward + loss + backward, ~110 launches "
+                    "on four streams) in a hipGraph and replay it; weight re-pack and optimizer step stay eager")
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--width", type=int, default=854)
     ap.add_argument("--batch", type=int, default=1)
@@ -385,9 +466,9 @@ def main():
     torch.cuda.set_device(device)
 
     wl = Workload(args.mode, args.precision, args.height, args.width, args.batch, args.graph, args.n_ave_grad, args.item_sync,
-                  device, rank, dist, args.force_dist)
+                  device, rank, dist, args.force_dist, graph_train=args.graph_train)
     res = measure(wl, args.steps, args.warmup, args.min_seconds, world, dist, device, use_prof=not args.no_prof)
-    default_workload = (args.mode, args.precision, args.height, args.width, args.batch, args.item_sync) == ("online", "fp32", 480, 854, 1, 0)
+    default_workload = (args.mode, args.precision, args.height, args.width, args.batch, args.item_sync) == ("online", "fp32x3", 480, 854, 1, 0)
     extras, item_line = None, None
     if world == 1 and dist is None and default_workload and not args.no_extra:
         # the headline loop with the reference's per-iteration loss.item() left in (train_online.py:128)
@@ -401,10 +482,12 @@ def main():
         torch.cuda.empty_cache()
         extras = []
         for (name, mode, prec, h, w, b, graph) in [
+                ("configs[1] on the EXACT fp32 MFMA kernels (v_mfma_f32_32x32x2_f32): same loop, precision 'fp32'", "online", "fp32", 480, 854, 1, 0),
                 ("configs[2]: 854x480 batch=12 parent training bf16 (MFMA path)", "parent", "bf16", 480, 854, 12, 0),
-                ("configs[4]: 1920x1080 inference-only forward, batch=4, hipGraph-captured", "infer", "fp32", 1080, 1920, 4, 1)]:
+                ("configs[4]: 1920x1080 inference-only forward, batch=4, hipGraph-captured (f32x3)", "infer", "fp32x3", 1080, 1920, 4, 1),
+                ("configs[4] on the EXACT fp32 MFMA kernels", "infer", "fp32", 1080, 1920, 4, 1)]:
             try:
-                w2 = Workload(mode, prec, h, w, b, graph, 0, 0, device, rank, None, False)
+                w2 = Workload(mode, prec, h, w, b, graph, 0, 0, device, rank, None, False, graph_train=(args.graph_train if mode != "infer" else 0))
                 r = measure(w2, max(10, min(args.steps, 30)), max(3, min(args.warmup, 5)), args.min_seconds, 1, None, device, use_prof=True)
                 extras.append({"config": name, "workload": w2.describe(), "value": round(r["value"], 3), "unit": "frames/s",
                                "steps": max(10, min(args.steps, 30)), "ms_per_step": round(r["ms_per_step"], 4), "dtype": DTYPE_NAME[prec],

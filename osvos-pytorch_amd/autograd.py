@@ -27,9 +27,10 @@ class NetRuntime:
         self.wbuf = None
         self.key = None
         self.deconv_key = None
-        # 'fp32' (exact fp32 MFMA everywhere) or 'bf16' (conv forward / data-gradient operands rounded to bf16,
-        # fp32 accumulate and fp32 tensors; weight gradients, head and loss stay fp32)
-        self.dtype = {"bf16": F32_BF16MFMA, "fp32x3": F32_X3}.get(os.environ.get("OSVOS_PRECISION", "fp32").lower(), F32)
+        # 'fp32x3' (default: fp32 tensors and fp32-grade results, the wide 3x3 convolutions on the bf16 matrix pipe with three-way
+        # split operands), 'fp32' (the same on the exact fp32 MFMA kernels) or 'bf16' (bf16 MFMA operands and bf16 trunk tensors,
+        # fp32 accumulate; head and loss stay fp32).  OSVOS_PRECISION sets the initial value.
+        self.dtype = {"bf16": F32_BF16MFMA, "fp32": F32, "fp32x3": F32_X3}.get(os.environ.get("OSVOS_PRECISION", "fp32x3").lower(), F32_X3)
         self.aux_stream = None        # second HIP stream: wgrad kernels overlap the dgrad kernels
         self.aux2_stream = None       # third: the slab reduces of the weight gradients
         self.auxf_stream = None       # forward side branches (own stream: a forward pipelined under the previous backward must not queue

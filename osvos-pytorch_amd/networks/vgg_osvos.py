@@ -74,9 +74,9 @@ class OSVOS(nn.Module):
         return list(outs)
 
     def set_precision(self, name):
-        """'fp32' (default, exact fp32 MFMA), 'fp32x3' (fp32 tensors and fp32-grade results, the wide convolutions on the bf16 matrix pipe with
-        three-way split operands) or 'bf16' (bf16 MFMA operands for the conv forward and
-        data-gradient kernels, fp32 accumulate, fp32 tensors).  Not part of the reference's API."""
+        """'fp32x3' (default: fp32 tensors, fp32-grade results -- the wide 3x3 convolutions run on the bf16 matrix pipe with three-way split
+        operands, six bf16 products per fp32 product), 'fp32' (the same arithmetic on the exact fp32 MFMA kernels, ~1.5x slower) or 'bf16'
+        (bf16 MFMA operands and bf16 trunk tensors, fp32 accumulate).  Not part of the reference's API."""
         self._runtime.set_precision(name)
         return self
 

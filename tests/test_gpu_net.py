@@ -19,7 +19,8 @@ IOU_TOL = 1e-3
 
 
 # the two fp32 arithmetics of the convolutions: exact fp32 MFMA and f32x3 (three-way bf16 split on the bf16 matrix pipe);
-# both are held to the same fp32 bars.  OSVOS_TEST_PRECISION=fp32x3 runs every fp32 test of the GPU tier under f32x3.
+# both are held to the same fp32 bars.  The module's default is fp32x3, so every un-parametrised test of the GPU tier runs under it;
+# OSVOS_TEST_PRECISION=fp32 runs them on the exact kernels instead.
 FP32_MODES = ["fp32", "fp32x3"]
 
 
@@ -426,3 +427,33 @@ def test_bf16_store_mode_odd_sizes_stay_close_to_fp32(shape):
         assert torch.isfinite(gb).all(), k
         if float(ga.norm()) > 0:
             assert float((ga - gb).norm() / ga.norm()) <= 0.5, (k, float((ga - gb).norm() / ga.norm()))
+
+
+@pytest.mark.parametrize("inplace", [False, True])
+def test_partially_frozen_layers_get_the_right_gradients(inplace):
+    """A conv whose weight is frozen while its bias trains (and the other way round) still receives the trainable half: the
+    weight-gradient kernel forms both halves in one launch, the unwanted one goes to scratch (the bias target was
+    returned uninitialised).  Checked against the all-trainable run, with and without in-place .grad accumulation."""
+    from layers.osvos_layers import class_balanced_cross_entropy_loss as cbce
+    from oracle import synth
+    wts, x, m = synth.calibrated_problem(1, 37, 53, seed=9)
+    xd, gt = torch.from_numpy(x).cuda(), torch.from_numpy(m).cuda()
+
+    def run(freeze):
+        net = build_net(wts)
+        net.set_inplace_grad_accumulation(inplace)
+        named = dict(net.named_parameters())
+        for k in freeze:
+            named[k].requires_grad_(False)
+        for rep in range(2 if inplace else 1):          # second pass accumulates into the existing .grad in place
+            outs = net.forward(xd)
+            loss = sum(cbce(o, gt, size_average=False) for o in outs)
+            loss.backward()
+        return {k: (None if v.grad is None else v.grad.clone()) for k, v in named.items()}
+
+    full = run([])
+    part = run(["stages.2.3.weight", "stages.0.0.bias", "side_prep.1.weight", "stages.4.5.bias"])
+    for k in ("stages.2.3.weight", "stages.0.0.bias", "side_prep.1.weight", "stages.4.5.bias"):
+        assert part[k] is None, k
+    for k in ("stages.2.3.bias", "stages.0.0.weight", "side_prep.1.bias", "stages.4.5.weight", "stages.1.1.weight", "fuse.weight"):
+        assert part[k] is not None and torch.equal(part[k], full[k]), k

@@ -4,8 +4,11 @@ Same entry point, knobs and file naming as the reference's train_online.py (SEQ_
 parent checkpoint ``<save_dir>/parent_epoch-239.pth``, result PNGs under ``<save_dir>/Results/<seq>``),
 running on the MI355X-native OSVOS path.  Differences by design:
   * the dataset / augmentation layer of the reference needs OpenCV (``cv2``), which this image
-    lacks; ``--synthetic`` runs the identical loop on a seeded synthetic frame instead (used for
-    benchmarking); with real data, install the reference's dataloaders next to this file
+    lacks: ``--device-augment`` replaces it (Pillow decode -> pinned uint8 staging -> one HIP kernel
+    for flip / scale+rotate / mean / CHW, osvos_pytorch_amd.augment; the first frame is decoded once
+    and re-augmented on the GPU every iteration); ``--synthetic`` runs the identical loop on a seeded
+    synthetic frame (benchmarking); with the reference's dataloaders package + cv2 installed next to
+    this file the original transform chain is used
   * the loss is accumulated on the device and read back only when it is printed
   * launched under torchrun with N processes, rank r fine-tunes sequences r, r+N, ... of the
     comma-separated SEQ_NAME list (independent replicas: online training has no exchange step)
@@ -57,12 +60,70 @@ def davis_loaders(db_root_dir, seq_name):
     return DataLoader(db_train, batch_size=1, shuffle=True, num_workers=1), DataLoader(db_test, batch_size=1, shuffle=False, num_workers=1)
 
 
+class DeviceTrainFrame(object):
+    """train_online.py:92-97 on the device: the sequence's first frame + annotation live on the GPU as uint8; every pass through
+    the 'loader' draws the reference's random flip / rotation / scale (same order, Python's random module) and runs one HIP kernel."""
+
+    def __init__(self, img_u8, lab_u8, device):
+        from osvos_pytorch_amd.augment import DeviceAugment
+        self.img, self.lab = torch.from_numpy(img_u8).to(device), torch.from_numpy(lab_u8).to(device)
+        self.aug = DeviceAugment(rots=(-30, 30), scales=(.75, 1.25))
+
+    def __len__(self):
+        return 1
+
+    def __iter__(self):
+        s = self.aug(self.img, self.lab)
+        yield {'image': s['image'][None], 'gt': s['gt'][None]}
+
+
+class DeviceTestFrames(object):
+    """train_online.py:98-100 on the device: every frame of the sequence, decoded on the host a few frames ahead, mean-subtracted and
+    laid out CHW by the augmentation kernel with the identity transform (the reference's test transform is ToTensor only)."""
+
+    def __init__(self, frames, device, depth):
+        self.frames, self.device, self.depth = frames, device, depth
+
+    def __len__(self):
+        return len(self.frames)
+
+    def __iter__(self):
+        from osvos_pytorch_amd.augment import augment_frame
+        from osvos_pytorch_amd.davis_io import DevicePrefetcher
+        for idx, img, lab in DevicePrefetcher(self.frames, range(len(self.frames)), self.device, depth=self.depth):
+            image, gt = augment_frame(img, lab, flip=False, rot=None)
+            out = {'image': image[None], 'fname': [self.frames.fname(idx)]}
+            if lab is not None:
+                out['gt'] = gt[None]
+            yield out
+
+
+def device_loaders(args, seq_name, device, seed):
+    import random
+    from osvos_pytorch_amd.davis_io import ArrayFrames, DavisFrames
+    random.seed(seed)
+    if args.synthetic:
+        s = synthetic_loader(args.height, args.width, seed)[0]
+        img = (s['image'][0].permute(1, 2, 0) + 116.0).clamp(0, 255).to(torch.uint8).numpy()
+        lab = (s['gt'][0, 0] * 255).to(torch.uint8).numpy()
+        train, test = ArrayFrames([(img, lab)]), ArrayFrames([(img, lab)])
+    else:
+        train, test = DavisFrames(True, Path.db_root_dir(), seq_name=seq_name), DavisFrames(False, Path.db_root_dir(), seq_name=seq_name)
+    img, lab = train[0]
+    return DeviceTrainFrame(img, lab, device), DeviceTestFrames(test, device, args.prefetch)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--synthetic', action='store_true', help='seeded synthetic 854x480 frame instead of DAVIS')
     ap.add_argument('--epochs', type=int, default=0, help='0 = reference value 2000 * nAveGrad')
     ap.add_argument('--height', type=int, default=480)
     ap.add_argument('--width', type=int, default=854)
+    ap.add_argument('--device-augment', action='store_true',
+                    help='input pipeline on the GPU: Pillow decode -> pinned uint8 -> osvos_augment_frame (flip, scale+rotate, mean, CHW); '
+                         'the first frame is decoded ONCE and re-augmented on the device every iteration')
+    ap.add_argument('--prefetch', type=int, default=3, help='--device-augment: test frames decoded / copied ahead of the forward')
+    ap.add_argument('--precision', default=os.environ.get('OSVOS_PRECISION', 'fp32x3'), choices=['fp32', 'fp32x3', 'bf16'])
     args = ap.parse_args()
 
     rank, world, device = init_distributed()
@@ -84,8 +145,11 @@ def main():
         elif not args.synthetic:
             raise SystemExit('parent model %s not found' % parent)
         net.to(device)
+        net.set_precision(args.precision)
         optimizer = make_sgd(net, 'online')
-        if args.synthetic:
+        if args.device_augment:
+            trainloader, testloader = device_loaders(args, seq_name, device, seed + si)
+        elif args.synthetic:
             trainloader = testloader = synthetic_loader(args.height, args.width, seed + si)
         else:
             trainloader, testloader = davis_loaders(Path.db_root_dir(), seq_name)

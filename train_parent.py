@@ -103,7 +103,7 @@ def main():
     ap.add_argument('--device-augment', action='store_true',
                     help='input pipeline on the GPU: Pillow decode -> pinned uint8 -> osvos_augment_frame (flip, scale+rotate, mean, CHW)')
     ap.add_argument('--prefetch', type=int, default=3, help='--device-augment: frames decoded / copied ahead of the training step')
-    ap.add_argument('--precision', default=os.environ.get('OSVOS_PRECISION', 'fp32'), choices=['fp32', 'fp32x3', 'bf16'])
+    ap.add_argument('--precision', default=os.environ.get('OSVOS_PRECISION', 'fp32x3'), choices=['fp32', 'fp32x3', 'bf16'])
     args = ap.parse_args()
 
     rank, world, device = init_distributed()
