@@ -39,25 +39,36 @@ class NetRuntime:
         # in-place accumulation into existing .grad tensors inside backward (see OSVOSNetFunction.backward): explicit opt-in
         self.inplace_accumulate = os.environ.get("OSVOS_INPLACE_GRAD", "0") == "1"
 
+    # The side streams are shared by every OSVOS module of the process (one set per device).  ROCm maps HIP streams onto a handful
+    # of hardware queues (GPU_MAX_HW_QUEUES); a second module with three more streams of its own ends up sharing queues with the
+    # first one's, two of the backward's streams serialise and the step loses its overlap (measured: 130 -> 98 frames/s for the
+    # second net built in one process).  Work of different modules on the same stream is ordered by the stream, as it should be.
+    _shared_streams = {}
+
+    @classmethod
+    def _stream_for(cls, device, name):
+        key = (device.type, device.index if device.index is not None else torch.cuda.current_device(), name)
+        st = cls._shared_streams.get(key)
+        if st is None:
+            st = cls._shared_streams[key] = torch.cuda.Stream(device=device)
+        return st
+
     def aux(self, device):
         if not self.two_streams:
             return None
-        if self.aux_stream is None or self.aux_stream.device != device:
-            self.aux_stream = torch.cuda.Stream(device=device)
+        self.aux_stream = self._stream_for(device, "wgrad")
         return C.c_void_p(self.aux_stream.cuda_stream)
 
     def auxf(self, device):
         if not self.two_streams:
             return None
-        if self.auxf_stream is None or self.auxf_stream.device != device:
-            self.auxf_stream = torch.cuda.Stream(device=device)
+        self.auxf_stream = self._stream_for(device, "side")
         return C.c_void_p(self.auxf_stream.cuda_stream)
 
     def aux2(self, device):
         if not self.two_streams or os.environ.get("OSVOS_THREE_STREAMS", "1") == "0":
             return None
-        if self.aux2_stream is None or self.aux2_stream.device != device:
-            self.aux2_stream = torch.cuda.Stream(device=device)
+        self.aux2_stream = self._stream_for(device, "reduce")
         return C.c_void_p(self.aux2_stream.cuda_stream)
 
     def set_precision(self, name):

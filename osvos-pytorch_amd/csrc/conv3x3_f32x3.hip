@@ -345,12 +345,13 @@ using X11 = CfgX<32, 1, 8, 4, 2, 2, 1, 1>;  // X0 ...
 using X12 = CfgX<32, 1, 8, 2, 4, 2, 1, 1>;  // X4 ...
 using X13 = CfgX<32, 1, 4, 2, 2, 2, 2, 1>;  // X5 ...
 using X14 = CfgX<16, 1, 8, 2, 4, 2, 1, 1>;  // X8 ...
-constexpr int kNumTilesX = 15;
+using X15 = CfgX<32, 1, 8, 1, 8, 1, 1, 1>;  // 32x8 px x 32 co, 8 waves (1x1): the skinny outputs (side_prep: 16 couts, input gradient: 3)
+constexpr int kNumTilesX = 16;
 template <class C>
 constexpr TileInfoX infoX() { return TileInfoX{C::TW, C::TH, C::BN, C::NT, C::LDS_BYTES}; }
 const TileInfoX kTilesX[kNumTilesX] = {infoX<X0>(), infoX<X1>(), infoX<X2>(), infoX<X3>(), infoX<X4>(),
                                        infoX<X5>(), infoX<X6>(), infoX<X7>(), infoX<X8>(), infoX<X9>(),
-                                       infoX<X10>(), infoX<X11>(), infoX<X12>(), infoX<X13>(), infoX<X14>()};
+                                       infoX<X10>(), infoX<X11>(), infoX<X12>(), infoX<X13>(), infoX<X14>(), infoX<X15>()};
 
 long tiles_of(const TileInfoX& t, int N, int H, int W, int CoutP) {
   return (long)N * ceil_div(H, t.th) * ceil_div(W, t.tw) * ceil_div(CoutP, t.bn);
@@ -362,6 +363,7 @@ long tiles_of(const TileInfoX& t, int N, int H, int W, int CoutP) {
 // 32-wide ones pad the frame by more than 10 % (the 107-pixel wide conv4_x); K splits top small grids up to ~200 workgroups.
 int pick_tile_x(int N, int H, int W, int CoutP) {
   const bool narrow = (long)ceil_div(W, 32) * 32 * 100 > (long)ceil_div(W, 16) * 16 * 110;
+  if (CoutP <= 32) return 15;
   if (CoutP >= 128 && !narrow && tiles_of(kTilesX[10], N, H, W, CoutP) >= 200) return 10;
   return narrow ? 14 : 12;
 }
@@ -378,20 +380,23 @@ int pick_ksplit_x(const TileInfoX& t, int N, int H, int W, int Cin, int Cout, in
 
 int osvos_conv3x3_f32x3_num_tiles(void) { return kNumTilesX; }
 
-bool osvos_conv3x3_f32x3_applicable(int Cin, int Cout, int y_cs) { return Cin % 16 == 0 && Cout % 4 == 0 && y_cs % 4 == 0 && Cout >= 32; }
+// Cout may be ragged (the 3-channel input gradient) as long as the output has room for the rounded-up channel quad: the pack's
+// padded couts carry zero weights, so the extra channel is written as 0
+bool osvos_conv3x3_f32x3_applicable(int Cin, int Cout, int y_cs) { return Cin % 16 == 0 && y_cs % 4 == 0 && ((Cout + 3) & ~3) <= y_cs; }
 
 // same contract as osvos_conv3x3_f32_ws (conv3x3_f32.hip); tile: -1 = automatic, 0..kNumTilesX-1 (+100: XCD-local halo map)
 int osvos_conv3x3_f32x3(const float* x, const float* wpk, const float* bias, const float* mask, float* y,
                         int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int tile, int ksplit, void* part_ws, hipStream_t stream) {
   OSVOS_ARG_CHECK(x && wpk && y, "conv3x3 f32x3: null pointer");
   OSVOS_ARG_CHECK(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv3x3 f32x3: bad shape");
-  OSVOS_ARG_CHECK(osvos_conv3x3_f32x3_applicable(Cin, Cout, y_cs), "conv3x3 f32x3: needs Cin %% 16 == 0 (%d), Cout, y_cs %% 4 == 0 (%d, %d), Cout >= 32",
+  OSVOS_ARG_CHECK(osvos_conv3x3_f32x3_applicable(Cin, Cout, y_cs), "conv3x3 f32x3: needs Cin %% 16 == 0 (%d), y_cs %% 4 == 0 and >= Cout rounded up to 4 (%d, %d)",
                   Cin, Cout, y_cs);
+  OSVOS_ARG_CHECK(Cout % 4 == 0 || (bias == nullptr && mask == nullptr), "conv3x3 f32x3: ragged Cout (%d) takes no bias / mask", Cout);
   OSVOS_ARG_CHECK(y_cs >= Cout, "conv3x3 f32x3: y channel stride %d < Cout %d", y_cs, Cout);
   OSVOS_ARG_CHECK((long)H * W * Cin < (1L << 29) && (long)H * W * y_cs < (1L << 29), "conv3x3 f32x3: image too large for 31-bit byte offsets");
   ConvArgsX a;
   a.x = x; a.wpk = wpk; a.bias = bias; a.mask = mask; a.y = y;
-  a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.CoutP = osvos_cout_pad(Cout); a.y_cs = y_cs;
+  a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = (Cout + 3) & ~3; a.CoutP = osvos_cout_pad(Cout); a.y_cs = y_cs;
   a.relu = relu;
   if (tile < 0) {
     OSVOS_ENV_INT(env_tile, "OSVOS_X3_TILE", -1);
@@ -406,7 +411,7 @@ int osvos_conv3x3_f32x3(const float* x, const float* wpk, const float* bias, con
   if (part_ws != nullptr) {
     OSVOS_ENV_INT(env_ks, "OSVOS_X3_KSPLIT", 0);
     a.ksplit = ksplit > 0 ? ksplit : (env_ks > 0 && Cin >= 256 ? env_ks : pick_ksplit_x(kTilesX[tile], N, H, W, Cin, Cout, a.CoutP));
-    if (a.ksplit < 1 || a.ksplit > 8 || a.ksplit > (Cin >> 4)) a.ksplit = 1;
+    if (a.ksplit < 1 || a.ksplit > 8 || a.ksplit > (Cin >> 4) || Cout % 4 != 0) a.ksplit = 1;
   }
   int rc;
   switch (tile) {
@@ -425,6 +430,7 @@ int osvos_conv3x3_f32x3(const float* x, const float* wpk, const float* bias, con
     case 12: rc = launch_x<X12>(a, stream); break;
     case 13: rc = launch_x<X13>(a, stream); break;
     case 14: rc = launch_x<X14>(a, stream); break;
+    case 15: rc = launch_x<X15>(a, stream); break;
     default: osvos_set_error("conv3x3 f32x3: unknown tile config %d", tile); return -1;
   }
   if (rc) return rc;

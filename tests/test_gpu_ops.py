@@ -76,11 +76,11 @@ X3_SHAPES = [
 
 
 @pytest.mark.parametrize("shape", X3_SHAPES)
-@pytest.mark.parametrize("tile", [200 + k for k in range(15)] + [301, 305, 310])
+@pytest.mark.parametrize("tile", [200 + k for k in range(16)] + [301, 305, 310])
 def test_conv3x3_f32x3_all_tiles(shape, tile):
     """f32x3 (three-way bf16 split on the bf16 matrix pipe) is held to the SAME float64 bars as the exact fp32 MFMA kernel."""
     ops = _ops()
-    assert ops.lib().osvos_conv3x3_f32x3_tiles() == 15
+    assert ops.lib().osvos_conv3x3_f32x3_tiles() == 16
     n, h, w, cin, cout = shape
     g = torch.Generator().manual_seed(hash(shape) % 1000 + 3)
     x = torch.randn(n, cin, h, w, generator=g)
@@ -130,6 +130,23 @@ def test_conv3x3_f32x3_is_fp32_grade_and_covers_mask_stride_dgrad_splitk():
     F.conv2d(x, wt, None, padding=1).backward(dy)
     dx = ops.conv3x3(nhwc(dy), ops.pack_dgrad(wt.float().cuda()), None, cin, relu=False, tile=205)
     assert rel_err(nchw(dx), x.grad)[0] < 3e-5
+    # (3b) skinny outputs: 16 couts (side_prep) and the ragged 3-channel input gradient written into a 4-channel buffer
+    n, h, w, cin = 1, 30, 54, 64
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(16, cin, 3, 3, generator=g) / 24
+    b = torch.randn(16, generator=g)
+    ref = F.conv2d(x.double(), wt.double(), b.double(), padding=1)
+    for t in (215, 205, -1):
+        y = ops.conv3x3(nhwc(x), ops.pack_fwd(wt.cuda()), b.cuda(), 16, relu=False, tile=t, dtype=F32_X3)
+        assert rel_err(nchw(y), ref)[0] < 2e-5, t
+    xin = torch.randn(n, 3, h, w, generator=g, dtype=torch.float64, requires_grad=True)
+    w1 = torch.randn(64, 3, 3, 3, generator=g, dtype=torch.float64) / 5
+    dy = torch.randn(n, 64, h, w, generator=g, dtype=torch.float64)
+    F.conv2d(xin, w1, None, padding=1).backward(dy)
+    for t in (215, -1):
+        dx = ops.conv3x3(nhwc(dy), ops.pack_dgrad(w1.float().cuda()), None, 3, relu=False, y_cs=4, tile=t, dtype=F32_X3)
+        assert rel_err(nchw(dx[..., :3]), xin.grad)[0] < 3e-5, t
+        assert float(dx[..., 3].abs().max()) == 0.0
     # (4) split-K through the f32x3 kernel (partial sums + finalize with bias / ReLU)
     n, h, w, cin, cout = 1, 15, 27, 256, 64
     x = torch.randn(n, cin, h, w, generator=g)
