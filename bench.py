@@ -49,6 +49,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
+PROF_EVERY = 4                     # instrument every 4th step of a timed region with launch events
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 BF16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense (no 2:1 sparsity)
 # algorithmic FLOPs per 854x480 frame, SURVEY.md 8(d): 3x3 convs only, fwd + dgrad + wgrad
@@ -282,6 +283,8 @@ class Workload(object):
         else:
             self.running.add_(loss.detach())
         loss /= self.n_ave
+        if self.reducer is not None and (self.ave + 1) % self.n_ave == 0:
+            self.reducer.arm()          # last micro-batch of the step: chunked all-reduce behind the gradient-ready events
         loss.backward()
         self.ave += 1
         self.nsteps += 1
@@ -325,11 +328,22 @@ def timed_region(wl, steps, dist, device, prof_lib=None):
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    # launch events: every PROF_EVERY-th step of the region is instrumented (an event pair around each of its ~56 conv launches / regions);
+    # the others run exactly as they would without bench.py looking.  Events are created and first-recorded before t0.
+    every = PROF_EVERY if steps >= 2 * PROF_EVERY else 1
+    n_prof = (steps + every - 1) // every
     if prof_lib is not None:
-        _lib.check(prof_lib.osvos_prof_start(steps * 64 + 64), "prof_start")
+        _lib.check(prof_lib.osvos_prof_start(n_prof * 64 + 64), "prof_start")
+        prof_lib.osvos_prof_pause(1)
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        wl.step()
+    for i in range(steps):
+        if prof_lib is not None and i % every == 0:
+            prof_lib.osvos_prof_pause(0)
+            wl.step()
+            prof_lib.osvos_prof_pause(1)
+        else:
+            wl.step()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -343,7 +357,7 @@ def timed_region(wl, steps, dist, device, prof_lib=None):
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    return elapsed, (list(ms), list(fl), list(cnt))
+    return elapsed, (list(ms), list(fl), list(cnt)), (n_prof if prof_lib is not None else 0)
 
 
 def measure(wl, steps, warmup, min_seconds, world, dist, device, use_prof=True):
@@ -353,13 +367,13 @@ def measure(wl, steps, warmup, min_seconds, world, dist, device, use_prof=True):
     for _ in range(warmup):
         wl.step()
     prof = use_prof and not (wl.mode == "infer" and wl.graph) and not getattr(wl, "graph_train", False)
-    elapsed, (ms, fl, cnt) = timed_region(wl, steps, dist, device, lib if prof else None)
+    elapsed, (ms, fl, cnt), n_prof = timed_region(wl, steps, dist, device, lib if prof else None)
     frames = steps * wl.batch * world
     res = {"value": frames / elapsed, "ms_per_step": elapsed / steps * 1e3, "elapsed": elapsed}
     if min_seconds > 0:
         n2 = max(steps, int(math.ceil(min_seconds / max(elapsed / steps, 1e-6))))
         n2 = -(-n2 // wl.n_ave) * wl.n_ave if wl.mode != "infer" else n2     # whole optimizer steps
-        e2, _ = timed_region(wl, n2, dist, device, None)
+        e2, _, _ = timed_region(wl, n2, dist, device, None)
         res["sustained"] = {"seconds": round(e2, 3), "steps": n2, "value": round(n2 * wl.batch * world / e2, 3),
                             "ms_per_step": round(e2 / n2 * 1e3, 4)}
     gf_fwd = conv_gflop_forward(wl.h, wl.w) * wl.batch
@@ -407,10 +421,11 @@ def measure(wl, steps, warmup, min_seconds, world, dist, device, use_prof=True):
                 "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                 "launches": int(cnt[0] + cnt[1]), "avg_launch_ms": round(conv_ms / (cnt[0] + cnt[1]), 4),
                 "algorithmic_gflop_per_launch": round(conv_fl / (cnt[0] + cnt[1]) / 1e9, 3),
-                "families": {"conv_fwd": {"ms_per_step": round(ms[0] / steps, 3), "tflops": round(mult * fl[0] / (ms[0] * 1e-3) / 1e12, 2) if ms[0] else None},
-                             "conv_bwd_dgrad+wgrad": {"ms_per_step": round(ms[1] / steps, 3), "tflops": round(mult * fl[1] / (ms[1] * 1e-3) / 1e12, 2) if ms[1] else None}},
+                "instrumented_steps": n_prof,
+                "families": {"conv_fwd": {"ms_per_step": round(ms[0] / n_prof, 3), "tflops": round(mult * fl[0] / (ms[0] * 1e-3) / 1e12, 2) if ms[0] else None},
+                             "conv_bwd_dgrad+wgrad": {"ms_per_step": round(ms[1] / n_prof, 3), "tflops": round(mult * fl[1] / (ms[1] * 1e-3) / 1e12, 2) if ms[1] else None}},
                 "step_conv_fraction_of_mfma_roofline": step_frac,
-                "traffic": load_traffic() if wl.precision == "fp32" else None}
+                "traffic": load_traffic() if wl.precision == "fp32x3" else None}
         roof.update(x3_extra(ach / mult))
     res["roofline"] = roof
     res["step_conv_fraction_of_mfma_roofline"] = step_frac

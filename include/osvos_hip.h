@@ -185,6 +185,15 @@ int osvos_net_forward(const float* x_nchw, const void* wbuf, void* ws, float* co
 int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, float* const* grads,
                        float* dx_nchw, int N, int H, int W, int dtype, int accumulate, void* stream, void* aux_stream,
                        void* aux2_stream);
+/* Gradient-ready events for overlapping the data-parallel all-reduce with the rest of the backward (extends
+ * train_parent.py:163-172; SURVEY 8e "overlap with the last micro-batch's backward, bucket order = reverse layer order").
+ * Arms the NEXT osvos_net_backward call made by THIS host thread: events[k] (hipEvent_t handles owned by the caller, k < 7) is
+ * recorded on whichever stream writes the last gradient of group k, right after that write:
+ *   0 = score_dsn + fuse, 1 = side_prep (all four), 2 = stages.4, 3 = stages.3, 4 = stages.2, 5 = stages.1, 6 = stages.0
+ * -- the order in which a backward completes them.  A communication stream that waits on events[k] may reduce group k's gradients
+ * while the shallower layers are still being computed.  n = 0 disarms.  Entries may be NULL. */
+#define OSVOS_NGRAD_GROUPS 7
+int osvos_net_arm_grad_events(void* const* events, int n);
 /* byte offset / element count of a saved activation inside ws (tests): which = 0..12 trunk conv
  * outputs, 13..16 pooled inputs of stages 1-4, 17..20 side_prep outputs, 21 NHWC input.  (fp32 elements; with dtype
  * OSVOS_F32_BF16MFMA the trunk tensors 0..16 are bf16 unless OSVOS_BF16_STORE=0.) */
@@ -225,6 +234,8 @@ int osvos_sgd_step_multi(float* const* params, const float* const* grads, float*
  * launches: 2*N*H*W*Cout*9*Cin) and count[4]; synchronise the stream before calling it. */
 int osvos_prof_start(int max_records);
 int osvos_prof_stop(double* ms, double* flops, long* count);
+/* between start and stop: paused != 0 suspends recording (no events are enqueued), 0 resumes it; returns the previous state */
+int osvos_prof_pause(int paused);
 
 /* ---- debug references (plain one-thread-per-output kernels, used only by tests) ----------- */
 int osvos_debug_conv3x3_naive(const float* x, const float* w_oihw, const float* bias, float* y,

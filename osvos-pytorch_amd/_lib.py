@@ -64,6 +64,7 @@ PROTOTYPES = {
     "osvos_net_pack": (_i, [_vp, _vp, _i, _i, _vp]),
     "osvos_net_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "osvos_net_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "osvos_net_arm_grad_events": (_i, [_vp, _i]),
     "osvos_net_ws_query": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "osvos_augment_frame": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "osvos_mask_to_bytes": (_i, [_vp, _vp, _vp, _l, _i, _vp]),
@@ -72,6 +73,7 @@ PROTOTYPES = {
     "osvos_sgd_step_multi": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _i, _vp]),
     "osvos_prof_start": (_i, [_i]),
     "osvos_prof_stop": (_i, [_vp, _vp, _vp]),
+    "osvos_prof_pause": (_i, [_i]),
     "osvos_debug_conv3x3_naive": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "osvos_debug_mfma_layout": (_i, [_vp, _vp]),
     "osvos_debug_mfma_peak": (_i, [_vp, _i, _i, _vp]),

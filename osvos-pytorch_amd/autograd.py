@@ -38,6 +38,8 @@ class NetRuntime:
         self.two_streams = os.environ.get("OSVOS_TWO_STREAMS", "1") != "0"
         # in-place accumulation into existing .grad tensors inside backward (see OSVOSNetFunction.backward): explicit opt-in
         self.inplace_accumulate = os.environ.get("OSVOS_INPLACE_GRAD", "0") == "1"
+        self.grad_events = None       # hipEvent_t handles for the NEXT backward (GradientAllReducer.arm), consumed by it
+        self.grad_events_recorded = False     # did the last backward record them (it does only when it accumulated in place)
 
     # The side streams are shared by every OSVOS module of the process (one set per device).  ROCm maps HIP streams onto a handful
     # of hardware queues (GPU_MAX_HW_QUEUES); a second module with three more streams of its own ends up sharing queues with the
@@ -186,6 +188,10 @@ class OSVOSNetFunction(torch.autograd.Function):
             targets = [scratch(i) if l else None for i, l in enumerate(launch)]
             grads = [t if w else None for t, w in zip(targets, wanted)]
         dx = torch.empty((n, 3, h, w), device=dev, dtype=torch.float32) if ctx.needs_input_grad[1] else None
+        ev, rt.grad_events = getattr(rt, "grad_events", None), None
+        rt.grad_events_recorded = bool(ev and inplace)
+        if ev and inplace:         # data-parallel overlap (parallel.GradientAllReducer.arm): one ready-event per completion group
+            check(l.osvos_net_arm_grad_events(ptr_array(ev), len(ev)), "net_arm_grad_events")
         check(l.osvos_net_backward(C.c_void_p(rt.wbuf.data_ptr()), C.c_void_p(ws.data_ptr()),
                                    ptr_array([None if g is None else g.data_ptr() for g in d]),
                                    ptr_array([None if g is None else g.data_ptr() for g in targets]),

@@ -208,6 +208,13 @@ inline int conv_main(const void* x, const void* x_b, const void* wpk, const floa
                                    -1, stream);
 }
 
+// gradient-ready events armed for the next backward of this host thread (osvos_net_arm_grad_events)
+struct GradEvents { hipEvent_t ev[OSVOS_NGRAD_GROUPS]; int n = 0; };
+GradEvents& grad_events() {
+  static thread_local GradEvents g;
+  return g;
+}
+
 inline double conv_flops(int N, int h, int w, int cin, int cout) { return 2.0 * N * h * w * (double)cout * 9.0 * cin; }
 
 __attribute__((unused)) inline char* at(void* base, size_t off) { return reinterpret_cast<char*>(base) + off; }
@@ -357,12 +364,26 @@ int osvos_net_forward(const float* x_nchw, const void* wbuf, void* ws, float* co
                              &L.hs[1], &L.ws[1], stream);
 }
 
+int osvos_net_arm_grad_events(void* const* events, int n) {
+  OSVOS_ARG_CHECK(n >= 0 && n <= OSVOS_NGRAD_GROUPS && (n == 0 || events != nullptr), "arm_grad_events: n = %d (0..%d)", n, OSVOS_NGRAD_GROUPS);
+  GradEvents& g = grad_events();
+  g.n = n;
+  for (int k = 0; k < n; ++k) g.ev[k] = (hipEvent_t)events[k];
+  return 0;
+}
+
 int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, float* const* grads,
                        float* dx_nchw, int N, int H, int W, int dtype, int accumulate, void* stream_, void* aux_stream_,
                        void* aux2_stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   hipStream_t aux = aux_stream_ ? (hipStream_t)aux_stream_ : stream;
   hipStream_t aux2 = aux2_stream_ ? (hipStream_t)aux2_stream_ : aux;
+  const GradEvents gev = grad_events();      // armed for this call only
+  grad_events().n = 0;
+  auto ready = [&](int group, hipStream_t st) -> int {      // group's gradients are complete once `st` gets here
+    if (group < gev.n && gev.ev[group] != nullptr) OSVOS_HIP_CHECK(hipEventRecord(gev.ev[group], st));
+    return 0;
+  };
   const bool two = aux != stream;
   const bool three = aux2 != aux;
   OSVOS_ARG_CHECK(wbuf && ws && douts && grads, "net_backward: null pointer");
@@ -455,6 +476,7 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
   }
   rc = osvos_head_grads_finalize(part, nblk, fb_part, fb_nblk, grads, accumulate, have_side ? 1 : 0, stream);
   if (rc) return rc;
+  if ((rc = ready(0, stream))) return rc;      // score_dsn + fuse gradients
 
   // ---- data-gradient chain on `stream`, weight gradients trailing on `aux` ----------------------
   // ready[k]: event recorded on `stream` when the k-th upstream gradient tensor is complete
@@ -479,6 +501,7 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
       if (rc) return rc;
     }
   }
+  if ((rc = ready(1, aux2))) return rc;        // the four side_prep layers (their slab reduces are the last writers, in order, on aux2)
   for (int i = 3; i >= 0; --i) {
     const int si = i + 1, sl = kNumTrunk + i, h = L.hs[si], w = L.ws[si];
     const int lx = last_of_stage(si);
@@ -503,6 +526,7 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
       rc = wgrad(xin, g, l, h, w);
       if (rc) return rc;
     }
+    if (first_of_stage && (rc = ready(2 + (4 - si), aux2))) return rc;      // stage si complete (its first conv is the last one processed)
     if (l == 0) {
       if (dx_nchw != nullptr) {
         rc = conv_main(g, g_b, at(wbuf, P.dgrad[0]), nullptr, nullptr, nullptr, at(ws, L.dxin), nullptr, N, h, w, d[0].cout, 3, 4, 0, dtype,

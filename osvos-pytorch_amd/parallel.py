@@ -6,7 +6,10 @@ this is the one exchange step the data-parallel version of those loops needs.
 Each rank runs its own micro-batches and accumulates locally; once per optimizer step the flat
 gradient buffer (15.27 M fp32 = 61 MB, frozen deconv weights carry no gradient) is summed across
 ranks with ONE all-reduce -- a single large collective, sized for the per-link-bound xGMI ring
-rather than many small buckets -- and every rank applies the identical SGD update.
+rather than many small buckets -- and every rank applies the identical SGD update.  From the second optimizer step on (gradients living in
+the flat arena, written in place by the backward kernels) the collective is issued as SEVEN chunks in the order the backward completes
+them (head, side_prep, stages.4 ... stages.0), each on a communication stream that waits for that group's gradient-ready event
+(osvos_net_arm_grad_events): the deep layers' 50 MB travel over xGMI while conv3_x .. conv1_x are still being differentiated.
 
 With the reference's per-frame class-balance weights (osvos_layers.py:30-32) W ranks x (nAveGrad/W)
 micro-batches reproduce the single-process gradient exactly (up to summation order) whenever W
@@ -18,6 +21,18 @@ import torch
 import torch.distributed as dist
 
 
+def _grad_group(name):
+    """Completion group of a parameter inside osvos_net_backward (include/osvos_hip.h, osvos_net_arm_grad_events):
+    0 = score_dsn + fuse, 1 = side_prep, 2..6 = stages.4 .. stages.0; modules that are not an OSVOS tree: one group."""
+    if name.startswith(("score_dsn.", "fuse.")):
+        return 0
+    if name.startswith("side_prep."):
+        return 1
+    if name.startswith("stages."):
+        return 2 + (4 - int(name.split(".")[1]))
+    return 0
+
+
 class GradientAllReducer:
     """Gradients live in ONE flat buffer: after the first backward every ``p.grad`` is re-pointed to a view into it
     (``attach``), the network's backward accumulates into those views in place, the collective runs on the flat buffer
@@ -25,13 +40,25 @@ class GradientAllReducer:
     per-tensor allocations.  If somebody replaces a ``.grad`` (``optimizer.zero_grad()`` with set_to_none) the next call
     copies it back in and re-attaches."""
 
-    def __init__(self, module, average=False, process_group=None, always=False):
-        self.params = [p for p in module.parameters() if p.requires_grad]
+    def __init__(self, module, average=False, process_group=None, always=False, overlap=True):
+        named = [(n, p) for n, p in module.named_parameters() if p.requires_grad]
+        # arena order = the order in which a backward COMPLETES the gradients (head, side_prep, stages.4 ... stages.0): every group is
+        # one contiguous slice, so a group can be reduced as soon as its ready-event fires while shallower layers still compute
+        named.sort(key=lambda np_: _grad_group(np_[0]))            # stable: state_dict order inside a group
+        self.params = [p for _, p in named]
+        self._group_of = {id(p): _grad_group(n) for n, p in named}
+        self.module = module
         self.average = average
         self.group = process_group
         self.always = always          # run the collective even in a 1-rank group (exercises RCCL on one GPU)
+        self.overlap = overlap and hasattr(module, "_runtime")
         self._flat = None
         self._views = {}              # id(param) -> view into _flat
+        self._slices = []             # [(group, start, stop)] of the flat buffer, in completion order
+        self._events = None
+        self._comm_stream = None
+        self._armed = False
+        self.overlapped_steps = 0
 
     def attach(self):
         """Point the .grad of every parameter that has one at its slice of the flat buffer.  Returns the flat buffer
@@ -45,9 +72,15 @@ class GradientAllReducer:
         if not layout_ok:
             self._flat = torch.empty(total, device=have[0].grad.device, dtype=have[0].grad.dtype)
             self._views, off = {}, 0
+            self._slices = []
             for p in have:
                 n = p.grad.numel()
                 self._views[id(p)] = self._flat[off:off + n].view_as(p.grad)
+                g = self._group_of[id(p)]
+                if self._slices and self._slices[-1][0] == g:
+                    self._slices[-1] = (g, self._slices[-1][1], off + n)
+                else:
+                    self._slices.append((g, off, off + n))
                 off += n
         stale = [p for p in have if p.grad.data_ptr() != self._views[id(p)].data_ptr()]
         if stale:
@@ -69,14 +102,59 @@ class GradientAllReducer:
             if v is not None:
                 p.grad = v
 
+    def _active(self):
+        return dist.is_initialized() and (dist.get_world_size(self.group) > 1 or self.always)
+
+    def arm(self):
+        """Call right BEFORE the backward of the LAST micro-batch of an optimizer step.  If the gradients already live in the flat
+        arena (every .grad is a view of it: the in-place accumulating backward then writes FINAL values straight into it), the next
+        osvos_net_backward records one event per completion group and ``all_reduce`` reduces group by group on a communication
+        stream, each chunk as soon as its event fires -- overlapped with the backward of the shallower layers.  Returns False (and
+        ``all_reduce`` falls back to one blocking collective after the backward) before the arena is attached, on CPU, or when
+        the module is not an OSVOS tree."""
+        self._armed = False
+        if not (self.overlap and self._active() and self._flat is not None and self._flat.is_cuda):
+            return False
+        rt = self.module._runtime
+        if not getattr(rt, "inplace_accumulate", False):
+            return False
+        if any(p.grad is None or p.grad.data_ptr() != self._views[id(p)].data_ptr() for p in self.params if id(p) in self._views):
+            return False
+        dev = self._flat.device
+        if self._events is None:
+            self._events = [torch.cuda.Event() for _ in range(7)]
+            self._comm_stream = torch.cuda.Stream(device=dev)
+            for e in self._events:
+                e.record(torch.cuda.current_stream(dev))       # torch creates the hipEvent_t lazily, at the first record
+        rt.grad_events = [e.cuda_event for e in self._events]
+        self._armed = True
+        return True
+
     def all_reduce(self):
         """Sum (or average) the .grad of every parameter that has one across all ranks."""
+        armed, self._armed = self._armed, False
+        if armed:      # only if the backward really recorded the events (it does so only when it accumulated in place into the arena)
+            rt = self.module._runtime
+            armed, rt.grad_events_recorded = bool(rt.grad_events_recorded), False
+            rt.grad_events = None
         flat = self.attach()
         if flat is None:
             return
-        if not dist.is_initialized() or (dist.get_world_size(self.group) == 1 and not self.always):
+        if not self._active():
             return
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        if armed:
+            main = torch.cuda.current_stream(flat.device)
+            works = []
+            with torch.cuda.stream(self._comm_stream):
+                for g, a, b in self._slices:                     # completion order: head, side_prep, stages.4 ... stages.0
+                    self._comm_stream.wait_event(self._events[g])
+                    works.append(dist.all_reduce(flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            for w in works:
+                w.wait()                                          # the optimizer's stream waits for the collectives, not the host
+            main.wait_stream(self._comm_stream)
+            self.overlapped_steps += 1
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
         if self.average:
             flat.div_(dist.get_world_size(self.group))
 

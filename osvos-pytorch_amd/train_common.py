@@ -79,6 +79,8 @@ class TrainLoop(object):
                 r += l.detach()
             loss = (1 - epoch / self.n_epochs) * sum(losses[:-1]) + losses[-1]
         loss /= self.n_ave_grad
+        if self.reducer is not None and (self.ave + 1) % self.local_ave == 0:
+            self.reducer.arm()          # last micro-batch of the step: reduce each gradient group as soon as its backward is done
         loss.backward()
         self.ave += 1
         stepped = False

@@ -29,3 +29,23 @@ def test_train_online_synthetic(tmp_path):
 def test_train_parent_synthetic(tmp_path):
     out = _run(["train_parent.py", "--synthetic", "4", "--epochs", "5", "--n-ave-grad", "2", "--height", "40", "--width", "56"], tmp_path)
     assert "Loss 4:" in out and "***Testing *** Loss 4" in out
+
+
+def test_data_parallel_path_on_rccl_single_rank(tmp_path):
+    """'nccl' (= RCCL) process group with one rank, all-reduce forced: bit-identical to the loop without a process group, and the
+    overlapped chunked path is the one that ran."""
+    out = _run(["tools/dp_selfcheck.py"], tmp_path, {"DP_H": "60", "DP_W": "107"})
+    assert "DP_SELFCHECK_OK" in out, out
+    assert "bit-identical" in out
+
+
+def test_train_parent_device_augment_synthetic(tmp_path):
+    """--device-augment: uint8 frames -> pinned staging -> copy stream -> osvos_augment_frame, through the parent loop."""
+    out = _run(["train_parent.py", "--synthetic", "4", "--epochs", "2", "--n-ave-grad", "2", "--height", "40", "--width", "56", "--device-augment"], tmp_path)
+    assert "Loss 4:" in out and "optimizer steps taken: 4" in out
+
+
+def test_train_online_device_augment_synthetic(tmp_path):
+    out = _run(["train_online.py", "--synthetic", "--epochs", "10", "--height", "48", "--width", "64", "--device-augment"], tmp_path,
+               {"SEQ_NAME": "blackswan"})
+    assert "Online training time" in out and os.path.exists(os.path.join(str(tmp_path), "Results", "blackswan", "00000.png"))

@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""Single-GPU check of the data-parallel path on the real backend: an 'nccl' (= RCCL) process group with ONE rank, the gradient
+all-reduce forced on (GradientAllReducer(always=True)), the parent TrainLoop on a small synthetic set -- against the same loop without
+any process group.  A one-rank sum is the identity, so parameters, momentum-free of noise, must come out BIT-IDENTICAL; the run also
+has to take the overlapped path (seven chunked collectives on the communication stream behind the gradient-ready events) from the
+second optimizer step on.  Prints one line per check; exit code 0 = all good.  (tests/test_gpu_scripts.py runs it; the log is kept
+under profiles/.)"""
+import os
+import sys
+import time
+
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+os.environ.setdefault("MASTER_PORT", "29571")
+
+import torch
+import torch.distributed as dist
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+import networks.vgg_osvos as vo  # noqa: E402
+from osvos_pytorch_amd.parallel import GradientAllReducer  # noqa: E402
+from osvos_pytorch_amd.train_common import TrainLoop, epoch_plan, make_sgd  # noqa: E402
+
+
+def frames(n, h, w, dev):
+    out = []
+    for i in range(n):
+        g = torch.Generator().manual_seed(300 + i)
+        img = torch.randn(1, 3, h, w, generator=g) * 40.0
+        yy, xx = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing="ij")
+        gt = ((((yy - 0.5 * h) / (0.3 * h)) ** 2 + ((xx - (0.3 + 0.05 * i) * w) / (0.2 * w)) ** 2) <= 1).float()[None, None]
+        out.append((img.to(dev), gt.to(dev)))
+    return out
+
+
+def run(dev, use_reducer, n_ave, epochs, data, sd0):
+    sys.stdout, keep = open(os.devnull, "w"), sys.stdout
+    try:
+        net = vo.OSVOS(pretrained=0)
+    finally:
+        sys.stdout.close()
+        sys.stdout = keep
+    net.load_state_dict(sd0)
+    net.to(dev)
+    opt = make_sgd(net, "parent", lr=1e-7)
+    red = GradientAllReducer(net, average=False, always=True) if use_reducer else None
+    loop = TrainLoop(net, opt, mode="parent", n_ave_grad=n_ave, n_epochs=8, reducer=red)
+    t0 = time.perf_counter()
+    for epoch in range(epochs):
+        for idx, _ in epoch_plan(len(data), epoch, n_ave, 0, 1, seed=3):
+            loop.micro_batch(data[idx][0].clone().requires_grad_(), data[idx][1], epoch=epoch)
+    torch.cuda.synchronize()
+    return net, loop, red, time.perf_counter() - t0
+
+
+def main():
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    h, w = int(os.environ.get("DP_H", "120")), int(os.environ.get("DP_W", "214"))
+    data = frames(6, h, w, dev)
+    sys.stdout, keep = open(os.devnull, "w"), sys.stdout
+    try:
+        ref_net = vo.OSVOS(pretrained=0)
+    finally:
+        sys.stdout.close()
+        sys.stdout = keep
+    g = torch.Generator().manual_seed(11)
+    for m in ref_net.modules():
+        if isinstance(m, torch.nn.Conv2d):
+            m.weight.data.copy_(torch.randn(m.weight.shape, generator=g) * (2.0 / (m.kernel_size[0] * m.kernel_size[1] * m.out_channels)) ** 0.5)
+    sd0 = {k: v.clone() for k, v in ref_net.state_dict().items()}
+    plain, loop_p, _, t_plain = run(dev, False, 3, 3, data, sd0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    forced, loop_f, red, t_forced = run(dev, True, 3, 3, data, sd0)
+    ok = True
+    same = all(torch.equal(a, b) for a, b in zip(plain.state_dict().values(), forced.state_dict().values()))
+    print("parameters after %d optimizer steps, RCCL one-rank all-reduce forced vs no process group: %s" % (loop_f.steps, "bit-identical" if same else "DIFFERENT"))
+    ok &= same and loop_f.steps == loop_p.steps == 6
+    moved = sum(int(not torch.equal(sd0[k].to(dev), v)) for k, v in forced.state_dict().items())
+    print("tensors changed by training: %d of %d" % (moved, len(sd0)))
+    ok &= moved >= 30
+    print("optimizer steps reduced on the overlapped path (chunked collectives behind gradient-ready events): %d of %d" % (red.overlapped_steps, loop_f.steps))
+    ok &= red.overlapped_steps >= loop_f.steps - 1
+    print("chunks of the flat gradient arena (group, first, last element):", red._slices)
+    ok &= len(red._slices) == 7 and red._slices[0][0] == 0 and red._slices[-1][0] == 6
+    print("wall time of the loop: %.3f s without a process group, %.3f s with the forced one-rank all-reduce (%dx%d, 18 micro-batches)" % (t_plain, t_forced, w, h))
+    dist.destroy_process_group()
+    print("DP_SELFCHECK_OK" if ok else "DP_SELFCHECK_FAILED")
+    return 0 if ok else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())
