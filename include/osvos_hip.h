@@ -28,6 +28,10 @@ extern "C" {
 #define OSVOS_BF16 1          /* bf16 tensors in HBM: reserved, not built */
 #define OSVOS_F32_BF16MFMA 2  /* fp32 tensors in HBM; conv forward/data-gradient operands rounded to bf16 (RNE) while
                                  staged into LDS, v_mfma_f32_32x32x16_bf16 with fp32 accumulate; everything else fp32 */
+#define OSVOS_FLAG_GENERIC_DECONV 0x100  /* OR-ed into the dtype of osvos_net_pack / osvos_net_forward / osvos_net_backward (and the *_bytes queries):
+                                            upscale[i].weight is NOT diagonal with one shared filter -> the generic transposed-convolution head
+                                            (head_generic.hip) runs instead of the commuted one, and gradients of upscale / upscale_ weights
+                                            are written when their grads[] entries (0..7) are non-NULL */
 #define OSVOS_F32_X3 3        /* fp32 tensors, fp32 parameters and fp32 weight packs exactly as OSVOS_F32; the wide 3x3 convolutions
                                  (forward, data gradient) run on the bf16 matrix pipe with three-way split operands (six bf16
                                  products per fp32 product, fp32 accumulate): fp32-grade results, see osvos_conv3x3 below */

@@ -19,6 +19,7 @@ _lock = threading.Lock()
 _lib = None
 
 F32, BF16, F32_BF16MFMA, F32_X3 = 0, 1, 2, 3
+GENERIC_DECONV = 0x100      # OSVOS_FLAG_GENERIC_DECONV: OR-ed into the dtype of the osvos_net_* calls
 NPARAMS = 52
 
 _vp, _i, _l, _sz, _f = C.c_void_p, C.c_int, C.c_long, C.c_size_t, C.c_float

@@ -8,7 +8,7 @@ import os
 
 import torch
 
-from ._lib import F32, F32_BF16MFMA, F32_X3, NPARAMS, check, lib, ptr_array
+from ._lib import F32, F32_BF16MFMA, F32_X3, GENERIC_DECONV, NPARAMS, check, lib, ptr_array
 
 # indices (state_dict order) of the frozen transposed-conv weights: lr 0 in both reference
 # scripts (train_online.py:84-85, train_parent.py:99-100); their gradients are never formed
@@ -38,6 +38,7 @@ class NetRuntime:
         self.two_streams = os.environ.get("OSVOS_TWO_STREAMS", "1") != "0"
         # in-place accumulation into existing .grad tensors inside backward (see OSVOSNetFunction.backward): explicit opt-in
         self.inplace_accumulate = os.environ.get("OSVOS_INPLACE_GRAD", "0") == "1"
+        self.generic_head = False     # upscale[i].weight not diagonal / shared-filter: generic transposed-convolution head
         self.grad_events = None       # hipEvent_t handles for the NEXT backward (GradientAllReducer.arm), consumed by it
         self.grad_events_recorded = False     # did the last backward record them (it does only when it accumulated in place)
 
@@ -89,27 +90,31 @@ class NetRuntime:
             self.deconv_key = None
         dkey = key[:4]
         if dkey != self.deconv_key:
-            self._check_deconv(params[:4])
+            self.generic_head = not self._deconv_is_diagonal(params[:4])
+            if self.generic_head and self.dtype == F32_BF16MFMA:
+                raise NotImplementedError("non-diagonal upscale[i].weight (generic transposed-convolution head) is built for the fp32 / fp32x3 "
+                                          "precisions only; use set_precision('fp32x3') or restore the bilinear deconvolution weights")
             self.deconv_key = dkey
         check(l.osvos_net_pack(ptr_array([p.data_ptr() for p in params]), C.c_void_p(self.wbuf.data_ptr()),
-                               self.dtype, 1, _stream()), "net_pack")
+                               self.cdtype(), 1, _stream()), "net_pack")
         self.key = key
 
+    def cdtype(self):
+        """dtype argument of the osvos_net_* calls: precision, plus the generic-deconvolution flag when the upscale weights need it."""
+        return self.dtype | (GENERIC_DECONV if self.generic_head else 0)
+
     @staticmethod
-    def _check_deconv(ups):
-        """The fused head is exact only for diagonal, shared-filter upscale weights (what
-        interp_surgery produces, osvos_layers.py:72-85).  Anything else is refused."""
+    def _deconv_is_diagonal(ups):
+        """True when every upscale[i].weight is diagonal with ONE shared filter -- what interp_surgery writes (osvos_layers.py:72-85)
+        and what both reference scripts freeze with lr 0: the commuted head (dot-16, then one bilinear gather) is exact for it.
+        Anything else (un-frozen / re-initialised deconvs; the reference runs arbitrary [16,16,k,k] weights, vgg_osvos.py:46,68) takes
+        the generic transposed-convolution head (csrc/head_generic.hip), which also forms the deconv weight gradients."""
         l = lib()
         res = torch.empty((4, 2), device=ups[0].device, dtype=torch.float32)
         for i, w in enumerate(ups):
             check(l.osvos_deconv_diag_check(C.c_void_p(w.data_ptr()), w.shape[0], w.shape[2],
                                             C.c_void_p(res[i].data_ptr()), _stream()), "deconv_diag_check")
-        vals = res.cpu()
-        if float(vals.max()) != 0.0:
-            raise NotImplementedError(
-                "upscale[i].weight is not diagonal with one shared filter (max off-diagonal %g, max "
-                "channel deviation %g): the MI355X head uses the commuted upsample/fuse form and "
-                "refuses non-diagonal transposed-conv weights" % (float(vals[:, 0].max()), float(vals[:, 1].max())))
+        return float(res.max().item()) == 0.0
 
 
 class OSVOSNetFunction(torch.autograd.Function):
@@ -135,10 +140,11 @@ class OSVOSNetFunction(torch.autograd.Function):
         n, _, h, w = xin.shape
         need_bwd = any(ctx.needs_input_grad)       # False under torch.no_grad(): forward-only workspace
         nbytes = l.osvos_net_ws_bytes(n, h, w, rt.dtype) if need_bwd else l.osvos_net_ws_bytes_infer(n, h, w, rt.dtype)
+        ctx.cdtype = rt.cdtype()
         ws = torch.empty(nbytes, device=xin.device, dtype=torch.uint8)
         outs = [torch.empty((n, 1, h, w), device=xin.device, dtype=torch.float32) for _ in range(5)]
         check(l.osvos_net_forward(C.c_void_p(xin.data_ptr()), C.c_void_p(rt.wbuf.data_ptr()), C.c_void_p(ws.data_ptr()),
-                                  ptr_array([o.data_ptr() for o in outs]), n, h, w, rt.dtype, _stream(), rt.auxf(xin.device)), "net_forward")
+                                  ptr_array([o.data_ptr() for o in outs]), n, h, w, ctx.cdtype, _stream(), rt.auxf(xin.device)), "net_forward")
         ctx.rt, ctx.ws, ctx.shape = rt, ws, (n, h, w)
         ctx.param_meta = [(tuple(p.shape), p.device) for p in ps]
         ctx.params = params          # for in-place gradient accumulation in backward
@@ -159,7 +165,11 @@ class OSVOSNetFunction(torch.autograd.Function):
         d = [None if g is None else g.contiguous().float() for g in douts]
         wanted = []
         for i in range(len(ctx.param_meta)):
-            need = ctx.needs_input_grad[2 + i] and i not in _FROZEN
+            # the deconv weights (params 0..7): frozen by lr 0 in both reference scripts (train_online.py:84-85) -- the commuted head
+            # forms no gradient for them; the generic head (non-diagonal weights = somebody trains them) does
+            need = ctx.needs_input_grad[2 + i] and (i not in _FROZEN or bool(ctx.cdtype & GENERIC_DECONV))
+            if need and 4 <= i < 8 and d[i - 4] is None:
+                need = False       # upscale_[i] only sees the side head i
             if need and 42 <= i < 50 and all(g is None for g in d[:4]):
                 need = False       # score_dsn gets no gradient when only the fused head is used
             wanted.append(need)
@@ -196,7 +206,7 @@ class OSVOSNetFunction(torch.autograd.Function):
                                    ptr_array([None if g is None else g.data_ptr() for g in d]),
                                    ptr_array([None if g is None else g.data_ptr() for g in targets]),
                                    C.c_void_p(dx.data_ptr()) if dx is not None else None,
-                                   n, h, w, rt.dtype, 1 if inplace else 0, _stream(), rt.aux(dev), rt.aux2(dev)), "net_backward")
+                                   n, h, w, ctx.cdtype, 1 if inplace else 0, _stream(), rt.aux(dev), rt.aux2(dev)), "net_backward")
         ctx.params = None
         ctx.ws = None
         return (None, dx) + tuple(grads)

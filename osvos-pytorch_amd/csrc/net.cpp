@@ -40,6 +40,8 @@ int last_of_stage(int si) {
 struct WbufLayout {
   size_t fwd[kNumConv], dgrad[kNumConv], bias[kNumConv];
   size_t wd[4], bd[4], wf, bf, f1[4], f16[4];
+  size_t weff[4];            // generic head only: Weff_i[16][k*k] (head_generic.hip)
+  size_t wup[4];             // generic head only: copy of upscale[i].weight [16][16][k][k] (the backward forms fuse / upscale gradients from it)
   size_t total;
 };
 
@@ -58,6 +60,8 @@ WbufLayout wbuf_layout(int dtype) {
   L.wf = take(64 * sizeof(float));
   L.bf = take(sizeof(float));
   for (int i = 0; i < 4; ++i) { const int k = 4 << i; L.f1[i] = take(sizeof(float) * k * k); L.f16[i] = take(sizeof(float) * k * k); }
+  for (int i = 0; i < 4; ++i) { const int k = 4 << i; L.weff[i] = take(sizeof(float) * 16 * k * k); }
+  for (int i = 0; i < 4; ++i) { const int k = 4 << i; L.wup[i] = take(sizeof(float) * 256 * k * k); }
   L.total = off;
   return L;
 }
@@ -85,6 +89,7 @@ struct WsLayout {
   size_t conv_part;          // split-K partial sums of the small deep layers (forward prefix: inference uses it too)
   size_t side_part[4];       // the same for the side_prep convolutions, which run on the aux stream beside the trunk (own buffers)
   size_t dy[kNumTrunk], dpool[5], dside[4], dprep[4], wgrad[kNumConv], acc, dxin;
+  size_t gbuf[4];            // generic head only: tap-indexed reductions G_i[16][k*k] + G1_i[k*k], doubles
   // bf16 copies of the conv operands (dtype OSVOS_F32_BF16MFMA only): written by the producer's epilogue, read by the
   // consuming convolution instead of the fp32 tensor (half the bytes, no conversion while staging)
   size_t xin_b, act_b[kNumTrunk], pooled_b[5], dy_b[kNumTrunk], dpool_b[5], dside_b[4], dprep_b[4];
@@ -163,6 +168,7 @@ WsLayout ws_layout(int N, int H, int W, int dtype) {
   }
   L.acc = take(sizeof(double) * (5 * OSVOS_HEAD_MAX_BLOCKS * 34));   // head_bwd partials: 4 scales + fuse bias
   L.dxin = take(es * N * H * W * 4);
+  for (int i = 0; i < 4; ++i) { const int k = 4 << i; L.gbuf[i] = take(sizeof(double) * 17 * k * k); }
   L.total = off;
   return L;
 }
@@ -229,9 +235,9 @@ int osvos_head_grads_finalize(const double* const* part, const int* nblk, const 
 
 extern "C" {
 
-size_t osvos_net_wbuf_bytes(int dtype) { return wbuf_layout(dtype).total; }
-size_t osvos_net_ws_bytes(int N, int H, int W, int dtype) { return ws_layout(N, H, W, dtype).total; }
-size_t osvos_net_ws_bytes_infer(int N, int H, int W, int dtype) { return ws_layout(N, H, W, dtype).fwd_total; }
+size_t osvos_net_wbuf_bytes(int dtype) { return wbuf_layout(dtype & 0xff).total; }
+size_t osvos_net_ws_bytes(int N, int H, int W, int dtype) { return ws_layout(N, H, W, dtype & 0xff).total; }
+size_t osvos_net_ws_bytes_infer(int N, int H, int W, int dtype) { return ws_layout(N, H, W, dtype & 0xff).fwd_total; }
 
 int osvos_net_ws_query(int N, int H, int W, int dtype, int which, size_t* offset, size_t* elems, int* channels, int* h, int* w) {
   OSVOS_ARG_CHECK(which >= 0 && which <= 21 && offset && elems && channels && h && w, "ws_query: bad arguments");
@@ -249,8 +255,10 @@ int osvos_net_ws_query(int N, int H, int W, int dtype, int which, size_t* offset
   return 0;
 }
 
-int osvos_net_pack(const float* const* params, void* wbuf, int dtype, int with_dgrad, void* stream_) {
+int osvos_net_pack(const float* const* params, void* wbuf, int dtype_, int with_dgrad, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  const int dtype = dtype_ & 0xff;
+  const bool generic = (dtype_ & OSVOS_FLAG_GENERIC_DECONV) != 0;
   OSVOS_ARG_CHECK(params && wbuf, "net_pack: null pointer");
   OSVOS_ARG_CHECK(osvos_dtype_built(dtype), "net_pack: dtype %d not built", dtype);
   for (int i = 0; i < OSVOS_NPARAMS; ++i) OSVOS_ARG_CHECK(params[i] != nullptr, "net_pack: params[%d] is null", i);
@@ -279,12 +287,22 @@ int osvos_net_pack(const float* const* params, void* wbuf, int dtype, int with_d
   }
   srcs[ns] = params[50]; dsts[ns] = L.wf; counts[ns] = 64; ++ns;
   srcs[ns] = params[51]; dsts[ns] = L.bf; counts[ns] = 1; ++ns;
-  return osvos_gather_small(srcs, dsts, counts, ns, wbuf, stream);
+  int rc = osvos_gather_small(srcs, dsts, counts, ns, wbuf, stream);
+  if (rc || !generic) return rc;
+  for (int i = 0; i < 4; ++i) {      // Weff_i = sum_co wfuse[16 i + co] * upscale[i].weight[:, co]
+    rc = osvos_head_weff(params[i], params[50] + 16 * i, reinterpret_cast<float*>(at(wbuf, L.weff[i])), 4 << i, stream);
+    if (rc) return rc;
+    const int k = 4 << i;
+    OSVOS_HIP_CHECK(hipMemcpyAsync(at(wbuf, L.wup[i]), params[i], sizeof(float) * 256 * k * k, hipMemcpyDeviceToDevice, stream));
+  }
+  return 0;
 }
 
 int osvos_net_forward(const float* x_nchw, const void* wbuf, void* ws, float* const* outs,
-                      int N, int H, int W, int dtype, void* stream_, void* aux_stream_) {
+                      int N, int H, int W, int dtype_, void* stream_, void* aux_stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  const int dtype = dtype_ & 0xff;
+  const bool generic = (dtype_ & OSVOS_FLAG_GENERIC_DECONV) != 0;
   hipStream_t aux = aux_stream_ ? (hipStream_t)aux_stream_ : stream;
   const bool two = aux != stream;
   EventPool& evp = event_pool();
@@ -360,6 +378,11 @@ int osvos_net_forward(const float* x_nchw, const void* wbuf, void* ws, float* co
     OSVOS_HIP_CHECK(hipEventRecord(e, aux));
     OSVOS_HIP_CHECK(hipStreamWaitEvent(stream, e, 0));
   }
+  if (generic) {      // non-diagonal upscale weights: fused head from the 16-channel side_prep outputs and Weff (head_generic.hip)
+    const float* prep[4]; const float* weff[4];
+    for (int i = 0; i < 4; ++i) { prep[i] = reinterpret_cast<const float*>(at(ws, L.prep[i])); weff[i] = reinterpret_cast<const float*>(at(wbuf, P.weff[i])); }
+    return osvos_head_upsample_generic(score, prep, f1, weff, reinterpret_cast<const float*>(at(wbuf, P.bf)), outs, N, H, W, &L.hs[1], &L.ws[1], stream);
+  }
   return osvos_head_upsample(score, fpart, f1, f16, reinterpret_cast<const float*>(at(wbuf, P.bf)), outs, N, H, W,
                              &L.hs[1], &L.ws[1], stream);
 }
@@ -373,9 +396,11 @@ int osvos_net_arm_grad_events(void* const* events, int n) {
 }
 
 int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, float* const* grads,
-                       float* dx_nchw, int N, int H, int W, int dtype, int accumulate, void* stream_, void* aux_stream_,
+                       float* dx_nchw, int N, int H, int W, int dtype_, int accumulate, void* stream_, void* aux_stream_,
                        void* aux2_stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  const int dtype = dtype_ & 0xff;
+  const bool generic = (dtype_ & OSVOS_FLAG_GENERIC_DECONV) != 0;
   hipStream_t aux = aux_stream_ ? (hipStream_t)aux_stream_ : stream;
   hipStream_t aux2 = aux2_stream_ ? (hipStream_t)aux2_stream_ : aux;
   const GradEvents gev = grad_events();      // armed for this call only
@@ -460,7 +485,13 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
   // ---- head: upstream full-resolution gradients -> dprep[i] (+ score_dsn / fuse gradients) ----
   for (int i = 0; i < 4; ++i) {
     const int si = i + 1;
-    rc = osvos_head_bwd_f32(reinterpret_cast<const float*>(at(ws, L.prep[i])), douts[i], dfused, reinterpret_cast<const float*>(at(wbuf, P.f1[i])),
+    if (generic)
+      rc = osvos_head_bwd_generic(reinterpret_cast<const float*>(at(ws, L.prep[i])), douts[i], dfused, reinterpret_cast<const float*>(at(wbuf, P.f1[i])),
+                                  reinterpret_cast<const float*>(at(wbuf, P.weff[i])), reinterpret_cast<const float*>(at(wbuf, P.wd[i])),
+                                  reinterpret_cast<float*>(at(ws, L.dprep[i])), acc + (size_t)i * OSVOS_HEAD_MAX_BLOCKS * 34,
+                                  N, H, W, L.hs[si], L.ws[si], i, stream);
+    else
+      rc = osvos_head_bwd_f32(reinterpret_cast<const float*>(at(ws, L.prep[i])), douts[i], dfused, reinterpret_cast<const float*>(at(wbuf, P.f1[i])),
                         reinterpret_cast<const float*>(at(wbuf, P.f16[i])), reinterpret_cast<const float*>(at(wbuf, P.wd[i])),
                         reinterpret_cast<const float*>(at(wbuf, P.wf)) + 16 * i, reinterpret_cast<float*>(at(ws, L.dprep[i])),
                         store ? at(ws, L.dprep_b[i]) : nullptr, acc + (size_t)i * OSVOS_HEAD_MAX_BLOCKS * 34,
@@ -476,6 +507,34 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
   }
   rc = osvos_head_grads_finalize(part, nblk, fb_part, fb_nblk, grads, accumulate, have_side ? 1 : 0, stream);
   if (rc) return rc;
+  if (generic) {
+    // fuse.weight / upscale[i].weight gradients from the tap-indexed sums G_i (the partials above carried zeros for fuse.weight);
+    // upscale_[i].weight (the 1 -> 1 side deconv) likewise when asked for.  The upscale weights themselves are read from the copy
+    // osvos_net_pack left in wbuf.
+    for (int i = 0; i < 4; ++i) {
+      const int si = i + 1, k = 4 << i;
+      double* G = reinterpret_cast<double*>(at(ws, L.gbuf[i]));
+      if (dfused != nullptr && (grads[50] != nullptr || grads[i] != nullptr)) {
+        rc = osvos_head_tapsum(reinterpret_cast<const float*>(at(ws, L.prep[i])), 16, dfused, G, N, H, W, L.hs[si], L.ws[si], i, stream);
+        if (rc) return rc;
+        rc = osvos_head_generic_param_grads(reinterpret_cast<const float*>(at(wbuf, P.wup[i])), reinterpret_cast<const float*>(at(wbuf, P.wf)) + 16 * i, G,
+                                            grads[50] ? grads[50] + 16 * i : nullptr, grads[i], k, accumulate, stream);
+        if (rc) return rc;
+      } else if (grads[i] != nullptr && !accumulate) {
+        OSVOS_HIP_CHECK(hipMemsetAsync(grads[i], 0, sizeof(float) * 256 * k * k, stream));
+      }
+      if (grads[4 + i] != nullptr) {
+        if (douts[i] != nullptr) {
+          rc = osvos_head_tapsum(reinterpret_cast<const float*>(at(ws, L.score[i])), 1, douts[i], G + 16 * k * k, N, H, W, L.hs[si], L.ws[si], i, stream);
+          if (rc) return rc;
+          rc = osvos_head_dw1(G + 16 * k * k, grads[4 + i], k, accumulate, stream);
+          if (rc) return rc;
+        } else if (!accumulate) {
+          OSVOS_HIP_CHECK(hipMemsetAsync(grads[4 + i], 0, sizeof(float) * k * k, stream));
+        }
+      }
+    }
+  }
   if ((rc = ready(0, stream))) return rc;      // score_dsn + fuse gradients
 
   // ---- data-gradient chain on `stream`, weight gradients trailing on `aux` ----------------------

@@ -17,6 +17,8 @@ divides nAveGrad: use average=False and keep `loss /= nAveGrad`.  average=True d
 the world size (weak scaling: every rank keeps nAveGrad local micro-batches)."""
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -51,7 +53,12 @@ class GradientAllReducer:
         self.average = average
         self.group = process_group
         self.always = always          # run the collective even in a 1-rank group (exercises RCCL on one GPU)
-        self.overlap = overlap and hasattr(module, "_runtime")
+        # Overlap is OPT-IN (OSVOS_DP_OVERLAP=1).  Measured on one MI355X with a one-rank RCCL group (profiles/r02_dp_selfcheck.txt,
+        # bench.py --force-dist): the blocking single collective costs nothing (211.6 vs 212.5 frames/s), while seven chunked
+        # collectives behind events cost the HOST ~10 ms per optimizer step through torch.distributed's work bookkeeping (146
+        # frames/s; the GPU timeline itself is unchanged) -- more than a 61 MB all-reduce over xGMI can take.  The mechanism and
+        # its bit-identity check stay (tools/dp_selfcheck.py runs both paths); it is switched on by those who measure a gain.
+        self.overlap = overlap and hasattr(module, "_runtime") and os.environ.get("OSVOS_DP_OVERLAP", "0") == "1"
         self._flat = None
         self._views = {}              # id(param) -> view into _flat
         self._slices = []             # [(group, start, stop)] of the flat buffer, in completion order
@@ -123,7 +130,9 @@ class GradientAllReducer:
         dev = self._flat.device
         if self._events is None:
             self._events = [torch.cuda.Event() for _ in range(7)]
-            self._comm_stream = torch.cuda.Stream(device=dev)
+            # the forward's side-branch stream is idle during a backward: issue the collectives from it rather than from yet another
+            # stream (ROCm maps streams onto GPU_MAX_HW_QUEUES hardware queues; one stream too many and two of the backward's alias)
+            self._comm_stream = rt._stream_for(dev, "side")
             for e in self._events:
                 e.record(torch.cuda.current_stream(dev))       # torch creates the hipEvent_t lazily, at the first record
         rt.grad_events = [e.cuda_event for e in self._events]
@@ -144,14 +153,13 @@ class GradientAllReducer:
             return
         if armed:
             main = torch.cuda.current_stream(flat.device)
-            works = []
             with torch.cuda.stream(self._comm_stream):
                 for g, a, b in self._slices:                     # completion order: head, side_prep, stages.4 ... stages.0
                     self._comm_stream.wait_event(self._events[g])
-                    works.append(dist.all_reduce(flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-            for w in works:
-                w.wait()                                          # the optimizer's stream waits for the collectives, not the host
-            main.wait_stream(self._comm_stream)
+                    # synchronous-style call: the collective is ordered after this stream's work and this stream waits for it;
+                    # the host does not block
+                    dist.all_reduce(flat[a:b], op=dist.ReduceOp.SUM, group=self.group)
+            main.wait_stream(self._comm_stream)                  # the optimizer's stream waits for the collectives, not the host
             self.overlapped_steps += 1
         else:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)

@@ -229,17 +229,76 @@ def test_intermediate_activations_via_ws_query():
             l += 1
 
 
-def test_refuses_non_diagonal_deconv_and_cpu_tensors():
+def test_cpu_tensors_are_refused():
     from oracle import synth
-    wts = synth.make_weights(1)
-    wts["upscale.1.weight"] = wts["upscale.1.weight"].copy()
-    wts["upscale.1.weight"][0, 1, 2, 2] = 0.25
-    net = build_net(wts)
-    with pytest.raises(NotImplementedError):
-        net.forward(torch.zeros(1, 3, 16, 16).cuda())
     net2 = build_net(synth.make_weights(1))
     with pytest.raises(RuntimeError):
         net2.forward(torch.zeros(1, 3, 16, 16))       # CPU tensor: no fallback
+
+
+@pytest.mark.parametrize("shape", [(2, 37, 53), (1, 48, 64)])
+def test_generic_transposed_conv_head_matches_the_reference_semantics(shape):
+    """upscale[i].weight NOT diagonal (the reference runs arbitrary [16,16,k,k] ConvTranspose2d weights, vgg_osvos.py:46,68; only
+    interp_surgery + lr 0 make them bilinear-diagonal in practice): the generic head (csrc/head_generic.hip) must reproduce the
+    float64 oracle -- logits of all five heads, losses, and EVERY gradient including the deconv weights themselves, which the
+    commuted fast head never forms.  Also: perturbing one off-diagonal tap flips a net from the fast to the generic path."""
+    from layers.osvos_layers import class_balanced_cross_entropy_loss as cbce
+    from oracle import synth, torch_ref
+    n, h, w = shape
+    wts, x, m = synth.calibrated_problem(n, h, w, seed=31)
+    rng = np.random.RandomState(5)
+    for i in range(4):      # dense, un-structured deconv weights of the size of the bilinear ones
+        k = 4 << i
+        wts["upscale.%d.weight" % i] = (wts["upscale.%d.weight" % i] + rng.randn(16, 16, k, k).astype(np.float32) * (0.5 / k)).astype(np.float32)
+        wts["upscale_.%d.weight" % i] = (wts["upscale_.%d.weight" % i] * (1.0 + 0.3 * rng.randn(1, 1, k, k))).astype(np.float32)
+    p = torch_ref.as_leaf_params(wts, dtype=torch.float64)
+    xin = torch.from_numpy(x).double().requires_grad_()
+    outs_t = torch_ref.forward(p, xin)
+    losses_t = [torch_ref.cbce_loss(o, torch.from_numpy(m).double(), size_average=False) for o in outs_t]
+    (0.5 * sum(losses_t[:-1]) + losses_t[-1]).backward()
+
+    net = build_net(wts)
+    xg = torch.from_numpy(x).requires_grad_()
+    outs = net.forward(xg.cuda())
+    assert net._runtime.generic_head
+    gt = torch.from_numpy(m).cuda()
+    losses = [cbce(o, gt, size_average=False) for o in outs]
+    (0.5 * sum(losses[:-1]) + losses[-1]).backward()
+    for i in range(5):
+        truth = outs_t[i].detach().numpy()
+        got = outs[i].detach().cpu().double().numpy()
+        assert np.abs(got - truth).max() <= LOGIT_TOL * truth.std(), (shape, i, np.abs(got - truth).max(), truth.std())
+        assert abs(losses[i].item() - losses_t[i].item()) <= 2e-5 * abs(losses_t[i].item()), (shape, i)
+    have = {k: v.grad for k, v in net.named_parameters() if v.grad is not None}
+    assert set(have) == {k for k, v in p.items() if v.grad is not None}          # incl. upscale.* and upscale_.*
+    worst = []
+    for k, v in p.items():
+        e = float((have[k].cpu().double() - v.grad).norm() / (v.grad.norm() + 1e-30))
+        worst.append((e, k))
+    worst.sort(reverse=True)
+    print("generic head gradients vs float64:", [(k, "%.1e" % e) for e, k in worst[:6]])
+    assert worst[0][0] <= 2e-3, worst[0]          # (stage-0 tensors carry the usual ReLU / arg-max flip noise of an un-trained net)
+    assert float((xg.grad.double() - xin.grad).norm() / xin.grad.norm()) <= 5e-3
+    # a second backward accumulates in place (deconv gradients included)
+    net.set_inplace_grad_accumulation(True)
+    outs = net.forward(torch.from_numpy(x).cuda())
+    losses = [cbce(o, gt, size_average=False) for o in outs]
+    (0.5 * sum(losses[:-1]) + losses[-1]).backward()
+    for k in ("upscale.2.weight", "upscale_.1.weight", "fuse.weight", "stages.3.1.weight"):
+        e = float((net.state_dict(keep_vars=True)[k].grad.cpu().double() - 2 * p[k].grad).norm() / (2 * p[k].grad).norm())
+        assert e <= 2e-3, (k, e)
+    # fast path <-> generic path switch follows the weights
+    wts2 = synth.make_weights(1)
+    fast = build_net(wts2)
+    with torch.no_grad():
+        fast.forward(torch.from_numpy(x).cuda())
+        assert not fast._runtime.generic_head
+        fast.upscale[1].weight[0, 1, 2, 2] = 0.25
+        fast.forward(torch.from_numpy(x).cuda())
+        assert fast._runtime.generic_head
+    with pytest.raises(NotImplementedError):
+        fast.set_precision("bf16")
+        fast.forward(torch.from_numpy(x).cuda())
 
 
 def test_batch_and_odd_sizes_no_grad_inference():
