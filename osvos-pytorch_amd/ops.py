@@ -223,3 +223,42 @@ def debug_mfma_layout(device="cuda"):
 def sgd_step(p, g, buf, lr, momentum, weight_decay, first):
     _need_cuda(p, g, buf)
     check(lib().osvos_sgd_step(_p(p), _p(g), _p(buf), p.numel(), lr, momentum, weight_decay, int(first), _stream()), "sgd_step")
+
+
+HEAD_MAX_BLOCKS = 1024      # OSVOS_HEAD_MAX_BLOCKS (include/osvos_hip.h): rows of 34 double partials per head_bwd launch
+
+
+def head_lowres(prep, wd, bd, wf16):
+    """prep [N,h,w,16] -> (score = bd + wd . prep, fpart = wf16 . prep), each [N,h,w]   (vgg_osvos.py:69 score_dsn; fuse commuted)"""
+    _need_cuda(prep, wd, bd, wf16)
+    n, h, w, _ = prep.shape
+    score = torch.empty((n, h, w), device=prep.device, dtype=torch.float32)
+    fpart = torch.empty((n, h, w), device=prep.device, dtype=torch.float32)
+    check(lib().osvos_head_lowres(_p(prep), _p(wd), _p(bd), _p(wf16), _p(score), _p(fpart), n, h, w, F32, _stream()), "head_lowres")
+    return score, fpart
+
+
+def head_upsample(scores, fparts, f1s, f16s, fuse_bias, H, W):
+    """four scales of (score, fpart) [N,h_i,w_i] + their k x k filters -> the five full-resolution logit maps [N,1,H,W]
+    (transposed conv k = 2s, stride s, center crop, sum over scales + fuse bias: vgg_osvos.py:68-72, osvos_layers.py:51-56)"""
+    _need_cuda(*scores, *fparts, *f1s, *f16s, fuse_bias)
+    n = scores[0].shape[0]
+    outs = [torch.empty((n, 1, H, W), device=scores[0].device, dtype=torch.float32) for _ in range(5)]
+    arr = lambda ts: (C.c_void_p * len(ts))(*[C.c_void_p(t.data_ptr()) for t in ts])      # noqa: E731
+    hs = (C.c_int * 4)(*[int(t.shape[1]) for t in scores])
+    ws = (C.c_int * 4)(*[int(t.shape[2]) for t in scores])
+    check(lib().osvos_head_upsample(arr(scores), arr(fparts), arr(f1s), arr(f16s), _p(fuse_bias), arr(outs), n, H, W, hs, ws, _stream()), "head_upsample")
+    return outs
+
+
+def head_bwd(prep, dside, dfused, f1, f16, wd, wf16, H, W, scale_idx):
+    """adjoint of one scale of the head: (dprep [N,h,w,16], dwf16 [16], dwd [16], dbd) from the upstream gradients of side output
+    `scale_idx` (dside, may be None) and of the fused map (dfused, may be None), both [N,1,H,W]"""
+    _need_cuda(prep, dside, dfused, f1, f16, wd, wf16)
+    n, h, w, _ = prep.shape
+    dprep = torch.empty_like(prep)
+    acc = torch.zeros((HEAD_MAX_BLOCKS, 34), device=prep.device, dtype=torch.float64)
+    check(lib().osvos_head_bwd(_p(prep), _p(dside), _p(dfused), _p(f1), _p(f16), _p(wd), _p(wf16), _p(dprep), _p(acc), n, H, W, h, w,
+                               scale_idx, F32, _stream()), "head_bwd")
+    tot = acc.sum(0)
+    return dprep, tot[0:16].float(), tot[16:32].float(), tot[32].float()

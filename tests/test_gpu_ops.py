@@ -664,3 +664,72 @@ def test_wgrad_bf16_forms_are_bit_identical(tmp_path):
                 assert np.array_equal(got[form][k], ref), (form, k)
             else:
                 assert np.allclose(got[form][k], ref, rtol=1e-5, atol=1e-4), (form, k)
+
+
+@pytest.mark.parametrize("HW", [(480, 854), (1080, 1920), (37, 53), (101, 135)])
+def test_head_lowres_upsample_and_backward_at_the_baseline_crop_sets(HW):
+    """Op-level check of the commuted head at the 854x480 crop set ((1,1,1,1),(3,3,2,2),(5,5,4,4),(13,13,8,8)), the 1080p one
+    ((1,1,1,1),(2,2,2,2),(4,4,4,4),(8,8,12,12)) and two odd sizes, against the reference's ops in float64: score_dsn 1x1 conv,
+    ConvTranspose2d(k = 2s, stride s) of the 1- and the 16-channel maps, center_crop, cat + fuse (vgg_osvos.py:68-72,
+    osvos_layers.py:51-56) -- and their adjoints."""
+    ops = _ops()
+    H, W = HW
+    g = torch.Generator().manual_seed(H)
+    n = 1 if H >= 480 else 2
+    hs, ws = [], []
+    h, w = H, W
+    for i in range(4):
+        h, w = (h + 1) // 2, (w + 1) // 2
+        hs.append(h)
+        ws.append(w)
+    preps = [torch.randn(n, 16, hs[i], ws[i], generator=g, dtype=torch.float64, requires_grad=True) for i in range(4)]
+    wd = [torch.randn(1, 16, 1, 1, generator=g, dtype=torch.float64, requires_grad=True) for _ in range(4)]
+    bd = [torch.randn(1, generator=g, dtype=torch.float64, requires_grad=True) for _ in range(4)]
+    wf = torch.randn(1, 64, 1, 1, generator=g, dtype=torch.float64, requires_grad=True)
+    bf = torch.randn(1, generator=g, dtype=torch.float64)
+
+    def filt(k):          # upsample_filt (osvos_layers.py:59-67)
+        f = (k + 1) // 2
+        c = f - 1 if k % 2 == 1 else f - 0.5
+        r = 1 - (torch.arange(k, dtype=torch.float64) - c).abs() / f
+        return r[:, None] * r[None, :]
+
+    def crop(t):          # center_crop (osvos_layers.py:51-56): floor(excess / 2) dropped at the top / left
+        eh, ew = t.shape[2] - H, t.shape[3] - W
+        return t[:, :, eh // 2:eh // 2 + H, ew // 2:ew // 2 + W]
+    f1 = [filt(4 << i) * (1.0 + 0.1 * i) for i in range(4)]          # upscale_[i]: arbitrary (here scaled bilinear) 1 -> 1 filter
+    f16 = [filt(4 << i) for i in range(4)]
+    sides, side_outs = [], []
+    for i in range(4):
+        s = 2 << i
+        w16 = torch.zeros(16, 16, 2 * s, 2 * s, dtype=torch.float64)
+        for c in range(16):
+            w16[c, c] = f16[i]
+        sides.append(crop(F.conv_transpose2d(preps[i], w16, stride=s)))
+        side_outs.append(crop(F.conv_transpose2d(F.conv2d(preps[i], wd[i], bd[i]), f1[i][None, None], stride=s)))
+    fused = F.conv2d(torch.cat(sides, 1), wf, bf)
+    dsides = [torch.randn(n, 1, H, W, generator=g, dtype=torch.float64) for _ in range(4)]
+    dfused = torch.randn(n, 1, H, W, generator=g, dtype=torch.float64)
+    (sum((o * d).sum() for o, d in zip(side_outs, dsides)) + (fused * dfused).sum()).backward()
+
+    cu = lambda t: t.detach().float().cuda().contiguous()      # noqa: E731
+    scores, fparts = [], []
+    for i in range(4):
+        sc, fp = ops.head_lowres(nhwc(preps[i].detach()), cu(wd[i].flatten()), cu(bd[i]), cu(wf.flatten()[16 * i:16 * i + 16]))
+        ref_sc = F.conv2d(preps[i].detach(), wd[i].detach(), bd[i].detach())[:, 0]
+        assert rel_err(sc.cpu(), ref_sc)[0] < 2e-6
+        scores.append(sc)
+        fparts.append(fp)
+    outs = ops.head_upsample(scores, fparts, [cu(f.flatten()) for f in f1], [cu(f.flatten()) for f in f16], cu(bf), H, W)
+    for i in range(4):
+        assert rel_err(outs[i].cpu(), side_outs[i].detach())[0] < 3e-6, (HW, i)
+        # the border rows / columns are where a wrong crop offset shows
+        assert rel_err(outs[i].cpu()[..., :3, :], side_outs[i].detach()[..., :3, :])[0] < 3e-6 and rel_err(outs[i].cpu()[..., -3:], side_outs[i].detach()[..., -3:])[0] < 3e-6
+    assert rel_err(outs[4].cpu(), fused.detach())[0] < 3e-6, HW
+    for i in range(4):
+        dprep, dwf, dwd, dbd = ops.head_bwd(nhwc(preps[i].detach()), cu(dsides[i]), cu(dfused), cu(f1[i].flatten()), cu(f16[i].flatten()),
+                                            cu(wd[i].flatten()), cu(wf.flatten()[16 * i:16 * i + 16]), H, W, i)
+        assert rel_err(nchw(dprep), preps[i].grad)[0] < 1e-5, (HW, i)
+        assert rel_err(dwf.cpu(), wf.grad.flatten()[16 * i:16 * i + 16])[0] < 1e-5
+        assert rel_err(dwd.cpu(), wd[i].grad.flatten())[0] < 1e-5
+        assert abs(float(dbd) - float(bd[i].grad)) <= 1e-5 * abs(float(bd[i].grad)) + 1e-3

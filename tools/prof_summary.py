@@ -25,7 +25,8 @@ try:
     namecol = "kernel_name" if "kernel_name" in cols else cols[-1]
     disp = list(db.execute("select s.%s, d.start, d.end, d.stream_id from rocpd_kernel_dispatch d join %s s on d.kernel_id = s.id order by d.start" % (namecol, ks)))
     bf16_run = any("conv3x3_bf16" in d[0] for d in disp)       # a bf16 run's fp32 conv launches are bench.py's calibration forward
-    conv_names = ("conv3x3_bf16_kernel", "conv3x3_bf16_dma_kernel") if bf16_run else ("conv3x3_f32_kernel",)
+    x3_run = any("conv3x3_f32x3" in d[0] for d in disp)           # default precision: f32x3 kernels + the exact one for conv1_1
+    conv_names = ("conv3x3_bf16_kernel", "conv3x3_bf16_dma_kernel") if bf16_run else (("conv3x3_f32x3_kernel", "conv3x3_f32_kernel") if x3_run else ("conv3x3_f32_kernel",))
     phase, acc, main = None, {"fwd": [], "bwd": []}, {"fwd": [], "bwd": []}
     main_stream = None
     for name, t0, t1, stream in disp:
