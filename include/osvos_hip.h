@@ -78,6 +78,14 @@ int osvos_conv3x3_num_tiles(void);
 int osvos_conv3x3_f32x3_tiles(void);
 int osvos_set_fp32_conv_mode(int mode);
 int osvos_get_fp32_conv_mode(void);
+/* f32x3 with PRE-SPLIT weights: the three bf16 piece planes of the filter are formed once (osvos_pack_conv3x3_x3; dgrad != 0 packs the
+ * rotated / transposed filter of the data gradient) instead of by every workgroup while staging -- same pieces, bit-identical results,
+ * less work between the two barriers of a K chunk.  osvos_net_* do this internally for dtype OSVOS_F32_X3 (OSVOS_X3_PRESPLIT=0: don't).
+ * osvos_conv3x3_x3: arguments as osvos_conv3x3 with dtype OSVOS_F32_X3; tile -1 or one of the eight-wave f32x3 tiles (10, 12, 14, 15). */
+size_t osvos_wpack_x3_bytes_abi(int Cout, int Cin, int dgrad);
+int osvos_pack_conv3x3_x3(const float* w_oihw, void* wpk3, int Cout, int Cin, int dgrad, void* stream);
+int osvos_conv3x3_x3(const void* x, const void* wpk3, const float* bias, const void* mask, void* y,
+                     int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int tile, void* stream);
 /* same convolution cut into `ksplit` parts along K = 9*Cin (0 = automatic, 1..8): layers too small to balance over
  * 256 CUs (conv4_x, conv5_x at batch 1) get more, shorter workgroups; partial sums go to part_ws
  * (osvos_conv3x3_splitk_ws_bytes) and a second kernel applies bias / ReLU / mask.  fp32 only. */

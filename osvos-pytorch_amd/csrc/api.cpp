@@ -54,6 +54,16 @@ int osvos_conv3x3(const void* x, const void* wpk, const float* bias, const void*
 }
 
 int osvos_conv3x3_f32x3_tiles(void) { return osvos_conv3x3_f32x3_num_tiles(); }
+size_t osvos_wpack_x3_bytes_abi(int Cout, int Cin, int dgrad) { return dgrad ? osvos_wpack_x3_bytes(Cin, Cout) : osvos_wpack_x3_bytes(Cout, Cin); }
+int osvos_pack_conv3x3_x3(const float* w, void* wpk3, int Cout, int Cin, int dgrad, void* stream) {
+  return osvos_pack_x3(w, wpk3, Cout, Cin, dgrad, (hipStream_t)stream);
+}
+int osvos_conv3x3_x3(const void* x, const void* wpk3, const float* bias, const void* mask, void* y,
+                     int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int tile, void* stream) {
+  OSVOS_ARG_CHECK(wpk3 != nullptr, "conv3x3_x3: null pack");
+  return osvos_conv3x3_f32x3_ps((const float*)x, nullptr, wpk3, bias, (const float*)mask, (float*)y, N, H, W, Cin, Cout, y_cs, relu,
+                                tile >= 200 ? tile - 200 : tile, 0, nullptr, (hipStream_t)stream);
+}
 
 // bf16-MFMA convolution with explicit operand / result formats: x fp32 (x_is_bf16 = 0) or bf16 NHWC; y fp32 and,
 // when y_bf16 != NULL, a bf16 copy of y with the same channel stride (the operand of the next convolution)

@@ -34,6 +34,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 struct ConvArgsX {
   const float* x;
   const float* wpk;      // fp32 pack [9][Cin/4][CoutP][4] (osvos_pack_fwd_f32 / osvos_pack_dgrad_f32)
+  const uint4* wpk3;     // PS kernels: pre-split pack [piece 3][9][Cin/8][CoutP][8 bf16] (osvos_pack_x3)
   const float* bias;
   const float* mask;
   float* y;
@@ -98,7 +99,10 @@ __device__ inline void split8(const u32x4& lo, const u32x4& hi, uint4& p0, uint4
   split2(b[2], b[3], p0.w, p1.w, p2.w);
 }
 
-template <class C>
+// PS = 1: the weights arrive PRE-SPLIT (three bf16 piece planes, made once per optimizer step by pack_x3_kernel): their staging is
+// a plain copy.  5 of the 7 items a thread stages per chunk are weights, re-split by every workgroup of every launch when PS = 0 --
+// 64 % of the VALU work between the two barriers of a chunk (profiles/r02_pmc_f32x3.txt).
+template <class C, int PS>
 __global__ __launch_bounds__(C::NT, C::OCC) void conv3x3_f32x3_kernel(ConvArgsX a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint4* As = reinterpret_cast<uint4*>(smem);
@@ -140,32 +144,52 @@ __global__ __launch_bounds__(C::NT, C::OCC) void conv3x3_f32x3_kernel(ConvArgsX 
     a_dst[i] = slot ? g * C::PLANE + hy * C::PITCH + hx : -1;
     a_off[i] = (slot && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? (unsigned)(((gy * a.W + gx) * a.Cin + 8 * g) * 4) : OOB;
   }
-  unsigned b_off[C::NBL];
+  constexpr int NBI = PS ? cdivx(3 * C::B_ITEMS, C::NT) : C::NBL;       // weight items per thread and chunk
+  constexpr int TPI = C::NT / (2 * C::BN);                              // PS: (piece, tap) rows a thread advances per item
+  static_assert(!PS || C::NT % (2 * C::BN) == 0, "pre-split staging: the thread block must cover whole (piece, tap) rows");
+  unsigned b_off[PS ? 1 : C::NBL];
+  unsigned b_step = 0;                                                  // PS: byte distance between a thread's consecutive items (uniform)
+  int b_row0 = 0;
+  if (PS) {
+    const int CG = a.Cin >> 3;
+    b_row0 = tid / (2 * C::BN);
+    const int rem = tid % (2 * C::BN), g = rem / C::BN, nn = rem % C::BN;
+    b_off[0] = (co0 + nn < a.CoutP) ? (unsigned)(((b_row0 * CG + g) * a.CoutP + co0 + nn) * 16) : OOB;
+    b_step = (unsigned)(TPI * CG * a.CoutP * 16);
+  } else {
 #pragma unroll
-  for (int i = 0; i < C::NBL; ++i) {
-    const int e = tid + i * C::NT;
-    const int tap = e / (2 * C::BN), rem = e % (2 * C::BN);
-    const int g = rem / C::BN, nn = rem % C::BN;
-    b_off[i] = (e < C::B_ITEMS && co0 + nn < a.CoutP) ? (unsigned)(((tap * CQ + 2 * g) * a.CoutP + co0 + nn) * 16) : OOB;
+    for (int i = 0; i < C::NBL; ++i) {
+      const int e = tid + i * C::NT;
+      const int tap = e / (2 * C::BN), rem = e % (2 * C::BN);
+      const int g = rem / C::BN, nn = rem % C::BN;
+      b_off[i] = (e < C::B_ITEMS && co0 + nn < a.CoutP) ? (unsigned)(((tap * CQ + 2 * g) * a.CoutP + co0 + nn) * 16) : OOB;
+    }
   }
   const unsigned b_q1 = (unsigned)a.CoutP * 16u;       // the second channel quad of a group sits one [CoutP][4] row further
+  const __amdgpu_buffer_rsrc_t w3rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(PS ? a.wpk3 : reinterpret_cast<const uint4*>(a.wpk)), 0,
+                                                                        PS ? (int)((size_t)27 * (a.Cin >> 3) * a.CoutP * 16) : 0, 0x00020000);
 
-  u32x4 ra[C::NA][2], rb[C::NBL][2];
+  u32x4 ra[C::NA][2], rb[NBI][PS ? 1 : 2];
   auto load_item = [&](int it, int kc) {      // it: compile-time item index (A items first)
     if (it < C::NA) {
       ra[it][0] = __builtin_amdgcn_raw_buffer_load_b128(xrs, a_off[it], kc * 64, 0);
       ra[it][1] = __builtin_amdgcn_raw_buffer_load_b128(xrs, a_off[it] + 16u, kc * 64, 0);
-    } else if (it < C::NA + C::NBL) {
+    } else if (it < C::NA + NBI) {
       const int i = it - C::NA;
-      rb[i][0] = __builtin_amdgcn_raw_buffer_load_b128(wrs, b_off[i], kc * 4 * a.CoutP * 16, 0);
-      rb[i][1] = __builtin_amdgcn_raw_buffer_load_b128(wrs, b_off[i] + b_q1, kc * 4 * a.CoutP * 16, 0);
+      if constexpr (PS != 0) {
+        const unsigned off = (b_row0 + i * TPI < 27) ? b_off[0] : OOB;       // (only a thread's last item can fall off the 27 rows)
+        rb[i][0] = __builtin_amdgcn_raw_buffer_load_b128(w3rs, off, kc * 2 * a.CoutP * 16 + i * b_step, 0);
+      } else {
+        rb[i][0] = __builtin_amdgcn_raw_buffer_load_b128(wrs, b_off[i], kc * 4 * a.CoutP * 16, 0);
+        rb[i][1] = __builtin_amdgcn_raw_buffer_load_b128(wrs, b_off[i] + b_q1, kc * 4 * a.CoutP * 16, 0);
+      }
     }
   };
   auto load_chunk = [&](int kc) {
 #pragma unroll
-    for (int it = 0; it < C::NA + C::NBL; ++it) load_item(it, kc);
+    for (int it = 0; it < C::NA + NBI; ++it) load_item(it, kc);
   };
-  static_assert(C::NA + C::NBL <= 9 * C::WM, "interleaved staging: one item per step must cover the chunk");
+  static_assert(!C::ILV || C::NA + NBI <= 9 * C::WM, "interleaved staging: one item per step must cover the chunk");
   auto store_chunk = [&]() {
 #pragma unroll
     for (int i = 0; i < C::NA; ++i) {
@@ -177,15 +201,23 @@ __global__ __launch_bounds__(C::NT, C::OCC) void conv3x3_f32x3_kernel(ConvArgsX 
         As[a_dst[i] + 4 * C::PLANE] = p2;
       }
     }
+    if constexpr (PS != 0) {
 #pragma unroll
-    for (int i = 0; i < C::NBL; ++i) {
-      uint4 p0, p1, p2;
-      split8(rb[i][0], rb[i][1], p0, p1, p2);
-      const int e = tid + i * C::NT;
-      if (C::B_ITEMS % C::NT == 0 || e < C::B_ITEMS) {
-        Bs[e] = p0;
-        Bs[e + C::B_ITEMS] = p1;
-        Bs[e + 2 * C::B_ITEMS] = p2;
+      for (int i = 0; i < NBI; ++i) {
+        const int e3 = tid + i * C::NT;                 // LDS image [piece][tap][group][BN] = the pack's order
+        if ((3 * C::B_ITEMS) % C::NT == 0 || e3 < 3 * C::B_ITEMS) Bs[e3] = __builtin_bit_cast(uint4, rb[i][0]);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NBI; ++i) {
+        uint4 p0, p1, p2;
+        split8(rb[i][0], rb[i][1], p0, p1, p2);
+        const int e = tid + i * C::NT;
+        if (C::B_ITEMS % C::NT == 0 || e < C::B_ITEMS) {
+          Bs[e] = p0;
+          Bs[e + C::B_ITEMS] = p1;
+          Bs[e + 2 * C::B_ITEMS] = p2;
+        }
       }
     }
   };
@@ -306,12 +338,12 @@ __global__ __launch_bounds__(C::NT, C::OCC) void conv3x3_f32x3_kernel(ConvArgsX 
   }
 }
 
-template <class C>
-int launch_x(const ConvArgsX& a0, hipStream_t stream) {
+template <class C, int PS>
+int launch_x2(const ConvArgsX& a0, hipStream_t stream) {
   static bool attr_set_dev[OSVOS_MAX_DEVICES] = {};      // hipFuncSetAttribute is per device
   bool& attr_set = attr_set_dev[osvos_current_device()];
   if (!attr_set) {
-    OSVOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f32x3_kernel<C>),
+    OSVOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f32x3_kernel<C, PS>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
     attr_set = true;
   }
@@ -322,9 +354,18 @@ int launch_x(const ConvArgsX& a0, hipStream_t stream) {
   a.nsp = a.tiles_x * a.tiles_y * a.N;
   const long blocks = a.map == 0 ? (long)a.nct * a.nsp : (long)a.nct * ((a.nsp + 7) / 8) * 8;
   OSVOS_ARG_CHECK(blocks > 0 && blocks < (1L << 31), "conv3x3 f32x3: grid of %ld blocks", blocks);
-  hipLaunchKernelGGL(conv3x3_f32x3_kernel<C>, dim3((unsigned)blocks, (unsigned)a.ksplit), dim3(C::NT), C::LDS_BYTES, stream, a);
+  hipLaunchKernelGGL((conv3x3_f32x3_kernel<C, PS>), dim3((unsigned)blocks, (unsigned)a.ksplit), dim3(C::NT), C::LDS_BYTES, stream, a);
   OSVOS_LAUNCH_CHECK();
   return 0;
+}
+// the pre-split form is built for the production tiles (eight waves, in-loop staging); the others take the fp32 pack
+template <class C>
+int launch_x(const ConvArgsX& a, hipStream_t stream) {
+  if constexpr (C::ILV != 0 && C::NT == 512) {
+    if (a.wpk3 != nullptr) return launch_x2<C, 1>(a, stream);
+  }
+  OSVOS_ARG_CHECK(a.wpk != nullptr, "conv3x3 f32x3: this tile config has no pre-split form and no fp32 pack was given");
+  return launch_x2<C, 0>(a, stream);
 }
 
 struct TileInfoX { int tw, th, bn, nt; size_t lds; };
@@ -376,7 +417,48 @@ int pick_ksplit_x(const TileInfoX& t, int N, int H, int W, int Cin, int Cout, in
   return ks;
 }
 
+// pre-split pack: wpk3[((piece * 9 + tap) * CG + cg) * CoutP + co][e] = piece(W[co][8 cg + e][tap])  (dgrad = 0), or the rotated /
+// transposed filter of the data gradient (dgrad = 1: roles of Cin and Cout swapped, tap -> 8 - tap); zero padded
+__global__ void pack_x3_kernel(const float* __restrict__ w, unsigned short* __restrict__ wpk3, int Cout, int Cin, int K, int M, int MP, int dgrad) {
+  // K = reduction channels (Cin of the conv this pack feeds), M = its output channels, MP = M rounded up to 32
+  const int CG = K / 8;
+  const long plane = 9L * CG * MP * 8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < plane; i += (long)gridDim.x * blockDim.x) {
+    const int e = (int)(i & 7);
+    long t = i >> 3;
+    const int m = (int)(t % MP);
+    t /= MP;
+    const int cg = (int)(t % CG);
+    const int tap = (int)(t / CG);
+    const int k = cg * 8 + e;
+    float v = 0.f;
+    if (m < M) v = dgrad ? w[((long)k * Cin + m) * 9 + (8 - tap)] : w[((long)m * Cin + k) * 9 + tap];      // dgrad: k runs over Cout, m over Cin
+    unsigned p0, p1, p2;
+    split2(v, 0.f, p0, p1, p2);
+    wpk3[i] = (unsigned short)(p0 & 0xffffu);
+    wpk3[plane + i] = (unsigned short)(p1 & 0xffffu);
+    wpk3[2 * plane + i] = (unsigned short)(p2 & 0xffffu);
+  }
+}
+
 }  // namespace
+
+// bytes of the pre-split pack of a conv with `K` reduction channels (multiple of 16) and `M` output channels
+size_t osvos_wpack_x3_bytes(int M, int K) { return (size_t)3 * 9 * K * osvos_cout_pad(M) * 2; }
+
+// w: OIHW fp32 [Cout][Cin][3][3].  dgrad = 0: pack for the forward conv (K = Cin, M = Cout); 1: for the data gradient (K = Cout, M = Cin)
+int osvos_pack_x3(const float* w, void* wpk3, int Cout, int Cin, int dgrad, hipStream_t stream) {
+  OSVOS_ARG_CHECK(w && wpk3 && Cout > 0 && Cin > 0, "pack_x3: bad arguments");
+  const int K = dgrad ? Cout : Cin, M = dgrad ? Cin : Cout;
+  OSVOS_ARG_CHECK(K % 16 == 0, "pack_x3: %d reduction channels (must be a multiple of 16)", K);
+  const long plane = 9L * K * osvos_cout_pad(M);
+  long blocks = (plane + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(pack_x3_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, w, reinterpret_cast<unsigned short*>(wpk3), Cout, Cin, K, M,
+                     osvos_cout_pad(M), dgrad);
+  OSVOS_LAUNCH_CHECK();
+  return 0;
+}
 
 int osvos_conv3x3_f32x3_num_tiles(void) { return kNumTilesX; }
 
@@ -387,7 +469,13 @@ bool osvos_conv3x3_f32x3_applicable(int Cin, int Cout, int y_cs) { return Cin % 
 // same contract as osvos_conv3x3_f32_ws (conv3x3_f32.hip); tile: -1 = automatic, 0..kNumTilesX-1 (+100: XCD-local halo map)
 int osvos_conv3x3_f32x3(const float* x, const float* wpk, const float* bias, const float* mask, float* y,
                         int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int tile, int ksplit, void* part_ws, hipStream_t stream) {
-  OSVOS_ARG_CHECK(x && wpk && y, "conv3x3 f32x3: null pointer");
+  return osvos_conv3x3_f32x3_ps(x, wpk, nullptr, bias, mask, y, N, H, W, Cin, Cout, y_cs, relu, tile, ksplit, part_ws, stream);
+}
+
+// wpk3 != NULL: pre-split pack (osvos_pack_x3) -- wpk (the fp32 pack) is then not read and may be NULL
+int osvos_conv3x3_f32x3_ps(const float* x, const float* wpk, const void* wpk3, const float* bias, const float* mask, float* y,
+                           int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int tile, int ksplit, void* part_ws, hipStream_t stream) {
+  OSVOS_ARG_CHECK(x && (wpk || wpk3) && y, "conv3x3 f32x3: null pointer");
   OSVOS_ARG_CHECK(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv3x3 f32x3: bad shape");
   OSVOS_ARG_CHECK(osvos_conv3x3_f32x3_applicable(Cin, Cout, y_cs), "conv3x3 f32x3: needs Cin %% 16 == 0 (%d), y_cs %% 4 == 0 and >= Cout rounded up to 4 (%d, %d)",
                   Cin, Cout, y_cs);
@@ -395,7 +483,7 @@ int osvos_conv3x3_f32x3(const float* x, const float* wpk, const float* bias, con
   OSVOS_ARG_CHECK(y_cs >= Cout, "conv3x3 f32x3: y channel stride %d < Cout %d", y_cs, Cout);
   OSVOS_ARG_CHECK((long)H * W * Cin < (1L << 29) && (long)H * W * y_cs < (1L << 29), "conv3x3 f32x3: image too large for 31-bit byte offsets");
   ConvArgsX a;
-  a.x = x; a.wpk = wpk; a.bias = bias; a.mask = mask; a.y = y;
+  a.x = x; a.wpk = wpk; a.wpk3 = reinterpret_cast<const uint4*>(wpk3); a.bias = bias; a.mask = mask; a.y = y;
   a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = (Cout + 3) & ~3; a.CoutP = osvos_cout_pad(Cout); a.y_cs = y_cs;
   a.relu = relu;
   if (tile < 0) {

@@ -39,6 +39,7 @@ int last_of_stage(int si) {
 
 struct WbufLayout {
   size_t fwd[kNumConv], dgrad[kNumConv], bias[kNumConv];
+  size_t fwd3[kNumConv], dgrad3[kNumConv];      // OSVOS_F32_X3: pre-split bf16x3 packs of the layers the f32x3 kernels take ((size_t)-1: none)
   size_t wd[4], bd[4], wf, bf, f1[4], f16[4];
   size_t weff[4];            // generic head only: Weff_i[16][k*k] (head_generic.hip)
   size_t wup[4];             // generic head only: copy of upscale[i].weight [16][16][k][k] (the backward forms fuse / upscale gradients from it)
@@ -55,6 +56,11 @@ WbufLayout wbuf_layout(int dtype) {
     L.fwd[l] = take(osvos_wpack_bytes(d[l].cout, d[l].cin_s, dtype));
     L.dgrad[l] = take(osvos_wpack_dgrad_bytes(d[l].cout, d[l].cin, dtype));
     L.bias[l] = take(sizeof(float) * d[l].cout);
+    L.fwd3[l] = L.dgrad3[l] = (size_t)-1;
+    if (dtype == OSVOS_F32_X3) {
+      if (d[l].cin_s % 16 == 0 && d[l].cin == d[l].cin_s) L.fwd3[l] = take(osvos_wpack_x3_bytes(d[l].cout, d[l].cin));
+      if (d[l].cout % 16 == 0) L.dgrad3[l] = take(osvos_wpack_x3_bytes(d[l].cin, d[l].cout));
+    }
   }
   for (int i = 0; i < 4; ++i) { L.wd[i] = take(16 * sizeof(float)); L.bd[i] = take(sizeof(float)); }
   L.wf = take(64 * sizeof(float));
@@ -197,15 +203,21 @@ EventPool& event_pool() {
   return p;
 }
 
+// f32x3: weights pre-split once per pack (default) or re-split by every workgroup from the fp32 pack (OSVOS_X3_PRESPLIT=0; bit-identical)
+inline bool use_presplit() {
+  static const bool on = [] { const char* e = getenv("OSVOS_X3_PRESPLIT"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
 // 3x3 conv on the main stream: fp32 launches may be cut along K (split-K, partial sums in `part`) when the layer
 // is too small to balance across 256 CUs; the bf16-MFMA dtype goes through the public entry point
 // (x_b: bf16 copy of x, preferred when present; y_b: where the bf16 copy of y goes, NULL = none)
 // (mask_b: bf16 mask, takes precedence over the fp32 `mask`; y may be NULL in the bf16 modes when y_b is given)
 inline int conv_main(const void* x, const void* x_b, const void* wpk, const float* bias, const void* mask, const void* mask_b, void* y, void* y_b,
-                     int N, int h, int w, int cin, int cout, int y_cs, int relu, int dtype, void* part, hipStream_t stream) {
+                     int N, int h, int w, int cin, int cout, int y_cs, int relu, int dtype, void* part, hipStream_t stream, const void* wpk3 = nullptr) {
   if (dtype == OSVOS_F32_X3 && osvos_conv3x3_f32x3_applicable(cin, cout, y_cs))      // three-way bf16 split on the bf16 matrix pipe
-    return osvos_conv3x3_f32x3((const float*)x, (const float*)wpk, bias, (const float*)mask, (float*)y, N, h, w, cin, cout, y_cs, relu, -1, 0,
-                               part, stream);
+    return osvos_conv3x3_f32x3_ps((const float*)x, (const float*)wpk, use_presplit() ? wpk3 : nullptr, bias, (const float*)mask, (float*)y, N, h, w,
+                                  cin, cout, y_cs, relu, -1, 0, part, stream);
   if (dtype == OSVOS_F32 || dtype == OSVOS_F32_X3)
     return osvos_conv3x3_f32_ws((const float*)x, (const float*)wpk, bias, (const float*)mask, (float*)y, N, h, w, cin, cout, y_cs,
                                 relu, -1, part, stream);
@@ -276,6 +288,8 @@ int osvos_net_pack(const float* const* params, void* wbuf, int dtype_, int with_
       rc = osvos_pack_conv3x3_dgrad(params[d[l].w_param], at(wbuf, L.dgrad[l]), d[l].cout, d[l].cin, dtype, stream);
       if (rc) return rc;
     }
+    if (L.fwd3[l] != (size_t)-1 && (rc = osvos_pack_x3(params[d[l].w_param], at(wbuf, L.fwd3[l]), d[l].cout, d[l].cin, 0, stream))) return rc;
+    if (with_dgrad && L.dgrad3[l] != (size_t)-1 && (rc = osvos_pack_x3(params[d[l].w_param], at(wbuf, L.dgrad3[l]), d[l].cout, d[l].cin, 1, stream))) return rc;
     srcs[ns] = params[d[l].b_param]; dsts[ns] = L.bias[l]; counts[ns] = d[l].cout; ++ns;
   }
   for (int i = 0; i < 4; ++i) {
@@ -339,7 +353,8 @@ int osvos_net_forward(const float* x_nchw, const void* wbuf, void* ws, float* co
       {
         ProfScope ps(OSVOS_PROF_CONV_FWD, conv_flops(N, h, w, d[l].cin, d[l].cout), stream);
         rc = conv_main(cur, cur_b, at(wbuf, P.fwd[l]), reinterpret_cast<const float*>(at(wbuf, P.bias[l])), nullptr, nullptr,
-                       f32(L.act[l]), sh(L.act_b[l]), N, h, w, d[l].cin_s, d[l].cout, d[l].cout, 1, dtype, at(ws, L.conv_part), stream);
+                       f32(L.act[l]), sh(L.act_b[l]), N, h, w, d[l].cin_s, d[l].cout, d[l].cout, 1, dtype, at(ws, L.conv_part), stream,
+                       P.fwd3[l] != (size_t)-1 ? at(wbuf, P.fwd3[l]) : nullptr);
       }
       if (rc) return rc;
       cur = at(ws, L.act[l]);
@@ -358,7 +373,8 @@ int osvos_net_forward(const float* x_nchw, const void* wbuf, void* ws, float* co
       {
         ProfScope ps(OSVOS_PROF_OTHER, conv_flops(N, h, w, d[sl].cin, 16), aux);
         rc = conv_main(cur, cur_b, at(wbuf, P.fwd[sl]), reinterpret_cast<const float*>(at(wbuf, P.bias[sl])), nullptr, nullptr,
-                       at(ws, L.prep[i]), nullptr, N, h, w, d[sl].cin_s, 16, 16, 0, dtype, L.side_part[i] != (size_t)-1 ? at(ws, L.side_part[i]) : nullptr, aux);
+                       at(ws, L.prep[i]), nullptr, N, h, w, d[sl].cin_s, 16, 16, 0, dtype, L.side_part[i] != (size_t)-1 ? at(ws, L.side_part[i]) : nullptr, aux,
+                       P.fwd3[sl] != (size_t)-1 ? at(wbuf, P.fwd3[sl]) : nullptr);
       }
       if (rc) return rc;
       float* sc = reinterpret_cast<float*>(at(ws, L.score[i]));
@@ -569,7 +585,8 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
     void* dst = (i == 3) ? f32(L.dy[lx]) : f32(L.dside[i]);
     void* dst_b = (i == 3) ? sh(L.dy_b[lx]) : (store ? at(ws, L.dside_b[i]) : nullptr);
     rc = conv_main(at(ws, L.dprep[i]), store ? at(ws, L.dprep_b[i]) : nullptr, at(wbuf, P.dgrad[sl]), nullptr, (i == 3) ? mk32(L.act[lx]) : nullptr,
-                   (i == 3) ? mk16(L.act_b[lx]) : nullptr, dst, dst_b, N, h, w, 16, d[sl].cin, d[sl].cin, 0, dtype, nullptr, stream);
+                   (i == 3) ? mk16(L.act_b[lx]) : nullptr, dst, dst_b, N, h, w, 16, d[sl].cin, d[sl].cin, 0, dtype, nullptr, stream,
+                   P.dgrad3[sl] != (size_t)-1 ? at(wbuf, P.dgrad3[sl]) : nullptr);
     if (rc) return rc;
   }
 
@@ -589,7 +606,7 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
     if (l == 0) {
       if (dx_nchw != nullptr) {
         rc = conv_main(g, g_b, at(wbuf, P.dgrad[0]), nullptr, nullptr, nullptr, at(ws, L.dxin), nullptr, N, h, w, d[0].cout, 3, 4, 0, dtype,
-                       nullptr, stream);
+                       nullptr, stream, P.dgrad3[0] != (size_t)-1 ? at(wbuf, P.dgrad3[0]) : nullptr);
         if (rc) return rc;
         rc = osvos_nhwc_to_nchw(at(ws, L.dxin), dx_nchw, N, 3, H, W, 4, dtype, stream);
         if (rc) return rc;
@@ -599,7 +616,7 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
     if (first_of_stage) {
       // through the pool into the previous stage's output (+ that stage's side branch, + ReLU mask)
       rc = conv_main(g, g_b, at(wbuf, P.dgrad[l]), nullptr, nullptr, nullptr, f32(L.dpool[si]), store ? at(ws, L.dpool_b[si]) : nullptr, N, h, w,
-                     d[l].cout, d[l].cin, d[l].cin, 0, dtype, at(ws, L.conv_part), stream);
+                     d[l].cout, d[l].cin, d[l].cin, 0, dtype, at(ws, L.conv_part), stream, P.dgrad3[l] != (size_t)-1 ? at(wbuf, P.dgrad3[l]) : nullptr);
       if (rc) return rc;
       const int ps2 = si - 1;
       const void* dside = ps2 >= 1 ? at(ws, L.dside[ps2 - 1]) : nullptr;
@@ -613,7 +630,7 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
       if (rc) return rc;
     } else {
       rc = conv_main(g, g_b, at(wbuf, P.dgrad[l]), nullptr, mk32(L.act[l - 1]), mk16(L.act_b[l - 1]), f32(L.dy[l - 1]), sh(L.dy_b[l - 1]), N, h, w,
-                     d[l].cout, d[l].cin, d[l].cin, 0, dtype, at(ws, L.conv_part), stream);
+                     d[l].cout, d[l].cin, d[l].cin, 0, dtype, at(ws, L.conv_part), stream, P.dgrad3[l] != (size_t)-1 ? at(wbuf, P.dgrad3[l]) : nullptr);
       if (rc) return rc;
     }
   }

@@ -262,3 +262,22 @@ def head_bwd(prep, dside, dfused, f1, f16, wd, wf16, H, W, scale_idx):
                                scale_idx, F32, _stream()), "head_bwd")
     tot = acc.sum(0)
     return dprep, tot[0:16].float(), tot[16:32].float(), tot[32].float()
+
+
+def pack_x3(w_oihw, dgrad=False):
+    """pre-split bf16x3 pack of an OIHW fp32 filter for the f32x3 convolution (forward, or the data gradient's rotated filter)"""
+    _need_cuda(w_oihw)
+    cout, cin = int(w_oihw.shape[0]), int(w_oihw.shape[1])
+    buf = torch.empty(lib().osvos_wpack_x3_bytes_abi(cout, cin, int(dgrad)), device=w_oihw.device, dtype=torch.uint8)
+    check(lib().osvos_pack_conv3x3_x3(_p(w_oihw.contiguous()), _p(buf), cout, cin, int(dgrad), _stream()), "pack_x3")
+    return buf
+
+
+def conv3x3_x3(x, wpk3, bias, cout, relu=False, mask=None, y_cs=None, tile=-1):
+    """f32x3 convolution with pre-split weights: x [N,H,W,Cin] fp32 -> [N,H,W,y_cs] fp32"""
+    _need_cuda(x, wpk3, bias, mask)
+    n, h, w, cin = x.shape
+    y_cs = y_cs or cout
+    y = torch.zeros((n, h, w, y_cs), device=x.device, dtype=torch.float32) if y_cs != cout else torch.empty((n, h, w, y_cs), device=x.device, dtype=torch.float32)
+    check(lib().osvos_conv3x3_x3(_p(x), _p(wpk3), _p(bias), _p(mask), _p(y), n, h, w, cin, cout, y_cs, int(relu), tile, _stream()), "conv3x3_x3")
+    return y

@@ -203,6 +203,33 @@ def test_wgrad_f32x3(shape):
     assert torch.equal(a1, a0)
 
 
+@pytest.mark.parametrize("shape", [(2, 17, 35, 16, 64), (1, 33, 70, 64, 128), (1, 40, 45, 32, 96), (1, 30, 54, 512, 64), (1, 21, 37, 64, 16)])
+def test_conv3x3_f32x3_presplit_weights_are_bit_identical(shape):
+    """the pre-split bf16x3 weight pack (formed once per optimizer step) feeds the SAME pieces to the MFMAs as the in-kernel split of the
+    fp32 pack: forward and data gradient must agree bit for bit on every eight-wave tile, and meet the float64 bars"""
+    ops = _ops()
+    n, h, w, cin, cout = shape
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)
+    b = torch.randn(cout, generator=g)
+    ref = F.relu(F.conv2d(x.double(), wt.double(), b.double(), padding=1))
+    xg, pk, pk3 = nhwc(x), ops.pack_fwd(wt.cuda()), ops.pack_x3(wt.cuda())
+    for t in (10, 12, 14, 15, -1):
+        y3 = ops.conv3x3_x3(xg, pk3, b.cuda(), cout, relu=True, tile=t)
+        assert rel_err(nchw(y3), ref)[0] < 2e-5, (shape, t)
+        if t >= 0:
+            assert torch.equal(y3, ops.conv3x3(xg, pk, b.cuda(), cout, relu=True, tile=200 + t)), (shape, t)
+    if cout % 16 == 0:
+        dy = torch.randn(n, cout, h, w, generator=g)
+        dpk, dpk3 = ops.pack_dgrad(wt.cuda()), ops.pack_x3(wt.cuda(), dgrad=True)
+        m = torch.randn(n, cin, h, w, generator=g)
+        a = ops.conv3x3_x3(nhwc(dy), dpk3, None, cin, mask=nhwc(m), tile=12)
+        assert torch.equal(a, ops.conv3x3(nhwc(dy), dpk, None, cin, mask=nhwc(m), tile=212))
+        ref_dx = torch.nn.grad.conv2d_input(x.shape, wt.double(), dy.double(), padding=1) * (m > 0)
+        assert rel_err(nchw(a), ref_dx)[0] < 3e-5
+
+
 def test_conv3x3_matches_naive_kernel_and_mask_and_stride():
     ops = _ops()
     g = torch.Generator().manual_seed(5)

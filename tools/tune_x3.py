@@ -51,7 +51,7 @@ nt = _lib.lib().osvos_conv3x3_f32x3_tiles()
 tiles = [int(t) for t in args.tiles.split(",")] if args.tiles else [200 + k for k in range(nt)]
 n = args.batch
 print("f32x3 sweep %dx%d batch %d; columns = tile id (200+k; +100 = XCD-local map); ms per launch" % (args.width, args.height, n))
-tot_x, tot_e = 0.0, 0.0
+tot_x, tot_e, tot_ps = 0.0, 0.0, 0.0
 for name, h, w, cin, cout in layers:
     if args.layers and name not in args.layers.split(","):
         continue
@@ -65,6 +65,9 @@ for name, h, w, cin, cout in layers:
         wpk = ops.pack_fwd(wt) if direction == "fwd" else ops.pack_dgrad(wt)
         exact = timeit(lambda: ops.conv3x3(x, wpk, None, kout, relu=True), args.reps)
         auto = timeit(lambda: ops.conv3x3(x, wpk, None, kout, relu=True, dtype=_lib.F32_X3), args.reps)
+        wpk3 = ops.pack_x3(wt, dgrad=(direction == "dgrad"))
+        auto_ps = timeit(lambda: ops.conv3x3_x3(x, wpk3, None, kout, relu=True), args.reps)
+        tot_ps += auto_ps
         best, bt = 1e9, None
         cells = []
         for t in tiles:
@@ -84,10 +87,10 @@ for name, h, w, cin, cout in layers:
             cells.append("%d:" % t + "/".join("%.3f" % r for r in row))
         tot_x += best
         tot_e += exact
-        print("%-8s %-5s %4dx%-4d %4d->%-4d %6.2f GF | exact %.3f ms %6.1f TF/s | x3 auto %.3f | best tile %s ks %s: %.3f ms %6.1f TF/s (%.2fx)"
-              % (name, direction, h, w, kin, kout, gf, exact, gf / exact, auto, bt[0], bt[1], best, gf / best, exact / best))
+        print("%-8s %-5s %4dx%-4d %4d->%-4d %6.2f GF | exact %.3f ms %6.1f TF/s | x3 auto %.3f, pre-split weights %.3f ms %6.1f TF/s | best tile %s ks %s: %.3f ms %6.1f TF/s (%.2fx)"
+              % (name, direction, h, w, kin, kout, gf, exact, gf / exact, auto, auto_ps, gf / auto_ps, bt[0], bt[1], best, gf / best, exact / best))
         print("    [k1 map0/map1%s] " % ("/k2../k4.." if kin >= 256 else "") + "  ".join(cells))
-print("sum over the listed layers: exact %.3f ms, f32x3 best %.3f ms" % (tot_e, tot_x))
+print("sum over the listed layers: exact %.3f ms, f32x3 best listed tile %.3f ms, f32x3 automatic choice with pre-split weights %.3f ms" % (tot_e, tot_x, tot_ps))
 print("weight gradient (fp32 x, dy -> fp32 dW, db; slabs + reduce included):")
 tw_e, tw_x = 0.0, 0.0
 for name, h, w, cin, cout in layers:
