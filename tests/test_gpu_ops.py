@@ -658,8 +658,6 @@ def test_result_writer_bytes_png_and_jaccard(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.skipif(__import__("os").environ.get("OSVOS_TEST_EXPERIMENTAL") != "1",
-                    reason="kernel forms that are not the default: OSVOS_TEST_EXPERIMENTAL=1 python -m pytest -m gpu -k wgrad_bf16_forms")
 def test_wgrad_bf16_forms_are_bit_identical(tmp_path):
     """OSVOS_WGRAD_FORM 0 / 1 / 3 (first staging form, four-wave item form, experimental pixel-major tiles read with
     ds_read_b64_tr_b16) against the default form: same patches, same splits, same k-order -> the weight gradient must be
