@@ -63,7 +63,7 @@ class NetRuntime:
         return C.c_void_p(self.aux_stream.cuda_stream)
 
     def auxf(self, device):
-        if not self.two_streams:
+        if not self.two_streams or os.environ.get("OSVOS_SIDE_STREAM", "1") == "0":
             return None
         self.auxf_stream = self._stream_for(device, "side")
         return C.c_void_p(self.auxf_stream.cuda_stream)

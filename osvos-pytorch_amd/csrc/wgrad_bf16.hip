@@ -11,7 +11,7 @@
 //                             64 couts x 64 cins x 9 taps per workgroup, wave (wc, wi) owns a 32 x 32 x 9 block = 9 accumulators.
 //   wgrad_bf16v2_kernel<W>    what runs for bf16 tensors (OSVOS_WGRAD_FORM 1 / 2): 16-byte item loads issued from inside the k-loop,
 //                             W = 8 waves on 128-cout tiles where Cout allows.  Same LDS image and k-loop as the first form.
-//   wgrad_bf16pm_kernel<W>    experimental (OSVOS_WGRAD_FORM=3): pixel-major LDS tiles gathered with ds_read_b64_tr_b16.
+//   wgrad_bf16pm_kernel<W>    the default for bf16 tensors since round 2 (OSVOS_WGRAD_FORM=3): pixel-major LDS tiles gathered with ds_read_b64_tr_b16.
 // All forms produce bit-identical weight gradients (same patches, splits and k-order).  Probe builds (-DOSVOS_WGRAD_PROF, -DOSVOS_WGRAD_ABL=n:
 // tools/native/) add s_memtime phase marks and timing ablations; the shipped library compiles none of that.
 #include "common.h"
@@ -603,7 +603,7 @@ __global__ __launch_bounds__(64 * WAVES) void wgrad_bf16v2_kernel(WbArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
-// EXPERIMENTAL (OSVOS_WGRAD_FORM=3, not the default): pixel-major tiles.  The tiles stay the way they lie in HBM -- [pixel][channel], one
+// OSVOS_WGRAD_FORM=3 (the default since round 2: bit-identical to the other forms, 1.6 % faster on configs[2]): pixel-major tiles.  The tiles stay the way they lie in HBM -- [pixel][channel], one
 // 16-byte piece per lane in, one ds_write_b128 out, no register transposition -- and the MFMA k-fragments (8 consecutive PIXELS of one
 // channel per lane) are gathered by the LDS itself: ds_read_b64_tr_b16 hands lane i of a 16-lane group column i of the 4 x 16 element
 // block its lanes address (tools/native/tr_probe; lane (i, g) points at pixel i/4, channels 4 (i%4) + 16 g).  A tap shift is then a plain
@@ -825,7 +825,7 @@ __global__ __launch_bounds__(64 * WAVES) void wgrad_bf16pm_kernel(WbArgs a) {
 constexpr size_t kLdsV2 = (size_t)DY_BYTES + X_BYTES, kLdsV2w = (size_t)2 * DY_BYTES + X_BYTES;
 
 constexpr int kDefaultMap = 1;      // bf16-input form: XCD-local split order (L2 hit rate 38 % -> 77 %, HBM reads / 3; OSVOS_WGRAD_MAP=0 turns it off)
-constexpr int kDefaultForm = 2;     // bf16-input kernel: 0 = first staging form, 1 = second (wgrad_bf16v2_kernel<4>), 2 = second with eight waves / 128-cout
+constexpr int kDefaultForm = 3;     // bf16-input kernel: 0 = first staging form, 1 = second (wgrad_bf16v2_kernel<4>), 2 = second with eight waves / 128-cout
 constexpr int kWideForm = 2;        // tiles where Cout allows (OSVOS_WGRAD_FORM)
 unsigned long long* g_wgrad_prof = nullptr;
 
@@ -905,7 +905,8 @@ int osvos_conv3x3_wgrad_bf16mfma_io(const void* x, const void* dy, int xb, void*
   }
   const int phase = osvos_wgrad_phase();
   if (phase != 2 && form == 3) {
-    static bool attr3_set = false;
+    static bool attr3_set_dev[OSVOS_MAX_DEVICES] = {};      // per device, like every other kernel attribute
+    bool& attr3_set = attr3_set_dev[osvos_current_device()];
     constexpr size_t lds4 = PM<4>::LDS, lds8 = PM<8>::LDS;
     if (!attr3_set) {
       OSVOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16pm_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
@@ -916,7 +917,8 @@ int osvos_conv3x3_wgrad_bf16mfma_io(const void* x, const void* dy, int xb, void*
     else hipLaunchKernelGGL(wgrad_bf16pm_kernel<4>, dim3((unsigned)blocks), dim3(256), lds4, stream, a);
     OSVOS_LAUNCH_CHECK();
   } else if (phase != 2 && form != 0) {
-    static bool attr2_set = false;
+    static bool attr2_set_dev[OSVOS_MAX_DEVICES] = {};
+    bool& attr2_set = attr2_set_dev[osvos_current_device()];
     if (!attr2_set) {
       OSVOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16v2_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsV2));
       OSVOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16v2_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsV2w));
