@@ -30,6 +30,7 @@ a captured hipGraph) -- and `with_loss_item_sync`, the headline loop with the re
 """
 import argparse
 import ctypes as C
+import gc
 import json
 import math
 import os
@@ -49,6 +50,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
+TIMING_DETAIL = {}                 # of the LAST timed region: host enqueue time, drain, closing barrier
 PROF_EVERY = 4                     # instrument every 4th step of a timed region with launch events
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 BF16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense (no 2:1 sparsity)
@@ -193,7 +195,11 @@ class Workload(object):
         self.net.set_precision(precision)
         self.net.set_inplace_grad_accumulation(True)      # what osvos_pytorch_amd.train_common.TrainLoop (the scripts' loop) does
         self.opt = make_optimizer(self.net, "online" if mode == "infer" else mode)
-        self.reducer = GradientAllReducer(self.net, average=True, always=force_dist) if dist is not None else None
+        comm = None
+        if dist is not None and os.environ.get("OSVOS_DP_BACKEND", "torch") == "abi":      # gradients through osvos_comm_* (RCCL via the C ABI)
+            from osvos_pytorch_amd.parallel import AbiCommunicator
+            comm = AbiCommunicator(int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), device)
+        self.reducer = GradientAllReducer(self.net, average=True, always=force_dist, comm=comm) if dist is not None else None
         self.running = torch.zeros((), device=device)
         self.ave, self.epoch, self.nsteps = 0, 0, 0
         self.keep = {}
@@ -336,6 +342,11 @@ def timed_region(wl, steps, dist, device, prof_lib=None):
         _lib.check(prof_lib.osvos_prof_start(n_prof * 64 + 64), "prof_start")
         prof_lib.osvos_prof_pause(1)
         torch.cuda.synchronize()
+    # host hygiene for a region that may be only 0.1 s long: no cyclic-GC pass in the middle of it (a generation-2 collection of a
+    # process that has imported torch costs tens of milliseconds)
+    gc.collect()
+    gc_was = gc.isenabled()
+    gc.disable()
     t0 = time.perf_counter()
     for i in range(steps):
         if prof_lib is not None and i % every == 0:
@@ -344,10 +355,16 @@ def timed_region(wl, steps, dist, device, prof_lib=None):
             prof_lib.osvos_prof_pause(1)
         else:
             wl.step()
+    t_host = time.perf_counter()
     torch.cuda.synchronize()
+    t_sync = time.perf_counter()
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    if gc_was:
+        gc.enable()
+    TIMING_DETAIL.update({"host_enqueue_ms": round((t_host - t0) * 1e3, 2), "drain_ms": round((t_sync - t_host) * 1e3, 2),
+                          "closing_barrier_ms": round((t0 + elapsed - t_sync) * 1e3, 2)})
     ms = (C.c_double * 4)()
     fl = (C.c_double * 4)()
     cnt = (C.c_long * 4)()
@@ -369,7 +386,7 @@ def measure(wl, steps, warmup, min_seconds, world, dist, device, use_prof=True):
     prof = use_prof and not (wl.mode == "infer" and wl.graph) and not getattr(wl, "graph_train", False)
     elapsed, (ms, fl, cnt), n_prof = timed_region(wl, steps, dist, device, lib if prof else None)
     frames = steps * wl.batch * world
-    res = {"value": frames / elapsed, "ms_per_step": elapsed / steps * 1e3, "elapsed": elapsed}
+    res = {"value": frames / elapsed, "ms_per_step": elapsed / steps * 1e3, "elapsed": elapsed, "timing_detail": dict(TIMING_DETAIL)}
     if min_seconds > 0:
         n2 = max(steps, int(math.ceil(min_seconds / max(elapsed / steps, 1e-6))))
         n2 = -(-n2 // wl.n_ave) * wl.n_ave if wl.mode != "infer" else n2     # whole optimizer steps
@@ -480,6 +497,12 @@ def main():
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
+    if dist is not None:       # bring the process group's communicator up before anything is timed (its first collective initialises RCCL)
+        for _ in range(2):
+            dist.barrier()
+        t = torch.zeros(1, device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        torch.cuda.synchronize()
     wl = Workload(args.mode, args.precision, args.height, args.width, args.batch, args.graph, args.n_ave_grad, args.item_sync,
                   device, rank, dist, args.force_dist, graph_train=args.graph_train)
     res = measure(wl, args.steps, args.warmup, args.min_seconds, world, dist, device, use_prof=not args.no_prof)
@@ -555,6 +578,7 @@ def main():
                        "loss_item_sync_each_iter": bool(args.item_sync)},
             "roofline": res["roofline"], "cpu_baseline": base,
             "sustained": res.get("sustained"),
+            "timed_region_detail": res.get("timing_detail"),
             "with_loss_item_sync": item_line,
             "extra_configs": extras,
             "running_loss": running_loss,

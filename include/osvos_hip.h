@@ -206,6 +206,23 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
  * while the shallower layers are still being computed.  n = 0 disarms.  Entries may be NULL. */
 #define OSVOS_NGRAD_GROUPS 7
 int osvos_net_arm_grad_events(void* const* events, int n);
+/* ---- RCCL through the C ABI: the gradient exchange of the data-parallel loop (one sum of the flat gradient buffer per
+ *      optimizer step; extends train_parent.py:163-172) without torch.distributed.  librccl is bound with dlopen at the first call.
+ *   osvos_comm_unique_id: on ONE rank; ship the 128 bytes to the others by any means (file, socket, torch.distributed broadcast).
+ *   osvos_comm_init: collective over all `world` ranks, on the calling process's current HIP device; *comm is the only library-owned
+ *     handle of this ABI (opaque; osvos_comm_destroy releases it).
+ *   osvos_comm_allreduce_f32: in-place sum of buf[0..count) over the ranks, enqueued on `stream` (no host synchronisation).
+ *   osvos_comm_allreduce_chunks_f32: the same as n chunks buf[first[k] .. first[k] + count[k]), chunk k enqueued on comm_stream behind
+ *     ready_events[k] (hipEvent_t, NULL = no wait): with the events of osvos_net_arm_grad_events and the chunks in the backward's
+ *     completion order, the deep layers' gradients travel while the shallow ones are still being computed.
+ *   Return: 0, < 0 argument / loader error, hipError_t, or 1000 + ncclResult_t. */
+#define OSVOS_COMM_ID_BYTES 128
+int osvos_comm_unique_id(void* id128);
+int osvos_comm_init(void** comm, int rank, int world, const void* id128);
+int osvos_comm_allreduce_f32(void* comm, float* buf, size_t count, void* stream);
+int osvos_comm_allreduce_chunks_f32(void* comm, float* buf, const size_t* first, const size_t* count, void* const* ready_events, int n,
+                                    void* comm_stream);
+int osvos_comm_destroy(void* comm);
 /* byte offset / element count of a saved activation inside ws (tests): which = 0..12 trunk conv
  * outputs, 13..16 pooled inputs of stages 1-4, 17..20 side_prep outputs, 21 NHWC input.  (fp32 elements; with dtype
  * OSVOS_F32_BF16MFMA the trunk tensors 0..16 are bf16 unless OSVOS_BF16_STORE=0.) */

@@ -69,6 +69,11 @@ PROTOTYPES = {
     "osvos_net_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "osvos_net_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "osvos_net_arm_grad_events": (_i, [_vp, _i]),
+    "osvos_comm_unique_id": (_i, [_vp]),
+    "osvos_comm_init": (_i, [_vp, _i, _i, _vp]),
+    "osvos_comm_allreduce_f32": (_i, [_vp, _vp, _sz, _vp]),
+    "osvos_comm_allreduce_chunks_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "osvos_comm_destroy": (_i, [_vp]),
     "osvos_net_ws_query": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "osvos_augment_frame": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "osvos_mask_to_bytes": (_i, [_vp, _vp, _vp, _l, _i, _vp]),

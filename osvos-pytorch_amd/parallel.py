@@ -35,6 +35,52 @@ def _grad_group(name):
     return 0
 
 
+class AbiCommunicator:
+    """RCCL communicator held through the C ABI (``osvos_comm_*``, csrc/comm.cpp) instead of torch.distributed: the gradient sum is
+    then a plain ``ncclAllReduce`` enqueued by the library -- and, chunked behind the backward's gradient-ready events, costs the host
+    seven stream-wait + enqueue pairs instead of seven torch.distributed work objects.  The 128-byte RCCL id travels from rank 0 to
+    the others through a ``torch.distributed.TCPStore`` at MASTER_ADDR : MASTER_PORT + 1 (no process group needed)."""
+
+    def __init__(self, rank, world, device):
+        import ctypes as C
+        from ._lib import check, lib
+        self._C, self._check, self._lib = C, check, lib()
+        self.rank, self.world, self.device = rank, world, torch.device(device)
+        ident = (C.c_char * 128)()
+        if rank == 0:
+            check(self._lib.osvos_comm_unique_id(ident), "comm_unique_id")
+        if world > 1:
+            port = int(os.environ.get("MASTER_PORT", "29500")) + 1
+            store = dist.TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), port, world, rank == 0)
+            if rank == 0:
+                store.set("osvos_comm_id", bytes(ident.raw))
+            else:
+                raw = store.get("osvos_comm_id")
+                C.memmove(ident, raw, 128)
+        self.handle = C.c_void_p()
+        with torch.cuda.device(self.device):
+            check(self._lib.osvos_comm_init(C.byref(self.handle), rank, world, ident), "comm_init")
+
+    def all_reduce(self, flat):
+        C = self._C
+        self._check(self._lib.osvos_comm_allreduce_f32(self.handle, C.c_void_p(flat.data_ptr()), flat.numel(),
+                                                       C.c_void_p(torch.cuda.current_stream(flat.device).cuda_stream)), "comm_allreduce")
+
+    def all_reduce_chunks(self, flat, slices, events, comm_stream):
+        C = self._C
+        n = len(slices)
+        first = (C.c_size_t * n)(*[a for _, a, _ in slices])
+        count = (C.c_size_t * n)(*[b - a for _, a, b in slices])
+        evs = (C.c_void_p * n)(*[C.c_void_p(events[g].cuda_event) for g, _, _ in slices])
+        self._check(self._lib.osvos_comm_allreduce_chunks_f32(self.handle, C.c_void_p(flat.data_ptr()), first, count, evs, n,
+                                                              C.c_void_p(comm_stream.cuda_stream)), "comm_allreduce_chunks")
+
+    def close(self):
+        if self.handle:
+            self._check(self._lib.osvos_comm_destroy(self.handle), "comm_destroy")
+            self.handle = self._C.c_void_p()
+
+
 class GradientAllReducer:
     """Gradients live in ONE flat buffer: after the first backward every ``p.grad`` is re-pointed to a view into it
     (``attach``), the network's backward accumulates into those views in place, the collective runs on the flat buffer
@@ -42,7 +88,7 @@ class GradientAllReducer:
     per-tensor allocations.  If somebody replaces a ``.grad`` (``optimizer.zero_grad()`` with set_to_none) the next call
     copies it back in and re-attaches."""
 
-    def __init__(self, module, average=False, process_group=None, always=False, overlap=True):
+    def __init__(self, module, average=False, process_group=None, always=False, overlap=True, comm=None):
         named = [(n, p) for n, p in module.named_parameters() if p.requires_grad]
         # arena order = the order in which a backward COMPLETES the gradients (head, side_prep, stages.4 ... stages.0): every group is
         # one contiguous slice, so a group can be reduced as soon as its ready-event fires while shallower layers still compute
@@ -53,6 +99,7 @@ class GradientAllReducer:
         self.average = average
         self.group = process_group
         self.always = always          # run the collective even in a 1-rank group (exercises RCCL on one GPU)
+        self.comm = comm              # AbiCommunicator: RCCL through the C ABI instead of torch.distributed (OSVOS_DP_BACKEND=abi in the scripts)
         # Overlap is OPT-IN (OSVOS_DP_OVERLAP=1).  Measured on one MI355X with a one-rank RCCL group (profiles/r02_dp_selfcheck.txt,
         # bench.py --force-dist): the blocking single collective costs nothing (211.6 vs 212.5 frames/s), while seven chunked
         # collectives behind events cost the HOST ~10 ms per optimizer step through torch.distributed's work bookkeeping (146
@@ -109,7 +156,12 @@ class GradientAllReducer:
             if v is not None:
                 p.grad = v
 
+    def _world(self):
+        return self.comm.world if self.comm is not None else dist.get_world_size(self.group)
+
     def _active(self):
+        if self.comm is not None:
+            return self.comm.world > 1 or self.always
         return dist.is_initialized() and (dist.get_world_size(self.group) > 1 or self.always)
 
     def arm(self):
@@ -151,7 +203,15 @@ class GradientAllReducer:
             return
         if not self._active():
             return
-        if armed:
+        if self.comm is not None:
+            if armed:
+                main = torch.cuda.current_stream(flat.device)
+                self.comm.all_reduce_chunks(flat, self._slices, self._events, self._comm_stream)
+                main.wait_stream(self._comm_stream)
+                self.overlapped_steps += 1
+            else:
+                self.comm.all_reduce(flat)
+        elif armed:
             main = torch.cuda.current_stream(flat.device)
             with torch.cuda.stream(self._comm_stream):
                 for g, a, b in self._slices:                     # completion order: head, side_prep, stages.4 ... stages.0
@@ -164,10 +224,18 @@ class GradientAllReducer:
         else:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
         if self.average:
-            flat.div_(dist.get_world_size(self.group))
+            flat.div_(self._world())
 
     def broadcast_parameters(self, src=0):
         """Make every rank start from rank `src`'s weights."""
+        if self.comm is not None:      # the ABI has one collective: broadcast = sum with every other rank contributing zeros
+            if self.comm.world > 1:
+                with torch.no_grad():
+                    for p in self.params:
+                        if self.comm.rank != src:
+                            p.data.zero_()
+                        self.comm.all_reduce(p.data.view(-1))
+            return
         if not dist.is_initialized():
             return
         for p in self.params:

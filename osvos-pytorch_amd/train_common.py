@@ -157,4 +157,12 @@ def init_distributed():
 
 
 def make_reducer(net, world, average=False):
-    return GradientAllReducer(net, average=average) if world > 1 else None
+    """The gradient exchange of the data-parallel loop: torch.distributed ('nccl' = RCCL) by default, RCCL through the library's own C ABI
+    with OSVOS_DP_BACKEND=abi (osvos_comm_*: no process group needed for the gradients; the chunked overlap is cheap there)."""
+    if world <= 1:
+        return None
+    comm = None
+    if os.environ.get('OSVOS_DP_BACKEND', 'torch') == 'abi' and torch.cuda.is_available():
+        from .parallel import AbiCommunicator
+        comm = AbiCommunicator(int(os.environ.get('RANK', '0')), world, torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0'))))
+    return GradientAllReducer(net, average=average, comm=comm)

@@ -36,7 +36,7 @@ def frames(n, h, w, dev):
     return out
 
 
-def run(dev, use_reducer, n_ave, epochs, data, sd0, overlap=True):
+def run(dev, use_reducer, n_ave, epochs, data, sd0, overlap=True, comm=None):
     sys.stdout, keep = open(os.devnull, "w"), sys.stdout
     try:
         net = vo.OSVOS(pretrained=0)
@@ -46,7 +46,7 @@ def run(dev, use_reducer, n_ave, epochs, data, sd0, overlap=True):
     net.load_state_dict(sd0)
     net.to(dev)
     opt = make_sgd(net, "parent", lr=1e-8)
-    red = GradientAllReducer(net, average=False, always=True, overlap=overlap) if use_reducer else None
+    red = GradientAllReducer(net, average=False, always=True, overlap=overlap, comm=comm) if use_reducer else None
     loop = TrainLoop(net, opt, mode="parent", n_ave_grad=n_ave, n_epochs=8, reducer=red)
     t0 = time.perf_counter()
     for epoch in range(epochs):
@@ -86,6 +86,16 @@ def main():
     report("blocking one-rank all-reduce vs no process group", blocking, plain)
     report("overlapped chunked all-reduce vs no process group", forced, plain)
     report("overlapped vs blocking", forced, blocking)
+    from osvos_pytorch_amd.parallel import AbiCommunicator
+    comm = AbiCommunicator(0, 1, dev)                      # RCCL through the C ABI (osvos_comm_*), one rank
+    abi_b, loop_ab, red_ab, t_ab = run(dev, True, 3, 3, data, sd0, overlap=False, comm=comm)
+    abi_o, loop_ao, red_ao, t_ao = run(dev, True, 3, 3, data, sd0, overlap=True, comm=comm)
+    report("C-ABI RCCL, blocking all-reduce vs no process group", abi_b, plain)
+    report("C-ABI RCCL, overlapped chunked all-reduce vs no process group", abi_o, plain)
+    same_abi = all(torch.equal(a, b) for a, b in zip(plain.state_dict().values(), abi_b.state_dict().values())) and \
+        all(torch.equal(a, b) for a, b in zip(plain.state_dict().values(), abi_o.state_dict().values()))
+    print("C-ABI RCCL paths: %s; overlapped steps %d of %d" % ("bit-identical" if same_abi else "DIFFERENT", red_ao.overlapped_steps, loop_ao.steps))
+    ok &= same_abi and red_ao.overlapped_steps >= loop_ao.steps - 1 and red_ab.overlapped_steps == 0
     print("wall time with the blocking all-reduce: %.3f s (%d overlapped steps)" % (t_block, red_b.overlapped_steps))
     same = all(torch.equal(a, b) for a, b in zip(plain.state_dict().values(), forced.state_dict().values()))
     print("parameters after %d optimizer steps, RCCL one-rank all-reduce forced vs no process group: %s" % (loop_f.steps, "bit-identical" if same else "DIFFERENT"))
@@ -107,6 +117,7 @@ def main():
             _, lp, _, _ = run(dev, kw["use_reducer"], 5, 10, big, sd0, overlap=kw.get("overlap", True))
             dt = time.perf_counter() - t0
             print("timing, %s: %.3f ms per micro-batch (60 micro-batches, nAveGrad 5, incl. building the net)" % (tag, dt / 60 * 1e3))
+    comm.close()
     dist.destroy_process_group()
     print("DP_SELFCHECK_OK" if ok else "DP_SELFCHECK_FAILED")
     return 0 if ok else 1
