@@ -27,17 +27,24 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
-constexpr int PW = 16, BCO = 64, BCI = 64, NT = 256;
-constexpr int PITCH = BCO * 2 + 64;            // bytes per pixel and plane (64 channels x 2 B + 64 B skew)
+constexpr int PW = 16, BCI = 64;
 
-template <int PH_>
+// WAVES = 4: 64 couts x 64 cins per workgroup, one wave per SIMD, double-buffered fragment sets.  WAVES = 8 (Cout % 128 == 0): 128 couts x
+// 64 cins, TWO waves per SIMD (<= 256 registers each: one fragment set, the partner wave covers the gather latency) -- the X tile and its
+// 54 gathers per k-step are shared by twice the MFMAs.
+template <int PH_, int WAVES_>
 struct G3 {
-  static constexpr int PH = PH_;
+  static constexpr int PH = PH_, WAVES = WAVES_, NT = 64 * WAVES_;
+  static constexpr int BCO = 16 * WAVES_;                              // couts per workgroup
+  static constexpr int DYP = BCO * 2 + 64, XP = BCI * 2 + 64;          // bytes per pixel and plane (+ 64 B skew: conflict-free gathers)
   static constexpr int PPIX = PW * PH, HW_ = PW + 2, XPIX = (PH + 2) * HW_;
-  static constexpr int DY_B = PPIX * PITCH, X_B = XPIX * PITCH;        // bytes of one piece plane
-  static constexpr int DY_ITEMS = PPIX * 8, X_ITEMS = XPIX * 8;        // (pixel, channel octet)
+  static constexpr int DY_B = PPIX * DYP, X_B = XPIX * XP;             // bytes of one piece plane
+  static constexpr int DOCT = BCO / 8;                                 // channel octets per dY pixel
+  static constexpr int DY_ITEMS = PPIX * DOCT, X_ITEMS = XPIX * 8;     // (pixel, channel octet)
+  static constexpr int DPG = NT / DOCT, XPG = NT / 8;                  // pixels covered per staging round
   static constexpr int NDY = (DY_ITEMS + NT - 1) / NT, NX = (X_ITEMS + NT - 1) / NT, NIT = NDY + NX;
   static constexpr int NST = 3 * PH;                                  // stages (k-step, tap row) per patch
+  static constexpr int NB = WAVES_ == 8 ? 1 : 2;                       // fragment sets
   static constexpr size_t LDS = (size_t)3 * (DY_B + X_B);
   static_assert(NIT <= NST, "one staged item per stage must cover the patch");
   static_assert(LDS <= 160 * 1024, "tiles exceed the LDS of a CU");
@@ -79,9 +86,10 @@ __device__ inline void split8w(const u32x4& lo, const u32x4& hi, u32x4& p0, u32x
   p2 = u32x4{q2[0], q2[1], q2[2], q2[3]};
 }
 
-template <int PH>
-__global__ __launch_bounds__(NT) void wgrad_f32x3_kernel(W3Args a) {
-  using G = G3<PH>;
+template <int PH, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void wgrad_f32x3_kernel(W3Args a) {
+  using G = G3<PH, WAVES>;
+  constexpr int NT = G::NT, BCO = G::BCO;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* dYs = smem;                         // [piece 3][PPIX][PITCH]
   char* Xs = smem + 3 * G::DY_B;            // [piece 3][XPIX][PITCH]
@@ -98,9 +106,10 @@ __global__ __launch_bounds__(NT) void wgrad_f32x3_kernel(W3Args a) {
   const int co0 = cot * BCO, ci0 = cit * BCI;
   const int p_begin = split * a.per_split, p_end = min(p_begin + a.per_split, a.npatches);
 
-  // staged items: (pixel, channel octet) = 32 bytes of fp32 in, 3 x 16 bytes of bf16 pieces out.  oct = tid & 7 for every item.
-  const int oct = tid & 7, pg = tid >> 3;
-  const bool dy_ch_ok = co0 + 8 * oct < a.Cout, x_ch_ok = ci0 + 8 * oct < a.Cin_s;
+  // staged items: (pixel, channel octet) = 32 bytes of fp32 in, 3 x 16 bytes of bf16 pieces out; a thread keeps its octet in every round
+  const int doct = tid % G::DOCT, dpg = tid / G::DOCT;      // dY: BCO / 8 octets per pixel
+  const int xoct = tid & 7, xpg = tid >> 3;                 // X: 8 octets per pixel
+  const bool dy_ch_ok = co0 + 8 * doct < a.Cout, x_ch_ok = ci0 + 8 * xoct < a.Cin_s;
   u32x4 rdy[G::NDY][2], rx[G::NX][2];
   float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const bool want_bias = a.bslab != nullptr && cit == 0;
@@ -123,16 +132,16 @@ __global__ __launch_bounds__(NT) void wgrad_f32x3_kernel(W3Args a) {
   // columns outside the image must be pushed out explicitly (they would alias the neighbouring row)
   auto issue = [&](const Patch& q, int it) {      // it: compile-time item index (dY items first)
     if (it < G::NDY) {
-      const int p = pg + (NT / 8) * it, py = p / PW, pxx = p - py * PW;
+      const int p = dpg + G::DPG * it, py = p / PW, pxx = p - py * PW;
       const bool ok = dy_ch_ok && (G::DY_ITEMS % NT == 0 || p < G::PPIX) && q.x0 + pxx < a.W;
-      const unsigned off = ok ? (unsigned)((((q.y0 + py) * a.W + q.x0 + pxx) * a.Cout_s + co0 + 8 * oct) * 4) : OOB;
+      const unsigned off = ok ? (unsigned)((((q.y0 + py) * a.W + q.x0 + pxx) * a.Cout_s + co0 + 8 * doct) * 4) : OOB;
       rdy[it][0] = __builtin_amdgcn_raw_buffer_load_b128(q.drs, off, 0, 0);
       rdy[it][1] = __builtin_amdgcn_raw_buffer_load_b128(q.drs, off + 16u, 0, 0);
     } else if (it < G::NIT) {
       const int j = it - G::NDY;
-      const int hp = pg + (NT / 8) * j, hy = hp / G::HW_, hx = hp - hy * G::HW_;
+      const int hp = xpg + G::XPG * j, hy = hp / G::HW_, hx = hp - hy * G::HW_;
       const bool ok = x_ch_ok && hp < G::XPIX && (unsigned)(q.x0 - 1 + hx) < (unsigned)a.W;
-      const unsigned off = ok ? (unsigned)((((q.y0 - 1 + hy) * a.W + q.x0 - 1 + hx) * a.Cin_s + ci0 + 8 * oct) * 4) : OOB;
+      const unsigned off = ok ? (unsigned)((((q.y0 - 1 + hy) * a.W + q.x0 - 1 + hx) * a.Cin_s + ci0 + 8 * xoct) * 4) : OOB;
       rx[j][0] = __builtin_amdgcn_raw_buffer_load_b128(q.xrs, off, 0, 0);
       rx[j][1] = __builtin_amdgcn_raw_buffer_load_b128(q.xrs, off + 16u, 0, 0);
     }
@@ -147,9 +156,9 @@ __global__ __launch_bounds__(NT) void wgrad_f32x3_kernel(W3Args a) {
       }
       u32x4 p0, p1, p2;
       split8w(rdy[i][0], rdy[i][1], p0, p1, p2);
-      const int p = pg + (NT / 8) * i;
+      const int p = dpg + G::DPG * i;
       if (G::DY_ITEMS % NT == 0 || p < G::PPIX) {
-        char* d = dYs + p * PITCH + oct * 16;
+        char* d = dYs + p * G::DYP + doct * 16;
         *reinterpret_cast<u32x4*>(d) = p0;
         *reinterpret_cast<u32x4*>(d + G::DY_B) = p1;
         *reinterpret_cast<u32x4*>(d + 2 * G::DY_B) = p2;
@@ -159,9 +168,9 @@ __global__ __launch_bounds__(NT) void wgrad_f32x3_kernel(W3Args a) {
     for (int j = 0; j < G::NX; ++j) {
       u32x4 p0, p1, p2;
       split8w(rx[j][0], rx[j][1], p0, p1, p2);
-      const int hp = pg + (NT / 8) * j;
+      const int hp = xpg + G::XPG * j;
       if (G::X_ITEMS % NT == 0 || hp < G::XPIX) {
-        char* d = Xs + hp * PITCH + oct * 16;
+        char* d = Xs + hp * G::XP + xoct * 16;
         *reinterpret_cast<u32x4*>(d) = p0;
         *reinterpret_cast<u32x4*>(d + G::X_B) = p1;
         *reinterpret_cast<u32x4*>(d + 2 * G::X_B) = p2;
@@ -178,11 +187,11 @@ __global__ __launch_bounds__(NT) void wgrad_f32x3_kernel(W3Args a) {
   // fragment gather: lane (fi = lane & 15, fg = (lane >> 4) & 1, lh = lane >> 5) addresses pixel 8 lh + fi / 4 (+4 for the second read),
   // channels 16 fg + 4 (fi % 4) .. +3 of its wave's 32-channel block, and receives channel 16 fg + fi of pixels 8 lh .. 8 lh + 7
   const int fi = lane & 15, fg = (lane >> 4) & 1, lh = lane >> 5;
-  const char* a_base = dYs + (8 * lh + (fi >> 2)) * PITCH + (32 * wc + 16 * fg + 4 * (fi & 3)) * 2;
-  const char* b_base = Xs + (8 * lh + (fi >> 2)) * PITCH + (32 * wi + 16 * fg + 4 * (fi & 3)) * 2;
-  auto tr8 = [&](const char* p) -> s16x8 {
+  const char* a_base = dYs + (8 * lh + (fi >> 2)) * G::DYP + (32 * wc + 16 * fg + 4 * (fi & 3)) * 2;
+  const char* b_base = Xs + (8 * lh + (fi >> 2)) * G::XP + (32 * wi + 16 * fg + 4 * (fi & 3)) * 2;
+  auto tr8 = [&](const char* p, int pitch) -> s16x8 {
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 4 * PITCH));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 4 * pitch));
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
   };
 
@@ -196,26 +205,34 @@ __global__ __launch_bounds__(NT) void wgrad_f32x3_kernel(W3Args a) {
     store_patch();
     __syncthreads();
     const Patch nx = locate(p + 1, p + 1 < p_end);
-    s16x8 af[2][3], bfr[2][3][3];      // [set][piece] / [set][piece][tap column]
+    constexpr int NB = G::NB;
+    s16x8 af[NB][3], bfr[NB][3][3];      // [set][piece] / [set][piece][tap column]
     auto lda = [&](int ks) {
 #pragma unroll
-      for (int pc = 0; pc < 3; ++pc) af[ks & 1][pc] = tr8(a_base + pc * G::DY_B + ks * PW * PITCH);
+      for (int pc = 0; pc < 3; ++pc) af[ks & (NB - 1)][pc] = tr8(a_base + pc * G::DY_B + ks * PW * G::DYP, G::DYP);
     };
     auto ldb = [&](int st) {
       const int ks = st / 3, r = st % 3;
 #pragma unroll
       for (int pc = 0; pc < 3; ++pc)
 #pragma unroll
-        for (int s = 0; s < 3; ++s) bfr[st & 1][pc][s] = tr8(b_base + pc * G::X_B + ((ks + r) * G::HW_ + s) * PITCH);
+        for (int s = 0; s < 3; ++s) bfr[st & (NB - 1)][pc][s] = tr8(b_base + pc * G::X_B + ((ks + r) * G::HW_ + s) * G::XP, G::XP);
     };
-    lda(0);
-    ldb(0);
+    if constexpr (NB == 2) {
+      lda(0);
+      ldb(0);
+    }
 #pragma unroll
     for (int st = 0; st < G::NST; ++st) {
       const int ks = st / 3, r = st % 3;
-      if (st + 1 < G::NST) {
-        if (r == 2) lda(ks + 1);
-        ldb(st + 1);
+      if constexpr (NB == 2) {
+        if (st + 1 < G::NST) {
+          if (r == 2) lda(ks + 1);
+          ldb(st + 1);
+        }
+      } else {      // two waves per SIMD cover each other's gather latency; 256 registers leave no room for a second set
+        if (r == 0) lda(ks);
+        ldb(st);
       }
       issue(nx, st);                    // next patch's fp32 pieces: one item (two 16-byte loads) per stage
       __builtin_amdgcn_sched_barrier(0);
@@ -226,8 +243,8 @@ __global__ __launch_bounds__(NT) void wgrad_f32x3_kernel(W3Args a) {
       for (int t = 0; t < 6; ++t)
 #pragma unroll
         for (int s = 0; s < 3; ++s)
-          acc[r * 3 + s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, bfr[st & 1][PX[t]][s]),
-                                                                  __builtin_bit_cast(bf16x8_t, af[ks & 1][PD[t]]), acc[r * 3 + s], 0, 0, 0);
+          acc[r * 3 + s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, bfr[st & (NB - 1)][PX[t]][s]),
+                                                                  __builtin_bit_cast(bf16x8_t, af[ks & (NB - 1)][PD[t]]), acc[r * 3 + s], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -252,28 +269,35 @@ __global__ __launch_bounds__(NT) void wgrad_f32x3_kernel(W3Args a) {
       }
   }
   if (want_bias) {
-    float* red = reinterpret_cast<float*>(smem);          // [32 pixel groups][64 channels]
+    float* red = reinterpret_cast<float*>(smem);          // [DPG pixel groups][BCO channels]
 #pragma unroll
-    for (int c = 0; c < 8; ++c) red[pg * BCO + oct * 8 + c] = bsum[c];
+    for (int c = 0; c < 8; ++c) red[dpg * BCO + doct * 8 + c] = bsum[c];
     __syncthreads();
     if (tid < BCO) {
       float sum = 0.f;
-      for (int g = 0; g < NT / 8; ++g) sum += red[g * BCO + tid];
+      for (int g = 0; g < G::DPG; ++g) sum += red[g * BCO + tid];
       if (co0 + tid < a.Cout) a.bslab[(size_t)split * a.Cout + co0 + tid] = sum;
     }
   }
 }
 
 struct W3Plan {
-  int ph, nco_t, nci_t, npx, npy, npatches, nsplit, per_split;
+  int ph, waves, bco, nco_t, nci_t, npx, npy, npatches, nsplit, per_split;
   size_t slab_floats, bslab_floats;
 };
 
-// one workgroup per CU (135 KB of LDS): aim at one round of ~256 workgroups, each with a long patch range
+// one workgroup per CU (124-135 KB of LDS): aim at one round of ~256 workgroups, each with a long patch range
 W3Plan make_plan3(int N, int H, int W, int Cin_s, int Cout) {
   W3Plan p;
-  p.ph = (ceil_div(H, 6) * 6 <= ceil_div(H, 4) * 4) ? 6 : 4;
-  p.nco_t = ceil_div(Cout, BCO);
+  OSVOS_ENV_INT(env_waves, "OSVOS_X3_WGRAD_WAVES", 0);
+  // measured (tools/gpu_r02_o.sh): the eight-wave tile is 3-4 % faster standalone on conv2_2 / conv3_2 (157 vs 165, 162 vs 168 us), level or
+  // slower elsewhere (twice the splits = twice the slab traffic), and the whole step is slower with it beside the data-gradient kernels
+  // (206 vs 210 frames/s): four waves stay the default, OSVOS_X3_WGRAD_WAVES=8 selects the other form
+  p.waves = env_waves == 8 ? 8 : 4;
+  if (Cout % 128 != 0) p.waves = 4;
+  p.bco = 16 * p.waves;
+  p.ph = p.waves == 8 ? 4 : ((ceil_div(H, 6) * 6 <= ceil_div(H, 4) * 4) ? 6 : 4);      // (the eight-wave tile fits the LDS with 16 x 4 patches only)
+  p.nco_t = ceil_div(Cout, p.bco);
   p.nci_t = ceil_div(Cin_s, BCI);
   p.npx = ceil_div(W, PW);
   p.npy = ceil_div(H, p.ph);
@@ -289,16 +313,17 @@ W3Plan make_plan3(int N, int H, int W, int Cin_s, int Cout) {
   return p;
 }
 
-template <int PH>
+template <int PH, int WAVES>
 int launch3(const W3Args& a, long blocks, hipStream_t stream) {
   static bool attr_set_dev[OSVOS_MAX_DEVICES] = {};
   bool& attr_set = attr_set_dev[osvos_current_device()];
   if (!attr_set) {
-    OSVOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_f32x3_kernel<PH>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)G3<PH>::LDS));
+    OSVOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_f32x3_kernel<PH, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)G3<PH, WAVES>::LDS));
     attr_set = true;
   }
-  hipLaunchKernelGGL(wgrad_f32x3_kernel<PH>, dim3((unsigned)blocks), dim3(NT), G3<PH>::LDS, stream, a);
+  constexpr size_t lds = G3<PH, WAVES>::LDS;
+  hipLaunchKernelGGL((wgrad_f32x3_kernel<PH, WAVES>), dim3((unsigned)blocks), dim3(64 * WAVES), lds, stream, a);
   OSVOS_LAUNCH_CHECK();
   return 0;
 }
@@ -315,8 +340,11 @@ bool osvos_wgrad_f32x3_applicable(int Cin, int Cin_s, int Cout, int Cout_s) {
 
 size_t osvos_wgrad_f32x3_ws_bytes(int N, int H, int W, int Cin_s, int Cout) {
   if (Cin_s % 64 != 0 || Cout % 64 != 0) return 0;
+  // whichever form runs (OSVOS_X3_WGRAD_WAVES): the eight-wave tiles need up to twice the splits of the four-wave ones
   const W3Plan p = make_plan3(N, H, W, Cin_s, Cout);
-  return align_up((p.slab_floats + p.bslab_floats) * sizeof(float), 256);
+  const size_t nsplit_max = 256;
+  const size_t worst = (size_t)(p.nsplit * 2 < (int)nsplit_max ? p.nsplit * 2 : nsplit_max);
+  return align_up(((size_t)worst * 9 * Cout * Cin_s + worst * Cout) * sizeof(float), 256);
 }
 
 int osvos_conv3x3_wgrad_f32x3(const float* x, const float* dy, void* ws, float* dw, float* db,
@@ -337,7 +365,7 @@ int osvos_conv3x3_wgrad_f32x3(const float* x, const float* dy, void* ws, float* 
   a.map = (map_env == 1 && blocks % 8 == 0) ? 1 : 0;
   const int phase = osvos_wgrad_phase();
   if (phase != 2) {
-    const int rc = p.ph == 6 ? launch3<6>(a, blocks, stream) : launch3<4>(a, blocks, stream);
+    const int rc = p.waves == 8 ? launch3<4, 8>(a, blocks, stream) : (p.ph == 6 ? launch3<6, 4>(a, blocks, stream) : launch3<4, 4>(a, blocks, stream));
     if (rc) return rc;
   }
   if (phase == 1) return 0;

@@ -171,7 +171,7 @@ def test_conv3x3_f32x3_is_fp32_grade_and_covers_mask_stride_dgrad_splitk():
 
 
 @pytest.mark.parametrize("shape", [(1, 13, 21, 64, 64), (2, 30, 54, 128, 64), (1, 60, 107, 64, 128), (1, 25, 37, 64, 64),
-                                   (3, 6, 16, 64, 64), (1, 121, 215, 64, 64)])
+                                   (3, 6, 16, 64, 64), (1, 121, 215, 64, 64), (2, 30, 54, 128, 256), (1, 25, 37, 64, 128), (2, 5, 17, 64, 128)])
 def test_wgrad_f32x3(shape):
     """f32x3 weight gradient (three-way bf16 split, pixel-major tiles gathered with ds_read_b64_tr_b16): the SAME float64 bars as the
     exact fp32 kernel (test_conv3x3_dgrad_and_wgrad); odd sizes, batch > 1, accumulation, and the error next to the exact kernel's."""

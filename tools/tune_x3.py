@@ -18,6 +18,7 @@ ap.add_argument("--batch", type=int, default=1)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--tiles", default="")
 ap.add_argument("--layers", default="")
+ap.add_argument("--wgrad-only", action="store_true")
 args = ap.parse_args()
 
 chans = [[64, 64], [128, 128], [256, 256, 256], [512, 512, 512], [512, 512, 512]]
@@ -53,7 +54,7 @@ n = args.batch
 print("f32x3 sweep %dx%d batch %d; columns = tile id (200+k; +100 = XCD-local map); ms per launch" % (args.width, args.height, n))
 tot_x, tot_e, tot_ps = 0.0, 0.0, 0.0
 for name, h, w, cin, cout in layers:
-    if args.layers and name not in args.layers.split(","):
+    if args.wgrad_only or (args.layers and name not in args.layers.split(",")):
         continue
     gf = 2.0 * n * h * w * cout * 9 * cin / 1e9
     for direction in ("fwd", "dgrad"):
