@@ -271,6 +271,9 @@ int osvos_debug_conv3x3_naive(const float* x, const float* w_oihw, const float* 
                               int N, int H, int W, int Cin, int Cin_s, int Cout, int relu, void* stream);
 int osvos_debug_mfma_layout(float* out /* 4*64*16 floats */, void* stream);
 int osvos_debug_mfma_peak(float* out /* blocks*256 floats */, int blocks, int iters, void* stream);
+/* bf16-store mode: conv1_1's weight gradient on the bf16 matrix pipe (1, default) or on the exact fp32 skinny kernel fed with the bf16 dY
+ * (0); returns the previous setting.  Tests compare the two. */
+int osvos_debug_set_c3_bf16(int on);
 /* LDS-DMA layout probe (buffer_load_dwordx4 ... lds): out[8*64*4] = LDS image after 4 waves x 2 DMA instructions; the test
  * pins "lane l of instruction j lands in 16-byte slot 64 j + l, out-of-range lanes land as zeros" (tests/test_gpu_ops.py) */
 int osvos_debug_lds_dma(const float* src, int ngroups, float* out, void* stream);

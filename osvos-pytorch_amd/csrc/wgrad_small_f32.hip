@@ -146,6 +146,153 @@ __global__ __launch_bounds__(256, 2) void wgrad_c3_f32_kernel(C3Args a) {
     a.bslab[(size_t)split * 64 + tid] = bred[tid] + bred[64 + tid] + bred[128 + tid] + bred[192 + tid];
 }
 
+// ---- conv1_1 weight gradient of the bf16-store mode on the bf16 matrix pipe ------------------------------------------------------------
+// dy arrives as bf16 (the trunk tensors of that mode); x (the 3-channel input, NHWC8 fp32) is rounded to bf16 like the mode's forward conv1_1
+// does while staging.  The fp32 kernel above walks 256-pixel patches with ONE workgroup per CU, dY widened to fp32 in LDS (64 KB) and two
+// fp32 MFMAs per pixel pair: 1.12 ms per step at batch 12 (profiles/r02_bench_bf16_b12_kernel_stats.txt) against ~0.15 ms that reading the
+// 630 MB of dY takes.  Here: 16 x 8 pixel patches, the dY tile stays bf16 and pixel-major (24 KB), the 27 (tap, ci) columns are built ONCE
+// per patch as a [pixel][32] bf16 im2col tile (8 KB) from the fp32 halo, both operands are gathered with ds_read_b64_tr_b16 and a patch
+// costs each wave 4 MFMAs (32x32x16); ~36 KB of LDS -> four workgroups per CU, next patch's loads in flight during the current one.
+// Same slab layout [split][64 co][32 j] and reduce kernel as above; bias gradient = fp32 column sums of the bf16 dY.
+constexpr int Q_W = 16, Q_H = 8, Q_PIX = Q_W * Q_H, Q_HW = Q_W + 2, Q_HH = Q_H + 2, Q_HPIX = Q_HW * Q_HH;
+constexpr int Q_DYP = 64 * 2 + 64, Q_BP = 64;                    // byte pitches of the dY tile (64 ch + skew) and the im2col tile (32 cols)
+constexpr int Q_DY_B = Q_PIX * Q_DYP, Q_XH_B = Q_HPIX * 16, Q_B_B = Q_PIX * Q_BP;
+constexpr size_t Q_LDS = (size_t)Q_DY_B + Q_XH_B + Q_B_B;
+
+__global__ __launch_bounds__(256, 4) void wgrad_c3_bf16_kernel(C3Args a) {
+  typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* dYs = smem;
+  float* Xh = reinterpret_cast<float*>(smem + Q_DY_B);          // [Q_HPIX][4]
+  char* Bs = smem + Q_DY_B + Q_XH_B;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int split = blockIdx.x;
+  const int p_begin = split * a.per_split, p_end = min(p_begin + a.per_split, a.npatches);
+  constexpr unsigned OOB = 0x80000000u;
+  const int oct = tid & 7, pg = tid >> 3;                        // dY items: (pixel pg + 32 i, channel octet)
+  const bool ch_ok = 8 * oct < a.Cout;
+  const int img_dy_bytes = a.H * a.W * a.Cout_s * 2, img_x_bytes = a.H * a.W * 8 * 4;
+
+  u32x4 rdy[4], rx;
+  struct Patch { __amdgpu_buffer_rsrc_t drs, xrs; int x0, y0; };
+  auto locate = [&](int p, bool live) -> Patch {
+    const int px = p % a.npx;
+    int t = p / a.npx;
+    const int py = t % a.npy;
+    const int n = live ? t / a.npy : 0;
+    Patch q;
+    q.x0 = live ? px * Q_W : 0x40000000;
+    q.y0 = py * Q_H;
+    q.drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(a.dy)) + (size_t)n * img_dy_bytes, 0, img_dy_bytes, 0x00020000);
+    q.xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(a.x)) + (size_t)n * img_x_bytes, 0, img_x_bytes, 0x00020000);
+    return q;
+  };
+  auto load_patch = [&](const Patch& q) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int p = pg + 32 * i, py = p / Q_W, pxx = p % Q_W;
+      const unsigned off = (ch_ok && q.x0 + pxx < a.W) ? (unsigned)((((q.y0 + py) * a.W + q.x0 + pxx) * a.Cout_s + 8 * oct) * 2) : OOB;
+      rdy[i] = __builtin_amdgcn_raw_buffer_load_b128(q.drs, off, 0, 0);
+    }
+    const int hy = tid / Q_HW, hx = tid % Q_HW;
+    const bool ok = tid < Q_HPIX && (unsigned)(q.x0 - 1 + hx) < (unsigned)a.W;
+    const unsigned off = ok ? (unsigned)((((q.y0 - 1 + hy) * a.W + q.x0 - 1 + hx) * 8) * 4) : OOB;      // rows outside fall out of the buffer range
+    rx = __builtin_amdgcn_raw_buffer_load_b128(q.xrs, off, 0, 0);
+  };
+
+  // im2col column j = tap * 3 + ci -> float offset inside the halo tile relative to the pixel; columns 27..31 read channel 3 (zero pad of NHWC8)
+  const int bpx = tid >> 1, bhalf = tid & 1;
+  const int bpy = bpx / Q_W, bpxx = bpx % Q_W;
+  const int fi = lane & 15, fg = (lane >> 4) & 1, lh = lane >> 5;
+  const int cb = wave & 1, kh = wave >> 1;                       // cout block, patch-row half
+  const char* a_base = dYs + (8 * lh + (fi >> 2)) * Q_DYP + (32 * cb + 16 * fg + 4 * (fi & 3)) * 2;
+  const char* b_base = Bs + (8 * lh + (fi >> 2)) * Q_BP + (16 * fg + 4 * (fi & 3)) * 2;
+  auto tr8 = [&](const char* p, int pitch) -> s16x8 {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 4 * pitch));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  };
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const bool want_bias = a.bslab != nullptr;
+
+  load_patch(locate(p_begin, p_begin < p_end));
+  for (int p = p_begin; p < p_end; ++p) {
+    __syncthreads();                       // every wave is done with the previous patch's tiles
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<u32x4*>(dYs + (pg + 32 * i) * Q_DYP + oct * 16) = rdy[i];
+      if (want_bias) {
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          bsum[2 * d] += __uint_as_float(rdy[i][d] << 16);
+          bsum[2 * d + 1] += __uint_as_float(rdy[i][d] & 0xffff0000u);
+        }
+      }
+    }
+    if (tid < Q_HPIX) *reinterpret_cast<u32x4*>(Xh + tid * 4) = rx;
+    __syncthreads();
+    load_patch(locate(p + 1, p + 1 < p_end));      // in flight during the rest of this patch
+    {   // build this thread's 16 im2col columns of its pixel
+      unsigned w[8];
+#pragma unroll
+      for (int jj = 0; jj < 16; jj += 2) {
+        float v[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int j = 16 * bhalf + jj + u;
+          const int tap = j / 3, ci = j - 3 * tap;
+          const int off = j < 27 ? (((bpy + tap / 3) * Q_HW + bpxx + tap % 3) * 4 + ci) : 3;
+          v[u] = Xh[off];
+        }
+        typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+        bf16x2_t h;
+        h[0] = (__bf16)v[0];
+        h[1] = (__bf16)v[1];
+        w[jj >> 1] = __builtin_bit_cast(unsigned, h);
+      }
+      *reinterpret_cast<u32x4*>(Bs + bpx * Q_BP + bhalf * 32) = u32x4{w[0], w[1], w[2], w[3]};
+      *reinterpret_cast<u32x4*>(Bs + bpx * Q_BP + bhalf * 32 + 16) = u32x4{w[4], w[5], w[6], w[7]};
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int row = 4 * kh + ks;
+      const s16x8 fa = tr8(a_base + row * Q_W * Q_DYP, Q_DYP);
+      const s16x8 fb = tr8(b_base + row * Q_W * Q_BP, Q_BP);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fb), __builtin_bit_cast(bf16x8_t, fa), acc, 0, 0, 0);
+    }
+  }
+  __syncthreads();
+  // D = [j rows][co columns]: lane (li, lh) holds co li of its block and columns j = 8 q + 4 lh + (0..3) in registers 4q..4q+3
+  float* red = reinterpret_cast<float*>(smem);      // [4 waves][16 regs][64 lanes]
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
+  float* bred = red + 4 * 16 * 64;                  // [32 pixel groups][64 channels]
+  if (want_bias)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) bred[pg * 64 + oct * 8 + c] = bsum[c];
+  __syncthreads();
+  for (int e = tid; e < 2 * 16 * 64; e += 256) {
+    const int ln = e & 63, r = (e >> 6) & 15, blk = e >> 10;      // blk = cout block; its two row-half waves are blk and blk + 2
+    const float s = red[(blk * 16 + r) * 64 + ln] + red[((blk + 2) * 16 + r) * 64 + ln];
+    const int co = blk * 32 + (ln & 31), j = (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
+    a.slab[((size_t)split * 64 + co) * 32 + j] = s;
+  }
+  if (want_bias && tid < 64) {
+    float s = 0.f;
+    for (int g = 0; g < 32; ++g) s += bred[g * 64 + tid];
+    a.bslab[(size_t)split * 64 + tid] = s;
+  }
+}
+
 // one wave per 4 outputs: lanes stride over the splits, shuffle-reduce (405 splits x 1728 outputs would
 // otherwise be 405 sequential loads per thread)
 __global__ __launch_bounds__(256) void wgrad_c3_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ bslab,
@@ -310,6 +457,19 @@ SmallPlan plan_c3(int N, int H, int W) {
   return p;
 }
 
+// bf16-operand form: 16 x 8 pixel patches, four workgroups per CU
+SmallPlan plan_c3_bf16(int N, int H, int W) {
+  SmallPlan p;
+  p.npx = ceil_div(W, Q_W); p.npy = ceil_div(H, Q_H); p.npatches = N * p.npx * p.npy; p.nci_t = 1;
+  int want = 1024;
+  if (want > p.npatches) want = p.npatches;
+  p.per_split = ceil_div(p.npatches, want);
+  p.nsplit = ceil_div(p.npatches, p.per_split);
+  p.slab_floats = (size_t)p.nsplit * 64 * 32;
+  p.bslab_floats = (size_t)p.nsplit * 64;
+  return p;
+}
+
 SmallPlan plan_co16(int N, int H, int W, int Cin_s) {
   SmallPlan p;
   p.npx = ceil_div(W, PW); p.npy = ceil_div(H, S_PH); p.npatches = N * p.npx * p.npy;
@@ -324,7 +484,15 @@ SmallPlan plan_co16(int N, int H, int W, int Cin_s) {
   return p;
 }
 
+int g_c3_bf16 = 1;      // the bf16-operand conv1_1 weight gradient (osvos_debug_set_c3_bf16: tests compare it with the fp32 kernel)
+
 }  // namespace
+
+extern "C" int osvos_debug_set_c3_bf16(int on) {
+  const int prev = g_c3_bf16;
+  g_c3_bf16 = on ? 1 : 0;
+  return prev;
+}
 
 // generic slab reduce of wgrad_f32.hip (layout [split][tap][co][ci])
 int osvos_wgrad_reduce_launch(const float* slab, const float* bslab, float* dw, float* db, int nsplit, int Cout, int Cin,
@@ -332,8 +500,9 @@ int osvos_wgrad_reduce_launch(const float* slab, const float* bslab, float* dw, 
 
 size_t osvos_wgrad_small_ws_bytes(int N, int H, int W, int Cin_s, int Cout) {
   if (Cin_s == 8 && Cout <= 64) {
-    SmallPlan p = plan_c3(N, H, W);
-    return align_up((p.slab_floats + p.bslab_floats) * sizeof(float), 256);
+    SmallPlan p = plan_c3(N, H, W), q = plan_c3_bf16(N, H, W);
+    const size_t a = p.slab_floats + p.bslab_floats, b = q.slab_floats + q.bslab_floats;
+    return align_up((a > b ? a : b) * sizeof(float), 256);
   }
   if (Cout == 16) {
     SmallPlan p = plan_co16(N, H, W, Cin_s);
@@ -347,6 +516,26 @@ size_t osvos_wgrad_small_ws_bytes(int N, int H, int W, int Cin_s, int Cout) {
 int osvos_conv3x3_wgrad_small_f32(const void* x, const void* dy, int wide_bf16, void* ws, float* dw, float* db,
                                   int N, int H, int W, int Cin, int Cin_s, int Cout, int Cout_s,
                                   int accumulate, hipStream_t stream) {
+  if (Cin == 3 && Cin_s == 8 && Cout == 64 && Cout_s % 8 == 0 && wide_bf16 && g_c3_bf16) {      // bf16-store mode: dY is bf16 -> bf16 matrix pipe
+    SmallPlan p = plan_c3_bf16(N, H, W);
+    C3Args a;
+    a.x = reinterpret_cast<const float*>(x); a.dy = dy; a.dy_bf16 = 1;
+    a.slab = reinterpret_cast<float*>(ws);
+    a.bslab = db ? a.slab + p.slab_floats : nullptr;
+    a.N = N; a.H = H; a.W = W; a.Cout = Cout; a.Cout_s = Cout_s;
+    a.npx = p.npx; a.npy = p.npy; a.npatches = p.npatches; a.per_split = p.per_split;
+    OSVOS_ARG_CHECK((long)H * W * Cout_s < (1L << 30), "wgrad c3 bf16: image too large for 31-bit byte offsets");
+    const int phase = osvos_wgrad_phase();
+    if (phase != 2) {
+      hipLaunchKernelGGL(wgrad_c3_bf16_kernel, dim3(p.nsplit), dim3(256), Q_LDS, stream, a);
+      OSVOS_LAUNCH_CHECK();
+    }
+    if (phase == 1) return 0;
+    hipLaunchKernelGGL(wgrad_c3_reduce_kernel, dim3(ceil_div(Cout * 28, 4)), dim3(256), 0, stream,
+                       a.slab, a.bslab, dw, db, p.nsplit, Cout, accumulate);
+    OSVOS_LAUNCH_CHECK();
+    return 0;
+  }
   if (Cin == 3 && Cin_s == 8 && Cout <= 64 && Cout % 4 == 0) {
     SmallPlan p = plan_c3(N, H, W);
     C3Args a;

@@ -516,3 +516,33 @@ def test_partially_frozen_layers_get_the_right_gradients(inplace):
         assert part[k] is None, k
     for k in ("stages.2.3.bias", "stages.0.0.weight", "side_prep.1.bias", "stages.4.5.weight", "stages.1.1.weight", "fuse.weight"):
         assert part[k] is not None and torch.equal(part[k], full[k]), k
+
+
+def test_bf16_mode_conv1_1_weight_gradient_on_the_bf16_pipe_matches_the_fp32_kernel():
+    """bf16-store mode: conv1_1's weight gradient runs on the bf16 matrix pipe (pixel-major dY tile + im2col tile gathered with
+    ds_read_b64_tr_b16); the exact fp32 skinny kernel fed with the same bf16 dY is the checker.  The only arithmetic difference is the
+    bf16 rounding of the 3-channel input (which the mode's forward conv1_1 applies as well): weight gradient within 3e-3 rel-L2, bias
+    gradient (fp32 column sums of the bf16 dY in both) within 1e-5; odd sizes and a batch."""
+    from layers.osvos_layers import class_balanced_cross_entropy_loss as cbce
+    from oracle import synth
+    from osvos_pytorch_amd import _lib
+    l = _lib.lib()
+    for (n, h, w) in [(2, 37, 53), (1, 120, 214), (3, 16, 17)]:
+        wts, x, m = synth.calibrated_problem(n, h, w, seed=13)
+        xd, gt = torch.from_numpy(x).cuda(), torch.from_numpy(m).cuda()
+        got = {}
+        for on in (0, 1):
+            prev = l.osvos_debug_set_c3_bf16(on)
+            try:
+                net = build_net(wts, "bf16")
+                outs = net.forward(xd)
+                sum(cbce(o, gt, size_average=False) for o in outs).backward()
+                torch.cuda.synchronize()
+                got[on] = (net.stages[0][0].weight.grad.double().cpu(), net.stages[0][0].bias.grad.double().cpu(), net.stages[0][2].weight.grad.double().cpu())
+            finally:
+                l.osvos_debug_set_c3_bf16(prev)
+        dw = float((got[1][0] - got[0][0]).norm() / got[0][0].norm())
+        db = float((got[1][1] - got[0][1]).norm() / got[0][1].norm())
+        print("conv1_1 wgrad bf16-pipe vs fp32 kernel at %dx%dx%d: dW rel-L2 %.2e, db rel-L2 %.2e" % (n, h, w, dw, db))
+        assert dw <= 3e-3 and db <= 1e-5, ((n, h, w), dw, db)
+        assert torch.equal(got[1][2], got[0][2])          # everything else in the network is untouched
