@@ -314,6 +314,35 @@ class Workload(object):
                    ", micro-batch (fwd+loss+bwd) replayed from a captured hipGraph" if self.graph_train else ""))
 
 
+def pipe_sustained_tflops(device):
+    """What the bf16 matrix pipe of THIS chip sustains: a register-only loop of v_mfma_f32_32x32x16_bf16 (osvos_debug_mfma_peak_bf16: no LDS, no
+    memory) on noise operands, timed with torch events on the current stream.  The spec peak (2.5 PFLOP/s) assumes 2.4 GHz; on toggling operand bits
+    the chip holds ~1.8 GHz (2.37 GHz / 2.48 PFLOP/s on all-zero operands: profiles/r02_mfma_probe.txt), so this -- not the spec figure -- is the
+    ceiling an MFMA-bound kernel can approach on this box.  Returns {"noise": TFLOP/s, "zeros": TFLOP/s}."""
+    import ctypes as C
+    from osvos_pytorch_amd import _lib
+    out = {}
+    blocks, iters = 2048, 2000
+    buf = torch.empty(blocks * 512, device=device, dtype=torch.float32)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for name in ("noise", "zeros"):
+        g = torch.Generator().manual_seed(7)
+        seed = ((torch.rand(128 * 8, generator=g) - 0.5) if name == "noise" else torch.zeros(128 * 8)).to(torch.bfloat16).to(device)
+        best = 0.0
+        for rep in range(3):        # the first launch also ramps the clock down to where it settles
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                _lib.check(_lib.lib().osvos_debug_mfma_peak_bf16(C.c_void_p(seed.data_ptr()), C.c_void_p(buf.data_ptr()), blocks, iters, st))
+            e1.record()
+            e1.synchronize()
+            tf = 3.0 * blocks * 8 * iters * 8 * 2.0 * 32 * 32 * 16 / (e0.elapsed_time(e1) * 1e-3) / 1e12
+            if rep > 0:
+                best = max(best, tf)
+        out[name] = round(best, 1)
+    return out
+
+
 def load_traffic():
     """HBM-side bytes per launch of the dominant kernel from the rocprofv3 --pmc passes (FETCH_SIZE x 2 on gfx950 +
     WRITE_SIZE, MI355X_MICROARCH.md section HBM), as written by tools/pmc_traffic.py into profiles/ together with the
@@ -444,6 +473,15 @@ def measure(wl, steps, warmup, min_seconds, world, dist, device, use_prof=True):
                 "step_conv_fraction_of_mfma_roofline": step_frac,
                 "traffic": load_traffic() if wl.precision == "fp32x3" else None}
         roof.update(x3_extra(ach / mult))
+    if roof is not None and wl.precision != "fp32" and torch.cuda.is_available():
+        # next to the spec peak: the rate the pipe sustains on this chip, measured now (see pipe_sustained_tflops)
+        try:
+            sus = pipe_sustained_tflops(device)
+            roof["pipe_sustained"] = {"tflops_noise_operands": sus["noise"], "tflops_zero_operands": sus["zeros"], "unit": "TFLOP/s",
+                                      "frac_of_sustained": round(roof["achieved"] / sus["noise"], 4) if sus["noise"] else None,
+                                      "how": "register-only v_mfma_f32_32x32x16_bf16 loop (osvos_debug_mfma_peak_bf16), 2048 workgroups x 8 waves, best of 2 after a clock-settling run"}
+        except Exception as e:      # a reporting extra: never fail the line over it
+            roof["pipe_sustained"] = {"error": str(e)[:200]}
     res["roofline"] = roof
     res["step_conv_fraction_of_mfma_roofline"] = step_frac
     return res

@@ -271,6 +271,9 @@ int osvos_debug_conv3x3_naive(const float* x, const float* w_oihw, const float* 
                               int N, int H, int W, int Cin, int Cin_s, int Cout, int relu, void* stream);
 int osvos_debug_mfma_layout(float* out /* 4*64*16 floats */, void* stream);
 int osvos_debug_mfma_peak(float* out /* blocks*256 floats */, int blocks, int iters, void* stream);
+/* register-only loop of v_mfma_f32_32x32x16_bf16 (blocks x 8 waves x iters x 8 MFMAs) on the caller's operand bits (seed: 2048 bytes of bf16):
+ * the rate the bf16 matrix pipe SUSTAINS on this chip -- 2.48 PFLOP/s at 2.37 GHz on zeros, 1.83 at 1.81 GHz on noise (bench.py reports it live) */
+int osvos_debug_mfma_peak_bf16(const void* seed, float* out /* blocks*512 floats */, int blocks, int iters, void* stream);
 /* bf16-store mode: conv1_1's weight gradient on the bf16 matrix pipe (1, default) or on the exact fp32 skinny kernel fed with the bf16 dY
  * (0); returns the previous setting.  Tests compare the two. */
 int osvos_debug_set_c3_bf16(int on);

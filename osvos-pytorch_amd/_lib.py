@@ -86,6 +86,7 @@ PROTOTYPES = {
     "osvos_debug_conv3x3_naive": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "osvos_debug_mfma_layout": (_i, [_vp, _vp]),
     "osvos_debug_mfma_peak": (_i, [_vp, _i, _i, _vp]),
+    "osvos_debug_mfma_peak_bf16": (_i, [_vp, _vp, _i, _i, _vp]),
     "osvos_debug_set_c3_bf16": (_i, [_i]),
     "osvos_debug_lds_dma": (_i, [_vp, _i, _vp, _vp]),
 }

@@ -61,6 +61,31 @@ __global__ __launch_bounds__(256) void mfma_peak_kernel(float* out, int iters) {
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// bf16 MFMA-only loop: 8 independent accumulators per wave, operands from memory (so the data is the caller's: the chip clocks
+// 2.37 GHz on all-zero operands and 1.81 GHz on noise -- what the bf16 pipe sustains depends on how many operand bits toggle)
+__global__ __launch_bounds__(512) void mfma_peak_bf16_kernel(const uint4* __restrict__ seed, float* out, int iters) {
+  typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+  uint4 a = seed[threadIdx.x & 63], b = seed[64 + (threadIdx.x & 63)];
+  f32x16 acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc[i], 0, 0, 0);
+    a = uint4{a.y, a.z, a.w, a.x};
+    b = uint4{b.w, b.x, b.y, b.z};
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += acc[i][r];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 // LDS-DMA probe (buffer_load_dwordx4 ... lds): 4 waves; wave w issues two DMA instructions, lane l fetching the 16-byte group
 // src[perm] with perm = (l * 7 + 3 * w + i) % nsrc (out-of-range for l == 5: must land as zeros); the LDS image is copied out.
 __global__ __launch_bounds__(256) void lds_dma_probe_kernel(const float* __restrict__ src, int nsrc, float* __restrict__ out) {
@@ -92,6 +117,14 @@ extern "C" int osvos_debug_lds_dma(const float* src, int ngroups, float* out, vo
 extern "C" int osvos_debug_mfma_peak(float* out, int blocks, int iters, void* stream) {
   OSVOS_ARG_CHECK(out && blocks > 0 && iters > 0, "debug mfma peak: bad arguments");
   hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, out, iters);
+  OSVOS_LAUNCH_CHECK();
+  return 0;
+}
+
+// runs `blocks` workgroups x 8 waves x iters x 8 MFMAs (32x32x16 bf16); FLOPs = blocks*8*iters*8*2*32*32*16; seed: 128 x 16 bytes of bf16 operands
+extern "C" int osvos_debug_mfma_peak_bf16(const void* seed, float* out, int blocks, int iters, void* stream) {
+  OSVOS_ARG_CHECK(seed && out && blocks > 0 && iters > 0, "debug mfma peak bf16: bad arguments");
+  hipLaunchKernelGGL(mfma_peak_bf16_kernel, dim3(blocks), dim3(512), 0, (hipStream_t)stream, reinterpret_cast<const uint4*>(seed), out, iters);
   OSVOS_LAUNCH_CHECK();
   return 0;
 }

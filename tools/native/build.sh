@@ -1,6 +1,6 @@
 #!/bin/bash
 # native probes (tools/native/bin/, git-ignored, travels with the gpurun snapshot)
-# usage: build.sh [ABL]   ABL = 1 no MFMA, 2 no LDS fragment reads, 3 no vmem inside the k-loop (timing ablations, wrong results)
+# usage: build.sh [ABL]   ABL = 1 no MFMA, 2 no LDS fragment reads, 3 no vmem / DMA inside the k-loop, 4 no ds_write per patch (timing ablations, wrong results)
 set -e
 cd "$(dirname "$0")"
 mkdir -p bin
@@ -11,5 +11,6 @@ OUT=bin/wgrad_probe; [ "$ABL" != "0" ] && OUT=bin/wgrad_probe_abl$ABL
   $C/wgrad_bf16.hip $C/wgrad_f32.hip $C/wgrad_small_f32.hip -x hip $C/errors.cpp wgrad_probe.cpp -o $OUT
 # convolution probe (production kernels, no instrumentation)
 /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -Wno-unused-function \
-  $C/conv3x3_f32.hip $C/conv3x3_bf16.hip $C/conv3x3_bf16_dma.hip $C/pack.hip -x hip $C/errors.cpp conv_probe.cpp -o bin/conv_probe
+  $C/conv3x3_f32.hip $C/conv3x3_f32x3.hip $C/conv3x3_bf16.hip $C/conv3x3_bf16_dma.hip $C/pack.hip -x hip $C/errors.cpp conv_probe.cpp -o bin/conv_probe
 /opt/rocm/bin/hipcc -O2 -std=c++17 --offload-arch=gfx950 tr_probe.cpp -o bin/tr_probe
+/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 mfma_probe.cpp -o bin/mfma_probe

@@ -23,8 +23,12 @@ static void run(int N, int H, int W, int Cin, int Cout) {
   std::vector<uint16_t> hx(nx), hy(ny);
   uint32_t s = 12345u;
   auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xffff) / 65536.0f - 0.5f; };
-  for (auto& v : hx) v = bf16(rnd());
-  for (auto& v : hy) v = bf16(rnd() * 0.25f);
+  // PROBE_DATA=zero | const | relu (half of x zero, like post-ReLU activations); default: uniform noise -- the matrix pipe's power draw, and with
+  // it the clock the chip sustains, depends on how many operand bits toggle
+  const char* mode = getenv("PROBE_DATA");
+  const int dm = !mode ? 0 : !strcmp(mode, "zero") ? 1 : !strcmp(mode, "const") ? 2 : !strcmp(mode, "relu") ? 3 : 0;
+  for (auto& v : hx) { const float r = rnd(); v = bf16(dm == 1 ? 0.f : dm == 2 ? 0.25f : dm == 3 ? (r > 0.f ? r : 0.f) : r); }
+  for (auto& v : hy) { const float r = rnd() * 0.25f; v = bf16(dm == 1 ? 0.f : dm == 2 ? 0.125f : r); }
   void *dx, *ddy, *ws; float *dw, *db; unsigned long long* prof;
   CK(hipMalloc(&dx, nx * 2)); CK(hipMalloc(&ddy, ny * 2));
   CK(hipMemcpy(dx, hx.data(), nx * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(ddy, hy.data(), ny * 2, hipMemcpyHostToDevice));
@@ -39,7 +43,7 @@ static void run(int N, int H, int W, int Cin, int Cout) {
     for (int i = 0; i < 3; ++i)
       if (osvos_conv3x3_wgrad_bf16mfma_io(dx, ddy, 1, ws, dw, db, N, H, W, Cin, Cin, Cout, Cout, 0, 0)) { fprintf(stderr, "launch failed: %s\n", osvos_last_error()); exit(1); }
     CK(hipDeviceSynchronize());
-    const int reps = 10;
+    const int reps = getenv("PROBE_REPS") ? atoi(getenv("PROBE_REPS")) : 10;
     CK(hipEventRecord(e0, 0));
     for (int i = 0; i < reps; ++i) osvos_conv3x3_wgrad_bf16mfma_io(dx, ddy, 1, ws, dw, db, N, H, W, Cin, Cin, Cout, Cout, 0, 0);
     CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
