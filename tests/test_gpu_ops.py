@@ -594,6 +594,37 @@ def test_wgrad_bf16act_equals_fp32_input_kernel_on_bf16_values(shape):
 
 
 @pytest.mark.gpu
+def test_bf16_matrix_pipe_probe_runs_and_depends_on_the_operand_bits():
+    """osvos_debug_mfma_peak_bf16 (what bench.py's roofline.pipe_sustained times): the register-only MFMA loop returns the exact sums
+    (zeros stay zero; constant operands give iters x 8 accumulators x 16 k x a x b in every accumulator element) and sustains a
+    plausible rate -- above 1 PFLOP/s on any operands, and not slower on zeros than on noise (the clock follows the toggling bits)."""
+    import ctypes as C
+    from osvos_pytorch_amd import _lib
+    blocks, iters = 1024, 500
+    out = torch.empty(blocks * 512, device="cuda")
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def run(seed_vals, reps=1):
+        seed = seed_vals.to(torch.bfloat16).cuda()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        _lib.check(_lib.lib().osvos_debug_mfma_peak_bf16(C.c_void_p(seed.data_ptr()), C.c_void_p(out.data_ptr()), blocks, iters, st))
+        e0.record()
+        for _ in range(reps):
+            _lib.check(_lib.lib().osvos_debug_mfma_peak_bf16(C.c_void_p(seed.data_ptr()), C.c_void_p(out.data_ptr()), blocks, iters, st))
+        e1.record()
+        e1.synchronize()
+        return reps * blocks * 8 * iters * 8 * 2.0 * 32 * 32 * 16 / (e0.elapsed_time(e1) * 1e-3) / 1e12
+
+    tz = run(torch.zeros(128 * 8), reps=4)
+    assert float(out.abs().max()) == 0.0
+    run(torch.full((128 * 8,), 0.5))
+    # every accumulator element: sum over iters of 16 k-products of 0.5 * 0.5; a thread sums its 8 accumulators x 16 registers
+    assert torch.all(out == iters * 16 * 0.25 * 8 * 16)
+    tn = run(torch.rand(128 * 8, generator=torch.Generator().manual_seed(3)) - 0.5, reps=4)
+    print("bf16 MFMA-only loop: %.0f TFLOP/s on zeros, %.0f on noise" % (tz, tn))
+    assert tz > 1000 and tn > 1000 and tz > 0.95 * tn
+
+
 def test_lds_dma_layout_probe():
     """buffer_load_dwordx4 ... lds: lane l of a wave instruction lands in LDS slot (M0 base)/16 + l; lanes whose buffer offset
     is out of range land as zeros -- the two facts the DMA-staged convolution kernel is built on"""
