@@ -597,7 +597,7 @@ def test_wgrad_bf16act_equals_fp32_input_kernel_on_bf16_values(shape):
 def test_bf16_matrix_pipe_probe_runs_and_depends_on_the_operand_bits():
     """osvos_debug_mfma_peak_bf16 (what bench.py's roofline.pipe_sustained times): the register-only MFMA loop returns the exact sums
     (zeros stay zero; constant operands give iters x 8 accumulators x 16 k x a x b in every accumulator element) and sustains a
-    plausible rate -- above 1 PFLOP/s on any operands, and not slower on zeros than on noise (the clock follows the toggling bits)."""
+    plausible rate -- above 0.8 PFLOP/s on any operands, and not slower on zeros than on noise (the clock follows the toggling bits)."""
     import ctypes as C
     from osvos_pytorch_amd import _lib
     blocks, iters = 1024, 500
@@ -622,7 +622,7 @@ def test_bf16_matrix_pipe_probe_runs_and_depends_on_the_operand_bits():
     assert torch.all(out == iters * 16 * 0.25 * 8 * 16)
     tn = run(torch.rand(128 * 8, generator=torch.Generator().manual_seed(3)) - 0.5, reps=4)
     print("bf16 MFMA-only loop: %.0f TFLOP/s on zeros, %.0f on noise" % (tz, tn))
-    assert tz > 1000 and tn > 1000 and tz > 0.95 * tn
+    assert tz > 800 and tn > 800 and tz > 0.95 * tn
 
 
 def test_lds_dma_layout_probe():
