@@ -243,23 +243,38 @@ __global__ __launch_bounds__(C::NT, C::OCC) void conv3x3_f32x3_kernel(ConvArgsX 
   const int nch_all = a.Cin >> 4;
   const int kc_begin = (int)((long)nch_all * blockIdx.y / a.ksplit);
   const int kc_end = (int)((long)nch_all * (blockIdx.y + 1) / a.ksplit);
+  // probe builds (tools/native/build.sh, -DOSVOS_X3_ABL=n; wrong results, timing only): 1 no MFMA, 2 no fragment reads after the first step,
+  // 3 no global loads inside the K loop, 4 tiles stored once (no split / ds_write per chunk), 5 no barriers
   load_chunk(kc_begin);
   for (int kc = kc_begin; kc < kc_end; ++kc) {
+#if !(defined(OSVOS_X3_ABL) && OSVOS_X3_ABL == 5)
     __syncthreads();                     // every wave is done with the previous chunk's tiles
+#endif
+#if defined(OSVOS_X3_ABL) && OSVOS_X3_ABL == 4
+    if (kc == kc_begin)
+#endif
     store_chunk();
+#if !(defined(OSVOS_X3_ABL) && OSVOS_X3_ABL == 5)
     __syncthreads();
+#endif
     const bool more = kc + 1 < kc_end;
     if (!C::ILV && more) load_chunk(kc + 1);      // in flight during the MFMAs below
     // 9 x WM steps (tap, M block); fragments of step s+1 (and, once per tap, the weights of tap+1) are requested
     // before the 6 WN MFMAs of step s issue
     uint4 fb[2][3][C::WN], fa[2][3];
     auto ldB = [&](int tap, int set) {
+#if defined(OSVOS_X3_ABL) && OSVOS_X3_ABL == 2
+      if (tap > 0) return;
+#endif
 #pragma unroll
       for (int p = 0; p < 3; ++p)
 #pragma unroll
         for (int ni = 0; ni < C::WN; ++ni) fb[set][p][ni] = Bs[b_idx + (p * 9 + tap) * 2 * C::BN + ni * 32];
     };
     auto ldA = [&](int tap, int mi, int set) {
+#if defined(OSVOS_X3_ABL) && OSVOS_X3_ABL == 2
+      if (tap > 0 || mi > 1) return;
+#endif
       const int r = tap / 3, s = tap % 3;
 #pragma unroll
       for (int p = 0; p < 3; ++p) fa[set][p] = As[a_idx[mi] + p * 2 * C::PLANE + r * C::PITCH + s];
@@ -274,7 +289,9 @@ __global__ __launch_bounds__(C::NT, C::OCC) void conv3x3_f32x3_kernel(ConvArgsX 
         if (mi + 1 < C::WM) ldA(tap, mi + 1, (step + 1) & 1);
         else if (tap + 1 < 9) ldA(tap + 1, 0, (step + 1) & 1);
         if (mi == 0 && tap + 1 < 9) ldB(tap + 1, (tap + 1) & 1);
+#if !(defined(OSVOS_X3_ABL) && OSVOS_X3_ABL == 3)
         if (C::ILV && more) load_item(step, kc + 1);
+#endif
         __builtin_amdgcn_sched_barrier(0);
         const int sa = step & 1, sb = tap & 1;
         // pieces: 0 = high, 1 = middle, 2 = low.  Small products first, the dominant hi x hi product last.
@@ -284,8 +301,12 @@ __global__ __launch_bounds__(C::NT, C::OCC) void conv3x3_f32x3_kernel(ConvArgsX 
         for (int t = 0; t < 6; ++t)
 #pragma unroll
           for (int ni = 0; ni < C::WN; ++ni)
+#if defined(OSVOS_X3_ABL) && OSVOS_X3_ABL == 1
+            acc[mi][ni][t] += __uint_as_float(fb[sb][PB[t]][ni].x ^ fb[sb][PB[t]][ni].w ^ fa[sa][PA[t]].x ^ fa[sa][PA[t]].w);
+#else
             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fb[sb][PB[t]][ni]),
                                                                   __builtin_bit_cast(bf16x8_t, fa[sa][PA[t]]), acc[mi][ni], 0, 0, 0);
+#endif
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -387,12 +408,14 @@ using X12 = CfgX<32, 1, 8, 2, 4, 2, 1, 1>;  // X4 ...
 using X13 = CfgX<32, 1, 4, 2, 2, 2, 2, 1>;  // X5 ...
 using X14 = CfgX<16, 1, 8, 2, 4, 2, 1, 1>;  // X8 ...
 using X15 = CfgX<32, 1, 8, 1, 8, 1, 1, 1>;  // 32x8 px x 32 co, 8 waves (1x1): the skinny outputs (side_prep: 16 couts, input gradient: 3)
-constexpr int kNumTilesX = 16;
+using X16 = CfgX<32, 1, 16, 2, 8, 1, 1, 1>; // 32x16 px x 64 co, 8 waves (2x2): twice the pixels per weight byte of X12, a third fewer staging instructions per MFMA than X10
+using X17 = CfgX<16, 1, 16, 2, 8, 1, 1, 1>; // 16x32 px x 64 co, 8 waves (2x2): the same for narrow maps
+constexpr int kNumTilesX = 18;
 template <class C>
 constexpr TileInfoX infoX() { return TileInfoX{C::TW, C::TH, C::BN, C::NT, C::LDS_BYTES}; }
 const TileInfoX kTilesX[kNumTilesX] = {infoX<X0>(), infoX<X1>(), infoX<X2>(), infoX<X3>(), infoX<X4>(),
                                        infoX<X5>(), infoX<X6>(), infoX<X7>(), infoX<X8>(), infoX<X9>(),
-                                       infoX<X10>(), infoX<X11>(), infoX<X12>(), infoX<X13>(), infoX<X14>(), infoX<X15>()};
+                                       infoX<X10>(), infoX<X11>(), infoX<X12>(), infoX<X13>(), infoX<X14>(), infoX<X15>(), infoX<X16>(), infoX<X17>()};
 
 long tiles_of(const TileInfoX& t, int N, int H, int W, int CoutP) {
   return (long)N * ceil_div(H, t.th) * ceil_div(W, t.tw) * ceil_div(CoutP, t.bn);
@@ -519,6 +542,8 @@ int osvos_conv3x3_f32x3_ps(const float* x, const float* wpk, const void* wpk3, c
     case 13: rc = launch_x<X13>(a, stream); break;
     case 14: rc = launch_x<X14>(a, stream); break;
     case 15: rc = launch_x<X15>(a, stream); break;
+    case 16: rc = launch_x<X16>(a, stream); break;
+    case 17: rc = launch_x<X17>(a, stream); break;
     default: osvos_set_error("conv3x3 f32x3: unknown tile config %d", tile); return -1;
   }
   if (rc) return rc;

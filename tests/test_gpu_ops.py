@@ -76,11 +76,11 @@ X3_SHAPES = [
 
 
 @pytest.mark.parametrize("shape", X3_SHAPES)
-@pytest.mark.parametrize("tile", [200 + k for k in range(16)] + [301, 305, 310])
+@pytest.mark.parametrize("tile", [200 + k for k in range(18)] + [301, 305, 310, 316])
 def test_conv3x3_f32x3_all_tiles(shape, tile):
     """f32x3 (three-way bf16 split on the bf16 matrix pipe) is held to the SAME float64 bars as the exact fp32 MFMA kernel."""
     ops = _ops()
-    assert ops.lib().osvos_conv3x3_f32x3_tiles() == 16
+    assert ops.lib().osvos_conv3x3_f32x3_tiles() == 18
     n, h, w, cin, cout = shape
     g = torch.Generator().manual_seed(hash(shape) % 1000 + 3)
     x = torch.randn(n, cin, h, w, generator=g)
@@ -215,7 +215,7 @@ def test_conv3x3_f32x3_presplit_weights_are_bit_identical(shape):
     b = torch.randn(cout, generator=g)
     ref = F.relu(F.conv2d(x.double(), wt.double(), b.double(), padding=1))
     xg, pk, pk3 = nhwc(x), ops.pack_fwd(wt.cuda()), ops.pack_x3(wt.cuda())
-    for t in (10, 12, 14, 15, -1):
+    for t in (10, 12, 14, 15, 16, 17, -1):
         y3 = ops.conv3x3_x3(xg, pk3, b.cuda(), cout, relu=True, tile=t)
         assert rel_err(nchw(y3), ref)[0] < 2e-5, (shape, t)
         if t >= 0:

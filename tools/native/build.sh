@@ -9,8 +9,10 @@ ABL=${1:-0}
 OUT=bin/wgrad_probe; [ "$ABL" != "0" ] && OUT=bin/wgrad_probe_abl$ABL
 /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -Wno-unused-function -DOSVOS_WGRAD_PROF -DOSVOS_WGRAD_ABL=$ABL \
   $C/wgrad_bf16.hip $C/wgrad_f32.hip $C/wgrad_small_f32.hip -x hip $C/errors.cpp wgrad_probe.cpp -o $OUT
-# convolution probe (production kernels, no instrumentation)
-/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -Wno-unused-function \
-  $C/conv3x3_f32.hip $C/conv3x3_f32x3.hip $C/conv3x3_bf16.hip $C/conv3x3_bf16_dma.hip $C/pack.hip -x hip $C/errors.cpp conv_probe.cpp -o bin/conv_probe
+# convolution probe (production kernels, no instrumentation); X3ABL=n builds bin/conv_probe_x3abl<n> with the f32x3 K-loop ablation n
+XABL=${X3ABL:-0}
+COUT=bin/conv_probe; [ "$XABL" != "0" ] && COUT=bin/conv_probe_x3abl$XABL
+/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -Wno-unused-function -DOSVOS_X3_ABL=$XABL \
+  $C/conv3x3_f32.hip $C/conv3x3_f32x3.hip $C/conv3x3_bf16.hip $C/conv3x3_bf16_dma.hip $C/pack.hip -x hip $C/errors.cpp conv_probe.cpp -o $COUT
 /opt/rocm/bin/hipcc -O2 -std=c++17 --offload-arch=gfx950 tr_probe.cpp -o bin/tr_probe
 /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 mfma_probe.cpp -o bin/mfma_probe

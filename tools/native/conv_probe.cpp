@@ -1,5 +1,5 @@
 // Native (no Python) timing + spot check of the 3x3 convolution kernels: seconds of GPU time per run.
-//   conv_probe bf16|f32 N H W Cin Cout tile[,tile...]      (tile -1 = the library's choice)
+//   conv_probe bf16|f32|x3ps N H W Cin Cout tile[,tile...]      (tile -1 = the library's choice; x3ps: f32x3 tile ids (+100: XCD-local block map) on the PRE-SPLIT pack)
 // bf16: bf16 NHWC in, bf16 NHWC out (what the network's bf16 mode runs: osvos_conv3x3_bf16mfma_io); f32: osvos_conv3x3_f32_ws.
 // Prints per tile the average of 20 launches and the largest relative error of 256 output samples against a double-precision
 // restatement on the host (operands rounded the way the kernel rounds them), so a variant that is fast but wrong shows up here.
@@ -18,7 +18,7 @@
 
 int main(int argc, char** argv) {
   if (argc < 8) { fprintf(stderr, "usage: conv_probe bf16|f32 N H W Cin Cout tile[,tile...]\n"); return 2; }
-  const bool bf = !strcmp(argv[1], "bf16");
+  const bool bf = !strcmp(argv[1], "bf16"), x3ps = !strcmp(argv[1], "x3ps");
   const int N = atoi(argv[2]), H = atoi(argv[3]), W = atoi(argv[4]), Cin = atoi(argv[5]), Cout = atoi(argv[6]);
   std::vector<int> tiles;
   for (char* t = strtok(argv[7], ","); t; t = strtok(nullptr, ",")) tiles.push_back(atoi(t));
@@ -26,7 +26,10 @@ int main(int argc, char** argv) {
   std::vector<float> hx(nx), hw(nw), hb(Cout);
   uint32_t s = 2024u;
   auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xffff) / 65536.0f - 0.5f; };
-  for (auto& v : hx) v = bf ? bf16_to_f32(f32_to_bf16(rnd())) : rnd();
+  // PROBE_DATA=zero | relu (half of the activations zero): the chip's clock follows the operand bits (profiles/r02_mfma_probe.txt)
+  const char* pd = getenv("PROBE_DATA");
+  const int dm = !pd ? 0 : !strcmp(pd, "zero") ? 1 : !strcmp(pd, "relu") ? 2 : 0;
+  for (auto& v : hx) { float r = rnd(); if (dm == 1) r = 0.f; if (dm == 2 && r < 0.f) r = 0.f; v = bf ? bf16_to_f32(f32_to_bf16(r)) : r; }
   for (auto& v : hw) v = rnd() * 0.1f;
   for (auto& v : hb) v = rnd();
   std::vector<uint16_t> hx16;
@@ -40,7 +43,14 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&dwp, (size_t)9 * CinP * CoutP * 4));
   if ((bf ? osvos_pack_fwd_bf16(dw, dwp, Cout, Cin, 0) : osvos_pack_fwd_f32(dw, (float*)dwp, Cout, Cin, 0))) { fprintf(stderr, "pack: %s\n", osvos_last_error()); return 1; }
   if (!bf) { const size_t pb = osvos_conv3x3_splitk_ws_bytes_f32(N, H, W, Cout); if (pb) CK(hipMalloc(&dpart, pb)); }
+  void* dwp3 = nullptr;
+  if (x3ps) {
+    CK(hipMalloc(&dwp3, osvos_wpack_x3_bytes(Cout, Cin)));
+    if (osvos_pack_x3(dw, dwp3, Cout, Cin, 0, 0)) { fprintf(stderr, "pack x3: %s\n", osvos_last_error()); return 1; }
+  }
+  const int ks_env = getenv("PROBE_KSPLIT") ? atoi(getenv("PROBE_KSPLIT")) : 0;
   auto launch = [&](int tile) {
+    if (x3ps) return osvos_conv3x3_f32x3_ps((const float*)dx, nullptr, dwp3, db, nullptr, (float*)dy, N, H, W, Cin, Cout, Cout, 1, tile, ks_env, dpart, 0);
     return bf ? osvos_conv3x3_bf16mfma_io(dx, 1, dwp, db, nullptr, 0, nullptr, dy, N, H, W, Cin, Cout, Cout, 1, tile, 0)
               : osvos_conv3x3_f32_ws((const float*)dx, (const float*)dwp, db, nullptr, (float*)dy, N, H, W, Cin, Cout, Cout, 1, tile, dpart, 0);
   };
