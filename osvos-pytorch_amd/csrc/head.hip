@@ -106,7 +106,7 @@ struct HbArgs {
 // reduced with wave shuffles; lane 0 of the group then forms dprep and the parameter-gradient
 // partials, which are wave-reduced and pushed with one double atomic per wave per value.
 template <int TPP>
-__global__ __launch_bounds__(256) void head_bwd_f32_kernel(HbArgs a) {
+__device__ __forceinline__ void head_bwd_body(const HbArgs& a, const unsigned bid, const unsigned nblocks, double (*red)[34]) {
   const int k = 2 * a.s, kk = k * k;
   const int top = ((a.h + 1) * a.s - a.H) / 2, left = ((a.w + 1) * a.s - a.W) / 2;
   const int sub = threadIdx.x % TPP;
@@ -115,10 +115,10 @@ __global__ __launch_bounds__(256) void head_bwd_f32_kernel(HbArgs a) {
   float pwf[16], pwd[16], pbd = 0.f;
 #pragma unroll
   for (int c = 0; c < 16; ++c) { pwf[c] = 0.f; pwd[c] = 0.f; }
-  const long ngroups_total = (long)gridDim.x * groups_per_block;
+  const long ngroups_total = (long)nblocks * groups_per_block;
   const long iters = (npix + ngroups_total - 1) / ngroups_total;
   for (long it = 0; it < iters; ++it) {
-    const long pix = it * ngroups_total + (long)blockIdx.x * groups_per_block + threadIdx.x / TPP;
+    const long pix = it * ngroups_total + (long)bid * groups_per_block + threadIdx.x / TPP;
     const bool live = pix < npix;      // whole groups go dead together; shuffles stay wave-uniform
     float df = 0.f, ds = 0.f;
     int x = 0, y = 0;
@@ -167,7 +167,6 @@ __global__ __launch_bounds__(256) void head_bwd_f32_kernel(HbArgs a) {
   }
   // workgroup partials (no atomics: deterministic, and 2048 waves hammering 33 addresses with
   // double atomics cost ~270 us per scale); osvos_head_grads_finalize sums them
-  __shared__ double red[4][34];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
   for (int c = 0; c < 16; ++c) {
@@ -179,7 +178,25 @@ __global__ __launch_bounds__(256) void head_bwd_f32_kernel(HbArgs a) {
   if (lane == 0) { red[wv][32] = s3; red[wv][33] = 0.0; }
   __syncthreads();
   if (threadIdx.x < 34)
-    a.acc[(size_t)blockIdx.x * 34 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    a.acc[(size_t)bid * 34 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+template <int TPP>
+__global__ __launch_bounds__(256) void head_bwd_f32_kernel(HbArgs a) {
+  __shared__ double red[4][34];
+  head_bwd_body<TPP>(a, blockIdx.x, gridDim.x, red);
+}
+
+// the four scales in ONE launch (they are independent; as four launches of ~20 us each they sit back to back on the backward's critical path):
+// workgroups [first[i], first[i + 1]) run scale i's body with its own lane-group width
+struct Hb4Args { HbArgs s[4]; unsigned first[5]; };
+__global__ __launch_bounds__(256) void head_bwd4_f32_kernel(Hb4Args a) {
+  __shared__ double red[4][34];
+  const unsigned b = blockIdx.x;
+  if (b < a.first[1]) head_bwd_body<1>(a.s[0], b, a.first[1], red);
+  else if (b < a.first[2]) head_bwd_body<4>(a.s[1], b - a.first[1], a.first[2] - a.first[1], red);
+  else if (b < a.first[3]) head_bwd_body<16>(a.s[2], b - a.first[2], a.first[3] - a.first[2], red);
+  else head_bwd_body<64>(a.s[3], b - a.first[3], a.first[4] - a.first[3], red);
 }
 
 // per-workgroup partial sums of x -> part[blockIdx.x]
@@ -277,6 +294,28 @@ int osvos_head_bwd_f32(const float* prep, const float* dside, const float* dfuse
     case 2: hipLaunchKernelGGL(head_bwd_f32_kernel<16>, dim3(g), dim3(256), 0, stream, a); break;
     default: hipLaunchKernelGGL(head_bwd_f32_kernel<64>, dim3(g), dim3(256), 0, stream, a); break;
   }
+  OSVOS_LAUNCH_CHECK();
+  return 0;
+}
+
+// all four scales in one launch: arrays indexed by scale; same partial layout per scale as osvos_head_bwd_f32 (acc[i]: osvos_head_bwd_blocks x 34)
+int osvos_head_bwd4_f32(const float* const* prep, const float* const* dside, const float* dfused, const float* const* f1, const float* const* f16,
+                        const float* const* wd, const float* wf, float* const* dprep, void* const* dprep_bf16, double* const* acc,
+                        int N, int H, int W, const int* hs, const int* ws, hipStream_t stream) {
+  Hb4Args a;
+  a.first[0] = 0;
+  for (int i = 0; i < 4; ++i) {
+    OSVOS_ARG_CHECK(prep[i] && f1[i] && f16[i] && wd[i] && wf && dprep[i] && acc[i] && hs[i] > 0 && ws[i] > 0, "head_bwd4: bad arguments for scale %d", i);
+    HbArgs& q = a.s[i];
+    q.prep = reinterpret_cast<const f32x4*>(prep[i]);
+    q.dside = dside[i]; q.dfused = dfused; q.f1 = f1[i]; q.f16 = f16[i]; q.wd = wd[i]; q.wf = wf + 16 * i;
+    q.dprep = reinterpret_cast<f32x4*>(dprep[i]);
+    q.dprep_b = reinterpret_cast<uint2*>(dprep_bf16 ? dprep_bf16[i] : nullptr);
+    q.acc = acc[i];
+    q.N = N; q.H = H; q.W = W; q.h = hs[i]; q.w = ws[i]; q.s = 2 << i;
+    a.first[i + 1] = a.first[i] + (unsigned)osvos_head_bwd_blocks(N, hs[i], ws[i], i);
+  }
+  hipLaunchKernelGGL(head_bwd4_f32_kernel, dim3(a.first[4]), dim3(256), 0, stream, a);
   OSVOS_LAUNCH_CHECK();
   return 0;
 }

@@ -43,6 +43,9 @@ int osvos_head_lowres_f32(const float* prep, const float* wd, const float* bd, c
 int osvos_head_bwd_f32(const float* prep, const float* dside, const float* dfused, const float* f1, const float* f16,
                        const float* wd, const float* wf, float* dprep, void* dprep_bf16, double* acc, int N, int H, int W, int h, int w,
                        int scale_idx, hipStream_t stream);
+int osvos_head_bwd4_f32(const float* const* prep, const float* const* dside, const float* dfused, const float* const* f1, const float* const* f16,
+                        const float* const* wd, const float* wf, float* const* dprep, void* const* dprep_bf16, double* const* acc,
+                        int N, int H, int W, const int* hs, const int* ws, hipStream_t stream);      // the four scales in one launch
 int osvos_head_bwd_blocks(int N, int h, int w, int scale_idx);   // workgroups (= partial rows of 34 doubles) head_bwd launches
 int osvos_sum_partials(const float* x, long count, double* part, int* nblocks, hipStream_t stream);
 // generic (non-diagonal upscale weights) head: head_generic.hip

@@ -317,8 +317,8 @@ int osvos_net_forward(const float* x_nchw, const void* wbuf, void* ws, float* co
   hipStream_t stream = (hipStream_t)stream_;
   const int dtype = dtype_ & 0xff;
   const bool generic = (dtype_ & OSVOS_FLAG_GENERIC_DECONV) != 0;
-  hipStream_t aux = aux_stream_ ? (hipStream_t)aux_stream_ : stream;
-  const bool two = aux != stream;
+  hipStream_t aux_all = aux_stream_ ? (hipStream_t)aux_stream_ : stream;
+  const bool two = aux_all != stream;
   EventPool& evp = event_pool();
   OSVOS_ARG_CHECK(x_nchw && wbuf && ws && outs, "net_forward: null pointer");
   OSVOS_ARG_CHECK(osvos_dtype_built(dtype), "net_forward: dtype %d not built", dtype);
@@ -364,7 +364,9 @@ int osvos_net_forward(const float* x_nchw, const void* wbuf, void* ws, float* co
       // side branch of this stage (skinny Cout=16 conv + the two 1x1 dots): latency-bound launches
       // that run on the aux stream in the shadow of the next stage's big convolutions
       const int i = si - 1, sl = kNumTrunk + i;
-      if (two) {
+      // the LAST stage's side branch has nothing left to hide behind: on the main stream it saves two cross-stream event hops (~12-25 us each)
+      hipStream_t aux = (si == 4) ? stream : aux_all;
+      if (two && aux != stream) {
         hipEvent_t e = evp.next();
         if (!e) return -1;
         OSVOS_HIP_CHECK(hipEventRecord(e, stream));
@@ -391,7 +393,7 @@ int osvos_net_forward(const float* x_nchw, const void* wbuf, void* ws, float* co
   if (two) {
     hipEvent_t e = evp.next();
     if (!e) return -1;
-    OSVOS_HIP_CHECK(hipEventRecord(e, aux));
+    OSVOS_HIP_CHECK(hipEventRecord(e, aux_all));
     OSVOS_HIP_CHECK(hipStreamWaitEvent(stream, e, 0));
   }
   if (generic) {      // non-diagonal upscale weights: fused head from the 16-channel side_prep outputs and Weff (head_generic.hip)
@@ -499,6 +501,27 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
   const float* dfused = douts[4];
 
   // ---- head: upstream full-resolution gradients -> dprep[i] (+ score_dsn / fuse gradients) ----
+  static const bool merged_head = [] { const char* e = getenv("OSVOS_HEAD_BWD_MERGED"); return !(e && e[0] == '0'); }();
+  if (!generic && merged_head) {        // the four scales in one launch (as four ~20 us launches they sit back to back on the critical path)
+    const float *prep4[4], *f1_4[4], *f16_4[4], *wd4[4];
+    float* dprep4[4];
+    void* dprepb4[4];
+    double* acc4[4];
+    for (int i = 0; i < 4; ++i) {
+      prep4[i] = reinterpret_cast<const float*>(at(ws, L.prep[i]));
+      f1_4[i] = reinterpret_cast<const float*>(at(wbuf, P.f1[i]));
+      f16_4[i] = reinterpret_cast<const float*>(at(wbuf, P.f16[i]));
+      wd4[i] = reinterpret_cast<const float*>(at(wbuf, P.wd[i]));
+      dprep4[i] = reinterpret_cast<float*>(at(ws, L.dprep[i]));
+      dprepb4[i] = store ? at(ws, L.dprep_b[i]) : nullptr;
+      acc4[i] = acc + (size_t)i * OSVOS_HEAD_MAX_BLOCKS * 34;
+      part[i] = acc4[i];
+      nblk[i] = osvos_head_bwd_blocks(N, L.hs[i + 1], L.ws[i + 1], i);
+    }
+    rc = osvos_head_bwd4_f32(prep4, douts, dfused, f1_4, f16_4, wd4, reinterpret_cast<const float*>(at(wbuf, P.wf)), dprep4, dprepb4, acc4, N, H, W,
+                             &L.hs[1], &L.ws[1], stream);
+    if (rc) return rc;
+  } else
   for (int i = 0; i < 4; ++i) {
     const int si = i + 1;
     if (generic)

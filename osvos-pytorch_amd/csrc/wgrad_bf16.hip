@@ -859,7 +859,7 @@ __global__ __launch_bounds__(64 * WAVES) void wgrad_bf16pm_kernel(WbArgs a) {
 //   * bias gradient: fp32 sums of the dY fragments the waves (wi = 0) hold anyway -- deterministic, a different summation order than the
 //     register-staged forms (the weight gradient itself is bit-identical to them: same patches, splits and k-order)
 struct DM {
-  static constexpr int WAVES = 8, BCOT = 128, NT = 64 * WAVES, HP = 4;
+  static constexpr int WAVES = 8, BCOT = 128, HP = 4;
   static constexpr int DYP = BCOT * 2, XP = BCI * 2;                        // pixel pitches in bytes: 256 and 128 (no padding)
   static constexpr int XW = 36, XPIX = (HP + 2) * XW;                       // halo rows of 36 pixels (34 used), 216 halo pixels
   static constexpr int X_B = XPIX * XP, DY_B = HP * PW * DYP;               // 27648 and 32768 bytes
@@ -890,7 +890,7 @@ __global__ __launch_bounds__(512) void wgrad_bf16dma_kernel(WbArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);    // wave-uniform by construction; a scalar for m0 and for the branches
-  const int wave = wv, wc = wv >> 1, wi = wv & 1;
+  const int wc = wv >> 1, wi = wv & 1;
   constexpr unsigned OOB = 0x80000000u;
 
   int id = blockIdx.x;
@@ -922,7 +922,6 @@ __global__ __launch_bounds__(512) void wgrad_bf16dma_kernel(WbArgs a) {
     xrow[j] = hy - 1;
   }
   const int img_dy_bytes = a.H * a.W * a.Cout_s * 2, img_x_bytes = a.H * a.W * a.Cin_s * 2;
-  const unsigned dy_row = (unsigned)(a.W * a.Cout_s * 2), x_row = (unsigned)(a.W * a.Cin_s * 2);
   const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem;
   // hidden from the compiler (inline asm): it would put s_waitcnt vmcnt(0) in front of the next LDS read otherwise; the ordering is kept
   // by hand -- vmcnt(0) + barrier at the end of every half patch
@@ -1145,7 +1144,7 @@ __global__ __launch_bounds__(512) void wgrad_bf16dma_kernel(WbArgs a) {
 #ifdef OSVOS_WGRAD_PROF
   WPROF(7);
   if (a.prof != nullptr && lane == 0) {
-    unsigned long long* qq = a.prof + ((size_t)blockIdx.x * G::WAVES + wave) * 10;
+    unsigned long long* qq = a.prof + ((size_t)blockIdx.x * G::WAVES + wv) * 10;
     for (int k = 0; k < 8; ++k) qq[k] = pt[k];
     qq[8] = t_begin;
     qq[9] = tp;
