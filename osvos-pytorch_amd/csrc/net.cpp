@@ -620,12 +620,15 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
     const void* xin = first_of_stage ? (si == 0 ? at(ws, L.xin) : at(ws, L.pooled[si])) : at(ws, L.act[l - 1]);
     const void* g = at(ws, L.dy[l]);
     const void* g_b = sh(L.dy_b[l]);
-    if (grads[d[l].w_param] != nullptr) {
+    // conv1_1's weight gradient is the LAST piece of work of the step and the weight-gradient stream is the one that finishes last (conv1_2's
+    // gradient is still running when the data-gradient chain ends): it goes on the main stream, behind the input gradient, beside conv1_2's
+    const bool tail_on_main = l == 0 && two;
+    if (grads[d[l].w_param] != nullptr && !tail_on_main) {
       if ((rc = signal())) return rc;   // dy[l] ready -> its weight gradient may start on aux
       rc = wgrad(xin, g, l, h, w);
       if (rc) return rc;
     }
-    if (first_of_stage && (rc = ready(2 + (4 - si), aux2))) return rc;      // stage si complete (its first conv is the last one processed)
+    if (first_of_stage && !tail_on_main && (rc = ready(2 + (4 - si), aux2))) return rc;      // stage si complete (its first conv is the last one processed)
     if (l == 0) {
       if (dx_nchw != nullptr) {
         rc = conv_main(g, g_b, at(wbuf, P.dgrad[0]), nullptr, nullptr, nullptr, at(ws, L.dxin), nullptr, N, h, w, d[0].cout, 3, 4, 0, dtype,
@@ -633,6 +636,11 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
         if (rc) return rc;
         rc = osvos_nhwc_to_nchw(at(ws, L.dxin), dx_nchw, N, 3, H, W, 4, dtype, stream);
         if (rc) return rc;
+      }
+      if (tail_on_main) {
+        if (grads[d[0].w_param] != nullptr && (rc = wgrad_launch(xin, g, 0, h, w, stream))) return rc;
+        if ((rc = join())) return rc;
+        return ready(2 + 4, stream);      // stage 0 complete: conv1_2's reduce (aux2, joined) and conv1_1's (main)
       }
       break;
     }
