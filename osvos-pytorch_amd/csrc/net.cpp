@@ -591,11 +591,23 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
     return 0;
   };
   if ((rc = signal())) return rc;       // dprep[0..3] ready
+  // The four skinny side_prep weight gradients (~65 us each at 854x480, bandwidth- and latency-bound) head the weight-gradient stream and push every
+  // trunk weight gradient back by their sum.  OSVOS_SIDE_WGRAD_AUX2=1 puts them, kernel and slab reduce both, on the third stream beside the first
+  // trunk gradients (each layer has its own slabs).  Measured on the headline: +0.1-0.25 %, inside the noise -- off by default.
+  static const bool side_on_aux2 = [] { const char* e = getenv("OSVOS_SIDE_WGRAD_AUX2"); return e && e[0] == '1'; }();
+  const bool side_aux2 = three && side_on_aux2;
+  if (side_aux2) {
+    hipEvent_t e = evp.next();
+    if (!e) return -1;
+    OSVOS_HIP_CHECK(hipEventRecord(e, stream));
+    OSVOS_HIP_CHECK(hipStreamWaitEvent(aux2, e, 0));
+  }
   for (int i = 0; i < 4; ++i) {
     const int si = i + 1, sl = kNumTrunk + i, h = L.hs[si], w = L.ws[si];
     const int lx = last_of_stage(si);
     if (grads[d[sl].w_param] != nullptr) {
-      rc = wgrad(at(ws, L.act[lx]), store ? at(ws, L.dprep_b[i]) : at(ws, L.dprep[i]), sl, h, w);      // (store mode: bf16 x and bf16 dprep)
+      const void* dp = store ? at(ws, L.dprep_b[i]) : at(ws, L.dprep[i]);      // (store mode: bf16 x and bf16 dprep)
+      rc = side_aux2 ? wgrad_launch(at(ws, L.act[lx]), dp, sl, h, w, aux2) : wgrad(at(ws, L.act[lx]), dp, sl, h, w);
       if (rc) return rc;
     }
   }
