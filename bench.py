@@ -73,6 +73,23 @@ def conv_gflop_forward(h, w):
     return total / 1e9
 
 
+def conv_gflop_parts(h, w):
+    """(conv1_1, the four side_prep convs) GFLOP of one forward pass -- the layers whose passes may run on the exact fp32 kernels in f32x3."""
+    c11 = 2.0 * h * w * 64 * 9 * 3 / 1e9
+    side, cin = 0.0, [128, 256, 512, 512]
+    for i in range(4):
+        h, w = (h + 1) // 2, (w + 1) // 2
+        side += 2.0 * h * w * 16 * 9 * cin[i] / 1e9
+    return c11, side
+
+
+# f32x3: which passes still run on the EXACT fp32 MFMA kernels (1 executed FLOP per algorithmic FLOP, not 6): conv1_1's forward (Cin = 3) and
+# weight gradient, and the side_prep (Cout = 16) weight gradients unless OSVOS_X3_SIDE_WGRAD puts them on the bf16 pipe (csrc/net.cpp)
+def x3_exact_gflop(h, w, side_wgrad_exact=True):
+    c11, side = conv_gflop_parts(h, w)
+    return {"fwd": c11, "bwd": c11 + (side if side_wgrad_exact else 0.0)}
+
+
 def synth_problem(n, h, w, device, seed):
     """Seeded synthetic frame + mask + He-init weights with calibrated heads, built
     on the product path itself (the oracle is not imported here)."""
@@ -107,32 +124,6 @@ def synth_problem(n, h, w, device, seed):
         net.fuse.weight.mul_(s)
         net.fuse.bias.fill_(-1.0 - float(outs[4].mean()) * s)
     return net, x, m
-
-
-def make_optimizer(net, mode):
-    """train_online.py:79-88 / train_parent.py:87-103."""
-    lr, wd = 1e-8, 0.0002
-    groups = [
-        {'params': [p for n, p in net.stages.named_parameters() if 'weight' in n], 'weight_decay': wd},
-        {'params': [p for n, p in net.stages.named_parameters() if 'bias' in n], 'lr': lr * 2},
-        {'params': [p for n, p in net.side_prep.named_parameters() if 'weight' in n], 'weight_decay': wd},
-        {'params': [p for n, p in net.side_prep.named_parameters() if 'bias' in n], 'lr': lr * 2},
-    ]
-    if mode == "parent":
-        groups += [
-            {'params': [p for n, p in net.score_dsn.named_parameters() if 'weight' in n], 'lr': lr / 10, 'weight_decay': wd},
-            {'params': [p for n, p in net.score_dsn.named_parameters() if 'bias' in n], 'lr': 2 * lr / 10},
-        ]
-    groups += [
-        {'params': [p for n, p in net.upscale.named_parameters() if 'weight' in n], 'lr': 0},
-        {'params': [p for n, p in net.upscale_.named_parameters() if 'weight' in n], 'lr': 0},
-        {'params': net.fuse.weight, 'lr': lr / 100, 'weight_decay': wd},
-        {'params': net.fuse.bias, 'lr': 2 * lr / 100},
-    ]
-    if os.environ.get("OSVOS_FUSED_SGD", "1") != "0":
-        from osvos_pytorch_amd.optim import FusedSGD
-        return FusedSGD(groups, lr=lr, momentum=0.9)
-    return torch.optim.SGD(groups, lr=lr, momentum=0.9)
 
 
 def cpu_baseline(h, w, mode, n_ave, budget_s=20.0):
@@ -194,7 +185,14 @@ def cpu_baseline(h, w, mode, n_ave, budget_s=20.0):
             break
     timed = times[1:]                                   # the selection iteration is not part of the sample
     med = float(np.median(timed))
-    return {"value": 1.0 / med, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            model = next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), "unknown")
+    except OSError:
+        pass
+    return {"value": 1.0 / med, "unit": "frames/s", "cores": torch.get_num_threads(), "threads_used": torch.get_num_threads(),
+            "host_nproc": ncpu, "cpu_model": model, "kind": "port",
             "sample": "%d fwd+bwd iterations of the restated train_%s.py loop at %dx%d, batch 1, fp32, torch %s CPU "
                       "(oneDNN), median after 1 warm-up" % (len(timed), mode, w, h, torch.__version__)}
 
@@ -204,7 +202,12 @@ class Workload(object):
 
     def __init__(self, mode, precision, height, width, batch, graph, n_ave, item_sync, device, rank, dist, force_dist, graph_train=0):
         from layers.osvos_layers import class_balanced_cross_entropy_loss as cbce
+        from osvos_pytorch_amd.layers.osvos_layers import class_balanced_cross_entropy_loss_step as cbce_step
         from osvos_pytorch_amd.parallel import GradientAllReducer
+        self.cbce_step = cbce_step
+        # what TrainLoop (the scripts' loop) does by default: upstream gradient (1 / nAveGrad ...) and running-loss add inside the loss
+        # kernel instead of five ATen launches per micro-batch; OSVOS_FUSED_LOSS_STEP=0 restores the plain autograd chain
+        self.fused_loss = os.environ.get("OSVOS_FUSED_LOSS_STEP", "1") != "0"
         self.mode, self.precision, self.h, self.w, self.batch, self.graph = mode, precision, height, width, batch, graph
         self.n_ave = n_ave or (5 if mode == "online" else 10)
         self.item_sync = item_sync
@@ -212,7 +215,8 @@ class Workload(object):
         self.net, self.x, self.gt = synth_problem(batch, height, width, device, seed=rank)
         self.net.set_precision(precision)
         self.net.set_inplace_grad_accumulation(True)      # what osvos_pytorch_amd.train_common.TrainLoop (the scripts' loop) does
-        self.opt = make_optimizer(self.net, "online" if mode == "infer" else mode)
+        from osvos_pytorch_amd.train_common import make_sgd      # the scripts' own parameter groups (train_online.py:79-88 / train_parent.py:87-103)
+        self.opt = make_sgd(self.net, "online" if mode == "infer" else mode)
         comm = None
         if dist is not None and os.environ.get("OSVOS_DP_BACKEND", "torch") == "abi":      # gradients through osvos_comm_* (RCCL via the C ABI)
             from osvos_pytorch_amd.parallel import AbiCommunicator
@@ -297,19 +301,35 @@ class Workload(object):
         # body of train_online.py:116-149 (train_parent.py:132-172 for --mode parent)
         inputs = self.x.detach().requires_grad_()         # train_online.py:121: the input gradient is computed
         outputs = self.net.forward(inputs)
-        if self.mode == "online":
-            loss = self.cbce(outputs[-1], self.gt, size_average=False)
+        arm = self.reducer is not None and (self.ave + 1) % self.n_ave == 0      # last micro-batch of the step: chunked all-reduce behind the gradient-ready events
+        if self.fused_loss:
+            # TrainLoop._micro_batch_fused: loss, running_loss += loss and the gradient of loss / nAveGrad out of ONE call per head
+            inv = np.float32(1.0) / np.float32(self.n_ave)
+            heads = [outputs[-1]] if self.mode == "online" else list(outputs)
+            scales = [inv] if self.mode == "online" else [np.float32(inv * np.float32(1 - self.epoch / 240))] * 4 + [inv]
+            grads = []
+            for k, (o, sc) in enumerate(zip(heads, scales)):
+                loss, g = self.cbce_step(o, self.gt, size_average=False, grad_scale=float(sc), running=self.running if k == len(heads) - 1 else None)
+                grads.append(g)
+            if self.item_sync:
+                loss.item()                               # train_online.py:128: D2H sync every iteration
+            if arm:
+                self.reducer.arm()
+            torch.autograd.backward(heads, grads)
         else:
-            losses = [self.cbce(o, self.gt, size_average=False) for o in outputs]
-            loss = (1 - self.epoch / 240) * sum(losses[:-1]) + losses[-1]
-        if self.item_sync:
-            self.running.add_(loss.item())                # train_online.py:128: D2H sync every iteration
-        else:
-            self.running.add_(loss.detach())
-        loss /= self.n_ave
-        if self.reducer is not None and (self.ave + 1) % self.n_ave == 0:
-            self.reducer.arm()          # last micro-batch of the step: chunked all-reduce behind the gradient-ready events
-        loss.backward()
+            if self.mode == "online":
+                loss = self.cbce(outputs[-1], self.gt, size_average=False)
+            else:
+                losses = [self.cbce(o, self.gt, size_average=False) for o in outputs]
+                loss = (1 - self.epoch / 240) * sum(losses[:-1]) + losses[-1]
+            if self.item_sync:
+                self.running.add_(loss.item())            # train_online.py:128: D2H sync every iteration
+            else:
+                self.running.add_(loss.detach())
+            loss /= self.n_ave
+            if arm:
+                self.reducer.arm()
+            loss.backward()
         self.ave += 1
         self.nsteps += 1
         if self.ave % self.n_ave == 0:
@@ -365,11 +385,13 @@ def load_traffic():
     """HBM-side bytes per launch of the dominant kernel from the rocprofv3 --pmc passes (FETCH_SIZE x 2 on gfx950 +
     WRITE_SIZE, MI355X_MICROARCH.md section HBM), as written by tools/pmc_traffic.py into profiles/ together with the
     commit it was measured at.  None when that file is absent -- bench.py itself cannot read PMC counters."""
-    path = os.path.join(REPO, "profiles", "r02_pmc_traffic.json")
+    name = next((n for n in ("r03_pmc_traffic.json", "r02_pmc_traffic.json") if os.path.exists(os.path.join(REPO, "profiles", n))), "r03_pmc_traffic.json")
+    path = os.path.join(REPO, "profiles", name)
     try:
         with open(path) as f:
             t = json.load(f)
-        t["source"] = "profiles/r02_pmc_traffic.json"
+        t["source"] = "profiles/" + name
+        t["static"] = True      # rocprofv3 PMC passes cannot run inside this process: measured by tools/pmc_traffic.py at the commit named in the file
         return t
     except Exception:
         return None
@@ -446,51 +468,61 @@ def measure(wl, steps, warmup, min_seconds, world, dist, device, use_prof=True):
     # bounds those kernels is the bf16 dense peak; `achieved` counts the EXECUTED bf16 FLOPs (6 x algorithmic), the algorithmic rate
     # and its ratio to the fp32-MFMA peak (the roofline of the exact kernels, which this mode is free to exceed) are given next to it.
     x3 = wl.precision == "fp32x3"
-    mult = 6.0 if x3 else 1.0
+    # executed / algorithmic FLOPs: 6 where a pass runs as f32x3, 1 where it stays on the exact fp32 kernel (conv1_1 forward and weight
+    # gradient; the side_prep weight gradients unless they run on the bf16 pipe) -- per family, from the layers' own FLOP shares
+    mult_f = mult_b = mult_s = 1.0
+    if x3:
+        ex = x3_exact_gflop(wl.h, wl.w, side_wgrad_exact=os.environ.get("OSVOS_X3_SIDE_WGRAD", "1") == "0")
+        gf1 = conv_gflop_forward(wl.h, wl.w)
+        mult_f = 6.0 - 5.0 * ex["fwd"] / gf1
+        mult_b = 6.0 - 5.0 * ex["bwd"] / (2.0 * gf1)
+        mult_s = 6.0 - 5.0 * (ex["fwd"] + ex["bwd"]) / (3.0 * gf1)
     peak = FP32_MFMA_PEAK_TFLOPS if wl.precision == "fp32" else BF16_MFMA_PEAK_TFLOPS
-    kname = {"fp32": ("conv3x3_f32_kernel", "wgrad_f32_kernel"), "fp32x3": ("conv3x3_f32x3_kernel", "wgrad_f32x3_kernel"),
+    kname = {"fp32": ("conv3x3_f32_kernel", "wgrad_f32_kernel"), "fp32x3": ("conv3x3 f32x3 kernels", "wgrad f32x3 kernels"),
              "bf16": ("conv3x3_bf16_kernel", "wgrad_bf16_kernel")}[wl.precision]
     roof = None
     step_alg = passes * gf_fwd / 1e3 / (elapsed / steps)
-    step_frac = round(mult * step_alg / peak, 4)
+    mult_step = mult_f if passes == 1 else mult_s
+    step_frac = round(mult_step * step_alg / peak, 4)
 
-    def x3_extra(alg_tflops):
+    def x3_extra(alg_tflops, m):
         if not x3:
             return {}
-        return {"executed_over_algorithmic": 6, "algorithmic_tflops": round(alg_tflops, 2),
+        return {"executed_over_algorithmic": round(m, 4), "algorithmic_tflops": round(alg_tflops, 2),
                 "algorithmic_over_fp32_mfma_peak": round(alg_tflops / FP32_MFMA_PEAK_TFLOPS, 4),
-                "note": "f32x3: 6 bf16 MFMA products per fp32 product; conv1_1 and the Cout=16 side_prep passes (3 % of the FLOPs) "
-                        "run on the exact fp32 kernels and are counted at 6x as well"}
+                "note": "f32x3: 6 bf16 MFMA products per fp32 product; the passes that stay on the exact fp32 kernels (conv1_1 forward / weight "
+                        "gradient%s) are counted at 1x" % ("" if os.environ.get("OSVOS_X3_SIDE_WGRAD", "1") != "0" else ", side_prep weight gradients")}
     if wl.mode == "infer" and wl.graph:
         # one captured graph per step: the family is the whole forward (17 conv launches + glue)
-        ach = mult * gf_fwd / 1e3 / (elapsed / steps)
+        ach = mult_f * gf_fwd / 1e3 / (elapsed / steps)
         act_gb = 0.904 * (wl.h * wl.w) / (480.0 * 854.0) * wl.batch * (0.5 if wl.precision == "bf16" else 1.0)   # min conv tensor traffic
         roof = {"bound": "mfma", "kernel": "hipGraph replay of osvos_net_forward (%s x17 + pool/head glue)" % kname[0],
                 "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                 "traffic": None, "algorithmic_hbm_GBps": round(act_gb / (elapsed / steps), 1), "hbm_peak_GBps": 8000}
-        roof.update(x3_extra(ach / mult))
+        roof.update(x3_extra(ach / mult_f, mult_f))
     elif getattr(wl, "graph_train", False):
         # the micro-batch is ONE graph launch: no per-launch events inside; the family is the step's conv work over the step time
-        ach = mult * step_alg
+        ach = mult_s * step_alg
         roof = {"bound": "mfma", "kernel": "hipGraph replay of one micro-batch: %s fwd + (%s dgrad || %s) + pool/head/loss glue" % (kname[0], kname[0], kname[1]),
                 "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None}
-        roof.update(x3_extra(step_alg))
+        roof.update(x3_extra(step_alg, mult_s))
     elif prof and cnt[0] + cnt[1] > 0:
         # dominant kernel family: the MFMA conv kernels.  Family 0 = conv3x3 forward launches (one event pair per
         # launch); family 1 = backward regions, i.e. the data-gradient launch of a layer running concurrently with its
         # weight-gradient launch (+ slab reduce) on the second stream, timed fork -> join.  FLOPs are algorithmic.
-        conv_ms, conv_fl = ms[0] + ms[1], mult * (fl[0] + fl[1])
+        conv_ms, conv_fl = ms[0] + ms[1], mult_f * fl[0] + mult_b * fl[1]
         ach = conv_fl / (conv_ms * 1e-3) / 1e12
+        m_all = conv_fl / max(fl[0] + fl[1], 1.0)
         roof = {"bound": "mfma", "kernel": "%s fwd launches + (%s dgrad || %s) backward regions" % (kname[0], kname[0], kname[1]),
                 "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                 "launches": int(cnt[0] + cnt[1]), "avg_launch_ms": round(conv_ms / (cnt[0] + cnt[1]), 4),
-                "algorithmic_gflop_per_launch": round(conv_fl / (cnt[0] + cnt[1]) / 1e9, 3),
+                "algorithmic_gflop_per_launch": round((fl[0] + fl[1]) / (cnt[0] + cnt[1]) / 1e9, 3),
                 "instrumented_steps": n_prof,
-                "families": {"conv_fwd": {"ms_per_step": round(ms[0] / n_prof, 3), "tflops": round(mult * fl[0] / (ms[0] * 1e-3) / 1e12, 2) if ms[0] else None},
-                             "conv_bwd_dgrad+wgrad": {"ms_per_step": round(ms[1] / n_prof, 3), "tflops": round(mult * fl[1] / (ms[1] * 1e-3) / 1e12, 2) if ms[1] else None}},
+                "families": {"conv_fwd": {"ms_per_step": round(ms[0] / n_prof, 3), "tflops": round(mult_f * fl[0] / (ms[0] * 1e-3) / 1e12, 2) if ms[0] else None},
+                             "conv_bwd_dgrad+wgrad": {"ms_per_step": round(ms[1] / n_prof, 3), "tflops": round(mult_b * fl[1] / (ms[1] * 1e-3) / 1e12, 2) if ms[1] else None}},
                 "step_conv_fraction_of_mfma_roofline": step_frac,
                 "traffic": load_traffic() if wl.precision == "fp32x3" else None}
-        roof.update(x3_extra(ach / mult))
+        roof.update(x3_extra(ach / m_all, m_all))
     if roof is not None and wl.precision != "fp32" and torch.cuda.is_available():
         # next to the spec peak: the rate the pipe sustains on this chip, measured now (see pipe_sustained_tflops)
         try:
@@ -503,6 +535,25 @@ def measure(wl, steps, warmup, min_seconds, world, dist, device, use_prof=True):
     res["roofline"] = roof
     res["step_conv_fraction_of_mfma_roofline"] = step_frac
     return res
+
+
+def launch_ranks(n):
+    """Re-run this command line under torch.distributed.run with `n` ranks on this node; stdout / stderr / exit code pass through."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n:
+        print("bench.py --gpus %d: this node shows %d GPU(s)" % (n, have), file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 DTYPE_NAME = {"fp32": "f32",
@@ -537,6 +588,10 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip extra_configs (configs[2], configs[4]) and the item-sync figure")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: stand the N ranks up ourselves (one process per GPU over RCCL), exactly what
+        # `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...` does
+        return launch_ranks(args.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -547,8 +602,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        world = dist.get_world_size()          # n_gpus of the JSON line = the process group's size, not an environment variable
     else:
         dist = None
+    ranks_seen = 1
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
@@ -556,9 +613,10 @@ def main():
     if dist is not None:       # bring the process group's communicator up before anything is timed (its first collective initialises RCCL)
         for _ in range(2):
             dist.barrier()
-        t = torch.zeros(1, device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        t = torch.ones(1, device=device, dtype=torch.float64)
+        dist.all_reduce(t)                      # = number of ranks RCCL actually reaches
         torch.cuda.synchronize()
+        ranks_seen = int(t.item())
     wl = Workload(args.mode, args.precision, args.height, args.width, args.batch, args.graph, args.n_ave_grad, args.item_sync,
                   device, rank, dist, args.force_dist, graph_train=args.graph_train)
     res = measure(wl, args.steps, args.warmup, args.min_seconds, world, dist, device, use_prof=not args.no_prof)
@@ -629,7 +687,8 @@ def main():
             "vs_baseline": None, "dtype": DTYPE_NAME[args.precision],
             "data": "synthetic",
             "config": {"workload": workload,
-                       "global_batch": args.batch * world, "parallelism": "dp%d" % world,
+                       "global_batch": args.batch * world, "parallelism": "dp%d" % world, "rccl_ranks_seen": ranks_seen,
+                       "gpus_requested": args.gpus,
                        "grad_allreduce": "per optimizer step (RCCL)" if dist is not None else "none",
                        "loss_item_sync_each_iter": bool(args.item_sync)},
             "roofline": res["roofline"], "cpu_baseline": base,
@@ -645,4 +704,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

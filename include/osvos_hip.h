@@ -167,6 +167,13 @@ int osvos_deconv_diag_check(const float* w, int C, int k, float* out2, void* str
  * scratch: 32 bytes, zeroed by this call. */
 int osvos_cbce(const float* out, const float* label, float* loss, float* grad, void* scratch,
                long count, int N, int mode, void* stream);
+/* The same loss as one step of the training loops sees it (train_online.py:127-141, train_parent.py:143-163): `loss` is the plain
+ * loss (what the reference adds to running_loss), `running` (device fp32[1] or NULL) += loss inside the final kernel, and
+ * grad = grad_scale * dLoss/dOut with grad_scale = the upstream gradient the reference's `loss /= nAveGrad; loss.backward()` hands the
+ * loss (1/nAveGrad, times (1 - epoch/nEpochs) for the parent loop's side heads) -- rounded like osvos_cbce followed by osvos_scale,
+ * but without the separate scale / add / divide launches between the loss and the head's backward. */
+int osvos_cbce_step(const float* out, const float* label, float* loss, float* grad, void* scratch,
+                    long count, int N, int mode, float grad_scale, float* running, void* stream);
 /* y[i] = x[i] * (*scalar)   (loss.backward() chain rule with a device-resident upstream grad) */
 int osvos_scale(const float* x, const float* scalar, float* y, long count, void* stream);
 

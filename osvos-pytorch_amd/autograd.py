@@ -245,3 +245,27 @@ class CBCELossFunction(torch.autograd.Function):
         check(lib().osvos_scale(C.c_void_p(grad.data_ptr()), C.c_void_p(g.data_ptr()), C.c_void_p(gx.data_ptr()),
                                 grad.numel(), _stream()), "scale")
         return gx, None, None
+
+
+def cbce_step(output, label, mode, grad_scale=1.0, running=None):
+    """One training-loop use of the class-balanced BCE without the autograd scalar chain behind it: returns ``(loss, grad)`` where ``loss``
+    is the plain 0-dim loss (detached; what the reference adds to ``running_loss``, train_online.py:128) and ``grad`` =
+    ``grad_scale * dLoss/dOutput`` -- ready for ``torch.autograd.backward([output], [grad])``.  ``grad_scale`` is the upstream gradient the
+    reference's ``loss /= nAveGrad; loss.backward()`` hands this loss (train_online.py:140-141); ``running`` (0-dim fp32 CUDA tensor) gets
+    ``+= loss`` inside the kernel.  Same roundings as ``class_balanced_cross_entropy_loss(...)``, ``/=``, ``.backward()``; five small
+    ATen launches (ones, div, its backward, add, scale) per micro-batch fewer between the loss and the head's backward."""
+    if not output.is_cuda:
+        raise RuntimeError("class_balanced_cross_entropy_loss (osvos_pytorch_amd) needs CUDA tensors; no CPU fallback")
+    out = output.detach().contiguous().float()
+    lab = label.detach().to(device=out.device, dtype=torch.float32).contiguous()
+    if lab.numel() != out.numel():
+        raise RuntimeError("output and label must have the same number of elements")
+    if running is not None and not (running.is_cuda and running.dtype == torch.float32 and running.numel() == 1):
+        raise RuntimeError("running must be a one-element float32 CUDA tensor")
+    loss = torch.empty((), device=out.device, dtype=torch.float32)
+    grad = torch.empty_like(out)
+    scratch = torch.empty(4, device=out.device, dtype=torch.float64)
+    check(lib().osvos_cbce_step(C.c_void_p(out.data_ptr()), C.c_void_p(lab.data_ptr()), C.c_void_p(loss.data_ptr()), C.c_void_p(grad.data_ptr()),
+                                C.c_void_p(scratch.data_ptr()), out.numel(), out.shape[0], int(mode), float(grad_scale),
+                                C.c_void_p(running.data_ptr()) if running is not None else None, _stream()), "cbce_step")
+    return loss, grad.view_as(output)

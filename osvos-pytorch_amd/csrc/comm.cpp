@@ -28,6 +28,7 @@ struct Rccl {
   ncclResult_t (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   bool ok = false;
+  char why[256] = "";                        // the loader's message, captured right after the failing dlopen / dlsym
 };
 
 Rccl& rccl() {
@@ -37,8 +38,11 @@ Rccl& rccl() {
     for (const char* n : names) {
       q.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
       if (q.lib) break;
+      const char* e = dlerror();             // (dlerror() clears the state: read it once)
+      snprintf(q.why, sizeof(q.why), "%s", e ? e : "dlopen failed");
     }
     if (!q.lib) return q;
+    q.why[0] = 0;
     q.GetUniqueId = reinterpret_cast<decltype(q.GetUniqueId)>(dlsym(q.lib, "ncclGetUniqueId"));
     q.CommInitRank = reinterpret_cast<decltype(q.CommInitRank)>(dlsym(q.lib, "ncclCommInitRank"));
     q.CommDestroy = reinterpret_cast<decltype(q.CommDestroy)>(dlsym(q.lib, "ncclCommDestroy"));
@@ -47,6 +51,10 @@ Rccl& rccl() {
     q.GroupEnd = reinterpret_cast<decltype(q.GroupEnd)>(dlsym(q.lib, "ncclGroupEnd"));
     q.GetErrorString = reinterpret_cast<decltype(q.GetErrorString)>(dlsym(q.lib, "ncclGetErrorString"));
     q.ok = q.GetUniqueId && q.CommInitRank && q.CommDestroy && q.AllReduce && q.GroupStart && q.GroupEnd && q.GetErrorString;
+    if (!q.ok) {
+      const char* e = dlerror();
+      snprintf(q.why, sizeof(q.why), "%s", e ? e : "a required ncclXxx symbol is missing");
+    }
     return q;
   }();
   return r;
@@ -63,7 +71,7 @@ Rccl& rccl() {
 
 int need_rccl() {
   if (!rccl().ok) {
-    osvos_set_error("librccl.so could not be loaded (dlopen / dlsym): %s", dlerror() ? dlerror() : "symbols missing");
+    osvos_set_error("librccl.so could not be loaded (dlopen / dlsym): %s", rccl().why[0] ? rccl().why : "symbols missing");
     return -2;
   }
   return 0;

@@ -33,7 +33,7 @@ __global__ void cbce_count_kernel(const float* __restrict__ label, long count, S
 }
 
 __global__ void cbce_main_kernel(const float* __restrict__ out, const float* __restrict__ label,
-                                 float* __restrict__ grad, long count, float inv_div, Scratch* sc) {
+                                 float* __restrict__ grad, long count, float inv_div, float gscale, Scratch* sc) {
   const float ntot = (float)count;
   const float npos = (float)sc->npos;
   const float wpos = (ntot - npos) / ntot, wneg = npos / ntot;
@@ -50,7 +50,10 @@ __global__ void cbce_main_kernel(const float* __restrict__ out, const float* __r
       // reference's expression; no cancellation for saturated logits (sigmoid(x) - y would lose it)
       const float ez = expf(-fabsf(x));
       const float sz = ez / (1.f + ez);
-      grad[i] = (y > 0.5f ? wpos : wneg) * ((1.f - 2.f * g) * sz - (y - g)) * inv_div;
+      const float gi = (y > 0.5f ? wpos : wneg) * ((1.f - 2.f * g) * sz - (y - g)) * inv_div;
+      // gscale: the upstream gradient of the loss (1 / nAveGrad, times the side-head weight in the parent loop), applied to the
+      // ROUNDED per-pixel gradient -- the same two roundings as this kernel followed by osvos_scale (autograd's chain)
+      grad[i] = gi * gscale;
     }
   }
   lpos = wave_sum(lpos);
@@ -64,11 +67,13 @@ __global__ void cbce_main_kernel(const float* __restrict__ out, const float* __r
   }
 }
 
-__global__ void cbce_final_kernel(const Scratch* sc, long count, float inv_div, float* loss) {
+__global__ void cbce_final_kernel(const Scratch* sc, long count, float inv_div, float* loss, float* running) {
   const float ntot = (float)count;
   const float npos = (float)sc->npos;
   const float wpos = (ntot - npos) / ntot, wneg = npos / ntot;
-  loss[0] = (float)(((double)wpos * sc->lpos + (double)wneg * sc->lneg) * (double)inv_div);
+  const float l = (float)(((double)wpos * sc->lpos + (double)wneg * sc->lneg) * (double)inv_div);
+  loss[0] = l;
+  if (running != nullptr) running[0] += l;      // running_loss += loss (train_online.py:128) without a host round trip or an extra launch
 }
 
 __global__ void scale_kernel(const float* __restrict__ x, const float* __restrict__ scalar, float* __restrict__ y, long count) {
@@ -100,6 +105,11 @@ inline int grid_for(long total, int cap) {
 
 extern "C" int osvos_cbce(const float* out, const float* label, float* loss, float* grad, void* scratch,
                           long count, int N, int mode, void* stream_) {
+  return osvos_cbce_step(out, label, loss, grad, scratch, count, N, mode, 1.f, nullptr, stream_);
+}
+
+extern "C" int osvos_cbce_step(const float* out, const float* label, float* loss, float* grad, void* scratch,
+                               long count, int N, int mode, float grad_scale, float* running, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   OSVOS_ARG_CHECK(out && label && loss && scratch && count > 0 && N > 0, "cbce: bad arguments");
   OSVOS_ARG_CHECK(mode >= 0 && mode <= 2, "cbce: mode %d", mode);
@@ -109,8 +119,8 @@ extern "C" int osvos_cbce(const float* out, const float* label, float* loss, flo
   // one double atomic pair per workgroup: few workgroups for a single frame (11 us), more for batches (94 -> ~25 us at batch 12)
   const int g = grid_for(count, count > (1L << 21) ? 512 : 128);
   hipLaunchKernelGGL(cbce_count_kernel, dim3(g), dim3(256), 0, stream, label, count, sc);
-  hipLaunchKernelGGL(cbce_main_kernel, dim3(g), dim3(256), 0, stream, out, label, grad, count, inv_div, sc);
-  hipLaunchKernelGGL(cbce_final_kernel, dim3(1), dim3(1), 0, stream, sc, count, inv_div, loss);
+  hipLaunchKernelGGL(cbce_main_kernel, dim3(g), dim3(256), 0, stream, out, label, grad, count, inv_div, grad_scale, sc);
+  hipLaunchKernelGGL(cbce_final_kernel, dim3(1), dim3(1), 0, stream, sc, count, inv_div, loss, running);
   OSVOS_LAUNCH_CHECK();
   return 0;
 }

@@ -8,7 +8,7 @@ from __future__ import division
 import numpy as np
 import torch
 
-from ..autograd import CBCELossFunction
+from ..autograd import CBCELossFunction, cbce_step
 
 
 def logit(x):
@@ -26,6 +26,14 @@ def class_balanced_cross_entropy_loss(output, label, size_average=True, batch_av
     Returns a 0-dim CUDA tensor that supports ``.item()``, ``/=`` and ``.backward()``."""
     mode = 0 if size_average else (1 if batch_average else 2)
     return CBCELossFunction.apply(output, label, mode)
+
+
+def class_balanced_cross_entropy_loss_step(output, label, size_average=True, batch_average=True, grad_scale=1.0, running=None):
+    """The loss as ONE micro-batch of the training loops uses it (train_online.py:127-141): ``(loss, grad)`` with ``grad`` already
+    multiplied by the upstream gradient ``grad_scale`` (1 / nAveGrad ...) and ``running += loss`` done on the device; hand ``grad`` to
+    ``torch.autograd.backward([output], [grad])``.  An extension next to the reference's function above, not a replacement."""
+    mode = 0 if size_average else (1 if batch_average else 2)
+    return cbce_step(output, label, mode, grad_scale, running)
 
 
 def center_crop(x, height, width):

@@ -9,7 +9,9 @@ import os
 import torch
 import torch.optim as optim
 
-from .layers.osvos_layers import class_balanced_cross_entropy_loss
+import numpy as np
+
+from .layers.osvos_layers import class_balanced_cross_entropy_loss, class_balanced_cross_entropy_loss_step
 from .parallel import GradientAllReducer
 
 
@@ -50,41 +52,86 @@ class TrainLoop(object):
     is kept on the device and only read back when the caller asks for it (the reference's
     ``loss.item()`` every iteration is a logging artefact that stalls the GPU)."""
 
-    def __init__(self, net, optimizer, mode='online', n_ave_grad=5, n_epochs=240, reducer=None, local_ave=None, loss_fn=None):
+    def __init__(self, net, optimizer, mode='online', n_ave_grad=5, n_epochs=240, reducer=None, local_ave=None, loss_fn=None,
+                 max_steps=None):
         """``n_ave_grad``: the loss divisor = micro-batches per optimizer step summed over ALL ranks (the reference's nAveGrad).
         ``local_ave``: micro-batches THIS rank contributes to a step (default: all of them); the step -- all-reduce, SGD update,
         one-memset zeroing of the flat gradient arena -- fires after that many local backwards.  The counter persists across
         epochs like the reference's ``aveGrad`` (train_parent.py:128,163-172).  ``loss_fn``: the class-balanced BCE (default: the
-        HIP kernel; the CPU tests of the data-parallel bookkeeping pass the oracle's)."""
+        HIP kernel; the CPU tests of the data-parallel bookkeeping pass the oracle's).  ``max_steps``: the number of COMPLETE
+        optimizer-step windows of the whole run (``StepSchedule.total_steps``): a rank whose share of the trailing partial window
+        happens to reach ``local_ave`` must not step (and must not enter a collective the other ranks never enter) -- like the
+        reference, whose ``aveGrad`` simply never reaches nAveGrad again, the tail's gradients are computed and dropped."""
         self.net, self.opt, self.mode = net, optimizer, mode
         self.n_ave_grad, self.n_epochs = n_ave_grad, n_epochs
         self.local_ave = int(local_ave) if local_ave else n_ave_grad
         self.loss_fn = loss_fn or class_balanced_cross_entropy_loss
+        # the HIP loss hands back (loss, scaled gradient) in one call and keeps the running loss on the device: no autograd scalar chain
+        # (ones / div / add / scale launches) between the loss kernel and the head's backward.  OSVOS_FUSED_LOSS_STEP=0: the plain chain.
+        self.fused_loss = loss_fn is None and os.environ.get("OSVOS_FUSED_LOSS_STEP", "1") != "0"
         self.reducer = reducer
+        self.max_steps = max_steps
         self.ave = 0
         self.steps = 0
         if hasattr(net, 'set_inplace_grad_accumulation'):
             net.set_inplace_grad_accumulation(True)      # every backward of this loop is loss.backward()
-        dev = next(net.parameters()).device
-        self.running = [torch.zeros((), device=dev) for _ in range(5 if mode == 'parent' else 1)]
+        self._dev = next(net.parameters()).device
+        self._nloss = 5 if mode == 'parent' else 1
+        self._running = {}                                # epoch -> [device scalars]: a step window may hold frames of two epochs
+        self.counts = {}                                  # epoch -> micro-batches this rank ran
+
+    def _acc(self, epoch):
+        r = self._running.get(epoch)
+        if r is None:
+            r = self._running[epoch] = [torch.zeros((), device=self._dev) for _ in range(self._nloss)]
+            self.counts[epoch] = 0
+        return r
 
     def micro_batch(self, inputs, gts, epoch=0):
         outputs = self.net.forward(inputs)
+        running = self._acc(epoch)
+        self.counts[epoch] += 1
+        if self.fused_loss and outputs[-1].is_cuda:
+            return self._micro_batch_fused(outputs, gts, running, epoch)
         if self.mode == 'online':
             loss = self.loss_fn(outputs[-1], gts, size_average=False)
-            self.running[0] += loss.detach()
+            running[0] += loss.detach()
         else:
             losses = [self.loss_fn(o, gts, size_average=False) for o in outputs]
-            for r, l in zip(self.running, losses):
+            for r, l in zip(running, losses):
                 r += l.detach()
             loss = (1 - epoch / self.n_epochs) * sum(losses[:-1]) + losses[-1]
         loss /= self.n_ave_grad
-        if self.reducer is not None and (self.ave + 1) % self.local_ave == 0:
+        will_step = (self.ave + 1) % self.local_ave == 0 and (self.max_steps is None or self.steps < self.max_steps)
+        if self.reducer is not None and will_step:
             self.reducer.arm()          # last micro-batch of the step: reduce each gradient group as soon as its backward is done
         loss.backward()
+        return loss, self._after_backward(will_step)
+
+    def _micro_batch_fused(self, outputs, gts, running, epoch):
+        """The same micro-batch with the upstream gradients of ``loss /= nAveGrad; loss.backward()`` (train_online.py:140-141;
+        train_parent.py:147,163-164: side heads weighted by 1 - epoch / nEpochs) folded into the loss kernel -- float32 products formed
+        the way autograd forms them (1 / nAveGrad, then times the float32 side weight)."""
+        inv = np.float32(1.0) / np.float32(self.n_ave_grad)
+        if self.mode == 'online':
+            heads, scales = [outputs[-1]], [inv]
+        else:
+            side = np.float32(inv * np.float32(1 - epoch / self.n_epochs))
+            heads, scales = list(outputs), [side] * (len(outputs) - 1) + [inv]
+        grads, loss = [], None
+        for o, s, r in zip(heads, scales, running):
+            loss, g = class_balanced_cross_entropy_loss_step(o, gts, size_average=False, grad_scale=float(s), running=r)
+            grads.append(g)
+        will_step = (self.ave + 1) % self.local_ave == 0 and (self.max_steps is None or self.steps < self.max_steps)
+        if self.reducer is not None and will_step:
+            self.reducer.arm()
+        torch.autograd.backward(heads, grads)
+        return loss, self._after_backward(will_step)       # (loss: the fused head's plain loss, not divided by nAveGrad)
+
+    def _after_backward(self, will_step):
         self.ave += 1
         stepped = False
-        if self.ave % self.local_ave == 0:
+        if will_step:
             if self.reducer is not None:
                 self.reducer.all_reduce()
             self.opt.step()
@@ -95,13 +142,53 @@ class TrainLoop(object):
             self.ave = 0
             self.steps += 1
             stepped = True
-        return loss, stepped
+        return stepped
 
-    def pop_running(self):
-        vals = [float(r.item()) for r in self.running]
-        for r in self.running:
-            r.zero_()
+    def pop_running(self, epoch=None):
+        """Running loss sums (host floats) of `epoch` (default: everything accumulated so far) and forget them."""
+        keys = list(self._running) if epoch is None else ([epoch] if epoch in self._running else [])
+        vals = [0.0] * self._nloss
+        for k in keys:
+            for i, r in enumerate(self._running.pop(k)):
+                vals[i] += float(r.item())
         return vals
+
+    def pop_count(self, epoch):
+        return self.counts.pop(epoch, 0)
+
+
+class StepSchedule(object):
+    """Where the optimizer steps of a run fall in the global micro-batch stream, and with them the only places at which every rank
+    of a data-parallel run is known to stand at the same point of its collective sequence.
+
+    The stream g = first_epoch * n_items, ... is cut into windows of nAveGrad iterations ACROSS epoch boundaries (the reference's
+    ``aveGrad`` counter persists: train_parent.py:128,163-172); window k ends with the k-th gradient all-reduce.  2079 DAVIS frames
+    and nAveGrad 10 never line up, so anything exchanged "at the end of an epoch" would be entered by the ranks at different
+    positions between two gradient collectives (round-2 deadlock).  Per-epoch statistics are therefore exchanged right after the
+    gradient collective of the window that holds the epoch's LAST iteration (``closing_step``) -- every rank has finished its share
+    of the epoch by then -- and epochs that end in the trailing partial window are exchanged after the last epoch."""
+
+    def __init__(self, n_items, n_ave_grad, first_epoch, n_epochs):
+        self.n_items, self.n_ave_grad = int(n_items), int(n_ave_grad)
+        self.first_epoch, self.n_epochs = int(first_epoch), int(n_epochs)
+        self.total_iterations = max(0, self.n_epochs - self.first_epoch) * self.n_items
+        self.total_steps = self.total_iterations // self.n_ave_grad          # complete windows: what EVERY rank steps, no more
+
+    def closing_step(self, epoch):
+        """Index of the optimizer step whose window holds the last iteration of `epoch`; None when that is the trailing partial
+        window (no step, no gradient collective: such epochs are closed after the training loop)."""
+        last = (epoch + 1 - self.first_epoch) * self.n_items - 1
+        k = last // self.n_ave_grad
+        return k if k < self.total_steps else None
+
+    def closed_by(self, steps_done, pending):
+        """The epochs of `pending` (ascending) whose statistics may be exchanged once `steps_done` optimizer steps are complete."""
+        out = []
+        for e in pending:
+            k = self.closing_step(e)
+            if k is not None and k < steps_done:
+                out.append(e)
+        return out
 
 
 def check_world_divides(n_ave_grad, world):

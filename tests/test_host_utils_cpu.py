@@ -58,3 +58,18 @@ def test_fused_sgd_argument_checks_and_cpu_refusal():
     with pytest.raises(RuntimeError):
         o.step()                               # CPU parameter: refused, no fallback
     assert torch.equal(p[0].detach(), torch.zeros(3))
+
+
+def test_bench_gpus_n_stands_up_its_own_ranks_or_says_why_not():
+    """`python bench.py --gpus N` with no launcher around it re-executes itself under torch.distributed.run with N ranks (VERDICT r02:
+    --gpus used to be parsed and ignored).  On a box with fewer GPUs it must refuse with a clear message instead of reporting n_gpus 1."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("multi-GPU box: the real launch is the driver's scaling run")
+    out = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 2 and "--gpus 2: this node shows" in out.stderr, (out.returncode, out.stderr[-400:])

@@ -149,3 +149,68 @@ def test_davis_frame_lists_follow_the_reference_and_prefetcher_needs_cuda(tmp_pa
     assert one_te[1][1] is None and one_te.fname(2) == os.path.join("bear", "00002")
     with pytest.raises(RuntimeError, match="CUDA"):
         DevicePrefetcher(ArrayFrames([(img, lab)]), [0], "cpu")
+
+
+def test_step_schedule_closes_every_epoch_once_and_in_collective_order():
+    """The round-2 deadlock, as arithmetic: with 2079 frames and nAveGrad 10 no epoch ends on a step boundary.  Simulate the collective
+    sequence every rank would issue (gradient all-reduce per complete window, statistics all-reduce per closed epoch) for W in {1,2,5,10}
+    and for a run whose tail window is partial: all ranks must issue the SAME sequence."""
+    from osvos_pytorch_amd.train_common import StepSchedule, check_world_divides, epoch_plan
+    for (n_items, n_ave, epochs, first) in [(2079, 10, 3, 0), (7, 4, 2, 0), (13, 10, 3, 1), (20, 10, 2, 0)]:
+        sched = StepSchedule(n_items, n_ave, first, epochs)
+        assert sched.total_steps == ((epochs - first) * n_items) // n_ave
+        seqs = []
+        for world in [w for w in (1, 2, 5, 10) if n_ave % w == 0]:
+            local_ave = check_world_divides(n_ave, world)
+            for rank in range(world):
+                seq, ave, steps, pending = [], 0, 0, []
+                for epoch in range(first, epochs):
+                    pending.append(epoch)
+                    for _ in epoch_plan(n_items, epoch, n_ave, rank, world, seed=3):
+                        ave += 1
+                        if ave % local_ave == 0 and steps < sched.total_steps:      # TrainLoop.micro_batch's rule
+                            ave, steps = 0, steps + 1
+                            seq.append(("grad", steps - 1))
+                            for e in sched.closed_by(steps, pending):
+                                pending.remove(e)
+                                seq.append(("stats", e))
+                for e in list(pending):
+                    seq.append(("stats", e))
+                assert steps == sched.total_steps, (n_items, world, rank)
+                seqs.append(seq)
+        assert all(s == seqs[0] for s in seqs), (n_items, n_ave)
+        assert [e for kind, e in seqs[0] if kind == "stats"] == list(range(first, epochs))          # every epoch once, in order
+
+
+def _main_worker(rank, world, port, out, argv):
+    sys.path.insert(0, REPO)
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_RANK": str(rank)})
+    os.environ["OSVOS_SAVE_ROOT"] = os.path.dirname(out)
+    torch.set_num_threads(2)
+    import train_parent
+    from oracle import torch_ref
+    net, loop = train_parent.main(argv, build_net=lambda: _cpu_net(seed=1), loss_fn=torch_ref.cbce_loss)
+    torch.save({"steps": loop.steps, "sd": {k: v.detach().clone() for k, v in net.state_dict().items()}}, out + ".%d" % rank)
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
+def test_train_parent_main_two_ranks_over_epoch_boundaries(tmp_path):
+    """train_parent.main() itself on two gloo ranks (network forward and loss swapped for the CPU oracle): 7 frames, nAveGrad 4, 3 epochs =
+    21 iterations = 5 complete windows + 1 left over; no epoch ends on a step boundary, and rank 0 owns the whole tail.  Both ranks must
+    come back (round 2: the per-epoch statistics all-reduce paired with the other rank's gradient all-reduce), take the same number
+    of steps, hold identical weights, and match the single-process run of the same script."""
+    sys.path.insert(0, REPO)
+    argv = ["--synthetic", "7", "--epochs", "3", "--n-ave-grad", "4", "--height", "24", "--width", "32", "--seed", "7", "--lr", "1e-6"]
+    out = str(tmp_path / "main")
+    port = 31700 + (os.getpid() % 2000)
+    mp.spawn(_main_worker, args=(2, port, out, argv), nprocs=2, join=True)
+    r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
+    mp.spawn(_main_worker, args=(1, port + 1, out + "_single", argv), nprocs=1, join=True)
+    single = torch.load(out + "_single.0")
+    assert r0["steps"] == r1["steps"] == single["steps"] == 5
+    for k in single["sd"]:
+        assert torch.equal(r0["sd"][k], r1["sd"][k]), k
+        torch.testing.assert_close(r0["sd"][k], single["sd"][k], rtol=2e-5, atol=1e-7, msg=k)
+    init = _cpu_net(seed=1).state_dict()
+    assert any(not torch.equal(single["sd"][k], init[k]) for k in single["sd"] if k.startswith("stages."))

@@ -32,7 +32,7 @@ import torch
 
 import networks.vgg_osvos as vo
 from mypath import Path
-from osvos_pytorch_amd.train_common import TrainLoop, check_world_divides, epoch_plan, init_distributed, make_reducer, make_sgd
+from osvos_pytorch_amd.train_common import StepSchedule, TrainLoop, check_world_divides, epoch_plan, init_distributed, make_reducer, make_sgd
 
 
 def synthetic_dataset(n, h, w):
@@ -91,7 +91,9 @@ def epoch_samples(args, trainset, plan, device, augment):
             yield s
 
 
-def main():
+def main(argv=None, build_net=None, loss_fn=None):
+    """``argv`` / ``build_net`` / ``loss_fn``: the CPU tests of the data-parallel bookkeeping run THIS function on two gloo ranks with
+    the network's forward and the loss swapped for the oracle's (tests/test_train_plan_cpu.py); the script passes none of them."""
     ap = argparse.ArgumentParser()
     ap.add_argument('--synthetic', type=int, default=0, help='N > 0: train on N seeded synthetic frames instead of DAVIS')
     ap.add_argument('--epochs', type=int, default=240)
@@ -104,7 +106,8 @@ def main():
                     help='input pipeline on the GPU: Pillow decode -> pinned uint8 -> osvos_augment_frame (flip, scale+rotate, mean, CHW)')
     ap.add_argument('--prefetch', type=int, default=3, help='--device-augment: frames decoded / copied ahead of the training step')
     ap.add_argument('--precision', default=os.environ.get('OSVOS_PRECISION', 'fp32x3'), choices=['fp32', 'fp32x3', 'bf16'])
-    args = ap.parse_args()
+    ap.add_argument('--lr', type=float, default=1e-8, help='base learning rate of the SGD groups (train_parent.py:83)')
+    args = ap.parse_args(argv)
 
     rank, world, device = init_distributed()
     nEpochs, nAveGrad, resume_epoch = args.epochs, args.n_ave_grad, args.resume_epoch
@@ -114,7 +117,9 @@ def main():
     os.makedirs(save_dir, exist_ok=True)
     modelName = 'parent'
 
-    if resume_epoch == 0:
+    if build_net is not None:
+        net = build_net()
+    elif resume_epoch == 0:
         have_caffe = os.path.exists(os.path.join(Path.models_dir(), 'vgg_caffe.mat'))
         have_pt = os.path.exists(os.path.join(Path.models_dir(), 'vgg_pytorch.pth'))
         net = vo.OSVOS(pretrained=2 if have_caffe else (1 if have_pt else 0))
@@ -124,12 +129,14 @@ def main():
         print("Updating weights from: {}".format(ckpt))
         net.load_state_dict(torch.load(ckpt, map_location=lambda storage, loc: storage))
     net.to(device)
-    net.set_precision(args.precision)
-    optimizer = make_sgd(net, 'parent')
+    if build_net is None:
+        net.set_precision(args.precision)
+    optimizer = make_sgd(net, 'parent', lr=args.lr, fused=None if device.type == 'cuda' else False)
     reducer = make_reducer(net, world, average=False)
     if reducer is not None:
         reducer.broadcast_parameters(0)
-        net.invalidate_packed_weights()      # broadcast writes through .data: the packed-weight cache cannot see it
+        if hasattr(net, 'invalidate_packed_weights'):
+            net.invalidate_packed_weights()  # broadcast writes through .data: the packed-weight cache cannot see it
     augment = None
     if args.device_augment:
         import random
@@ -143,33 +150,45 @@ def main():
         trainset, testset = synthetic_dataset(args.synthetic, args.height, args.width), synthetic_dataset(2, args.height, args.width)
     else:
         trainset, testset = davis_datasets(Path.db_root_dir())
-    # loss divisor = the global nAveGrad (sum over all ranks); this rank contributes nAveGrad / world micro-batches per step
-    loop = TrainLoop(net, optimizer, mode='parent', n_ave_grad=nAveGrad, n_epochs=nEpochs, reducer=reducer, local_ave=local_ave)
+    # loss divisor = the global nAveGrad (sum over all ranks); this rank contributes nAveGrad / world micro-batches per step.
+    # Optimizer steps straddle epoch boundaries (2079 frames, nAveGrad 10), so "the end of an epoch" is NOT a point at which the ranks
+    # stand at the same place of their collective sequence: the schedule says after which gradient all-reduce an epoch's statistics
+    # may be exchanged, and how many complete step windows the run has (no rank steps on the trailing partial one).
+    sched = StepSchedule(len(trainset), nAveGrad, resume_epoch, nEpochs)
+    loop = TrainLoop(net, optimizer, mode='parent', n_ave_grad=nAveGrad, n_epochs=nEpochs, reducer=reducer, local_ave=local_ave,
+                     loss_fn=loss_fn, max_steps=sched.total_steps)
+    pending, started = [], {}          # epochs whose frames this rank has finished but whose statistics are not exchanged yet
+
+    def close_epochs(epochs):
+        """Exchange + print the statistics of `epochs`: called by every rank right after the same gradient collective (or after the
+        last epoch), so the small all-reduce below can never pair with another rank's gradient all-reduce."""
+        for e in epochs:
+            pending.remove(e)
+            running, count = loop.pop_running(e), loop.pop_count(e)
+            if reducer is not None:
+                import torch.distributed as dist
+                t = torch.tensor(running + [float(count)], device=device, dtype=torch.float64)
+                dist.all_reduce(t)
+                running, count = t[:-1].tolist(), int(t[-1].item())
+            if rank == 0:
+                print('[Epoch: %d, numImages: %5d]' % (e, count))
+                for l, v in enumerate(running):
+                    print('Loss %d: %f' % (l, v / max(1, count)))
+                print("Execution time: " + str(timeit.default_timer() - started[e]))
+
     print("Training Network")
     for epoch in range(resume_epoch, nEpochs):
-        start_time = timeit.default_timer()
+        started[epoch] = timeit.default_timer()
+        pending.append(epoch)          # (before its first frame: the window that closes the PREVIOUS epoch may end inside this one)
         # one permutation per epoch, the same on every rank; rank r runs the iterations g = r (mod world) of the global stream
         plan = epoch_plan(len(trainset), epoch, nAveGrad, rank, world, seed=args.seed)
-        count = 0
         for sample in epoch_samples(args, trainset, plan, device, augment):
             inputs, gts = sample['image'], sample['gt']
             inputs.requires_grad_()                         # train_parent.py:136: the input gradient is computed
             inputs, gts = inputs.to(device), gts.to(device)
-            loop.micro_batch(inputs, gts, epoch=epoch)      # forward, 5 losses, /= nAveGrad, backward, step every local_ave
-            count += 1
-        running = loop.pop_running()
-        if reducer is not None:                             # epoch statistics over ALL ranks' frames (one tiny collective per epoch)
-            import torch.distributed as dist
-            t = torch.tensor(running + [float(count)], device=device, dtype=torch.float64)
-            dist.all_reduce(t)
-            running, count_all = t[:-1].tolist(), int(t[-1].item())
-        else:
-            count_all = count
-        if rank == 0:
-            print('[Epoch: %d, numImages: %5d]' % (epoch, count_all))
-            for l, v in enumerate(running):
-                print('Loss %d: %f' % (l, v / max(1, count_all)))
-            print("Execution time: " + str(timeit.default_timer() - start_time))
+            _, stepped = loop.micro_batch(inputs, gts, epoch=epoch)      # forward, 5 losses, /= nAveGrad, backward, step every local_ave
+            if stepped:
+                close_epochs(sched.closed_by(loop.steps, pending))      # right after the SAME gradient collective on every rank
         if (epoch % snapshot) == snapshot - 1 and epoch != 0 and rank == 0:
             torch.save(net.state_dict(), os.path.join(save_dir, modelName + '_epoch-' + str(epoch) + '.pth'))
         if testset is not None and epoch % nTestInterval == (nTestInterval - 1):
@@ -183,9 +202,12 @@ def main():
                 if rank == 0:
                     for l, v in enumerate(tot):
                         print('***Testing *** Loss %d: %f' % (l, v / max(1, len(testset))))
+    close_epochs(list(pending))        # epochs that end in the trailing partial window: every rank has left the loop, same order everywhere
     if rank == 0:
         print("optimizer steps taken: %d" % loop.steps)
+    return net, loop
 
 
 if __name__ == '__main__':
-    sys.exit(main())
+    main()
+    sys.exit(0)
