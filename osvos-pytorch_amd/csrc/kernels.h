@@ -21,6 +21,18 @@ bool osvos_wgrad_f32x3_applicable(int Cin, int Cin_s, int Cout, int Cout_s);
 size_t osvos_wgrad_f32x3_ws_bytes(int N, int H, int W, int Cin_s, int Cout);
 int osvos_conv3x3_wgrad_f32x3(const float* x, const float* dy, void* ws, float* dw, float* db,
                               int N, int H, int W, int Cin, int Cin_s, int Cout, int Cout_s, int accumulate, hipStream_t stream);
+int osvos_conv3x3_wgrad_p3(const void* x3, const void* dy3, void* ws, float* dw, float* db,
+                           int N, int H, int W, int Cin, int Cin_s, int Cout, int Cout_s, int accumulate, hipStream_t stream);
+// P3 storage of the f32x3 network (p3.h): conv3x3_p3.hip, p3_ops.hip
+bool osvos_conv3x3_p3_applicable(int Cin, int Cout, int y_cs, int y3_cs);
+int osvos_conv3x3_p3_num_tiles(void);
+size_t osvos_conv3x3_p3_splitk_ws_bytes(int N, int H, int W, int Cout);
+int osvos_conv3x3_p3(const void* x3, const void* wpk3, const float* bias, const void* mask, int mask_p3, int mask_cs, float* y, int y_cs,
+                     void* y3, int y3_cs, int N, int H, int W, int Cin, int Cout, int relu, int tile, int ksplit, void* part_ws, hipStream_t stream);
+int osvos_f32_to_p3(const float* src, void* dst3, int N, int H, int W, int C, int cs, int cd, hipStream_t stream);
+int osvos_p3_to_f32(const void* src3, float* dst, int N, int H, int W, int C, hipStream_t stream);
+int osvos_maxpool2x2_p3(const float* x, float* y, void* y3, int N, int H, int W, int C, hipStream_t stream);
+int osvos_maxpool2x2_bwd_p3(const float* x, const float* dy, const float* dside, float* dx, void* dx3, int N, int H, int W, int C, hipStream_t stream);
 size_t osvos_wpack_x3_bytes(int M, int K);
 int osvos_pack_x3(const float* w, void* wpk3, int Cout, int Cin, int dgrad, hipStream_t stream);
 int osvos_conv3x3_f32x3_ps(const float* x, const float* wpk, const void* wpk3, const float* bias, const float* mask, float* y,

@@ -15,8 +15,13 @@
 //   * per (k-step, tap row): 3 tap columns x 3 pieces of X gathered (18 reads) -> 18 MFMAs; fragment sets double buffered
 //   * the next patch's fp32 pieces are loaded from INSIDE the k-loop (one item per stage) and split / written after the barrier
 //   * deterministic: fixed patch -> split assignment, fp32 slabs [split][tap][co][ci] + the shared slab reduce (wgrad_f32.hip)
+//
+// P3IN = 1 (the P3 storage mode of the network, p3.h): x and dy arrive as their three bf16 piece planes, formed once by the producers'
+// epilogues -- staging is three 16-byte loads and three 16-byte LDS writes per item, no conversion or subtraction between the barriers
+// (the fp32 form spends 44 VALU operations per 8 values there, with the matrix pipe of its one-wave-per-SIMD workgroup idle).
 #include "common.h"
 #include "kernels.h"
+#include "p3.h"
 
 namespace {
 
@@ -51,8 +56,8 @@ struct G3 {
 };
 
 struct W3Args {
-  const float* x;
-  const float* dy;
+  const void* x;       // fp32 NHWC, or (P3IN) P3 [N][3][H][W][Cin_s]
+  const void* dy;      // fp32 NHWC, or (P3IN) P3 [N][3][H][W][Cout_s]
   float* slab;
   float* bslab;
   int N, H, W, Cin_s, Cout, Cout_s;
@@ -86,7 +91,7 @@ __device__ inline void split8w(const u32x4& lo, const u32x4& hi, u32x4& p0, u32x
   p2 = u32x4{q2[0], q2[1], q2[2], q2[3]};
 }
 
-template <int PH, int WAVES>
+template <int PH, int WAVES, int P3IN>
 __global__ __launch_bounds__(64 * WAVES) void wgrad_f32x3_kernel(W3Args a) {
   using G = G3<PH, WAVES>;
   constexpr int NT = G::NT, BCO = G::BCO;
@@ -110,10 +115,14 @@ __global__ __launch_bounds__(64 * WAVES) void wgrad_f32x3_kernel(W3Args a) {
   const int doct = tid % G::DOCT, dpg = tid / G::DOCT;      // dY: BCO / 8 octets per pixel
   const int xoct = tid & 7, xpg = tid >> 3;                 // X: 8 octets per pixel
   const bool dy_ch_ok = co0 + 8 * doct < a.Cout, x_ch_ok = ci0 + 8 * xoct < a.Cin_s;
-  u32x4 rdy[G::NDY][2], rx[G::NX][2];
+  constexpr int NR = P3IN ? 3 : 2, ES = P3IN ? 2 : 4;        // registers per staged item (P3: one per piece), element size in HBM
+  u32x4 rdy[G::NDY][NR], rx[G::NX][NR];
   float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const bool want_bias = a.bslab != nullptr && cit == 0;
-  const int img_dy_bytes = a.H * a.W * a.Cout_s * 4, img_x_bytes = a.H * a.W * a.Cin_s * 4;
+  // P3: the image's three planes sit in ONE buffer range, so a row outside the image must be pushed out explicitly (it would alias
+  // the neighbouring plane); the fp32 form lets such rows fall out of the per-image range by themselves
+  const unsigned dy_plane = (unsigned)a.H * a.W * a.Cout_s * 2u, x_plane = (unsigned)a.H * a.W * a.Cin_s * 2u;
+  const int img_dy_bytes = P3IN ? (int)(3u * dy_plane) : a.H * a.W * a.Cout_s * 4, img_x_bytes = P3IN ? (int)(3u * x_plane) : a.H * a.W * a.Cin_s * 4;
 
   struct Patch { __amdgpu_buffer_rsrc_t drs, xrs; int x0, y0; };
   auto locate = [&](int p, bool live) -> Patch {
@@ -133,29 +142,50 @@ __global__ __launch_bounds__(64 * WAVES) void wgrad_f32x3_kernel(W3Args a) {
   auto issue = [&](const Patch& q, int it) {      // it: compile-time item index (dY items first)
     if (it < G::NDY) {
       const int p = dpg + G::DPG * it, py = p / PW, pxx = p - py * PW;
-      const bool ok = dy_ch_ok && (G::DY_ITEMS % NT == 0 || p < G::PPIX) && q.x0 + pxx < a.W;
-      const unsigned off = ok ? (unsigned)((((q.y0 + py) * a.W + q.x0 + pxx) * a.Cout_s + co0 + 8 * doct) * 4) : OOB;
-      rdy[it][0] = __builtin_amdgcn_raw_buffer_load_b128(q.drs, off, 0, 0);
-      rdy[it][1] = __builtin_amdgcn_raw_buffer_load_b128(q.drs, off + 16u, 0, 0);
+      const bool ok = dy_ch_ok && (G::DY_ITEMS % NT == 0 || p < G::PPIX) && q.x0 + pxx < a.W && (!P3IN || q.y0 + py < a.H);
+      const unsigned off = ok ? (unsigned)((((q.y0 + py) * a.W + q.x0 + pxx) * a.Cout_s + co0 + 8 * doct) * ES) : OOB;
+      if constexpr (P3IN != 0) {
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) rdy[it][pc] = __builtin_amdgcn_raw_buffer_load_b128(q.drs, ok ? off + pc * dy_plane : OOB, 0, 0);
+      } else {
+        rdy[it][0] = __builtin_amdgcn_raw_buffer_load_b128(q.drs, off, 0, 0);
+        rdy[it][1] = __builtin_amdgcn_raw_buffer_load_b128(q.drs, off + 16u, 0, 0);
+      }
     } else if (it < G::NIT) {
       const int j = it - G::NDY;
       const int hp = xpg + G::XPG * j, hy = hp / G::HW_, hx = hp - hy * G::HW_;
-      const bool ok = x_ch_ok && hp < G::XPIX && (unsigned)(q.x0 - 1 + hx) < (unsigned)a.W;
-      const unsigned off = ok ? (unsigned)((((q.y0 - 1 + hy) * a.W + q.x0 - 1 + hx) * a.Cin_s + ci0 + 8 * xoct) * 4) : OOB;
-      rx[j][0] = __builtin_amdgcn_raw_buffer_load_b128(q.xrs, off, 0, 0);
-      rx[j][1] = __builtin_amdgcn_raw_buffer_load_b128(q.xrs, off + 16u, 0, 0);
+      const bool ok = x_ch_ok && hp < G::XPIX && (unsigned)(q.x0 - 1 + hx) < (unsigned)a.W && (!P3IN || (unsigned)(q.y0 - 1 + hy) < (unsigned)a.H);
+      const unsigned off = ok ? (unsigned)((((q.y0 - 1 + hy) * a.W + q.x0 - 1 + hx) * a.Cin_s + ci0 + 8 * xoct) * ES) : OOB;
+      if constexpr (P3IN != 0) {
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) rx[j][pc] = __builtin_amdgcn_raw_buffer_load_b128(q.xrs, ok ? off + pc * x_plane : OOB, 0, 0);
+      } else {
+        rx[j][0] = __builtin_amdgcn_raw_buffer_load_b128(q.xrs, off, 0, 0);
+        rx[j][1] = __builtin_amdgcn_raw_buffer_load_b128(q.xrs, off + 16u, 0, 0);
+      }
     }
   };
   auto store_patch = [&]() {
 #pragma unroll
     for (int i = 0; i < G::NDY; ++i) {
-      if (want_bias) {                              // bias gradient: exact fp32 column sums of dY (zeros outside the image)
-        const f32x4 lo = __builtin_bit_cast(f32x4, rdy[i][0]), hi = __builtin_bit_cast(f32x4, rdy[i][1]);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) { bsum[c] += lo[c]; bsum[4 + c] += hi[c]; }
-      }
       u32x4 p0, p1, p2;
-      split8w(rdy[i][0], rdy[i][1], p0, p1, p2);
+      if constexpr (P3IN != 0) {
+        p0 = rdy[i][0]; p1 = rdy[i][1]; p2 = rdy[i][2];
+        if (want_bias) {                            // bias gradient: exact fp32 column sums of dY = hi + mid + lo (zeros outside the image)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            bsum[2 * c] += p3_join((unsigned short)(p0[c] & 0xffffu), (unsigned short)(p1[c] & 0xffffu), (unsigned short)(p2[c] & 0xffffu));
+            bsum[2 * c + 1] += p3_join((unsigned short)(p0[c] >> 16), (unsigned short)(p1[c] >> 16), (unsigned short)(p2[c] >> 16));
+          }
+        }
+      } else {
+        if (want_bias) {                            // bias gradient: exact fp32 column sums of dY (zeros outside the image)
+          const f32x4 lo = __builtin_bit_cast(f32x4, rdy[i][0]), hi = __builtin_bit_cast(f32x4, rdy[i][1]);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) { bsum[c] += lo[c]; bsum[4 + c] += hi[c]; }
+        }
+        split8w(rdy[i][0], rdy[i][1], p0, p1, p2);
+      }
       const int p = dpg + G::DPG * i;
       if (G::DY_ITEMS % NT == 0 || p < G::PPIX) {
         char* d = dYs + p * G::DYP + doct * 16;
@@ -167,7 +197,11 @@ __global__ __launch_bounds__(64 * WAVES) void wgrad_f32x3_kernel(W3Args a) {
 #pragma unroll
     for (int j = 0; j < G::NX; ++j) {
       u32x4 p0, p1, p2;
-      split8w(rx[j][0], rx[j][1], p0, p1, p2);
+      if constexpr (P3IN != 0) {
+        p0 = rx[j][0]; p1 = rx[j][1]; p2 = rx[j][2];
+      } else {
+        split8w(rx[j][0], rx[j][1], p0, p1, p2);
+      }
       const int hp = xpg + G::XPG * j;
       if (G::X_ITEMS % NT == 0 || hp < G::XPIX) {
         char* d = Xs + hp * G::XP + xoct * 16;
@@ -313,17 +347,17 @@ W3Plan make_plan3(int N, int H, int W, int Cin_s, int Cout) {
   return p;
 }
 
-template <int PH, int WAVES>
+template <int PH, int WAVES, int P3IN>
 int launch3(const W3Args& a, long blocks, hipStream_t stream) {
   static bool attr_set_dev[OSVOS_MAX_DEVICES] = {};
   bool& attr_set = attr_set_dev[osvos_current_device()];
   if (!attr_set) {
-    OSVOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_f32x3_kernel<PH, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    OSVOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_f32x3_kernel<PH, WAVES, P3IN>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)G3<PH, WAVES>::LDS));
     attr_set = true;
   }
   constexpr size_t lds = G3<PH, WAVES>::LDS;
-  hipLaunchKernelGGL((wgrad_f32x3_kernel<PH, WAVES>), dim3((unsigned)blocks), dim3(64 * WAVES), lds, stream, a);
+  hipLaunchKernelGGL((wgrad_f32x3_kernel<PH, WAVES, P3IN>), dim3((unsigned)blocks), dim3(64 * WAVES), lds, stream, a);
   OSVOS_LAUNCH_CHECK();
   return 0;
 }
@@ -347,12 +381,14 @@ size_t osvos_wgrad_f32x3_ws_bytes(int N, int H, int W, int Cin_s, int Cout) {
   return align_up(((size_t)worst * 9 * Cout * Cin_s + worst * Cout) * sizeof(float), 256);
 }
 
-int osvos_conv3x3_wgrad_f32x3(const float* x, const float* dy, void* ws, float* dw, float* db,
-                              int N, int H, int W, int Cin, int Cin_s, int Cout, int Cout_s, int accumulate, hipStream_t stream) {
+namespace {
+int wgrad3_run(const void* x, const void* dy, int p3in, void* ws, float* dw, float* db,
+               int N, int H, int W, int Cin, int Cin_s, int Cout, int Cout_s, int accumulate, hipStream_t stream) {
   OSVOS_ARG_CHECK(x && dy && ws && dw, "wgrad f32x3: null pointer");
   OSVOS_ARG_CHECK(N > 0 && H > 0 && W > 0, "wgrad f32x3: bad shape");
-  OSVOS_ARG_CHECK(osvos_wgrad_f32x3_applicable(Cin, Cin_s, Cout, Cout_s), "wgrad f32x3: unsupported shape (Cin %d/%d Cout %d/%d)", Cin, Cin_s, Cout, Cout_s);
-  OSVOS_ARG_CHECK((long)H * W * Cin_s < (1L << 29) && (long)H * W * Cout_s < (1L << 29), "wgrad f32x3: image too large for 31-bit byte offsets");
+  OSVOS_ARG_CHECK(osvos_wgrad_f32x3_applicable(Cin, Cin_s, Cout, Cout_s) && (!p3in || Cout_s % 8 == 0),
+                  "wgrad f32x3: unsupported shape (Cin %d/%d Cout %d/%d)", Cin, Cin_s, Cout, Cout_s);
+  OSVOS_ARG_CHECK((long)H * W * Cin_s < (1L << 28) && (long)H * W * Cout_s < (1L << 28), "wgrad f32x3: image too large for 31-bit byte offsets");
   const W3Plan p = make_plan3(N, H, W, Cin_s, Cout);
   W3Args a;
   a.x = x; a.dy = dy;
@@ -365,9 +401,25 @@ int osvos_conv3x3_wgrad_f32x3(const float* x, const float* dy, void* ws, float* 
   a.map = (map_env == 1 && blocks % 8 == 0) ? 1 : 0;
   const int phase = osvos_wgrad_phase();
   if (phase != 2) {
-    const int rc = p.waves == 8 ? launch3<4, 8>(a, blocks, stream) : (p.ph == 6 ? launch3<6, 4>(a, blocks, stream) : launch3<4, 4>(a, blocks, stream));
+    int rc;
+    if (p3in)
+      rc = p.waves == 8 ? launch3<4, 8, 1>(a, blocks, stream) : (p.ph == 6 ? launch3<6, 4, 1>(a, blocks, stream) : launch3<4, 4, 1>(a, blocks, stream));
+    else
+      rc = p.waves == 8 ? launch3<4, 8, 0>(a, blocks, stream) : (p.ph == 6 ? launch3<6, 4, 0>(a, blocks, stream) : launch3<4, 4, 0>(a, blocks, stream));
     if (rc) return rc;
   }
   if (phase == 1) return 0;
   return osvos_wgrad_reduce_launch(a.slab, a.bslab, dw, db, p.nsplit, Cout, Cin, Cin_s, accumulate, stream);
+}
+}  // namespace
+
+int osvos_conv3x3_wgrad_f32x3(const float* x, const float* dy, void* ws, float* dw, float* db,
+                              int N, int H, int W, int Cin, int Cin_s, int Cout, int Cout_s, int accumulate, hipStream_t stream) {
+  return wgrad3_run(x, dy, 0, ws, dw, db, N, H, W, Cin, Cin_s, Cout, Cout_s, accumulate, stream);
+}
+
+// x3 / dy3: P3 tensors [N][3][H][W][Cin_s] / [N][3][H][W][Cout_s]; same workspace, slabs and reduce as the fp32 form
+int osvos_conv3x3_wgrad_p3(const void* x3, const void* dy3, void* ws, float* dw, float* db,
+                           int N, int H, int W, int Cin, int Cin_s, int Cout, int Cout_s, int accumulate, hipStream_t stream) {
+  return wgrad3_run(x3, dy3, 1, ws, dw, db, N, H, W, Cin, Cin_s, Cout, Cout_s, accumulate, stream);
 }
