@@ -45,6 +45,23 @@ def test_oracle_invariants_identity_flip_and_integer_shift():
     assert abs(float(c.sum()) - 1.0) < 1e-6 and abs(float(c[0]) + 0.09375) < 1e-6          # A = -0.75 half-sample taps
 
 
+def test_restatement_matches_the_cv2_goldens():
+    """oracle/augment_ref.py against the REAL reference chain (cv2.flip / cv2.getRotationMatrix2D / cv2.warpAffine through the reference's
+    own transform classes), as recorded by tools/make_cv2_goldens.py on a box that has OpenCV.  Until that file is committed the
+    restatement -- and with it rows f1 of SURVEY 8f -- stays "parity unpinned"."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "augment_cv2.npz")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/augment_cv2.npz absent: OpenCV is not installed here; run `python tools/make_cv2_goldens.py --reference "
+                    "<OSVOS-PyTorch checkout>` where cv2 is available and commit the file")
+    g = np.load(path)
+    for ci, (h, w, flip, rot, sc, soft) in enumerate(g["cases"]):
+        h, w = int(h), int(w)
+        img, lab = _frame(h, w, 7 + h, bool(soft))
+        ei, eg = A.augment(img, lab, bool(flip), None if np.isnan(rot) else float(rot), None if np.isnan(sc) else float(sc))
+        assert np.array_equal(ei, g["image%d" % ci]), (ci, np.abs(ei - g["image%d" % ci]).max())
+        assert np.array_equal(eg, g["gt%d" % ci]), ci
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", [(13, 17, False, None, None, False), (13, 17, True, None, None, False), (24, 31, False, 0.0, 1.0, False),
                                   (24, 31, True, 17.0, 1.1, False), (33, 40, False, -29.5, 0.77, False), (20, 27, True, 8.25, 1.24, True),

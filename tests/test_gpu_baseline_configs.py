@@ -34,14 +34,16 @@ def _oracle_forward(wts, x, dtype):
         return [o.double().numpy() for o in torch_ref.forward(p, torch.from_numpy(x).to(dtype))]
 
 
-def test_1080p_forward_fp32_against_cpu_oracle_and_batch4_graph():
+@pytest.mark.parametrize("precision", ["fp32", "fp32x3"])
+def test_1080p_forward_fp32_against_cpu_oracle_and_batch4_graph(precision):
+    """both fp32 arithmetics: the exact fp32 MFMA kernels (the 95 frames/s configs[4] line) and f32x3 (the module default)"""
     from oracle import synth
     n, h, w = 4, 1080, 1920
     x = synth.make_frame(n, h, w, seed=41)
     wts = synth.calibrate_heads(synth.make_weights(1), synth.torch_forward_fn(), x[:1])
     truth = _oracle_forward(wts, x[:1], torch.float64)          # frame 0: float64 ground truth
     ref = _oracle_forward(wts, x[:1], torch.float32)            # frame 0: the reference CPU path
-    net = build_net(wts)
+    net = build_net(wts, precision)
     xs = torch.from_numpy(x).cuda()
     with torch.no_grad():
         single = [[o.clone() for o in net.forward(xs[i:i + 1])] for i in range(n)]
@@ -191,3 +193,56 @@ def test_fp32_parent_854x480_batch12_equals_single_frames():
             l = cbce(batch[i], gt, size_average=False).item()
             r = torch_ref.cbce_loss(batch[i].cpu(), torch.from_numpy(m), size_average=False).item()
             assert abs(l - r) <= LOSS_RTOL * abs(r), (i, l, r)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp32x3"])
+def test_online_trajectory_854x480_two_optimizer_steps_against_float64(precision):
+    """SURVEY section 4 (iii) at the BASELINE size: 2 x nAveGrad micro-batches of the online fine-tune loop (train_online.py:112-149 --
+    fused-head loss, loss /= 5, backward, SGD step with the 8 parameter groups every 5th) through the scripts' own TrainLoop (fused loss
+    step, in-place gradient accumulation, FusedSGD), against the same loop on the torch-CPU oracle in float64.  Frames alternate between
+    two seeds so that both steps see different data.  Bars: every loss to 1e-5 relative; the parameter CHANGE of the two steps per tensor
+    within 3e-3 rel-L2 of the float64 trajectory (the bar of the golden SGD test; the float32 CPU reference itself sits at ~1e-3 on the
+    stage-0 tensors, test_gpu_net.py) -- a drifting accumulation, a lost micro-batch or a wrong momentum step shows up at 1e-1 and above."""
+    from oracle import synth, torch_ref
+    from osvos_pytorch_amd.train_common import TrainLoop, make_sgd
+    n_ave, h, w = 5, 480, 854
+    frames = [(synth.make_frame(1, h, w, seed=71 + k), synth.make_mask(1, h, w, seed=71 + k)) for k in range(2)]
+    wts = synth.calibrate_heads(synth.make_weights(1), synth.torch_forward_fn(), frames[0][0])
+    lr = 1e-8      # the reference's (train_online.py:76)
+    # float64 trajectory on the CPU oracle
+    p = torch_ref.as_leaf_params(wts, dtype=torch.float64)
+    opt = torch.optim.SGD(torch_ref.sgd_groups(p, lr=lr, mode="online"), lr=lr, momentum=0.9)
+    ref_losses = []
+    for it in range(2 * n_ave):
+        x, m = frames[it % 2]
+        loss, _ = torch_ref.train_loss(p, torch.from_numpy(x).double(), torch.from_numpy(m).double(), mode="online")
+        ref_losses.append(float(loss.item()))
+        (loss / n_ave).backward()
+        if it % n_ave == n_ave - 1:
+            opt.step()
+            opt.zero_grad()
+    net = build_net(wts, precision)
+    loop = TrainLoop(net, make_sgd(net, "online", lr=lr), mode="online", n_ave_grad=n_ave)
+    w0 = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    losses = []
+    for it in range(2 * n_ave):
+        x, m = frames[it % 2]
+        loss, _ = loop.micro_batch(torch.from_numpy(x).cuda().requires_grad_(), torch.from_numpy(m).cuda())
+        losses.append(float(loss.item()))
+    assert loop.steps == 2
+    np.testing.assert_allclose(losses, ref_losses, rtol=1e-5)
+    assert abs(sum(loop.pop_running()) - sum(ref_losses)) <= 1e-5 * abs(sum(ref_losses))          # the in-kernel running-loss add
+    sd = net.state_dict()
+    worst = []
+    for k, v0 in w0.items():
+        delta = (sd[k] - v0).double().cpu()
+        ref_delta = p[k].detach() - torch.from_numpy(np.asarray(wts[k])).double()
+        if k.startswith("upscale") or k.startswith("score_dsn"):       # lr 0 / not optimised in the online loop
+            assert float(delta.abs().max()) == 0.0, k
+            continue
+        e = float((delta - ref_delta).norm() / (ref_delta.norm() + 1e-300))
+        worst.append((e, k))
+        # v0 + delta is rounded to fp32: the change itself is resolved to ~ulp(w) / |delta|
+        floor = float(v0.abs().max()) * 2 ** -23 * np.sqrt(delta.numel()) / (float(ref_delta.norm()) + 1e-300)
+        assert e <= 3e-3 + 2 * floor, (k, e, floor)
+    print("%s trajectory 854x480: worst parameter-change errors vs float64:" % precision, sorted(worst, reverse=True)[:4])

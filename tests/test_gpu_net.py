@@ -221,8 +221,15 @@ def test_intermediate_activations_via_ws_query():
         for nm in names[si]:
             cur = F.relu(F.conv2d(cur, p[nm + ".weight"], p[nm + ".bias"], padding=1))
             off, el, ch, hh, ww = C.c_size_t(), C.c_size_t(), C.c_int(), C.c_int(), C.c_int()
-            _lib.check(lib.osvos_net_ws_query(n, h, w, 0, l, C.byref(off), C.byref(el), C.byref(ch), C.byref(hh), C.byref(ww)))
-            act = ws[off.value:off.value + 4 * el.value].view(torch.float32).view(n, hh.value, ww.value, ch.value)
+            dt = net._runtime.dtype
+            _lib.check(lib.osvos_net_ws_query(n, h, w, dt, l, C.byref(off), C.byref(el), C.byref(ch), C.byref(hh), C.byref(ww)))
+            fmt = lib.osvos_net_ws_format(dt)
+            if fmt == 2:      # P3 trunk tensors (the f32x3 default): three bf16 piece planes whose sum is the fp32 value
+                from osvos_pytorch_amd import ops
+                act = ops.p3_to_f32(ws[off.value:off.value + 6 * el.value].view(torch.bfloat16).view(n, 3, hh.value, ww.value, ch.value))
+            else:
+                assert fmt == 0
+                act = ws[off.value:off.value + 4 * el.value].view(torch.float32).view(n, hh.value, ww.value, ch.value)
             got = act.permute(0, 3, 1, 2).cpu()
             err = float((got - cur).abs().max() / (cur.abs().max() + 1e-30))
             assert err < 1e-4, ("trunk conv", l, err)
