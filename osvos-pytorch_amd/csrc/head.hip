@@ -12,6 +12,7 @@
 // <= 2x2 taps per scale per output pixel.  The caller verifies the diagonal/shared-filter
 // precondition with osvos_deconv_diag_check and refuses to run otherwise.
 #include "kernels.h"
+#include "p3.h"
 
 namespace {
 
@@ -96,7 +97,8 @@ struct HbArgs {
   const float* wd;
   const float* wf;
   f32x4* dprep;
-  uint2* dprep_b;   // optional bf16 copy of dprep (operand of the bf16 side_prep weight gradient)
+  uint2* dprep_b;   // optional bf16 copy of dprep (operand of the bf16 side_prep weight gradient); with b_p3: the P3 form [N][3][h][w][16]
+  int b_p3;         // (p3.h: operand of the f32x3 side_prep data gradient in the P3 storage mode)
   double* acc;   // per-workgroup partials [gridDim.x][34]: [0..15] dwf, [16..31] dwd, [32] dbd, [33] spare
   int N, H, W, h, w, s;
 };
@@ -155,7 +157,14 @@ __device__ __forceinline__ void head_bwd_body(const HbArgs& a, const unsigned bi
           pwd[c] += p[e] * ds;
         }
         a.dprep[pix * 4 + q] = o;
-        if (a.dprep_b != nullptr) {
+        if (a.dprep_b != nullptr && a.b_p3) {
+          uint2 ph, pm, pl;
+          p3_split4(o, ph, pm, pl);
+          const long hw = (long)a.h * a.w, base = (n * 3 * hw + (pix - n * hw)) * 4 + q;      // uint2 units: 4 per pixel and plane
+          a.dprep_b[base] = ph;
+          a.dprep_b[base + hw * 4] = pm;
+          a.dprep_b[base + 2 * hw * 4] = pl;
+        } else if (a.dprep_b != nullptr) {
           typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
           bf16x4_t hb;
           hb[0] = (__bf16)o[0]; hb[1] = (__bf16)o[1]; hb[2] = (__bf16)o[2]; hb[3] = (__bf16)o[3];
@@ -277,7 +286,7 @@ int osvos_head_bwd_blocks(int N, int h, int w, int scale_idx) {
 
 int osvos_head_bwd_f32(const float* prep, const float* dside, const float* dfused, const float* f1, const float* f16,
                        const float* wd, const float* wf, float* dprep, void* dprep_bf16, double* acc, int N, int H, int W, int h, int w,
-                       int scale_idx, hipStream_t stream) {
+                       int scale_idx, hipStream_t stream, int b_p3) {
   OSVOS_ARG_CHECK(prep && f1 && f16 && wd && wf && dprep && acc, "head_bwd: null pointer");
   OSVOS_ARG_CHECK(scale_idx >= 0 && scale_idx < 4 && N > 0 && H > 0 && W > 0 && h > 0 && w > 0, "head_bwd: bad shape");
   HbArgs a;
@@ -285,6 +294,7 @@ int osvos_head_bwd_f32(const float* prep, const float* dside, const float* dfuse
   a.dside = dside; a.dfused = dfused; a.f1 = f1; a.f16 = f16; a.wd = wd; a.wf = wf;
   a.dprep = reinterpret_cast<f32x4*>(dprep);
   a.dprep_b = reinterpret_cast<uint2*>(dprep_bf16);
+  a.b_p3 = b_p3;
   a.acc = acc;
   a.N = N; a.H = H; a.W = W; a.h = h; a.w = w; a.s = 2 << scale_idx;
   const int g = osvos_head_bwd_blocks(N, h, w, scale_idx);
@@ -301,7 +311,7 @@ int osvos_head_bwd_f32(const float* prep, const float* dside, const float* dfuse
 // all four scales in one launch: arrays indexed by scale; same partial layout per scale as osvos_head_bwd_f32 (acc[i]: osvos_head_bwd_blocks x 34)
 int osvos_head_bwd4_f32(const float* const* prep, const float* const* dside, const float* dfused, const float* const* f1, const float* const* f16,
                         const float* const* wd, const float* wf, float* const* dprep, void* const* dprep_bf16, double* const* acc,
-                        int N, int H, int W, const int* hs, const int* ws, hipStream_t stream) {
+                        int N, int H, int W, const int* hs, const int* ws, hipStream_t stream, int b_p3) {
   Hb4Args a;
   a.first[0] = 0;
   for (int i = 0; i < 4; ++i) {
@@ -311,6 +321,7 @@ int osvos_head_bwd4_f32(const float* const* prep, const float* const* dside, con
     q.dside = dside[i]; q.dfused = dfused; q.f1 = f1[i]; q.f16 = f16[i]; q.wd = wd[i]; q.wf = wf + 16 * i;
     q.dprep = reinterpret_cast<f32x4*>(dprep[i]);
     q.dprep_b = reinterpret_cast<uint2*>(dprep_bf16 ? dprep_bf16[i] : nullptr);
+    q.b_p3 = b_p3;
     q.acc = acc[i];
     q.N = N; q.H = H; q.W = W; q.h = hs[i]; q.w = ws[i]; q.s = 2 << i;
     a.first[i + 1] = a.first[i] + (unsigned)osvos_head_bwd_blocks(N, hs[i], ws[i], i);

@@ -8,6 +8,8 @@ size_t osvos_conv3x3_splitk_ws_bytes_f32(int N, int H, int W, int Cout);
 void osvos_conv3x3_force_ksplit(int k);
 int osvos_conv3x3_f32_ws(const float* x, const float* wpk, const float* bias, const float* mask, float* y,
                          int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int tile, void* part_ws, hipStream_t stream);
+int osvos_conv3x3_f32_p3out(const float* x, const float* wpk, const float* bias, const float* mask, float* y, void* y3, int y3_cs,
+                            int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int tile, void* part_ws, hipStream_t stream);
 int osvos_conv3x3_splitk_finalize_f32(const float* part, const float* bias, const float* mask, float* y, long npix, int Cout, int y_cs,
                                       int ksplit, int relu, hipStream_t stream);
 // f32x3 (conv3x3_f32x3.hip): fp32 tensors and fp32 packs, three-way bf16 split operands on the bf16 matrix pipe
@@ -54,10 +56,10 @@ int osvos_head_lowres_f32(const float* prep, const float* wd, const float* bd, c
                           float* score, float* fpart, int N, int h, int w, hipStream_t stream);
 int osvos_head_bwd_f32(const float* prep, const float* dside, const float* dfused, const float* f1, const float* f16,
                        const float* wd, const float* wf, float* dprep, void* dprep_bf16, double* acc, int N, int H, int W, int h, int w,
-                       int scale_idx, hipStream_t stream);
+                       int scale_idx, hipStream_t stream, int b_p3 = 0);      // b_p3: dprep_bf16 is the P3 form [N][3][h][w][16] (p3.h)
 int osvos_head_bwd4_f32(const float* const* prep, const float* const* dside, const float* dfused, const float* const* f1, const float* const* f16,
                         const float* const* wd, const float* wf, float* const* dprep, void* const* dprep_bf16, double* const* acc,
-                        int N, int H, int W, const int* hs, const int* ws, hipStream_t stream);      // the four scales in one launch
+                        int N, int H, int W, const int* hs, const int* ws, hipStream_t stream, int b_p3 = 0);      // the four scales in one launch
 int osvos_head_bwd_blocks(int N, int h, int w, int scale_idx);   // workgroups (= partial rows of 34 doubles) head_bwd launches
 int osvos_sum_partials(const float* x, long count, double* part, int* nblocks, hipStream_t stream);
 // generic (non-diagonal upscale weights) head: head_generic.hip

@@ -130,7 +130,7 @@ WsLayout ws_layout(int N, int H, int W, int dtype) {
     for (int l = 0; l < kNumTrunk; ++l) {
       const size_t e = (size_t)N * L.hs[d[l].stage] * L.ws[d[l].stage] * d[l].cout;
       L.act3[l] = take(6 * e);
-      L.act[l] = (l == 0 || stage_last(l)) ? take(4 * e) : (size_t)-1;
+      L.act[l] = stage_last(l) ? take(4 * e) : (size_t)-1;
     }
     for (int si = 1; si < 5; ++si) {
       L.pooled3[si] = take((size_t)6 * N * L.hs[si] * L.ws[si] * kStageC[si - 1]);
@@ -323,12 +323,10 @@ int forward_p3(const float* x_nchw, const void* wbuf, void* ws, float* const* ou
   auto bias = [&](int l) { return reinterpret_cast<const float*>(at(wbuf, P.bias[l])); };
   int rc = osvos_nchw_to_nhwc_f32(x_nchw, f32at(ws, L.xin), nullptr, N, 3, H, W, kInPad, stream);
   if (rc) return rc;
-  {   // conv1_1 (Cin = 3) on the exact fp32 kernel, then its pieces
+  {   // conv1_1 (Cin = 3) on the exact fp32 kernel, whose epilogue forms the pieces
     ProfScope ps(OSVOS_PROF_CONV_FWD, conv_flops(N, H, W, d[0].cin, d[0].cout), stream);
-    rc = osvos_conv3x3_f32_ws(f32at(ws, L.xin), reinterpret_cast<const float*>(at(wbuf, P.fwd[0])), bias(0), nullptr, f32at(ws, L.act[0]), N, H, W,
-                              d[0].cin_s, d[0].cout, d[0].cout, 1, -1, nullptr, stream);
-    if (rc) return rc;
-    rc = osvos_f32_to_p3(f32at(ws, L.act[0]), at(ws, L.act3[0]), N, H, W, d[0].cout, d[0].cout, d[0].cout, stream);
+    rc = osvos_conv3x3_f32_p3out(f32at(ws, L.xin), reinterpret_cast<const float*>(at(wbuf, P.fwd[0])), bias(0), nullptr, nullptr, at(ws, L.act3[0]),
+                                 d[0].cout, N, H, W, d[0].cin_s, d[0].cout, d[0].cout, 1, -1, nullptr, stream);
     if (rc) return rc;
   }
   const void* cur3 = at(ws, L.act3[0]);
@@ -389,7 +387,7 @@ int forward_p3(const float* x_nchw, const void* wbuf, void* ws, float* const* ou
 
 // the trunk + side_prep half of the backward (everything behind the head's dprep[i]); streams, events and hazards as in the fp32 form
 int backward_trunk_p3(const void* wbuf, void* ws, float* const* grads, float* dx_nchw, int N, int H, int W, int dtype, int accumulate,
-                      hipStream_t stream, hipStream_t aux, hipStream_t aux2, const GradEvents& gev) {
+                      hipStream_t stream, hipStream_t aux, hipStream_t aux2, const GradEvents& gev, bool dprep3_ready) {
   const bool two = aux != stream, three = aux2 != aux;
   const WbufLayout P = wbuf_layout(dtype);
   const WsLayout L = ws_layout(N, H, W, dtype);
@@ -456,8 +454,9 @@ int backward_trunk_p3(const void* wbuf, void* ws, float* const* grads, float* dx
   for (int l = 0; l < kNumConv; ++l) bwd_flops += 2.0 * conv_flops(N, L.hs[d[l].stage], L.ws[d[l].stage], d[l].cin, d[l].cout);
   if (dx_nchw == nullptr) bwd_flops -= conv_flops(N, H, W, 3, d[0].cout);
   ProfScope ps(OSVOS_PROF_CONV_BWD, bwd_flops, stream);
-  // the pieces of the four 16-channel head gradients (operands of the side_prep data gradients)
-  for (int i = 0; i < 4; ++i) {
+  // the pieces of the four 16-channel head gradients (operands of the side_prep data gradients): written by the commuted head's
+  // backward itself; the generic head leaves fp32 only
+  for (int i = 0; i < 4 && !dprep3_ready; ++i) {
     rc = osvos_f32_to_p3(f32at(ws, L.dprep[i]), at(ws, L.dprep3[i]), N, L.hs[i + 1], L.ws[i + 1], 16, 16, 16, stream);
     if (rc) return rc;
   }
@@ -720,6 +719,7 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
   ConvDesc d[kNumConv];
   conv_table(d);
   const bool store = use_store(dtype), shadow = use_shadow(dtype) && !store;
+  const bool p3 = use_p3(dtype);
   auto sh = [&](size_t off) -> void* { return (shadow || store) ? at(ws, off) : nullptr; };
   auto f32 = [&](size_t off) -> void* { return store ? nullptr : at(ws, off); };
   auto mk32 = [&](size_t off) -> const void* { return store ? nullptr : at(ws, off); };           // ReLU mask operand: fp32 ...
@@ -797,13 +797,13 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
       f16_4[i] = reinterpret_cast<const float*>(at(wbuf, P.f16[i]));
       wd4[i] = reinterpret_cast<const float*>(at(wbuf, P.wd[i]));
       dprep4[i] = reinterpret_cast<float*>(at(ws, L.dprep[i]));
-      dprepb4[i] = store ? at(ws, L.dprep_b[i]) : nullptr;
+      dprepb4[i] = store ? at(ws, L.dprep_b[i]) : (p3 ? at(ws, L.dprep3[i]) : nullptr);
       acc4[i] = acc + (size_t)i * OSVOS_HEAD_MAX_BLOCKS * 34;
       part[i] = acc4[i];
       nblk[i] = osvos_head_bwd_blocks(N, L.hs[i + 1], L.ws[i + 1], i);
     }
     rc = osvos_head_bwd4_f32(prep4, douts, dfused, f1_4, f16_4, wd4, reinterpret_cast<const float*>(at(wbuf, P.wf)), dprep4, dprepb4, acc4, N, H, W,
-                             &L.hs[1], &L.ws[1], stream);
+                             &L.hs[1], &L.ws[1], stream, p3 ? 1 : 0);
     if (rc) return rc;
   } else
   for (int i = 0; i < 4; ++i) {
@@ -817,8 +817,8 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
       rc = osvos_head_bwd_f32(reinterpret_cast<const float*>(at(ws, L.prep[i])), douts[i], dfused, reinterpret_cast<const float*>(at(wbuf, P.f1[i])),
                         reinterpret_cast<const float*>(at(wbuf, P.f16[i])), reinterpret_cast<const float*>(at(wbuf, P.wd[i])),
                         reinterpret_cast<const float*>(at(wbuf, P.wf)) + 16 * i, reinterpret_cast<float*>(at(ws, L.dprep[i])),
-                        store ? at(ws, L.dprep_b[i]) : nullptr, acc + (size_t)i * OSVOS_HEAD_MAX_BLOCKS * 34,
-                        N, H, W, L.hs[si], L.ws[si], i, stream);
+                        store ? at(ws, L.dprep_b[i]) : (p3 ? at(ws, L.dprep3[i]) : nullptr), acc + (size_t)i * OSVOS_HEAD_MAX_BLOCKS * 34,
+                        N, H, W, L.hs[si], L.ws[si], i, stream, p3 ? 1 : 0);
     if (rc) return rc;
     part[i] = acc + (size_t)i * OSVOS_HEAD_MAX_BLOCKS * 34;
     nblk[i] = osvos_head_bwd_blocks(N, L.hs[si], L.ws[si], i);
@@ -860,7 +860,7 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
   }
   if ((rc = ready(0, stream))) return rc;      // score_dsn + fuse gradients
 
-  if (use_p3(dtype)) return backward_trunk_p3(wbuf, ws, grads, dx_nchw, N, H, W, dtype, accumulate, stream, aux, aux2, gev);
+  if (p3) return backward_trunk_p3(wbuf, ws, grads, dx_nchw, N, H, W, dtype, accumulate, stream, aux, aux2, gev, /*dprep3_ready=*/!generic);
 
   // ---- data-gradient chain on `stream`, weight gradients trailing on `aux` ----------------------
   // ready[k]: event recorded on `stream` when the k-th upstream gradient tensor is complete
