@@ -261,9 +261,9 @@ int osvos_comm_destroy(void* comm);
  * outputs, 13..16 pooled inputs of stages 1-4, 17..20 side_prep outputs, 21 NHWC input.  (fp32 elements; with dtype
  * OSVOS_F32_BF16MFMA the trunk tensors 0..16 are bf16 unless OSVOS_BF16_STORE=0.) */
 int osvos_net_ws_query(int N, int H, int W, int dtype, int which, size_t* offset, size_t* elems, int* channels, int* h, int* w);
-/* storage format of the trunk tensors (which = 0..16) for `dtype`: 0 fp32 NHWC, 1 bf16 NHWC (OSVOS_F32_BF16MFMA store mode),
- * 2 P3 (OSVOS_F32_X3: [N][3][H][W][C] bf16 pieces, 6 bytes per element) */
-int osvos_net_ws_format(int dtype);
+/* storage format of trunk tensor `which` (0..16) for `dtype`: 0 fp32 NHWC, 1 bf16 NHWC (OSVOS_F32_BF16MFMA store mode),
+ * 2 P3 (OSVOS_F32_X3: [N][3][H][W][C] bf16 pieces, 6 bytes per element; stage 0 keeps fp32) */
+int osvos_net_ws_format(int dtype, int which);
 
 /* ---- training-time input pipeline (dataloaders/davis_2016.py:99-106 + custom_transforms.py: flip, ScaleNRotate, ToTensor) ------
  * One frame: uint8 BGR [H][W][3] (+ uint8 label [H][W] or NULL) -> float32 image [3][H][W] = (flipped, warped) frame minus mean3,

@@ -84,7 +84,7 @@ PROTOTYPES = {
     "osvos_comm_allreduce_chunks_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "osvos_comm_destroy": (_i, [_vp]),
     "osvos_net_ws_query": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
-    "osvos_net_ws_format": (_i, [_i]),
+    "osvos_net_ws_format": (_i, [_i, _i]),
     "osvos_augment_frame": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "osvos_mask_to_bytes": (_i, [_vp, _vp, _vp, _l, _i, _vp]),
     "osvos_mask_iou_counts": (_i, [_vp, _vp, _vp, _l, _i, _f, _vp]),

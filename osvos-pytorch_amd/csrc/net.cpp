@@ -99,6 +99,14 @@ inline bool use_p3(int dtype) {
   return dtype == OSVOS_F32_X3 && on;
 }
 
+// first stage whose tensors are P3 (OSVOS_P3_FROM_STAGE, default 1; 0 = all of them).  Stage 0 (conv1_2: 64 -> 64 channels at full
+// resolution, K = 4 chunks) is bound by its 105 MB tensors, not by the matrix pipe: 6-byte elements cost it 25 % (0.220 vs 0.175 ms,
+// profiles/r03_tune_p3_first.txt), its only consumers are fp32 anyway (the pool pair) -- it keeps fp32 tensors and in-kernel splitting.
+inline int p3_first_stage() {
+  static const int v = [] { const char* e = getenv("OSVOS_P3_FROM_STAGE"); return e ? (atoi(e) <= 0 ? 0 : 1) : 1; }();
+  return v;
+}
+
 struct WsLayout {
   int hs[5], ws[5];
   // P3 mode: byte offsets of the P3 tensors ((size_t)-1 = absent).  In that mode act[] / dy[] hold an fp32 tensor only where noted above.
@@ -127,10 +135,12 @@ WsLayout ws_layout(int N, int H, int W, int dtype) {
   if (use_p3(dtype)) {
     auto stage_last = [&](int l) { return l + 1 == kNumTrunk || d[l + 1].stage != d[l].stage; };
     L.xin = take(sizeof(float) * N * H * W * kInPad);
+    const int s0 = p3_first_stage();
     for (int l = 0; l < kNumTrunk; ++l) {
       const size_t e = (size_t)N * L.hs[d[l].stage] * L.ws[d[l].stage] * d[l].cout;
-      L.act3[l] = take(6 * e);
-      L.act[l] = stage_last(l) ? take(4 * e) : (size_t)-1;
+      const bool fp32_stage = d[l].stage < s0;
+      L.act3[l] = fp32_stage ? (size_t)-1 : take(6 * e);
+      L.act[l] = (fp32_stage || stage_last(l)) ? take(4 * e) : (size_t)-1;
     }
     for (int si = 1; si < 5; ++si) {
       L.pooled3[si] = take((size_t)6 * N * L.hs[si] * L.ws[si] * kStageC[si - 1]);
@@ -160,8 +170,9 @@ WsLayout ws_layout(int N, int H, int W, int dtype) {
     }
     for (int l = 0; l < kNumTrunk; ++l) {
       const size_t e = (size_t)N * L.hs[d[l].stage] * L.ws[d[l].stage] * d[l].cout;
-      L.dy3[l] = take(6 * e);
-      L.dy[l] = l == 0 ? take(4 * e) : (size_t)-1;
+      const bool fp32_stage = d[l].stage < s0;
+      L.dy3[l] = fp32_stage ? (size_t)-1 : take(6 * e);
+      L.dy[l] = (fp32_stage || l == 0) ? take(4 * e) : (size_t)-1;
     }
     for (int si = 1; si < 5; ++si) L.dpool[si] = take(sizeof(float) * N * L.hs[si] * L.ws[si] * kStageC[si - 1]);
     for (int l = 0; l < kNumConv; ++l) {
@@ -323,14 +334,22 @@ int forward_p3(const float* x_nchw, const void* wbuf, void* ws, float* const* ou
   auto bias = [&](int l) { return reinterpret_cast<const float*>(at(wbuf, P.bias[l])); };
   int rc = osvos_nchw_to_nhwc_f32(x_nchw, f32at(ws, L.xin), nullptr, N, 3, H, W, kInPad, stream);
   if (rc) return rc;
-  {   // conv1_1 (Cin = 3) on the exact fp32 kernel, whose epilogue forms the pieces
+  const int s0 = p3_first_stage();
+  {   // conv1_1 (Cin = 3) on the exact fp32 kernel; its epilogue forms the pieces when stage 0 is P3
     ProfScope ps(OSVOS_PROF_CONV_FWD, conv_flops(N, H, W, d[0].cin, d[0].cout), stream);
-    rc = osvos_conv3x3_f32_p3out(f32at(ws, L.xin), reinterpret_cast<const float*>(at(wbuf, P.fwd[0])), bias(0), nullptr, nullptr, at(ws, L.act3[0]),
-                                 d[0].cout, N, H, W, d[0].cin_s, d[0].cout, d[0].cout, 1, -1, nullptr, stream);
+    rc = osvos_conv3x3_f32_p3out(f32at(ws, L.xin), reinterpret_cast<const float*>(at(wbuf, P.fwd[0])), bias(0), nullptr, f32at(ws, L.act[0]),
+                                 s0 == 0 ? at(ws, L.act3[0]) : nullptr, d[0].cout, N, H, W, d[0].cin_s, d[0].cout, d[0].cout, 1, -1, nullptr, stream);
     if (rc) return rc;
   }
-  const void* cur3 = at(ws, L.act3[0]);
+  const void* cur3 = s0 == 0 ? at(ws, L.act3[0]) : nullptr;
   int l = 1;
+  if (s0 > 0) {   // conv1_2 on fp32 tensors (f32x3 with in-kernel splitting), like the fp32 form of the network
+    ProfScope ps(OSVOS_PROF_CONV_FWD, conv_flops(N, H, W, d[1].cin, d[1].cout), stream);
+    rc = osvos_conv3x3_f32x3_ps(f32at(ws, L.act[0]), reinterpret_cast<const float*>(at(wbuf, P.fwd[1])), at(wbuf, P.fwd3[1]), bias(1), nullptr, f32at(ws, L.act[1]),
+                                N, H, W, d[1].cin, d[1].cout, d[1].cout, 1, -1, 0, nullptr, stream);
+    if (rc) return rc;
+    l = 2;
+  }
   const float* score[4]; const float* fpart[4]; const float* f1[4]; const float* f16[4];
   for (int si = 0; si < 5; ++si) {
     const int h = L.hs[si], w = L.ws[si];
@@ -339,7 +358,7 @@ int forward_p3(const float* x_nchw, const void* wbuf, void* ws, float* const* ou
       if (rc) return rc;
       cur3 = at(ws, L.pooled3[si]);
     }
-    for (int j = (si == 0 ? 1 : 0); j < kStageN[si]; ++j, ++l) {
+    for (int j = (si == 0 ? (s0 > 0 ? kStageN[0] : 1) : 0); j < kStageN[si]; ++j, ++l) {
       ProfScope ps(OSVOS_PROF_CONV_FWD, conv_flops(N, h, w, d[l].cin, d[l].cout), stream);
       rc = osvos_conv3x3_p3(cur3, at(wbuf, P.fwd3[l]), bias(l), nullptr, 0, 0, f32at(ws, L.act[l]), d[l].cout, at(ws, L.act3[l]), d[l].cout, N, h, w,
                             d[l].cin, d[l].cout, 1, -1, 0, at(ws, L.conv_part), stream);
@@ -422,7 +441,11 @@ int backward_trunk_p3(const void* wbuf, void* ws, float* const* grads, float* dx
     return 0;
   };
   // weight gradient of layer l: wide layers from the P3 tensors, conv1_1 / side_prep on their exact skinny kernels from the fp32 ones
+  const int s0 = p3_first_stage();
   auto wgrad_launch = [&](int l, int h, int w, hipStream_t st) -> int {
+    if (l >= 1 && l < kNumTrunk && d[l].stage < s0)      // fp32 stage: fp32-input f32x3 weight gradient
+      return osvos_conv3x3_wgrad(at(ws, L.act[l - 1]), at(ws, L.dy[l]), at(ws, L.wgrad[l]), grads[d[l].w_param], grads[d[l].b_param], N, h, w, d[l].cin,
+                                 d[l].cin_s, d[l].cout, d[l].cout, accumulate, dtype, st);
     if (l >= 1 && l < kNumTrunk) {
       const bool first_of_stage = d[l - 1].stage != d[l].stage;
       const void* x3 = first_of_stage ? at(ws, L.pooled3[d[l].stage]) : at(ws, L.act3[l - 1]);
@@ -490,8 +513,12 @@ int backward_trunk_p3(const void* wbuf, void* ws, float* const* grads, float* dx
     if (first_of_stage && !tail_on_main && (rc = ready(2 + (4 - si), aux2))) return rc;
     if (l == 0) {
       if (dx_nchw != nullptr) {
-        rc = osvos_conv3x3_p3(at(ws, L.dy3[0]), at(wbuf, P.dgrad3[0]), nullptr, nullptr, 0, 0, f32at(ws, L.dxin), 4, nullptr, 0, N, h, w, d[0].cout, 3, 0, -1, 0,
-                              nullptr, stream);
+        if (s0 > 0)
+          rc = osvos_conv3x3_f32x3_ps(f32at(ws, L.dy[0]), reinterpret_cast<const float*>(at(wbuf, P.dgrad[0])), at(wbuf, P.dgrad3[0]), nullptr, nullptr,
+                                      f32at(ws, L.dxin), N, h, w, d[0].cout, 3, 4, 0, -1, 0, nullptr, stream);
+        else
+          rc = osvos_conv3x3_p3(at(ws, L.dy3[0]), at(wbuf, P.dgrad3[0]), nullptr, nullptr, 0, 0, f32at(ws, L.dxin), 4, nullptr, 0, N, h, w, d[0].cout, 3, 0, -1, 0,
+                                nullptr, stream);
         if (rc) return rc;
         rc = osvos_nhwc_to_nchw(at(ws, L.dxin), dx_nchw, N, 3, H, W, 4, dtype, stream);
         if (rc) return rc;
@@ -509,8 +536,16 @@ int backward_trunk_p3(const void* wbuf, void* ws, float* const* grads, float* dx
                             d[l].cin, 0, -1, 0, at(ws, L.conv_part), stream);
       if (rc) return rc;
       const int ps2 = si - 1;
-      rc = osvos_maxpool2x2_bwd_p3(f32at(ws, L.act[l - 1]), f32at(ws, L.dpool[si]), ps2 >= 1 ? f32at(ws, L.dside[ps2 - 1]) : nullptr, nullptr,
-                                   at(ws, L.dy3[l - 1]), N, L.hs[ps2], L.ws[ps2], kStageC[ps2], stream);
+      if (ps2 < s0)      // into an fp32 stage
+        rc = osvos_maxpool2x2_bwd_f32(f32at(ws, L.act[l - 1]), f32at(ws, L.dpool[si]), ps2 >= 1 ? f32at(ws, L.dside[ps2 - 1]) : nullptr, f32at(ws, L.dy[l - 1]),
+                                      nullptr, N, L.hs[ps2], L.ws[ps2], kStageC[ps2], stream);
+      else
+        rc = osvos_maxpool2x2_bwd_p3(f32at(ws, L.act[l - 1]), f32at(ws, L.dpool[si]), ps2 >= 1 ? f32at(ws, L.dside[ps2 - 1]) : nullptr, nullptr,
+                                     at(ws, L.dy3[l - 1]), N, L.hs[ps2], L.ws[ps2], kStageC[ps2], stream);
+      if (rc) return rc;
+    } else if (si < s0) {      // fp32 stage: f32x3 data gradient with in-kernel splitting, fp32 mask
+      rc = osvos_conv3x3_f32x3_ps(f32at(ws, L.dy[l]), reinterpret_cast<const float*>(at(wbuf, P.dgrad[l])), at(wbuf, P.dgrad3[l]), nullptr,
+                                  f32at(ws, L.act[l - 1]), f32at(ws, L.dy[l - 1]), N, h, w, d[l].cout, d[l].cin, d[l].cin, 0, -1, 0, at(ws, L.conv_part), stream);
       if (rc) return rc;
     } else {
       rc = osvos_conv3x3_p3(at(ws, L.dy3[l]), at(wbuf, P.dgrad3[l]), nullptr, at(ws, L.act3[l - 1]), 1, d[l].cin, l == 1 ? f32at(ws, L.dy[0]) : nullptr, d[l].cin,
@@ -537,7 +572,7 @@ int osvos_net_ws_query(int N, int H, int W, int dtype, int which, size_t* offset
   int si, c;
   size_t off;
   const bool p3 = use_p3(dtype & 0xff);      // P3 mode: the trunk tensors are P3 (osvos_net_ws_format)
-  if (which < 13) { si = d[which].stage; c = d[which].cout; off = p3 ? L.act3[which] : L.act[which]; }
+  if (which < 13) { si = d[which].stage; c = d[which].cout; off = (p3 && si >= p3_first_stage()) ? L.act3[which] : L.act[which]; }
   else if (which < 17) { si = which - 12; c = kStageC[si - 1]; off = p3 ? L.pooled3[si] : L.pooled[si]; }
   else if (which < 21) { si = which - 16; c = 16; off = L.prep[which - 17]; }
   else { si = 0; c = kInPad; off = L.xin; }
@@ -546,8 +581,15 @@ int osvos_net_ws_query(int N, int H, int W, int dtype, int which, size_t* offset
   return 0;
 }
 
-// storage format of the trunk tensors osvos_net_ws_query 0..16 point at: 0 fp32 NHWC, 1 bf16 NHWC, 2 P3 ([N][3][H][W][C] bf16 pieces)
-int osvos_net_ws_format(int dtype) { return use_p3(dtype & 0xff) ? 2 : (use_store(dtype & 0xff) ? 1 : 0); }
+// storage format of trunk tensor `which` (osvos_net_ws_query 0..16): 0 fp32 NHWC, 1 bf16 NHWC, 2 P3 ([N][3][H][W][C] bf16 pieces)
+int osvos_net_ws_format(int dtype, int which) {
+  if (use_store(dtype & 0xff)) return 1;
+  if (!use_p3(dtype & 0xff) || which < 0 || which > 16) return 0;
+  if (which >= 13) return 2;
+  ConvDesc d[kNumConv];
+  conv_table(d);
+  return d[which].stage >= p3_first_stage() ? 2 : 0;
+}
 
 int osvos_net_pack(const float* const* params, void* wbuf, int dtype_, int with_dgrad, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;

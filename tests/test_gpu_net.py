@@ -223,7 +223,7 @@ def test_intermediate_activations_via_ws_query():
             off, el, ch, hh, ww = C.c_size_t(), C.c_size_t(), C.c_int(), C.c_int(), C.c_int()
             dt = net._runtime.dtype
             _lib.check(lib.osvos_net_ws_query(n, h, w, dt, l, C.byref(off), C.byref(el), C.byref(ch), C.byref(hh), C.byref(ww)))
-            fmt = lib.osvos_net_ws_format(dt)
+            fmt = lib.osvos_net_ws_format(dt, l)
             if fmt == 2:      # P3 trunk tensors (the f32x3 default): three bf16 piece planes whose sum is the fp32 value
                 from osvos_pytorch_amd import ops
                 act = ops.p3_to_f32(ws[off.value:off.value + 6 * el.value].view(torch.bfloat16).view(n, 3, hh.value, ww.value, ch.value))
