@@ -452,6 +452,11 @@ int backward_trunk_p3(const void* wbuf, void* ws, float* const* grads, float* dx
       return osvos_conv3x3_wgrad_p3(x3, at(ws, L.dy3[l]), at(ws, L.wgrad[l]), grads[d[l].w_param], grads[d[l].b_param], N, h, w, d[l].cin, d[l].cin_s,
                                     d[l].cout, d[l].cout, accumulate, st);
     }
+    // side_prep (Cout = 16): on the bf16 pipe from the P3 stage output and the P3 head gradient (OSVOS_X3_SIDE_WGRAD=0: the exact fp32 skinny kernel)
+    static const bool side_x3 = [] { const char* e = getenv("OSVOS_X3_SIDE_WGRAD"); return !(e && e[0] == '0'); }();
+    if (l >= kNumTrunk && side_x3 && d[l].cin % 128 == 0)
+      return osvos_conv3x3_wgrad_p3(at(ws, L.act3[last_of_stage(d[l].stage)]), at(ws, L.dprep3[l - kNumTrunk]), at(ws, L.wgrad[l]), grads[d[l].w_param],
+                                    grads[d[l].b_param], N, h, w, d[l].cin, d[l].cin_s, 16, 16, accumulate, st);
     const void* x = l == 0 ? at(ws, L.xin) : at(ws, L.act[last_of_stage(d[l].stage)]);
     const void* g = l == 0 ? at(ws, L.dy[0]) : at(ws, L.dprep[l - kNumTrunk]);
     return osvos_conv3x3_wgrad(x, g, at(ws, L.wgrad[l]), grads[d[l].w_param], grads[d[l].b_param], N, h, w, d[l].cin, d[l].cin_s, d[l].cout,

@@ -32,21 +32,26 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
-constexpr int PW = 16, BCI = 64;
+constexpr int PW = 16;
 
+// S16 = 1: the skinny shape of side_prep (Cout = 16; reference vgg_osvos.py:41): the four waves take four 32-cin blocks of ONE 32-cout block
+// whose upper 16 couts are zero rows of the dY tile (2x padding instead of the 4x a 64-cout tile would spend): 128 cins x 16 couts per
+// workgroup.  The exact-fp32 skinny kernel it replaces in the P3 mode runs at 26 TFLOP/s (263 us per step, VERDICT r02 "furthest below any roofline").
 // WAVES = 4: 64 couts x 64 cins per workgroup, one wave per SIMD, double-buffered fragment sets.  WAVES = 8 (Cout % 128 == 0): 128 couts x
 // 64 cins, TWO waves per SIMD (<= 256 registers each: one fragment set, the partner wave covers the gather latency) -- the X tile and its
 // 54 gathers per k-step are shared by twice the MFMAs.
-template <int PH_, int WAVES_>
+template <int PH_, int WAVES_, int S16_ = 0>
 struct G3 {
-  static constexpr int PH = PH_, WAVES = WAVES_, NT = 64 * WAVES_;
-  static constexpr int BCO = 16 * WAVES_;                              // couts per workgroup
+  static constexpr int PH = PH_, WAVES = WAVES_, NT = 64 * WAVES_, S16 = S16_;
+  static constexpr int BCO = S16_ ? 32 : 16 * WAVES_;                  // couts per workgroup (S16: 16 real ones)
+  static constexpr int BCI = S16_ ? 128 : 64;                          // cins per workgroup
+  static constexpr int XOCT = BCI / 8;                                 // channel octets per X pixel
   static constexpr int DYP = BCO * 2 + 64, XP = BCI * 2 + 64;          // bytes per pixel and plane (+ 64 B skew: conflict-free gathers)
   static constexpr int PPIX = PW * PH, HW_ = PW + 2, XPIX = (PH + 2) * HW_;
   static constexpr int DY_B = PPIX * DYP, X_B = XPIX * XP;             // bytes of one piece plane
   static constexpr int DOCT = BCO / 8;                                 // channel octets per dY pixel
-  static constexpr int DY_ITEMS = PPIX * DOCT, X_ITEMS = XPIX * 8;     // (pixel, channel octet)
-  static constexpr int DPG = NT / DOCT, XPG = NT / 8;                  // pixels covered per staging round
+  static constexpr int DY_ITEMS = PPIX * DOCT, X_ITEMS = XPIX * XOCT;  // (pixel, channel octet)
+  static constexpr int DPG = NT / DOCT, XPG = NT / XOCT;               // pixels covered per staging round
   static constexpr int NDY = (DY_ITEMS + NT - 1) / NT, NX = (X_ITEMS + NT - 1) / NT, NIT = NDY + NX;
   static constexpr int NST = 3 * PH;                                  // stages (k-step, tap row) per patch
   static constexpr int NB = WAVES_ == 8 ? 1 : 2;                       // fragment sets
@@ -91,15 +96,15 @@ __device__ inline void split8w(const u32x4& lo, const u32x4& hi, u32x4& p0, u32x
   p2 = u32x4{q2[0], q2[1], q2[2], q2[3]};
 }
 
-template <int PH, int WAVES, int P3IN>
+template <int PH, int WAVES, int P3IN, int S16 = 0>
 __global__ __launch_bounds__(64 * WAVES) void wgrad_f32x3_kernel(W3Args a) {
-  using G = G3<PH, WAVES>;
-  constexpr int NT = G::NT, BCO = G::BCO;
+  using G = G3<PH, WAVES, S16>;
+  constexpr int NT = G::NT, BCO = G::BCO, BCI = G::BCI;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* dYs = smem;                         // [piece 3][PPIX][PITCH]
   char* Xs = smem + 3 * G::DY_B;            // [piece 3][XPIX][PITCH]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wc = wave >> 1, wi = wave & 1;
+  const int wc = S16 ? 0 : wave >> 1, wi = S16 ? wave : wave & 1;
   constexpr unsigned OOB = 0x80000000u;
 
   int id = blockIdx.x;
@@ -113,7 +118,7 @@ __global__ __launch_bounds__(64 * WAVES) void wgrad_f32x3_kernel(W3Args a) {
 
   // staged items: (pixel, channel octet) = 32 bytes of fp32 in, 3 x 16 bytes of bf16 pieces out; a thread keeps its octet in every round
   const int doct = tid % G::DOCT, dpg = tid / G::DOCT;      // dY: BCO / 8 octets per pixel
-  const int xoct = tid & 7, xpg = tid >> 3;                 // X: 8 octets per pixel
+  const int xoct = tid % G::XOCT, xpg = tid / G::XOCT;      // X: BCI / 8 octets per pixel
   const bool dy_ch_ok = co0 + 8 * doct < a.Cout, x_ch_ok = ci0 + 8 * xoct < a.Cin_s;
   constexpr int NR = P3IN ? 3 : 2, ES = P3IN ? 2 : 4;        // registers per staged item (P3: one per piece), element size in HBM
   u32x4 rdy[G::NDY][NR], rx[G::NX][NR];
@@ -323,6 +328,22 @@ struct W3Plan {
 // one workgroup per CU (124-135 KB of LDS): aim at one round of ~256 workgroups, each with a long patch range
 W3Plan make_plan3(int N, int H, int W, int Cin_s, int Cout) {
   W3Plan p;
+  if (Cout == 16) {      // skinny form (S16): 128 cins x 16 couts per workgroup, 16 x 4 pixel patches
+    p.waves = 4; p.bco = 32; p.ph = 4;
+    p.nco_t = 1;
+    p.nci_t = ceil_div(Cin_s, 128);
+    p.npx = ceil_div(W, PW);
+    p.npy = ceil_div(H, p.ph);
+    p.npatches = N * p.npx * p.npy;
+    int want = ceil_div(256, p.nci_t);
+    const int max_split = p.npatches / 2 > 0 ? p.npatches / 2 : 1;
+    if (want > max_split) want = max_split;
+    p.per_split = ceil_div(p.npatches, want);
+    p.nsplit = ceil_div(p.npatches, p.per_split);
+    p.slab_floats = (size_t)p.nsplit * 9 * Cout * Cin_s;
+    p.bslab_floats = (size_t)p.nsplit * Cout;
+    return p;
+  }
   OSVOS_ENV_INT(env_waves, "OSVOS_X3_WGRAD_WAVES", 0);
   // measured (tools/gpu_r02_o.sh): the eight-wave tile is 3-4 % faster standalone on conv2_2 / conv3_2 (157 vs 165, 162 vs 168 us), level or
   // slower elsewhere (twice the splits = twice the slab traffic), and the whole step is slower with it beside the data-gradient kernels
@@ -332,7 +353,7 @@ W3Plan make_plan3(int N, int H, int W, int Cin_s, int Cout) {
   p.bco = 16 * p.waves;
   p.ph = p.waves == 8 ? 4 : ((ceil_div(H, 6) * 6 <= ceil_div(H, 4) * 4) ? 6 : 4);      // (the eight-wave tile fits the LDS with 16 x 4 patches only)
   p.nco_t = ceil_div(Cout, p.bco);
-  p.nci_t = ceil_div(Cin_s, BCI);
+  p.nci_t = ceil_div(Cin_s, 64);
   p.npx = ceil_div(W, PW);
   p.npy = ceil_div(H, p.ph);
   p.npatches = N * p.npx * p.npy;
@@ -347,17 +368,17 @@ W3Plan make_plan3(int N, int H, int W, int Cin_s, int Cout) {
   return p;
 }
 
-template <int PH, int WAVES, int P3IN>
+template <int PH, int WAVES, int P3IN, int S16 = 0>
 int launch3(const W3Args& a, long blocks, hipStream_t stream) {
   static bool attr_set_dev[OSVOS_MAX_DEVICES] = {};
   bool& attr_set = attr_set_dev[osvos_current_device()];
   if (!attr_set) {
-    OSVOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_f32x3_kernel<PH, WAVES, P3IN>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)G3<PH, WAVES>::LDS));
+    OSVOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_f32x3_kernel<PH, WAVES, P3IN, S16>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)G3<PH, WAVES, S16>::LDS));
     attr_set = true;
   }
-  constexpr size_t lds = G3<PH, WAVES>::LDS;
-  hipLaunchKernelGGL((wgrad_f32x3_kernel<PH, WAVES, P3IN>), dim3((unsigned)blocks), dim3(64 * WAVES), lds, stream, a);
+  constexpr size_t lds = G3<PH, WAVES, S16>::LDS;
+  hipLaunchKernelGGL((wgrad_f32x3_kernel<PH, WAVES, P3IN, S16>), dim3((unsigned)blocks), dim3(64 * WAVES), lds, stream, a);
   OSVOS_LAUNCH_CHECK();
   return 0;
 }
@@ -373,6 +394,10 @@ bool osvos_wgrad_f32x3_applicable(int Cin, int Cin_s, int Cout, int Cout_s) {
 }
 
 size_t osvos_wgrad_f32x3_ws_bytes(int N, int H, int W, int Cin_s, int Cout) {
+  if (Cout == 16 && Cin_s % 128 == 0) {
+    const W3Plan p = make_plan3(N, H, W, Cin_s, Cout);
+    return align_up((p.slab_floats + p.bslab_floats) * sizeof(float), 256);
+  }
   if (Cin_s % 64 != 0 || Cout % 64 != 0) return 0;
   // whichever form runs (OSVOS_X3_WGRAD_WAVES): the eight-wave tiles need up to twice the splits of the four-wave ones
   const W3Plan p = make_plan3(N, H, W, Cin_s, Cout);
@@ -386,7 +411,8 @@ int wgrad3_run(const void* x, const void* dy, int p3in, void* ws, float* dw, flo
                int N, int H, int W, int Cin, int Cin_s, int Cout, int Cout_s, int accumulate, hipStream_t stream) {
   OSVOS_ARG_CHECK(x && dy && ws && dw, "wgrad f32x3: null pointer");
   OSVOS_ARG_CHECK(N > 0 && H > 0 && W > 0, "wgrad f32x3: bad shape");
-  OSVOS_ARG_CHECK(osvos_wgrad_f32x3_applicable(Cin, Cin_s, Cout, Cout_s) && (!p3in || Cout_s % 8 == 0),
+  const bool skinny = p3in && Cout == 16 && Cout_s == 16 && Cin == Cin_s && Cin_s % 128 == 0;      // side_prep (P3 inputs only)
+  OSVOS_ARG_CHECK(skinny || (osvos_wgrad_f32x3_applicable(Cin, Cin_s, Cout, Cout_s) && (!p3in || Cout_s % 8 == 0)),
                   "wgrad f32x3: unsupported shape (Cin %d/%d Cout %d/%d)", Cin, Cin_s, Cout, Cout_s);
   OSVOS_ARG_CHECK((long)H * W * Cin_s < (1L << 28) && (long)H * W * Cout_s < (1L << 28), "wgrad f32x3: image too large for 31-bit byte offsets");
   const W3Plan p = make_plan3(N, H, W, Cin_s, Cout);
@@ -402,7 +428,9 @@ int wgrad3_run(const void* x, const void* dy, int p3in, void* ws, float* dw, flo
   const int phase = osvos_wgrad_phase();
   if (phase != 2) {
     int rc;
-    if (p3in)
+    if (skinny)
+      rc = launch3<4, 4, 1, 1>(a, blocks, stream);
+    else if (p3in)
       rc = p.waves == 8 ? launch3<4, 8, 1>(a, blocks, stream) : (p.ph == 6 ? launch3<6, 4, 1>(a, blocks, stream) : launch3<4, 4, 1>(a, blocks, stream));
     else
       rc = p.waves == 8 ? launch3<4, 8, 0>(a, blocks, stream) : (p.ph == 6 ? launch3<6, 4, 0>(a, blocks, stream) : launch3<4, 4, 0>(a, blocks, stream));

@@ -165,3 +165,25 @@ def test_pools_with_p3_results_equal_the_fp32_pools(shape):
         dx, dx3 = ops.maxpool2x2_bwd_p3(x, dy, side, want_f32=True)
         dr = ops.maxpool2x2_bwd(x, dy, side)
         assert torch.equal(dx, dr) and torch.equal(ops.p3_to_f32(dx3), dr)
+
+
+@pytest.mark.parametrize("shape", [(1, 24, 32, 128), (2, 17, 21, 256), (1, 30, 54, 512), (1, 7, 5, 128)])
+def test_skinny_side_prep_wgrad_on_the_bf16_pipe(shape):
+    """side_prep's weight gradient (Cout = 16; vgg_osvos.py:41) from the P3 stage output and the P3 head gradient -- the S16 form of
+    wgrad_f32x3.hip -- against float64 and against the exact fp32 skinny kernel it replaces in the P3 mode"""
+    ops = _ops()
+    from osvos_pytorch_amd._lib import F32
+    n, h, w, cin = shape
+    cout = 16
+    g = torch.Generator().manual_seed(51 + h)
+    x = F.relu(torch.randn(n, cin, h, w, generator=g))
+    dy = torch.randn(n, cout, h, w, generator=g)
+    wt = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), wt, padding=1).backward(dy.double())
+    dw3, db3 = ops.conv3x3_wgrad_p3(ops.f32_to_p3(nhwc(x)), ops.f32_to_p3(nhwc(dy), cd=16), cin, cout)
+    emax, el2 = rel_err(dw3.cpu(), wt.grad)
+    assert el2 < 1e-6 and emax < 1e-5, (shape, emax, el2)
+    torch.testing.assert_close(db3.cpu().double(), dy.double().sum((0, 2, 3)), rtol=1e-5, atol=1e-4)
+    dw, db = ops.conv3x3_wgrad(nhwc(x), nhwc(dy), cin, cout, dtype=F32)
+    e2 = rel_err(dw3, dw)
+    assert e2[1] < 1e-6, (shape, e2)
