@@ -43,9 +43,22 @@ struct P3Args {
 constexpr int cdivp(int a, int b) { return (a + b - 1) / b; }
 constexpr unsigned OOB = 0x80000000u;
 
-template <int RBW_, int NB_, int WGM_, int WGN_>
+// scheduling groups of one (tap, M block) step: each of its NM MFMAs followed by its share of the NDS fragment reads of the NEXT step
+template <int NM, int NDS, int I = 0>
+__device__ __forceinline__ void step_groups() {
+  if constexpr (I < NM) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    constexpr int nds = (NDS * (I + 1)) / NM - (NDS * I) / NM;
+    if constexpr (nds > 0) __builtin_amdgcn_sched_group_barrier(0x100, nds, 0);
+    step_groups<NM, NDS, I + 1>();
+  }
+}
+
+// ILV = 1: the next step's fragment reads are interleaved with the step's MFMAs (sched_group_barrier) instead of being issued as a
+// block in front of them -- what a one-wave-per-SIMD workgroup needs (nothing else covers the issue time of that block)
+template <int RBW_, int NB_, int WGM_, int WGN_, int ILV_ = 0>
 struct PCfg {
-  static constexpr int RBW = RBW_, NB = NB_, WGM = WGM_, WGN = WGN_;
+  static constexpr int RBW = RBW_, NB = NB_, WGM = WGM_, WGN = WGN_, ILV = ILV_;
   static constexpr int NW = WGM * WGN, NT = 64 * NW;
   static constexpr int RBH = 32 / RBW;                      // rows of one 32-pixel M block
   static constexpr int TW = RBW, TH = 8 * RBH;              // eight M blocks stacked vertically: 32 x 8 or 16 x 16 pixels
@@ -199,9 +212,6 @@ __global__ __launch_bounds__(C::NT, C::NW == 8 ? 2 : 1) void conv3x3_p3_kernel(P
 #pragma unroll
         for (int mi = 0; mi < WM; ++mi) {
           const int step = s * WM + mi;
-          if (mi + 1 < WM) ldA(s, mi + 1, (step + 1) & 1);
-          else if (s + 1 < 3) ldA(s + 1, 0, (step + 1) & 1);
-          if (mi == 0 && s + 1 < 3) ldB(s + 1, (s + 1) & 1);
           // DMA issue slots d = 0 .. NDS-1 of this stage, spread over its first steps: first the A instructions of the next chunk
           // (ordinals i = r, r + 3, ...), then the next stage's weights
 #pragma unroll
@@ -214,7 +224,12 @@ __global__ __launch_bounds__(C::NT, C::NW == 8 ? 2 : 1) void conv3x3_p3_kernel(P
               dma_b(d - C::NAS, nkc, nr, bb ^ 1, dead_b);
             }
           }
-          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (C::ILV != 0) __builtin_amdgcn_sched_barrier(0);
+          const bool rdA = (mi + 1 < WM) || (s + 1 < 3), rdB = mi == 0 && s + 1 < 3;      // (compile-time after unrolling)
+          if (mi + 1 < WM) ldA(s, mi + 1, (step + 1) & 1);
+          else if (s + 1 < 3) ldA(s + 1, 0, (step + 1) & 1);
+          if (rdB) ldB(s + 1, (s + 1) & 1);
+          if constexpr (C::ILV == 0) __builtin_amdgcn_sched_barrier(0);
           const int sa = step & 1, sb = s & 1;
           // pieces: 0 = high, 1 = middle, 2 = low.  Small products first, the dominant hi x hi product last (as conv3x3_f32x3.hip)
           constexpr int PB[6] = {2, 0, 1, 1, 0, 0};
@@ -225,6 +240,11 @@ __global__ __launch_bounds__(C::NT, C::NW == 8 ? 2 : 1) void conv3x3_p3_kernel(P
             for (int ni = 0; ni < WN; ++ni)
               acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fb[sb][PB[t]][ni]),
                                                                     __builtin_bit_cast(bf16x8_t, fa[sa][PA[t]]), acc[mi][ni], 0, 0, 0);
+          if constexpr (C::ILV != 0) {
+            if (rdA && rdB) step_groups<6 * WN, 3 + 3 * WN>();
+            else if (rdA) step_groups<6 * WN, 3>();
+            else if (rdB) step_groups<6 * WN, 3 * WN>();
+          }
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -387,10 +407,17 @@ using Q6 = PCfg<16, 2, 2, 2>;   // 16 x 16 px x  64 co, 4 waves
 using Q7 = PCfg<32, 1, 8, 1>;   // 32 x 8 px x  32 co, 8 waves (1 x 1): the skinny outputs (side_prep: 16 couts, input gradient: 3)
 using Q8 = PCfg<32, 1, 4, 1>;   // 32 x 8 px x  32 co, 4 waves (2 x 1)
 using Q9 = PCfg<16, 1, 8, 1>;   // 16 x 16 px x 32 co, 8 waves
-constexpr int kNumTilesP = 10;
+using Q10 = PCfg<32, 4, 2, 2, 1>;  // Q1 (4 waves, one per SIMD) with the fragment reads interleaved into the MFMA stream
+using Q11 = PCfg<32, 2, 2, 2, 1>;  // Q3 ...
+using Q12 = PCfg<16, 2, 2, 2, 1>;  // Q6 ...
+using Q13 = PCfg<32, 4, 4, 2, 1>;  // Q0 (8 waves) ...
+using Q14 = PCfg<16, 2, 4, 2, 1>;  // Q5 (8 waves) ...
+using Q15 = PCfg<32, 2, 4, 2, 1>;  // Q2 (8 waves) ...
+constexpr int kNumTilesP = 16;
 template <class C>
 constexpr TileInfoP infoP() { return TileInfoP{C::TW, C::TH, C::BN, C::NT, C::LDS_BYTES}; }
-const TileInfoP kTilesP[kNumTilesP] = {infoP<Q0>(), infoP<Q1>(), infoP<Q2>(), infoP<Q3>(), infoP<Q4>(), infoP<Q5>(), infoP<Q6>(), infoP<Q7>(), infoP<Q8>(), infoP<Q9>()};
+const TileInfoP kTilesP[kNumTilesP] = {infoP<Q0>(), infoP<Q1>(), infoP<Q2>(), infoP<Q3>(), infoP<Q4>(), infoP<Q5>(), infoP<Q6>(), infoP<Q7>(), infoP<Q8>(), infoP<Q9>(),
+                                       infoP<Q10>(), infoP<Q11>(), infoP<Q12>(), infoP<Q13>(), infoP<Q14>(), infoP<Q15>()};
 
 long tiles_of(const TileInfoP& t, int N, int H, int W, int CoutP) {
   return (long)N * ceil_div(H, t.th) * ceil_div(W, t.tw) * ceil_div(CoutP, t.bn);
@@ -468,6 +495,12 @@ int osvos_conv3x3_p3(const void* x3, const void* wpk3, const float* bias, const 
     case 7: rc = launch_p3<Q7>(a, stream); break;
     case 8: rc = launch_p3<Q8>(a, stream); break;
     case 9: rc = launch_p3<Q9>(a, stream); break;
+    case 10: rc = launch_p3<Q10>(a, stream); break;
+    case 11: rc = launch_p3<Q11>(a, stream); break;
+    case 12: rc = launch_p3<Q12>(a, stream); break;
+    case 13: rc = launch_p3<Q13>(a, stream); break;
+    case 14: rc = launch_p3<Q14>(a, stream); break;
+    case 15: rc = launch_p3<Q15>(a, stream); break;
     default: osvos_set_error("conv3x3 p3: unknown tile config %d", tile); return -1;
   }
   if (rc || a.ksplit == 1) return rc;

@@ -96,7 +96,24 @@ __device__ inline void split8w(const u32x4& lo, const u32x4& hi, u32x4& p0, u32x
   p2 = u32x4{q2[0], q2[1], q2[2], q2[3]};
 }
 
-template <int PH, int WAVES, int P3IN, int S16 = 0>
+// scheduling groups of one stage, in program order: MFMA, then what may hide in its 32-cycle shadow -- its share of the NDS gathers and NVM
+// staging loads of the stage, a few VALU / SALU (the builtin wants literal sizes: compile-time recursion)
+template <int NDS, int NVM, int I = 0>
+__device__ __forceinline__ void stage_groups() {
+  if constexpr (I < 18) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    constexpr int nds = (NDS * (I + 1)) / 18 - (NDS * I) / 18, nvm = (NVM * (I + 1)) / 18 - (NVM * I) / 18;
+    if constexpr (nds > 0) __builtin_amdgcn_sched_group_barrier(0x100, nds, 0);
+    if constexpr (nvm > 0) __builtin_amdgcn_sched_group_barrier(0x020, nvm, 0);
+    __builtin_amdgcn_sched_group_barrier(0x006, 3, 0);
+    stage_groups<NDS, NVM, I + 1>();
+  }
+}
+
+// ILV = 1 (four-wave forms): the next stage's 18-24 fragment gathers and the staging loads are INTERLEAVED with the stage's 18 MFMAs (one
+// gather per MFMA, sched_group_barrier) instead of being issued as a block in front of them: with one wave per SIMD nothing else covers
+// the ~150-250 cycles that block takes while the matrix pipe drains (576 cycles of MFMA per stage; the pipe was busy 51 % of the time).
+template <int PH, int WAVES, int P3IN, int S16 = 0, int ILV = 0>
 __global__ __launch_bounds__(64 * WAVES) void wgrad_f32x3_kernel(W3Args a) {
   using G = G3<PH, WAVES, S16>;
   constexpr int NT = G::NT, BCO = G::BCO, BCI = G::BCI;
@@ -274,7 +291,7 @@ __global__ __launch_bounds__(64 * WAVES) void wgrad_f32x3_kernel(W3Args a) {
         ldb(st);
       }
       issue(nx, st);                    // next patch's fp32 pieces: one item (two 16-byte loads) per stage
-      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (ILV == 0) __builtin_amdgcn_sched_barrier(0);
       // pieces: 0 = high, 1 = middle, 2 = low; small products first.  First operand = X (rows = cin), second = dY (columns = cout)
       constexpr int PX[6] = {2, 0, 1, 1, 0, 0};
       constexpr int PD[6] = {0, 2, 1, 0, 1, 0};
@@ -284,6 +301,14 @@ __global__ __launch_bounds__(64 * WAVES) void wgrad_f32x3_kernel(W3Args a) {
         for (int s = 0; s < 3; ++s)
           acc[r * 3 + s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, bfr[st & (NB - 1)][PX[t]][s]),
                                                                   __builtin_bit_cast(bf16x8_t, af[ks & (NB - 1)][PD[t]]), acc[r * 3 + s], 0, 0, 0);
+      if constexpr (ILV != 0) {
+        // gathers of the NEXT stage (independent registers: the fragment sets are double buffered) and this stage's staging loads
+        constexpr int V = P3IN ? 3 : 2;
+        const bool last = st + 1 >= G::NST, wide = r == 2, vm = st < G::NIT;      // (compile-time after unrolling)
+        if (last) { if (vm) stage_groups<0, V>(); else stage_groups<0, 0>(); }
+        else if (wide) { if (vm) stage_groups<24, V>(); else stage_groups<24, 0>(); }
+        else { if (vm) stage_groups<18, V>(); else stage_groups<18, 0>(); }
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -368,17 +393,17 @@ W3Plan make_plan3(int N, int H, int W, int Cin_s, int Cout) {
   return p;
 }
 
-template <int PH, int WAVES, int P3IN, int S16 = 0>
+template <int PH, int WAVES, int P3IN, int S16 = 0, int ILV = 0>
 int launch3(const W3Args& a, long blocks, hipStream_t stream) {
   static bool attr_set_dev[OSVOS_MAX_DEVICES] = {};
   bool& attr_set = attr_set_dev[osvos_current_device()];
   if (!attr_set) {
-    OSVOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_f32x3_kernel<PH, WAVES, P3IN, S16>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    OSVOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_f32x3_kernel<PH, WAVES, P3IN, S16, ILV>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)G3<PH, WAVES, S16>::LDS));
     attr_set = true;
   }
   constexpr size_t lds = G3<PH, WAVES, S16>::LDS;
-  hipLaunchKernelGGL((wgrad_f32x3_kernel<PH, WAVES, P3IN, S16>), dim3((unsigned)blocks), dim3(64 * WAVES), lds, stream, a);
+  hipLaunchKernelGGL((wgrad_f32x3_kernel<PH, WAVES, P3IN, S16, ILV>), dim3((unsigned)blocks), dim3(64 * WAVES), lds, stream, a);
   OSVOS_LAUNCH_CHECK();
   return 0;
 }
@@ -428,12 +453,17 @@ int wgrad3_run(const void* x, const void* dy, int p3in, void* ws, float* dw, flo
   const int phase = osvos_wgrad_phase();
   if (phase != 2) {
     int rc;
+    OSVOS_ENV_INT(ilv, "OSVOS_WGRAD_ILV", 1);      // 1: gathers / staging loads interleaved with the MFMAs (four-wave forms); 0: issued as a block
     if (skinny)
-      rc = launch3<4, 4, 1, 1>(a, blocks, stream);
+      rc = ilv ? launch3<4, 4, 1, 1, 1>(a, blocks, stream) : launch3<4, 4, 1, 1, 0>(a, blocks, stream);
     else if (p3in)
-      rc = p.waves == 8 ? launch3<4, 8, 1>(a, blocks, stream) : (p.ph == 6 ? launch3<6, 4, 1>(a, blocks, stream) : launch3<4, 4, 1>(a, blocks, stream));
+      rc = p.waves == 8 ? launch3<4, 8, 1>(a, blocks, stream)
+                        : (p.ph == 6 ? (ilv ? launch3<6, 4, 1, 0, 1>(a, blocks, stream) : launch3<6, 4, 1, 0, 0>(a, blocks, stream))
+                                     : (ilv ? launch3<4, 4, 1, 0, 1>(a, blocks, stream) : launch3<4, 4, 1, 0, 0>(a, blocks, stream)));
     else
-      rc = p.waves == 8 ? launch3<4, 8, 0>(a, blocks, stream) : (p.ph == 6 ? launch3<6, 4, 0>(a, blocks, stream) : launch3<4, 4, 0>(a, blocks, stream));
+      rc = p.waves == 8 ? launch3<4, 8, 0>(a, blocks, stream)
+                        : (p.ph == 6 ? (ilv ? launch3<6, 4, 0, 0, 1>(a, blocks, stream) : launch3<6, 4, 0, 0, 0>(a, blocks, stream))
+                                     : (ilv ? launch3<4, 4, 0, 0, 1>(a, blocks, stream) : launch3<4, 4, 0, 0, 0>(a, blocks, stream)));
     if (rc) return rc;
   }
   if (phase == 1) return 0;

@@ -103,6 +103,15 @@ for name, h, w, cin, cout in layers:
         x3, dy3 = ops.f32_to_p3(x), ops.f32_to_p3(dy)
         m0 = timeit(lambda: ops.conv3x3_wgrad(x, dy, cin, cout, dtype=_lib.F32_X3), args.reps)
         m1 = timeit(lambda: ops.conv3x3_wgrad_p3(x3, dy3, cin, cout), args.reps)
+    elif cout == 16 and cin % 128 == 0:
+        x = torch.relu(torch.randn(n, h, w, cin, device="cuda"))
+        dy = torch.randn(n, h, w, cout, device="cuda")
+        x3, dy3 = ops.f32_to_p3(x), ops.f32_to_p3(dy, cd=16)
+        m0 = timeit(lambda: ops.conv3x3_wgrad(x, dy, cin, cout, dtype=_lib.F32), args.reps)
+        m1 = timeit(lambda: ops.conv3x3_wgrad_p3(x3, dy3, cin, cout), args.reps)
+    else:
+        m0 = None
+    if m0 is not None:
         tot["wx3"] += m0
         tot["wp3"] += m1
         print("%-9s wgrad %4dx%-4d %4d->%-4d %6.2f | fp32-in %.3f ms (%.1f TF/s)  P3-in %.3f ms (%.1f TF/s)  %.2fx" % (name, h, w, cin, cout, gf, m0, gf / m0, m1, gf / m1, m0 / m1))
