@@ -98,7 +98,7 @@ int osvos_conv3x3_splitk(const void* x, const void* wpk, const float* bias, cons
  * A "P3" tensor is an fp32 NHWC tensor held as its three bf16 pieces: [N][3][H][W][C] bf16, plane 0 = hi = bf16(v), plane 1 = mid =
  * bf16(v - hi), plane 2 = lo = bf16(v - hi - mid) (round-to-nearest-even; v = hi + mid + lo EXACTLY: a lossless 6-byte encoding).
  * It is what the f32x3 kernels multiply; with the pieces formed once in the producer's epilogue the consumers stage their operands
- * by LDS-DMA / plain copies.  osvos_net_* use it internally for dtype OSVOS_F32_X3 (OSVOS_X3_P3=0: fp32 tensors, split while staging).
+ * by LDS-DMA / plain copies.  osvos_net_* use it internally for dtype OSVOS_F32_X3 when OSVOS_X3_P3=1 (opt-in: measured 3-5 % slower than fp32 tensors split while staging).
  *   osvos_f32_to_p3_abi / osvos_p3_to_f32_abi: conversions (src channel stride cs, C channels copied, dst channel stride cd % 8 == 0,
  *     padding channels zero; the way back needs C % 4 == 0 and a dense source).
  *   osvos_conv3x3_p3_abi: y = epi(bias + conv3x3(x)) as osvos_conv3x3, x3 a P3 tensor (Cin % 16 == 0), wpk3 from

@@ -118,7 +118,8 @@ int osvos_conv3x3_wgrad(const void* x, const void* dy, void* ws, float* dw, floa
                                         accumulate, (hipStream_t)stream);
   // f32x3 (dtype OSVOS_F32_X3, or OSVOS_F32 under the process-wide f32x3 mode): the wide trunk layers on the bf16 matrix pipe with
   // three-way split operands; conv1_1 and side_prep keep their exact skinny kernels
-  if ((dtype == OSVOS_F32_X3 || (dtype == OSVOS_F32 && osvos_fp32_conv_mode() == 1)) && osvos_wgrad_f32x3_applicable(Cin, Cin_s, Cout, Cout_s))
+  if ((dtype == OSVOS_F32_X3 || (dtype == OSVOS_F32 && osvos_fp32_conv_mode() == 1)) &&
+      (osvos_wgrad_f32x3_applicable(Cin, Cin_s, Cout, Cout_s) || osvos_wgrad_f32x3_skinny_applicable(Cin, Cin_s, Cout, Cout_s)))
     return osvos_conv3x3_wgrad_f32x3((const float*)x, (const float*)dy, ws, dw, db, N, H, W, Cin, Cin_s, Cout, Cout_s, accumulate,
                                      (hipStream_t)stream);
   return osvos_conv3x3_wgrad_f32((const float*)x, (const float*)dy, ws, dw, db, N, H, W, Cin, Cin_s, Cout, Cout_s,

@@ -20,6 +20,7 @@ int osvos_conv3x3_f32x3(const float* x, const float* wpk, const float* bias, con
                         int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int tile, int ksplit, void* part_ws, hipStream_t stream);
 // f32x3 weight gradient (wgrad_f32x3.hip): fp32 x / dy, three-way bf16 split, fp32 slabs + the shared reduce
 bool osvos_wgrad_f32x3_applicable(int Cin, int Cin_s, int Cout, int Cout_s);
+bool osvos_wgrad_f32x3_skinny_applicable(int Cin, int Cin_s, int Cout, int Cout_s);
 size_t osvos_wgrad_f32x3_ws_bytes(int N, int H, int W, int Cin_s, int Cout);
 int osvos_conv3x3_wgrad_f32x3(const float* x, const float* dy, void* ws, float* dw, float* db,
                               int N, int H, int W, int Cin, int Cin_s, int Cout, int Cout_s, int accumulate, hipStream_t stream);

@@ -89,13 +89,13 @@ inline bool use_store(int dtype) {
   return dtype == OSVOS_F32_BF16MFMA && on;
 }
 
-// P3 storage of the f32x3 mode (p3.h; default, OSVOS_X3_P3=0 keeps fp32 trunk tensors that every consumer splits while staging): the trunk
+// P3 storage of the f32x3 mode (p3.h; OPT-IN with OSVOS_X3_P3=1 -- measured 3-5 % slower than fp32 tensors split while staging): the trunk
 // tensors (conv outputs, pooled tensors, their gradients) live in HBM as their three bf16 piece planes, formed once in the producer's
 // epilogue; the convolutions stage them by LDS-DMA (conv3x3_p3.hip), the weight gradients copy them (wgrad_f32x3.hip, P3IN).  fp32 copies
 // exist only where an fp32 consumer remains: the five stage outputs (pooling + arg-max recompute, side_prep's exact skinny weight
 // gradient), conv1_1's output (made by the exact kernel) and its gradient (conv1_1's exact weight gradient), the pooled / side gradients.
 inline bool use_p3(int dtype) {
-  static const bool on = [] { const char* e = getenv("OSVOS_X3_P3"); return !(e && e[0] == '0'); }();
+  static const bool on = [] { const char* e = getenv("OSVOS_X3_P3"); return e && e[0] == '1'; }();
   return dtype == OSVOS_F32_X3 && on;
 }
 
@@ -453,8 +453,7 @@ int backward_trunk_p3(const void* wbuf, void* ws, float* const* grads, float* dx
                                     d[l].cout, d[l].cout, accumulate, st);
     }
     // side_prep (Cout = 16): on the bf16 pipe from the P3 stage output and the P3 head gradient (OSVOS_X3_SIDE_WGRAD=0: the exact fp32 skinny kernel)
-    static const bool side_x3 = [] { const char* e = getenv("OSVOS_X3_SIDE_WGRAD"); return !(e && e[0] == '0'); }();
-    if (l >= kNumTrunk && side_x3 && d[l].cin % 128 == 0)
+    if (l >= kNumTrunk && osvos_wgrad_f32x3_skinny_applicable(d[l].cin, d[l].cin_s, 16, 16))
       return osvos_conv3x3_wgrad_p3(at(ws, L.act3[last_of_stage(d[l].stage)]), at(ws, L.dprep3[l - kNumTrunk]), at(ws, L.wgrad[l]), grads[d[l].w_param],
                                     grads[d[l].b_param], N, h, w, d[l].cin, d[l].cin_s, 16, 16, accumulate, st);
     const void* x = l == 0 ? at(ws, L.xin) : at(ws, L.act[last_of_stage(d[l].stage)]);

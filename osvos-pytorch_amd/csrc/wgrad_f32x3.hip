@@ -417,6 +417,11 @@ int osvos_wgrad_reduce_launch(const float* slab, const float* bslab, float* dw, 
 bool osvos_wgrad_f32x3_applicable(int Cin, int Cin_s, int Cout, int Cout_s) {
   return Cin == Cin_s && Cin_s % 64 == 0 && Cout % 64 == 0 && Cout_s % 4 == 0;
 }
+// side_prep's shape (Cout = 16): the S16 form (OSVOS_X3_SIDE_WGRAD=0 keeps the exact fp32 skinny kernel)
+bool osvos_wgrad_f32x3_skinny_applicable(int Cin, int Cin_s, int Cout, int Cout_s) {
+  static const bool on = [] { const char* e = getenv("OSVOS_X3_SIDE_WGRAD"); return !(e && e[0] == '0'); }();
+  return on && Cout == 16 && Cout_s == 16 && Cin == Cin_s && Cin_s % 128 == 0;
+}
 
 size_t osvos_wgrad_f32x3_ws_bytes(int N, int H, int W, int Cin_s, int Cout) {
   if (Cout == 16 && Cin_s % 128 == 0) {
@@ -436,7 +441,7 @@ int wgrad3_run(const void* x, const void* dy, int p3in, void* ws, float* dw, flo
                int N, int H, int W, int Cin, int Cin_s, int Cout, int Cout_s, int accumulate, hipStream_t stream) {
   OSVOS_ARG_CHECK(x && dy && ws && dw, "wgrad f32x3: null pointer");
   OSVOS_ARG_CHECK(N > 0 && H > 0 && W > 0, "wgrad f32x3: bad shape");
-  const bool skinny = p3in && Cout == 16 && Cout_s == 16 && Cin == Cin_s && Cin_s % 128 == 0;      // side_prep (P3 inputs only)
+  const bool skinny = Cout == 16 && Cout_s == 16 && Cin == Cin_s && Cin_s % 128 == 0;      // side_prep
   OSVOS_ARG_CHECK(skinny || (osvos_wgrad_f32x3_applicable(Cin, Cin_s, Cout, Cout_s) && (!p3in || Cout_s % 8 == 0)),
                   "wgrad f32x3: unsupported shape (Cin %d/%d Cout %d/%d)", Cin, Cin_s, Cout, Cout_s);
   OSVOS_ARG_CHECK((long)H * W * Cin_s < (1L << 28) && (long)H * W * Cout_s < (1L << 28), "wgrad f32x3: image too large for 31-bit byte offsets");
@@ -454,8 +459,10 @@ int wgrad3_run(const void* x, const void* dy, int p3in, void* ws, float* dw, flo
   if (phase != 2) {
     int rc;
     OSVOS_ENV_INT(ilv, "OSVOS_WGRAD_ILV", 1);      // 1: gathers / staging loads interleaved with the MFMAs (four-wave forms); 0: issued as a block
-    if (skinny)
+    if (skinny && p3in)
       rc = ilv ? launch3<4, 4, 1, 1, 1>(a, blocks, stream) : launch3<4, 4, 1, 1, 0>(a, blocks, stream);
+    else if (skinny)
+      rc = ilv ? launch3<4, 4, 0, 1, 1>(a, blocks, stream) : launch3<4, 4, 0, 1, 0>(a, blocks, stream);
     else if (p3in)
       rc = p.waves == 8 ? launch3<4, 8, 1>(a, blocks, stream)
                         : (p.ph == 6 ? (ilv ? launch3<6, 4, 1, 0, 1>(a, blocks, stream) : launch3<6, 4, 1, 0, 0>(a, blocks, stream))

@@ -187,3 +187,67 @@ def test_skinny_side_prep_wgrad_on_the_bf16_pipe(shape):
     dw, db = ops.conv3x3_wgrad(nhwc(x), nhwc(dy), cin, cout, dtype=F32)
     e2 = rel_err(dw3, dw)
     assert e2[1] < 1e-6, (shape, e2)
+
+
+def test_skinny_wgrad_fp32_inputs_equal_the_p3_form():
+    """the same S16 kernel fed with fp32 tensors (pieces formed while staging: what the default, non-P3 network runs for side_prep)"""
+    ops = _ops()
+    from osvos_pytorch_amd._lib import F32_X3
+    n, h, w, cin, cout = 1, 30, 54, 256, 16
+    g = torch.Generator().manual_seed(77)
+    x = F.relu(torch.randn(n, h, w, cin, generator=g)).cuda()
+    dy = torch.randn(n, h, w, cout, generator=g).cuda()
+    dw3, db3 = ops.conv3x3_wgrad_p3(ops.f32_to_p3(x), ops.f32_to_p3(dy, cd=16), cin, cout)
+    dw, db = ops.conv3x3_wgrad(x, dy, cin, cout, dtype=F32_X3)
+    assert torch.equal(dw, dw3)
+    torch.testing.assert_close(db, db3, rtol=1e-6, atol=1e-5)
+
+
+@pytest.mark.parametrize("stage0", ["0", "1"])
+def test_whole_network_in_p3_storage_mode_matches_the_reference_goldens(tmp_path, stage0):
+    """OSVOS_X3_P3=1 (opt-in): trunk tensors as P3, convolutions by LDS-DMA, P3 weight gradients and pools -- forward, losses and every
+    gradient of a golden case of the REAL reference, at the fp32 bars; and within fp32 round-off of the default (fp32-tensor) f32x3 network.
+    OSVOS_P3_FROM_STAGE = 0 / 1: with and without stage 0 in P3."""
+    import os, subprocess, sys, textwrap
+    code = textwrap.dedent('''
+        import sys, numpy as np, torch
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        import test_gpu_net as T
+        from golden_util import load_case
+        from layers.osvos_layers import class_balanced_cross_entropy_loss as cbce
+        g, wts, x, m = load_case("c37x53_n2")
+        net = T.build_net(wts, "fp32x3")
+        xin = torch.from_numpy(x).requires_grad_()
+        outs = net.forward(xin.cuda())
+        gt = torch.from_numpy(m).cuda()
+        losses = [cbce(o, gt, size_average=False) for o in outs]
+        loss = (1 - 60 / 240) * sum(losses[:-1]) + losses[-1]
+        (loss / 5).backward()
+        res = {"out%%d" %% i: o.detach().cpu().numpy() for i, o in enumerate(outs)}
+        res["loss"] = np.array(loss.item())
+        res.update({"g:" + k: v.grad.cpu().numpy() for k, v in net.named_parameters() if v.grad is not None})
+        res["g:input"] = xin.grad.numpy()
+        np.savez(sys.argv[1], **res)
+    ''') % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    got = {}
+    for flag in ("0", "1"):
+        out = str(tmp_path / ("p%s.npz" % flag))
+        subprocess.run([sys.executable, "-c", code, out], check=True, env=dict(os.environ, OSVOS_X3_P3=flag, OSVOS_P3_FROM_STAGE=stage0), timeout=900)
+        got[flag] = dict(np.load(out))
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from golden_util import check_grad_either, grad_keys, load_case
+    g, _, _, _ = load_case("c37x53_n2")
+    a, b = got["0"], got["1"]
+    for i in range(5):
+        ref = g["f32|out%d" % i]
+        assert np.abs(b["out%d" % i] - ref).max() <= 1e-3 * ref.std(), i
+        assert np.abs(b["out%d" % i] - a["out%d" % i]).max() <= 2e-5 * ref.std(), i
+    assert abs(float(b["loss"]) - float(g["f32|parent|loss"])) <= 1e-5 * abs(float(g["f32|parent|loss"]))
+    n_checked = 0
+    for k in grad_keys(g, "f32|parent|grad|"):
+        if k.startswith("upscale"):
+            continue
+        check_grad_either(g, "parent", k, b["g:" + k], 1e-3, what="p3")
+        n_checked += 1
+    assert n_checked > 40
