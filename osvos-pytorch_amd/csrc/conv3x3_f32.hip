@@ -395,6 +395,27 @@ __global__ void conv_splitk_finalize_kernel(const float* __restrict__ part, cons
   }
 }
 
+// split-K finalize fused with the pool backward (epi.h): one thread per (pooled pixel, 4 channels) sums the K parts and routes the result
+// through the 2 x 2 window into dx at the pool's input resolution
+__global__ void conv_splitk_finalize_poolbwd_kernel(const float* __restrict__ part, ConvEpi epi, int N, int H, int W, int Cout, int ksplit) {
+  const int c4n = Cout / 4;
+  const long npix = (long)N * H * W, total = npix * c4n;
+  const size_t pimg = (size_t)epi.pool_H * epi.pool_W * Cout;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long pix = i / c4n;
+    const int c4 = (int)(i % c4n) * 4;
+    f32x4 s = *reinterpret_cast<const f32x4*>(part + pix * Cout + c4);
+    for (int k = 1; k < ksplit; ++k) s += *reinterpret_cast<const f32x4*>(part + ((size_t)k * npix + pix) * Cout + c4);
+    const int ox = (int)(pix % W), oy = (int)((pix / W) % H);
+    const long n = pix / ((long)W * H);
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(epi.pool_x) + n * pimg, 0, (int)(pimg * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(epi.pool_dside != nullptr ? epi.pool_dside : epi.pool_x) + n * pimg, 0,
+                                                                         epi.pool_dside != nullptr ? (int)(pimg * 4) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(epi.pool_dx + n * pimg, 0, (int)(pimg * 4), 0x00020000);
+    epi_pool_bwd_quad(s, xrs, srs, drs, oy, ox, epi.pool_H, epi.pool_W, Cout, c4, true);
+  }
+}
+
 // how many K parts a launch should be cut into so the machine sees >= ~7 workgroups per CU (balance) without
 // drowning in partial-sum traffic; 1 for the big shallow layers
 int pick_ksplit(const TileInfo& t, int N, int H, int W, int Cin, int Cout, int CoutP, int y_cs) {
@@ -507,6 +528,15 @@ int osvos_conv3x3_splitk_finalize_f32(const float* part, const float* bias, cons
   long blocks = (npix * (Cout / 4) + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(conv_splitk_finalize_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, part, bias, mask, y, npix, Cout, y_cs, ksplit, relu);
+  OSVOS_LAUNCH_CHECK();
+  return 0;
+}
+
+int osvos_conv3x3_splitk_finalize_poolbwd_f32(const float* part, const ConvEpi* epi, int N, int H, int W, int Cout, int ksplit, hipStream_t stream) {
+  OSVOS_ARG_CHECK(part && epi && epi->pool_x && epi->pool_dx && Cout % 4 == 0 && ksplit >= 1, "splitk finalize (pool backward): bad arguments");
+  long blocks = ((long)N * H * W * (Cout / 4) + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(conv_splitk_finalize_poolbwd_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, part, *epi, N, H, W, Cout, ksplit);
   OSVOS_LAUNCH_CHECK();
   return 0;
 }

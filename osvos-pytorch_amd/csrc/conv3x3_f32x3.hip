@@ -24,6 +24,7 @@
 //     of the producer fused, split-K partial sums)
 #include "common.h"
 #include "kernels.h"
+#include "epi.h"
 
 namespace {
 
@@ -43,6 +44,7 @@ struct ConvArgsX {
   int relu, map, nsp;
   int ksplit;
   float* part;
+  ConvEpi epi;           // optional fused pooling epilogues (epi.h)
 };
 
 constexpr int cdivx(int a, int b) { return (a + b - 1) / b; }
@@ -326,18 +328,33 @@ __global__ __launch_bounds__(C::NT, C::OCC) void conv3x3_f32x3_kernel(ConvArgsX 
   const bool use_bias = !split && a.bias != nullptr;
   const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(use_bias ? a.bias : a.y), 0, use_bias ? a.Cout * 4 : 0, 0x00020000);
   const bool relu = !split && a.relu;
+  // fused pool backward (epi.h): this launch is the data gradient of the first convolution of a stage
+  const bool pool_bwd = !split && a.epi.pool_dx != nullptr;
+  const size_t pimg = (size_t)a.epi.pool_H * a.epi.pool_W * a.y_cs;
+  float* const anyf = const_cast<float*>(a.wpk != nullptr ? a.wpk : reinterpret_cast<const float*>(a.wpk3));
+  const __amdgpu_buffer_rsrc_t pxrs = __builtin_amdgcn_make_buffer_rsrc(pool_bwd ? const_cast<float*>(a.epi.pool_x) + n * pimg : anyf, 0, pool_bwd ? (int)(pimg * 4) : 0, 0x00020000);
+  const bool have_ds = pool_bwd && a.epi.pool_dside != nullptr;
+  const __amdgpu_buffer_rsrc_t psrs = __builtin_amdgcn_make_buffer_rsrc(have_ds ? const_cast<float*>(a.epi.pool_dside) + n * pimg : anyf, 0, have_ds ? (int)(pimg * 4) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t pdrs = __builtin_amdgcn_make_buffer_rsrc(pool_bwd ? a.epi.pool_dx + n * pimg : anyf, 0, pool_bwd ? (int)(pimg * 4) : 0, 0x00020000);
+  // fused pool forward: this launch is the last convolution of a stage (post-ReLU values >= 0, so positions outside the image count as 0)
+  const bool pool_fwd = !split && a.epi.pooled != nullptr;
+  const int PHo = (a.H + 1) / 2, PWo = (a.W + 1) / 2;
+  const size_t poimg = (size_t)PHo * PWo * a.y_cs;
+  const __amdgpu_buffer_rsrc_t pors = __builtin_amdgcn_make_buffer_rsrc(pool_fwd ? a.epi.pooled + n * poimg : anyf, 0, pool_fwd ? (int)(poimg * 4) : 0, 0x00020000);
 #pragma unroll
   for (int ni = 0; ni < C::WN; ++ni) {
     const int cb = co0 + (wn * C::WN + ni) * 32 + 4 * lh;
     f32x4 bv[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) bv[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brs, (cb + 8 * q) * 4, 0, 0));
+    f32x4 keep[C::WM][4];      // (pool forward only: the wave's values, zero outside the image)
 #pragma unroll
     for (int mi = 0; mi < C::WM; ++mi) {
       const int mb = wm * C::WM + mi;
       const int oy = y0 + (mb / C::TBX) * C::RBH + li / C::RBW;
       const int ox = x0 + (mb % C::TBX) * C::RBW + li % C::RBW;
-      const unsigned pix = (oy < a.H && ox < a.W) ? (unsigned)((oy * a.W + ox) * cs) * 4u : OOB;
+      const bool inside = oy < a.H && ox < a.W;
+      const unsigned pix = inside ? (unsigned)((oy * a.W + ox) * cs) * 4u : OOB;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int co = cb + 8 * q;
@@ -353,7 +370,44 @@ __global__ __launch_bounds__(C::NT, C::OCC) void conv3x3_f32x3_kernel(ConvArgsX 
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = m[e] > 0.f ? v[e] : 0.f;
         }
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, off, 0, 0);
+        if (pool_bwd) {
+          epi_pool_bwd_quad(v, pxrs, psrs, pdrs, oy, ox, a.epi.pool_H, a.epi.pool_W, a.y_cs, co, inside && co < a.Cout);
+        } else {
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, off, 0, 0);
+        }
+        if (pool_fwd) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) keep[mi][q][e] = inside ? v[e] : 0.f;
+        }
+      }
+    }
+    if (pool_fwd) {
+      // windows: RBW 32 -- M blocks 2j, 2j+1 of this wave are the two rows, lane ^ 1 the neighbouring column;
+      //          RBW 16 -- an M block holds both rows (lanes li and li ^ 16), lane ^ 1 the neighbouring column
+      constexpr int NP = C::RBW == 32 ? C::WM / 2 : C::WM;
+#pragma unroll
+      for (int j = 0; j < NP; ++j) {
+        const int mb = wm * C::WM + (C::RBW == 32 ? 2 * j : j);
+        const int oy = y0 + (mb / C::TBX) * C::RBH, ox = x0 + (mb % C::TBX) * C::RBW + li % C::RBW;      // top row of the window pair
+        const bool writer = (li & 1) == 0 && (C::RBW == 32 || li < 16) && oy < a.H && ox < a.W;
+        const unsigned ppix = writer ? (unsigned)(((oy >> 1) * PWo + (ox >> 1)) * a.y_cs) * 4u : OOB;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int co = cb + 8 * q;
+          f32x4 m;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float t;
+            if constexpr (C::RBW == 32) {
+              t = fmaxf(keep[2 * j][q][e], keep[2 * j + 1][q][e]);
+            } else {
+              t = keep[j][q][e];
+              t = fmaxf(t, __shfl_xor(t, 16, 64));
+            }
+            m[e] = fmaxf(t, __shfl_xor(t, 1, 64));
+          }
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, m), pors, (co < a.Cout && ppix != OOB) ? ppix + (unsigned)co * 4u : OOB, 0, 0);
+        }
       }
     }
   }
@@ -498,7 +552,21 @@ int osvos_conv3x3_f32x3(const float* x, const float* wpk, const float* bias, con
 // wpk3 != NULL: pre-split pack (osvos_pack_x3) -- wpk (the fp32 pack) is then not read and may be NULL
 int osvos_conv3x3_f32x3_ps(const float* x, const float* wpk, const void* wpk3, const float* bias, const float* mask, float* y,
                            int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int tile, int ksplit, void* part_ws, hipStream_t stream) {
-  OSVOS_ARG_CHECK(x && (wpk || wpk3) && y, "conv3x3 f32x3: null pointer");
+  return osvos_conv3x3_f32x3_epi(x, wpk, wpk3, bias, mask, y, N, H, W, Cin, Cout, y_cs, relu, tile, ksplit, part_ws, nullptr, stream);
+}
+
+// epi (may be NULL): fused pooling epilogues (epi.h).  epi->pool_dx: y may be NULL (the pooled-resolution gradient is not written);
+// epi->pooled: the launch never splits K and needs one of the eight-wave tiles whose waves hold whole 2 x 2 windows (10, 12, 14)
+int osvos_conv3x3_f32x3_epi(const float* x, const float* wpk, const void* wpk3, const float* bias, const float* mask, float* y,
+                            int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int tile, int ksplit, void* part_ws, const ConvEpi* epi,
+                            hipStream_t stream) {
+  const bool pool_bwd = epi != nullptr && epi->pool_dx != nullptr, pool_fwd = epi != nullptr && epi->pooled != nullptr;
+  OSVOS_ARG_CHECK(x && (wpk || wpk3) && (y || pool_bwd), "conv3x3 f32x3: null pointer");
+  OSVOS_ARG_CHECK(!pool_bwd || (epi->pool_x != nullptr && Cout % 4 == 0 && y_cs == Cout && (epi->pool_H + 1) / 2 == H && (epi->pool_W + 1) / 2 == W &&
+                                mask == nullptr && bias == nullptr && !relu && (long)epi->pool_H * epi->pool_W * y_cs < (1L << 29)),
+                  "conv3x3 f32x3: fused pool backward needs x, a dense Cout %% 4 == 0 result and pool_H/W = the pool's input size (%d x %d for %d x %d)",
+                  epi ? epi->pool_H : 0, epi ? epi->pool_W : 0, H, W);
+  OSVOS_ARG_CHECK(!pool_fwd || (relu && Cout % 4 == 0 && y_cs == Cout && !pool_bwd), "conv3x3 f32x3: fused pool forward needs ReLU and a dense Cout %% 4 == 0 result");
   OSVOS_ARG_CHECK(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv3x3 f32x3: bad shape");
   OSVOS_ARG_CHECK(osvos_conv3x3_f32x3_applicable(Cin, Cout, y_cs), "conv3x3 f32x3: needs Cin %% 16 == 0 (%d), y_cs %% 4 == 0 and >= Cout rounded up to 4 (%d, %d)",
                   Cin, Cout, y_cs);
@@ -509,6 +577,7 @@ int osvos_conv3x3_f32x3_ps(const float* x, const float* wpk, const void* wpk3, c
   a.x = x; a.wpk = wpk; a.wpk3 = reinterpret_cast<const uint4*>(wpk3); a.bias = bias; a.mask = mask; a.y = y;
   a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = (Cout + 3) & ~3; a.CoutP = osvos_cout_pad(Cout); a.y_cs = y_cs;
   a.relu = relu;
+  if (epi != nullptr) a.epi = *epi;
   if (tile < 0) {
     OSVOS_ENV_INT(env_tile, "OSVOS_X3_TILE", -1);
     tile = env_tile >= 0 ? env_tile : pick_tile_x(N, H, W, a.CoutP);
@@ -523,6 +592,10 @@ int osvos_conv3x3_f32x3_ps(const float* x, const float* wpk, const void* wpk3, c
     OSVOS_ENV_INT(env_ks, "OSVOS_X3_KSPLIT", 0);
     a.ksplit = ksplit > 0 ? ksplit : (env_ks > 0 && Cin >= 256 ? env_ks : pick_ksplit_x(kTilesX[tile], N, H, W, Cin, Cout, a.CoutP));
     if (a.ksplit < 1 || a.ksplit > 8 || a.ksplit > (Cin >> 4) || Cout % 4 != 0) a.ksplit = 1;
+  }
+  if (pool_fwd) {
+    a.ksplit = 1;
+    OSVOS_ARG_CHECK(tile == 10 || tile == 12 || tile == 14, "conv3x3 f32x3: fused pool forward is built for tiles 10, 12 and 14 (got %d)", tile);
   }
   int rc;
   switch (tile) {
@@ -547,5 +620,6 @@ int osvos_conv3x3_f32x3_ps(const float* x, const float* wpk, const void* wpk3, c
     default: osvos_set_error("conv3x3 f32x3: unknown tile config %d", tile); return -1;
   }
   if (rc) return rc;
+  if (a.ksplit > 1 && pool_bwd) return osvos_conv3x3_splitk_finalize_poolbwd_f32(a.part, epi, N, H, W, Cout, a.ksplit, stream);
   return a.ksplit > 1 ? osvos_conv3x3_splitk_finalize_f32(a.part, bias, mask, y, (long)N * H * W, Cout, y_cs, a.ksplit, relu, stream) : 0;
 }

@@ -1,6 +1,7 @@
 // Internal (non-ABI) launchers implemented by the .hip translation units.
 #pragma once
 #include "common.h"
+#include "epi.h"
 
 int osvos_conv3x3_f32(const float* x, const float* wpk, const float* bias, const float* mask, float* y,
                       int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int tile, hipStream_t stream);
@@ -40,6 +41,10 @@ size_t osvos_wpack_x3_bytes(int M, int K);
 int osvos_pack_x3(const float* w, void* wpk3, int Cout, int Cin, int dgrad, hipStream_t stream);
 int osvos_conv3x3_f32x3_ps(const float* x, const float* wpk, const void* wpk3, const float* bias, const float* mask, float* y,
                            int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int tile, int ksplit, void* part_ws, hipStream_t stream);
+int osvos_conv3x3_f32x3_epi(const float* x, const float* wpk, const void* wpk3, const float* bias, const float* mask, float* y,
+                            int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int tile, int ksplit, void* part_ws, const ConvEpi* epi,
+                            hipStream_t stream);
+int osvos_conv3x3_splitk_finalize_poolbwd_f32(const float* part, const ConvEpi* epi, int N, int H, int W, int Cout, int ksplit, hipStream_t stream);
 size_t osvos_wgrad_ws_bytes_f32(int N, int H, int W, int Cin_s, int Cout);
 int osvos_conv3x3_wgrad_f32(const float* x, const float* dy, void* ws, float* dw, float* db,
                             int N, int H, int W, int Cin, int Cin_s, int Cout, int Cout_s,

@@ -286,17 +286,25 @@ inline bool use_presplit() {
 // is too small to balance across 256 CUs; the bf16-MFMA dtype goes through the public entry point
 // (x_b: bf16 copy of x, preferred when present; y_b: where the bf16 copy of y goes, NULL = none)
 // (mask_b: bf16 mask, takes precedence over the fp32 `mask`; y may be NULL in the bf16 modes when y_b is given)
+// (epi: fused pooling epilogues, f32x3 only -- fuse_pool() says when the caller may ask for them)
 inline int conv_main(const void* x, const void* x_b, const void* wpk, const float* bias, const void* mask, const void* mask_b, void* y, void* y_b,
-                     int N, int h, int w, int cin, int cout, int y_cs, int relu, int dtype, void* part, hipStream_t stream, const void* wpk3 = nullptr) {
+                     int N, int h, int w, int cin, int cout, int y_cs, int relu, int dtype, void* part, hipStream_t stream, const void* wpk3 = nullptr,
+                     const ConvEpi* epi = nullptr) {
   if (dtype == OSVOS_F32_X3 && osvos_conv3x3_f32x3_applicable(cin, cout, y_cs))      // three-way bf16 split on the bf16 matrix pipe
-    return osvos_conv3x3_f32x3_ps((const float*)x, (const float*)wpk, use_presplit() ? wpk3 : nullptr, bias, (const float*)mask, (float*)y, N, h, w,
-                                  cin, cout, y_cs, relu, -1, 0, part, stream);
+    return osvos_conv3x3_f32x3_epi((const float*)x, (const float*)wpk, use_presplit() ? wpk3 : nullptr, bias, (const float*)mask, (float*)y, N, h, w,
+                                   cin, cout, y_cs, relu, -1, 0, part, epi, stream);
   if (dtype == OSVOS_F32 || dtype == OSVOS_F32_X3)
     return osvos_conv3x3_f32_ws((const float*)x, (const float*)wpk, bias, (const float*)mask, (float*)y, N, h, w, cin, cout, y_cs,
                                 relu, -1, part, stream);
   return osvos_conv3x3_bf16mfma_io(x_b ? x_b : x, x_b ? 1 : 0, wpk, bias, mask_b ? mask_b : mask, mask_b ? 1 : 0, (float*)y, y_b, N, h, w, cin,
                                    cout, y_cs, relu,
                                    -1, stream);
+}
+
+// f32x3: the pooling kernels of the stage boundaries run as epilogues of the convolutions next to them (epi.h; OSVOS_FUSE_POOL=0: own launches)
+inline bool fuse_pool(int dtype) {
+  static const bool on = [] { const char* e = getenv("OSVOS_FUSE_POOL"); return !(e && e[0] == '0'); }();
+  return on && dtype == OSVOS_F32_X3;
 }
 
 // gradient-ready events armed for the next backward of this host thread (osvos_net_arm_grad_events)
@@ -668,7 +676,10 @@ int osvos_net_forward(const float* x_nchw, const void* wbuf, void* ws, float* co
   const float* score[4]; const float* fpart[4]; const float* f1[4]; const float* f16[4];
   for (int si = 0; si < 5; ++si) {
     const int h = L.hs[si], w = L.ws[si];
-    if (si > 0) {
+    if (si > 0 && fuse_pool(dtype)) {      // pooled[si] was written by the previous stage's last convolution
+      cur = at(ws, L.pooled[si]);
+      cur_b = nullptr;
+    } else if (si > 0) {
       if (store)
         rc = osvos_maxpool2x2_bf16(cur_b, at(ws, L.pooled_b[si]), N, L.hs[si - 1], L.ws[si - 1], kStageC[si - 1], stream);
       else
@@ -681,9 +692,12 @@ int osvos_net_forward(const float* x_nchw, const void* wbuf, void* ws, float* co
     for (int j = 0; j < kStageN[si]; ++j, ++l) {
       {
         ProfScope ps(OSVOS_PROF_CONV_FWD, conv_flops(N, h, w, d[l].cin, d[l].cout), stream);
+        ConvEpi epi;
+        const bool pool_here = fuse_pool(dtype) && si < 4 && j == kStageN[si] - 1;      // last convolution of stages 0-3: + the pooled tensor
+        if (pool_here) epi.pooled = reinterpret_cast<float*>(at(ws, L.pooled[si + 1]));
         rc = conv_main(cur, cur_b, at(wbuf, P.fwd[l]), reinterpret_cast<const float*>(at(wbuf, P.bias[l])), nullptr, nullptr,
                        f32(L.act[l]), sh(L.act_b[l]), N, h, w, d[l].cin_s, d[l].cout, d[l].cout, 1, dtype, at(ws, L.conv_part), stream,
-                       P.fwd3[l] != (size_t)-1 ? at(wbuf, P.fwd3[l]) : nullptr);
+                       P.fwd3[l] != (size_t)-1 ? at(wbuf, P.fwd3[l]) : nullptr, pool_here ? &epi : nullptr);
       }
       if (rc) return rc;
       cur = at(ws, L.act[l]);
@@ -988,7 +1002,19 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
       }
       break;
     }
-    if (first_of_stage) {
+    if (first_of_stage && fuse_pool(dtype)) {
+      // through the pool into the previous stage's output (+ that stage's side branch, + ReLU mask) inside the convolution's epilogue:
+      // the pooled-resolution gradient is never written
+      const int ps2 = si - 1;
+      ConvEpi epi;
+      epi.pool_x = reinterpret_cast<const float*>(at(ws, L.act[l - 1]));
+      epi.pool_dside = ps2 >= 1 ? reinterpret_cast<const float*>(at(ws, L.dside[ps2 - 1])) : nullptr;
+      epi.pool_dx = reinterpret_cast<float*>(at(ws, L.dy[l - 1]));
+      epi.pool_H = L.hs[ps2]; epi.pool_W = L.ws[ps2];
+      rc = conv_main(g, g_b, at(wbuf, P.dgrad[l]), nullptr, nullptr, nullptr, nullptr, nullptr, N, h, w, d[l].cout, d[l].cin, d[l].cin, 0, dtype,
+                     at(ws, L.conv_part), stream, P.dgrad3[l] != (size_t)-1 ? at(wbuf, P.dgrad3[l]) : nullptr, &epi);
+      if (rc) return rc;
+    } else if (first_of_stage) {
       // through the pool into the previous stage's output (+ that stage's side branch, + ReLU mask)
       rc = conv_main(g, g_b, at(wbuf, P.dgrad[l]), nullptr, nullptr, nullptr, f32(L.dpool[si]), store ? at(ws, L.dpool_b[si]) : nullptr, N, h, w,
                      d[l].cout, d[l].cin, d[l].cin, 0, dtype, at(ws, L.conv_part), stream, P.dgrad3[l] != (size_t)-1 ? at(wbuf, P.dgrad3[l]) : nullptr);

@@ -553,3 +553,42 @@ def test_bf16_mode_conv1_1_weight_gradient_on_the_bf16_pipe_matches_the_fp32_ker
         print("conv1_1 wgrad bf16-pipe vs fp32 kernel at %dx%dx%d: dW rel-L2 %.2e, db rel-L2 %.2e" % (n, h, w, dw, db))
         assert dw <= 3e-3 and db <= 1e-5, ((n, h, w), dw, db)
         assert torch.equal(got[1][2], got[0][2])          # everything else in the network is untouched
+
+
+def test_pooling_fused_into_the_convolutions_is_bit_identical_to_its_own_launches(tmp_path):
+    """f32x3 default: the four max-pools run in the epilogue of each stage's last convolution and their backward in the epilogue of the next
+    stage's first data gradient (csrc/epi.h).  Same values, same first-maximum rule, same order of operations: logits, losses and every
+    gradient must equal the OSVOS_FUSE_POOL=0 run (own pooling launches) BIT FOR BIT -- at odd sizes (ceil-mode partial windows on both
+    axes), batch 2, and at a size where the deep data gradients are cut along K (fused finalize kernel)."""
+    import os, subprocess, sys, textwrap
+    code = textwrap.dedent('''
+        import sys, numpy as np, torch
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        import test_gpu_net as T
+        from oracle import synth
+        from layers.osvos_layers import class_balanced_cross_entropy_loss as cbce
+        res = {}
+        for tag, (n, h, w) in {"a": (2, 37, 53), "b": (1, 120, 214), "c": (1, 61, 107)}.items():
+            wts, x, m = synth.calibrated_problem(n, h, w, seed=9)
+            net = T.build_net(wts, "fp32x3")
+            xg = torch.from_numpy(x).requires_grad_()
+            outs = net.forward(xg.cuda())
+            gt = torch.from_numpy(m).cuda()
+            losses = [cbce(o, gt, size_average=False) for o in outs]
+            (0.5 * sum(losses[:-1]) + losses[-1]).backward()
+            for i, o in enumerate(outs):
+                res["%%s:out%%d" %% (tag, i)] = o.detach().cpu().numpy()
+            for k, v in net.named_parameters():
+                if v.grad is not None:
+                    res["%%s:g:%%s" %% (tag, k)] = v.grad.cpu().numpy()
+            res[tag + ":dx"] = xg.grad.numpy()
+        np.savez(sys.argv[1], **res)
+    ''') % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    got = {}
+    for flag in ("0", "1"):
+        out = str(tmp_path / ("f%s.npz" % flag))
+        subprocess.run([sys.executable, "-c", code, out], check=True, env=dict(os.environ, OSVOS_FUSE_POOL=flag), timeout=900)
+        got[flag] = dict(np.load(out))
+    assert got["0"].keys() == got["1"].keys() and len(got["0"]) > 120
+    for k in got["0"]:
+        assert np.array_equal(got["0"][k], got["1"][k]), (k, float(np.abs(got["0"][k] - got["1"][k]).max()))
