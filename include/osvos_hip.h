@@ -94,6 +94,11 @@ int osvos_conv3x3_splitk(const void* x, const void* wpk, const float* bias, cons
                          int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int dtype, int tile, int ksplit,
                          void* part_ws, void* stream);
 
+/* Input gradient of the FIRST convolution (Cin = 3; train_online.py:121 makes the input require grad): dy NHWC fp32 [N][H][W][Cout]
+ * (Cout % 16 == 0), wpk_dgrad = osvos_pack_conv3x3_dgrad(w, .., Cout, 3, OSVOS_F32) -> dx_nchw fp32 [N][3][H][W] directly.  A bandwidth
+ * kernel (fp32 FMAs, filter through scalar loads) in place of a 32-cout MFMA tile that would waste 10x the matrix work. */
+int osvos_conv3x3_dgrad_c3(const float* dy, const float* wpk_dgrad, float* dx_nchw, int N, int H, int W, int Cout, void* stream);
+
 /* ---- P3 operand storage for the f32x3 arithmetic ------------------------------------------------------------------------
  * A "P3" tensor is an fp32 NHWC tensor held as its three bf16 pieces: [N][3][H][W][C] bf16, plane 0 = hi = bf16(v), plane 1 = mid =
  * bf16(v - hi), plane 2 = lo = bf16(v - hi - mid) (round-to-nearest-even; v = hi + mid + lo EXACTLY: a lossless 6-byte encoding).

@@ -52,6 +52,7 @@ PROTOTYPES = {
     "osvos_nchw_to_nhwc_bf16copy": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "osvos_maxpool2x2_bf16copy": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "osvos_maxpool2x2_bwd_bf16copy": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "osvos_conv3x3_dgrad_c3": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "osvos_f32_to_p3_abi": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "osvos_p3_to_f32_abi": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "osvos_conv3x3_p3_tiles": (_i, []),

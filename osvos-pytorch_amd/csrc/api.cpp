@@ -143,6 +143,10 @@ int osvos_maxpool2x2_bwd_bf16copy(const float* x, const float* dy, const float* 
   return osvos_maxpool2x2_bwd_f32(x, dy, dside, dx, dx_bf16, N, H, W, C, (hipStream_t)stream);
 }
 
+int osvos_conv3x3_dgrad_c3(const float* dy, const float* wpk_dgrad, float* dx_nchw, int N, int H, int W, int Cout, void* stream) {
+  return osvos_conv3x3_dgrad_c3_f32(dy, wpk_dgrad, dx_nchw, N, H, W, Cout, (hipStream_t)stream);
+}
+
 // ---- P3 storage of the f32x3 arithmetic (p3.h): fp32 tensors held as their three bf16 piece planes [N][3][H][W][C] ----
 int osvos_f32_to_p3_abi(const float* src, void* dst3, int N, int H, int W, int C, int cs, int cd, void* stream) {
   return osvos_f32_to_p3(src, dst3, N, H, W, C, cs, cd, (hipStream_t)stream);

@@ -307,6 +307,12 @@ inline bool fuse_pool(int dtype) {
   return on && dtype == OSVOS_F32_X3;
 }
 
+// the 3-channel input gradient on its own bandwidth kernel (dgrad_c3.hip) instead of a 32-cout MFMA tile (OSVOS_DGRAD_C3=0: the MFMA tile)
+inline bool use_dgrad_c3() {
+  static const bool on = [] { const char* e = getenv("OSVOS_DGRAD_C3"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
 // gradient-ready events armed for the next backward of this host thread (osvos_net_arm_grad_events)
 struct GradEvents { hipEvent_t ev[OSVOS_NGRAD_GROUPS]; int n = 0; };
 GradEvents& grad_events() {
@@ -524,7 +530,10 @@ int backward_trunk_p3(const void* wbuf, void* ws, float* const* grads, float* dx
     }
     if (first_of_stage && !tail_on_main && (rc = ready(2 + (4 - si), aux2))) return rc;
     if (l == 0) {
-      if (dx_nchw != nullptr) {
+      if (dx_nchw != nullptr && use_dgrad_c3()) {
+        rc = osvos_conv3x3_dgrad_c3_f32(f32at(ws, L.dy[0]), reinterpret_cast<const float*>(at(wbuf, P.dgrad[0])), dx_nchw, N, h, w, d[0].cout, stream);
+        if (rc) return rc;
+      } else if (dx_nchw != nullptr) {
         if (s0 > 0)
           rc = osvos_conv3x3_f32x3_ps(f32at(ws, L.dy[0]), reinterpret_cast<const float*>(at(wbuf, P.dgrad[0])), at(wbuf, P.dgrad3[0]), nullptr, nullptr,
                                       f32at(ws, L.dxin), N, h, w, d[0].cout, 3, 4, 0, -1, 0, nullptr, stream);
@@ -988,7 +997,10 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
     }
     if (first_of_stage && !tail_on_main && (rc = ready(2 + (4 - si), aux2))) return rc;      // stage si complete (its first conv is the last one processed)
     if (l == 0) {
-      if (dx_nchw != nullptr) {
+      if (dx_nchw != nullptr && (dtype == OSVOS_F32 || dtype == OSVOS_F32_X3) && use_dgrad_c3()) {
+        rc = osvos_conv3x3_dgrad_c3_f32(reinterpret_cast<const float*>(g), reinterpret_cast<const float*>(at(wbuf, P.dgrad[0])), dx_nchw, N, h, w, d[0].cout, stream);
+        if (rc) return rc;
+      } else if (dx_nchw != nullptr) {
         rc = conv_main(g, g_b, at(wbuf, P.dgrad[0]), nullptr, nullptr, nullptr, at(ws, L.dxin), nullptr, N, h, w, d[0].cout, 3, 4, 0, dtype,
                        nullptr, stream, P.dgrad3[0] != (size_t)-1 ? at(wbuf, P.dgrad3[0]) : nullptr);
         if (rc) return rc;

@@ -349,3 +349,12 @@ def maxpool2x2_bwd_p3(x, dy, dside=None, want_f32=False):
     dx3 = torch.empty((n, 3, h, w, c), device=x.device, dtype=torch.bfloat16)
     check(lib().osvos_maxpool2x2_bwd_p3_abi(_p(x), _p(dy), _p(dside), _p(dx), _p(dx3), n, h, w, c, _stream()), "maxpool_bwd_p3")
     return dx, dx3
+
+
+def conv3x3_dgrad_c3(dy, w_oihw):
+    """input gradient of a 3-input-channel convolution: dy fp32 [N,H,W,Cout], filter [Cout,3,3,3] -> dx fp32 NCHW [N,3,H,W]"""
+    _need_cuda(dy, w_oihw)
+    n, h, w, cout = dy.shape
+    dx = torch.empty((n, 3, h, w), device=dy.device, dtype=torch.float32)
+    check(lib().osvos_conv3x3_dgrad_c3(_p(dy.contiguous()), _p(pack_dgrad(w_oihw)), _p(dx), n, h, w, cout, _stream()), "dgrad_c3")
+    return dx

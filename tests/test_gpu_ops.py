@@ -789,3 +789,18 @@ def test_head_lowres_upsample_and_backward_at_the_baseline_crop_sets(HW):
         assert rel_err(dwf.cpu(), wf.grad.flatten()[16 * i:16 * i + 16])[0] < 1e-5
         assert rel_err(dwd.cpu(), wd[i].grad.flatten())[0] < 1e-5
         assert abs(float(dbd) - float(bd[i].grad)) <= 1e-5 * abs(float(bd[i].grad)) + 1e-3
+
+
+@pytest.mark.parametrize("shape", [(1, 9, 11, 64), (2, 17, 35, 64), (1, 40, 70, 16), (1, 8, 33, 32)])
+def test_input_gradient_of_the_first_convolution(shape):
+    """dgrad_c3.hip: dx = conv_transpose(dy, W) for Cin = 3 straight into NCHW, against float64"""
+    ops = _ops()
+    n, h, w, cout = shape
+    g = torch.Generator().manual_seed(91 + w)
+    dy = torch.randn(n, cout, h, w, generator=g)
+    wt = torch.randn(cout, 3, 3, 3, generator=g) / 5
+    ref = F.conv_transpose2d(dy.double(), wt.double(), padding=1)
+    dx = ops.conv3x3_dgrad_c3(nhwc(dy), wt.cuda())
+    assert dx.shape == (n, 3, h, w)
+    emax, el2 = rel_err(dx.cpu(), ref)
+    assert emax < 2e-5 and el2 < 1e-5, (shape, emax, el2)
