@@ -5,19 +5,21 @@
 //
 // 1.4 GFLOP over a 105 MB tensor: a bandwidth problem.  As a 32-cout MFMA tile of the f32x3 convolution it wasted 10x the matrix work
 // and, one workgroup per CU, took 120-176 us at the tail of the step next to conv1_2's weight gradient (profiles/r03_*timeline*).  Here:
-// plain fp32 FMAs, one thread per pixel and its 3 input channels; dy's halo tile goes through LDS in 16-channel chunks as planes of
-// 16-byte channel quads ([quad][pixel]: a wave's 64 consecutive pixels read 64 consecutive slots), two buffers, the next chunk's loads in
-// flight during the FMAs; the filter never touches LDS or a vector register -- every (tap, channel quad) is 12 consecutive floats of the
-// data-gradient pack [tap][co / 4][32][4] (osvos_pack_dgrad_f32), uniform across the wave, i.e. scalar loads feeding v_fma's SGPR operand.
-// Result written straight into the caller's NCHW tensor (three planes, lanes = consecutive x).
+// plain fp32 FMAs, one thread per TWO pixels (rows y, y + 8 of a 32 x 16 tile) and their 3 input channels; per 16-channel chunk dy's
+// halo tile sits in LDS as planes of 16-byte channel quads ([quad][pixel]: a wave's 64 consecutive pixels read 64 consecutive slots) and
+// the chunk's filter slice (9 taps x 4 quads x 12 floats of the data-gradient pack [tap][co / 4][32][4], osvos_pack_dgrad_f32) next to it,
+// read as wave-wide broadcasts: 2 + 3 LDS reads per 24 FMAs.  40 KB of LDS and <= 128 registers: four workgroups per CU cover each
+// other's load / barrier phases.  (A first form fed the filter through scalar loads: every (tap, quad) then waited out an s_load --
+// 202 us per launch.)  Result written straight into the caller's NCHW tensor (three planes, lanes = consecutive x).
 #include "common.h"
 #include "kernels.h"
 
 namespace {
 
-constexpr int TW = 32, TH = 8, HWD = TW + 2, HHT = TH + 2, PLANE = HHT * HWD;      // 256 pixels, 340 halo pixels
+constexpr int TW = 32, TH = 16, HWD = TW + 2, HHT = TH + 2, PLANE = HHT * HWD;    // 512 pixels per workgroup, 612 halo pixels
 constexpr int CQ = 4;                                                             // channel quads per chunk (16 channels)
 constexpr int ITEMS = CQ * PLANE, NT = 256, NLD = (ITEMS + NT - 1) / NT;          // 16-byte items per chunk; loads per thread
+constexpr int WITEMS = 9 * CQ * 3;                                                // 16-byte filter items per chunk: [tap][quad][ci] x 4 couts
 
 struct D3Args {
   const float* dy;       // NHWC [N][H][W][Cout], Cout = 64
@@ -26,15 +28,16 @@ struct D3Args {
   int N, H, W, Cout, tiles_x, tiles_y;
 };
 
-__global__ __launch_bounds__(NT) void dgrad_c3_kernel(D3Args a) {
-  __shared__ f32x4 tile[2][ITEMS];
+__global__ __launch_bounds__(NT, 4) void dgrad_c3_kernel(D3Args a) {
+  __shared__ f32x4 tile[ITEMS];
+  __shared__ f32x4 wl[WITEMS];
   const int tid = threadIdx.x;
   int t = blockIdx.x;
   const int tx = t % a.tiles_x;
   t /= a.tiles_x;
   const int ty = t % a.tiles_y, n = t / a.tiles_y;
   const int x0 = tx * TW, y0 = ty * TH;
-  const int lx = tid % TW, ly = tid / TW;
+  const int lx = tid % TW, ly = tid / TW;              // this thread's pixels: (ly, lx) and (ly + 8, lx)
   const int nchunks = a.Cout / 16;
   const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy) + (size_t)n * a.H * a.W * a.Cout, 0,
                                                                        (int)((size_t)a.H * a.W * a.Cout * 4), 0x00020000);
@@ -48,46 +51,48 @@ __global__ __launch_bounds__(NT) void dgrad_c3_kernel(D3Args a) {
     off[i] = (e < ITEMS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? (unsigned)(((gy * a.W + gx) * a.Cout + 4 * q) * 4) : OOB;
   }
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-  u32x4 reg[NLD];
-  auto load = [&](int kc) {
+  // filter item of this thread (tid < WITEMS): (tap, quad, ci) -> 4 consecutive couts of the pack
+  const int wtap = tid / (CQ * 3), wq = (tid / 3) % CQ, wci = tid % 3;
+  float acc[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+  for (int kc = 0; kc < nchunks; ++kc) {
+    u32x4 reg[NLD];
 #pragma unroll
     for (int i = 0; i < NLD; ++i) reg[i] = __builtin_amdgcn_raw_buffer_load_b128(drs, off[i], kc * 64, 0);
-  };
-  auto store = [&](int buf) {
+    f32x4 wreg = {0.f, 0.f, 0.f, 0.f};
+    if (tid < WITEMS) wreg = *reinterpret_cast<const f32x4*>(a.wpk + ((size_t)(wtap * (a.Cout / 4) + kc * CQ + wq) * 32 + wci) * 4);
+    __syncthreads();          // everybody is done with the previous chunk's tiles
 #pragma unroll
     for (int i = 0; i < NLD; ++i)
-      if (ITEMS % NT == 0 || tid + i * NT < ITEMS) tile[buf][tid + i * NT] = __builtin_bit_cast(f32x4, reg[i]);
-  };
-  float acc[3] = {0.f, 0.f, 0.f};
-  load(0);
-  store(0);
-  __syncthreads();
-  for (int kc = 0; kc < nchunks; ++kc) {
-    const int buf = kc & 1;
-    if (kc + 1 < nchunks) load(kc + 1);
+      if (ITEMS % NT == 0 || tid + i * NT < ITEMS) tile[tid + i * NT] = __builtin_bit_cast(f32x4, reg[i]);
+    if (tid < WITEMS) wl[tid] = wreg;
+    __syncthreads();
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int r = tap / 3, s = tap % 3;
 #pragma unroll
       for (int q = 0; q < CQ; ++q) {
-        const f32x4 v = tile[buf][q * PLANE + (ly + r) * HWD + lx + s];
-        const float* w = a.wpk + ((size_t)(tap * (a.Cout / 4) + kc * CQ + q) * 32) * 4;      // uniform: [ci 0..2][co % 4]
+        const f32x4 v0 = tile[q * PLANE + (ly + r) * HWD + lx + s];
+        const f32x4 v1 = tile[q * PLANE + (ly + 8 + r) * HWD + lx + s];
 #pragma unroll
-        for (int ci = 0; ci < 3; ++ci)
+        for (int ci = 0; ci < 3; ++ci) {
+          const f32x4 w = wl[(tap * CQ + q) * 3 + ci];          // same address in every lane: a broadcast read
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc[ci] = __builtin_fmaf(v[e], w[ci * 4 + e], acc[ci]);
+          for (int e = 0; e < 4; ++e) {
+            acc[0][ci] = __builtin_fmaf(v0[e], w[e], acc[0][ci]);
+            acc[1][ci] = __builtin_fmaf(v1[e], w[e], acc[1][ci]);
+          }
+        }
       }
     }
-    if (kc + 1 < nchunks) {
-      store(buf ^ 1);        // (the other buffer was last read in iteration kc - 1, behind the barrier below)
-      __syncthreads();
-    }
   }
-  const int oy = y0 + ly, ox = x0 + lx;
-  if (oy < a.H && ox < a.W) {
-    float* o = a.dx + ((size_t)n * 3 * a.H + oy) * a.W + ox;
 #pragma unroll
-    for (int ci = 0; ci < 3; ++ci) o[(size_t)ci * a.H * a.W] = acc[ci];
+  for (int h = 0; h < 2; ++h) {
+    const int oy = y0 + ly + 8 * h, ox = x0 + lx;
+    if (oy < a.H && ox < a.W) {
+      float* o = a.dx + ((size_t)n * 3 * a.H + oy) * a.W + ox;
+#pragma unroll
+      for (int ci = 0; ci < 3; ++ci) o[(size_t)ci * a.H * a.W] = acc[h][ci];
+    }
   }
 }
 

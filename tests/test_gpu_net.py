@@ -558,8 +558,9 @@ def test_bf16_mode_conv1_1_weight_gradient_on_the_bf16_pipe_matches_the_fp32_ker
 def test_pooling_fused_into_the_convolutions_is_bit_identical_to_its_own_launches(tmp_path):
     """f32x3 default: the four max-pools run in the epilogue of each stage's last convolution and their backward in the epilogue of the next
     stage's first data gradient (csrc/epi.h).  Same values, same first-maximum rule, same order of operations: logits, losses and every
-    gradient must equal the OSVOS_FUSE_POOL=0 run (own pooling launches) BIT FOR BIT -- at odd sizes (ceil-mode partial windows on both
-    axes), batch 2, and at a size where the deep data gradients are cut along K (fused finalize kernel)."""
+    gradient must equal the OSVOS_FUSE_POOL=0 run (own pooling launches) BIT FOR BIT when no launch is cut along K (OSVOS_X3_KSPLIT=1) --
+    at odd sizes (ceil-mode partial windows on both axes) and batch 2 -- and to fp32 round-off with the automatic K splits (another
+    summation order in the deep layers; there the fused backward runs in the split-K finalize kernel)."""
     import os, subprocess, sys, textwrap
     code = textwrap.dedent('''
         import sys, numpy as np, torch
@@ -585,10 +586,20 @@ def test_pooling_fused_into_the_convolutions_is_bit_identical_to_its_own_launche
         np.savez(sys.argv[1], **res)
     ''') % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     got = {}
-    for flag in ("0", "1"):
-        out = str(tmp_path / ("f%s.npz" % flag))
-        subprocess.run([sys.executable, "-c", code, out], check=True, env=dict(os.environ, OSVOS_FUSE_POOL=flag), timeout=900)
-        got[flag] = dict(np.load(out))
-    assert got["0"].keys() == got["1"].keys() and len(got["0"]) > 120
-    for k in got["0"]:
-        assert np.array_equal(got["0"][k], got["1"][k]), (k, float(np.abs(got["0"][k] - got["1"][k]).max()))
+    for fuse, ks in (("0", "1"), ("1", "1"), ("0", ""), ("1", "")):
+        out = str(tmp_path / ("f%s%s.npz" % (fuse, ks)))
+        env = dict(os.environ, OSVOS_FUSE_POOL=fuse)
+        if ks:
+            env["OSVOS_X3_KSPLIT"] = ks
+        subprocess.run([sys.executable, "-c", code, out], check=True, env=env, timeout=900)
+        got[(fuse, ks)] = dict(np.load(out))
+    a, b = got[("0", "1")], got[("1", "1")]
+    assert a.keys() == b.keys() and len(a) > 120
+    for k in a:      # no K split anywhere: the fused epilogues see exactly the values the pooling launches would read
+        assert np.array_equal(a[k], b[k]), (k, float(np.abs(a[k] - b[k]).max()))
+    a, b = got[("0", "")], got[("1", "")]
+    for k in a:      # automatic K splits (the fused forward pool keeps its convolution un-split, the fused backward runs in the finalize kernel)
+        if ":out" in k:
+            assert float(np.abs(a[k] - b[k]).max()) <= 2e-5 * float(a[k].std()), k
+        else:      # (an arg-max / ReLU flip at a near-tie moves single stage-0 gradient entries: rel-L2, the bar of the golden tests)
+            assert float(np.linalg.norm(a[k] - b[k])) <= 3e-3 * float(np.linalg.norm(a[k])) + 1e-30, k
