@@ -518,7 +518,63 @@ __global__ void pack_x3_kernel(const float* __restrict__ w, unsigned short* __re
   }
 }
 
+// every layer's pre-split packs in ONE launch (the table rides in the kernel arguments): osvos_net_pack re-packs all 17 filters, forward and
+// data-gradient form, after every optimizer step -- 34 launches of ~5 us each back to back on the stream the next forward waits on
+struct PackX3Table {
+  const float* w[OSVOS_PACK_MAX];
+  unsigned short* dst[OSVOS_PACK_MAX];
+  int Cout[OSVOS_PACK_MAX], Cin[OSVOS_PACK_MAX], dgrad[OSVOS_PACK_MAX];
+  long start[OSVOS_PACK_MAX + 1];      // in 256-element blocks of the (piece-plane) index space
+  int n;
+};
+
+__global__ __launch_bounds__(256) void pack_x3_multi_kernel(PackX3Table t) {
+  for (long blk = blockIdx.x; blk < t.start[t.n]; blk += gridDim.x) {
+    int k = 0;
+    while (blk >= t.start[k + 1]) ++k;                       // uniform per workgroup: scalar loop
+    const int dgrad = t.dgrad[k], Cout = t.Cout[k], Cin = t.Cin[k];
+    const int K = dgrad ? Cout : Cin, M = dgrad ? Cin : Cout, MP = (M + 31) / 32 * 32, CG = K / 8;
+    const long plane = 9L * CG * MP * 8;
+    const long i = (blk - t.start[k]) * 256 + threadIdx.x;
+    if (i >= plane) continue;
+    const int e = (int)(i & 7);
+    long r = i >> 3;
+    const int m = (int)(r % MP);
+    r /= MP;
+    const int cg = (int)(r % CG);
+    const int tap = (int)(r / CG);
+    const int kk = cg * 8 + e;
+    float v = 0.f;
+    if (m < M) v = dgrad ? t.w[k][((long)kk * Cin + m) * 9 + (8 - tap)] : t.w[k][((long)m * Cin + kk) * 9 + tap];
+    unsigned p0, p1, p2;
+    split2(v, 0.f, p0, p1, p2);
+    unsigned short* d = t.dst[k];
+    d[i] = (unsigned short)(p0 & 0xffffu);
+    d[plane + i] = (unsigned short)(p1 & 0xffffu);
+    d[2 * plane + i] = (unsigned short)(p2 & 0xffffu);
+  }
+}
+
 }  // namespace
+
+// n packs (n <= OSVOS_PACK_MAX) in one launch: ws[k] OIHW fp32 [Couts[k]][Cins[k]][3][3] -> dsts[k] (osvos_pack_x3 layout; dgrads[k] != 0: data-gradient form)
+int osvos_pack_x3_multi(const float* const* ws, void* const* dsts, const int* Couts, const int* Cins, const int* dgrads, int n, hipStream_t stream) {
+  OSVOS_ARG_CHECK(ws && dsts && Couts && Cins && dgrads && n >= 0 && n <= OSVOS_PACK_MAX, "pack_x3_multi: bad table (n = %d)", n);
+  if (n == 0) return 0;
+  PackX3Table t;
+  t.n = n;
+  t.start[0] = 0;
+  for (int k = 0; k < n; ++k) {
+    const int K = dgrads[k] ? Couts[k] : Cins[k], M = dgrads[k] ? Cins[k] : Couts[k];
+    OSVOS_ARG_CHECK(ws[k] && dsts[k] && K % 16 == 0 && M > 0, "pack_x3_multi: entry %d (K = %d, M = %d)", k, K, M);
+    t.w[k] = ws[k]; t.dst[k] = reinterpret_cast<unsigned short*>(dsts[k]); t.Cout[k] = Couts[k]; t.Cin[k] = Cins[k]; t.dgrad[k] = dgrads[k] ? 1 : 0;
+    t.start[k + 1] = t.start[k] + (9L * K * osvos_cout_pad(M) + 255) / 256;
+  }
+  const long blocks = t.start[n] < 8192 ? t.start[n] : 8192;
+  hipLaunchKernelGGL(pack_x3_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, t);
+  OSVOS_LAUNCH_CHECK();
+  return 0;
+}
 
 // bytes of the pre-split pack of a conv with `K` reduction channels (multiple of 16) and `M` output channels
 size_t osvos_wpack_x3_bytes(int M, int K) { return (size_t)3 * 9 * K * osvos_cout_pad(M) * 2; }

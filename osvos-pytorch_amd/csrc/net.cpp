@@ -291,8 +291,9 @@ inline int conv_main(const void* x, const void* x_b, const void* wpk, const floa
                      int N, int h, int w, int cin, int cout, int y_cs, int relu, int dtype, void* part, hipStream_t stream, const void* wpk3 = nullptr,
                      const ConvEpi* epi = nullptr) {
   if (dtype == OSVOS_F32_X3 && osvos_conv3x3_f32x3_applicable(cin, cout, y_cs))      // three-way bf16 split on the bf16 matrix pipe
-    return osvos_conv3x3_f32x3_epi((const float*)x, (const float*)wpk, use_presplit() ? wpk3 : nullptr, bias, (const float*)mask, (float*)y, N, h, w,
-                                   cin, cout, y_cs, relu, -1, 0, part, epi, stream);
+    // (with a pre-split pack the fp32 pack of the layer is not even built -- osvos_net_pack -- so it is not handed over either)
+    return osvos_conv3x3_f32x3_epi((const float*)x, (use_presplit() && wpk3) ? nullptr : (const float*)wpk, use_presplit() ? wpk3 : nullptr, bias,
+                                   (const float*)mask, (float*)y, N, h, w, cin, cout, y_cs, relu, -1, 0, part, epi, stream);
   if (dtype == OSVOS_F32 || dtype == OSVOS_F32_X3)
     return osvos_conv3x3_f32_ws((const float*)x, (const float*)wpk, bias, (const float*)mask, (float*)y, N, h, w, cin, cout, y_cs,
                                 relu, -1, part, stream);
@@ -359,7 +360,7 @@ int forward_p3(const float* x_nchw, const void* wbuf, void* ws, float* const* ou
   int l = 1;
   if (s0 > 0) {   // conv1_2 on fp32 tensors (f32x3 with in-kernel splitting), like the fp32 form of the network
     ProfScope ps(OSVOS_PROF_CONV_FWD, conv_flops(N, H, W, d[1].cin, d[1].cout), stream);
-    rc = osvos_conv3x3_f32x3_ps(f32at(ws, L.act[0]), reinterpret_cast<const float*>(at(wbuf, P.fwd[1])), at(wbuf, P.fwd3[1]), bias(1), nullptr, f32at(ws, L.act[1]),
+    rc = osvos_conv3x3_f32x3_ps(f32at(ws, L.act[0]), nullptr, at(wbuf, P.fwd3[1]), bias(1), nullptr, f32at(ws, L.act[1]),
                                 N, H, W, d[1].cin, d[1].cout, d[1].cout, 1, -1, 0, nullptr, stream);
     if (rc) return rc;
     l = 2;
@@ -535,7 +536,7 @@ int backward_trunk_p3(const void* wbuf, void* ws, float* const* grads, float* dx
         if (rc) return rc;
       } else if (dx_nchw != nullptr) {
         if (s0 > 0)
-          rc = osvos_conv3x3_f32x3_ps(f32at(ws, L.dy[0]), reinterpret_cast<const float*>(at(wbuf, P.dgrad[0])), at(wbuf, P.dgrad3[0]), nullptr, nullptr,
+          rc = osvos_conv3x3_f32x3_ps(f32at(ws, L.dy[0]), nullptr, at(wbuf, P.dgrad3[0]), nullptr, nullptr,
                                       f32at(ws, L.dxin), N, h, w, d[0].cout, 3, 4, 0, -1, 0, nullptr, stream);
         else
           rc = osvos_conv3x3_p3(at(ws, L.dy3[0]), at(wbuf, P.dgrad3[0]), nullptr, nullptr, 0, 0, f32at(ws, L.dxin), 4, nullptr, 0, N, h, w, d[0].cout, 3, 0, -1, 0,
@@ -565,7 +566,7 @@ int backward_trunk_p3(const void* wbuf, void* ws, float* const* grads, float* dx
                                      at(ws, L.dy3[l - 1]), N, L.hs[ps2], L.ws[ps2], kStageC[ps2], stream);
       if (rc) return rc;
     } else if (si < s0) {      // fp32 stage: f32x3 data gradient with in-kernel splitting, fp32 mask
-      rc = osvos_conv3x3_f32x3_ps(f32at(ws, L.dy[l]), reinterpret_cast<const float*>(at(wbuf, P.dgrad[l])), at(wbuf, P.dgrad3[l]), nullptr,
+      rc = osvos_conv3x3_f32x3_ps(f32at(ws, L.dy[l]), nullptr, at(wbuf, P.dgrad3[l]), nullptr,
                                   f32at(ws, L.act[l - 1]), f32at(ws, L.dy[l - 1]), N, h, w, d[l].cout, d[l].cin, d[l].cin, 0, -1, 0, at(ws, L.conv_part), stream);
       if (rc) return rc;
     } else {
@@ -626,16 +627,23 @@ int osvos_net_pack(const float* const* params, void* wbuf, int dtype_, int with_
   size_t dsts[64];
   int counts[64];
   int ns = 0;
+  // f32x3 with pre-split weights: the fp32 packs are read only where no pre-split pack exists (conv1_1 forward: the exact kernel) and by
+  // the input-gradient kernel (layer 0's data-gradient pack); all pre-split packs are formed by ONE launch
+  const bool x3ps = dtype == OSVOS_F32_X3 && use_presplit();
+  const float* xw[OSVOS_PACK_MAX]; void* xd[OSVOS_PACK_MAX]; int xco[OSVOS_PACK_MAX], xci[OSVOS_PACK_MAX], xdg[OSVOS_PACK_MAX];
+  int nx = 0;
   for (int l = 0; l < kNumConv; ++l) {
-    int rc = osvos_pack_conv3x3_fwd(params[d[l].w_param], at(wbuf, L.fwd[l]), d[l].cout, d[l].cin, dtype, stream);
-    if (rc) return rc;
-    if (with_dgrad) {
-      rc = osvos_pack_conv3x3_dgrad(params[d[l].w_param], at(wbuf, L.dgrad[l]), d[l].cout, d[l].cin, dtype, stream);
-      if (rc) return rc;
-    }
-    if (L.fwd3[l] != (size_t)-1 && (rc = osvos_pack_x3(params[d[l].w_param], at(wbuf, L.fwd3[l]), d[l].cout, d[l].cin, 0, stream))) return rc;
-    if (with_dgrad && L.dgrad3[l] != (size_t)-1 && (rc = osvos_pack_x3(params[d[l].w_param], at(wbuf, L.dgrad3[l]), d[l].cout, d[l].cin, 1, stream))) return rc;
+    int rc;
+    if (!(x3ps && L.fwd3[l] != (size_t)-1) && (rc = osvos_pack_conv3x3_fwd(params[d[l].w_param], at(wbuf, L.fwd[l]), d[l].cout, d[l].cin, dtype, stream))) return rc;
+    if (with_dgrad && !(x3ps && L.dgrad3[l] != (size_t)-1 && l != 0) &&
+        (rc = osvos_pack_conv3x3_dgrad(params[d[l].w_param], at(wbuf, L.dgrad[l]), d[l].cout, d[l].cin, dtype, stream))) return rc;
+    if (L.fwd3[l] != (size_t)-1) { xw[nx] = params[d[l].w_param]; xd[nx] = at(wbuf, L.fwd3[l]); xco[nx] = d[l].cout; xci[nx] = d[l].cin; xdg[nx] = 0; ++nx; }
+    if (with_dgrad && L.dgrad3[l] != (size_t)-1) { xw[nx] = params[d[l].w_param]; xd[nx] = at(wbuf, L.dgrad3[l]); xco[nx] = d[l].cout; xci[nx] = d[l].cin; xdg[nx] = 1; ++nx; }
     srcs[ns] = params[d[l].b_param]; dsts[ns] = L.bias[l]; counts[ns] = d[l].cout; ++ns;
+  }
+  if (nx > 0) {
+    const int rc = osvos_pack_x3_multi(xw, xd, xco, xci, xdg, nx, stream);
+    if (rc) return rc;
   }
   for (int i = 0; i < 4; ++i) {
     const int k = 4 << i;

@@ -319,11 +319,16 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 // LDS, and the 576 results leave as ONE contiguous run of dw (OIHW: [co][ci][tap], 2304 bytes) -- the kernel above writes the same
 // values as 4-byte stores 36 bytes apart (47 us for 37.7 MB of slabs at batch 1, 90 us beside full-chip kernels at batch 12: 1.45 ms of
 // the 13 ms bf16 parent step).  Workgroups of the first cin block also reduce their cout's bias partials.
-__global__ __launch_bounds__(256) void wgrad_reduce_t_kernel(const float* __restrict__ slab, const float* __restrict__ bslab,
-                                                             float* __restrict__ dw, float* __restrict__ db,
-                                                             int nsplit, int Cout, int Cin_s, int accumulate) {
-  __shared__ float red[4][9][64];
+// NW waves per workgroup: 4 where the grid is large (deep layers: few splits, thousands of workgroups), 16 where it is not -- conv1_2 has
+// 256 splits and ONE channel tile pair: 64 workgroups each walking 64 x 9 dependent 256-byte loads per wave took 46 us at the very end
+// of the step (the last slab reduce is exposed: nothing is left to run beside it).
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void wgrad_reduce_t_kernel(const float* __restrict__ slab, const float* __restrict__ bslab,
+                                                                 float* __restrict__ dw, float* __restrict__ db,
+                                                                 int nsplit, int Cout, int Cin_s, int accumulate) {
+  __shared__ float red[NW][9][64];
   __shared__ float outb[576];
+  constexpr int NT = 64 * NW;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int ci0 = blockIdx.x * 64, co = blockIdx.y;
   const size_t tap_stride = (size_t)Cout * Cin_s, split_stride = 9 * tap_stride;
@@ -331,7 +336,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_t_kernel(const float* __rest
   float acc[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) acc[t] = 0.f;
-  for (int sp = wave; sp < nsplit; sp += 4) {
+  for (int sp = wave; sp < nsplit; sp += NW) {
     const float* q = src + (size_t)sp * split_stride;
 #pragma unroll
     for (int t = 0; t < 9; ++t) acc[t] += q[(size_t)t * tap_stride];
@@ -339,22 +344,27 @@ __global__ __launch_bounds__(256) void wgrad_reduce_t_kernel(const float* __rest
 #pragma unroll
   for (int t = 0; t < 9; ++t) red[wave][t][lane] = acc[t];
   __syncthreads();
-  for (int e = threadIdx.x; e < 576; e += 256) {
+  for (int e = threadIdx.x; e < 576; e += NT) {
     const int t = e / 64, ci = e % 64;
-    outb[ci * 9 + t] = (red[0][t][ci] + red[1][t][ci]) + (red[2][t][ci] + red[3][t][ci]);
+    float v = 0.f;
+#pragma unroll
+    for (int g = 0; g < NW; g += 4) v += (red[g][t][ci] + red[g + 1][t][ci]) + (red[g + 2][t][ci] + red[g + 3][t][ci]);      // fixed order
+    outb[ci * 9 + t] = v;
   }
   __syncthreads();
   float* dst = dw + ((size_t)co * Cin_s + ci0) * 9;        // Cin == Cin_s for these layers
-  for (int e = threadIdx.x; e < 576; e += 256) dst[e] = accumulate ? dst[e] + outb[e] : outb[e];
+  for (int e = threadIdx.x; e < 576; e += NT) dst[e] = accumulate ? dst[e] + outb[e] : outb[e];
   if (db != nullptr && blockIdx.x == 0) {
     float b = 0.f;
-    for (int sp = threadIdx.x; sp < nsplit; sp += 256) b += bslab[(size_t)sp * Cout + co];
+    for (int sp = threadIdx.x; sp < nsplit; sp += NT) b += bslab[(size_t)sp * Cout + co];
     b = wave_sum(b);
     __syncthreads();
     if (lane == 0) red[0][0][wave] = b;
     __syncthreads();
     if (threadIdx.x == 0) {
-      const float s = (red[0][0][0] + red[0][0][1]) + (red[0][0][2] + red[0][0][3]);
+      float s = 0.f;
+#pragma unroll
+      for (int g = 0; g < NW; g += 4) s += (red[0][0][g] + red[0][0][g + 1]) + (red[0][0][g + 2] + red[0][0][g + 3]);
       db[co] = accumulate ? db[co] + s : s;
     }
   }
@@ -442,7 +452,10 @@ int osvos_wgrad_reduce_launch(const float* slab, const float* bslab, float* dw, 
                               int Cin_s, int accumulate, hipStream_t stream) {
   OSVOS_ENV_INT(env_t, "OSVOS_WGRAD_REDUCE_T", 1);
   if (env_t && Cin == Cin_s && Cin_s % 64 == 0 && Cout <= 65535) {      // wide layers: LDS-transposing reduce, contiguous OIHW writes
-    hipLaunchKernelGGL(wgrad_reduce_t_kernel, dim3(Cin_s / 64, Cout), dim3(256), 0, stream, slab, bslab, dw, db, nsplit, Cout, Cin_s, accumulate);
+    if ((long)(Cin_s / 64) * Cout <= 1024 && nsplit >= 32)      // few workgroups, many splits: 16 waves each
+      hipLaunchKernelGGL(wgrad_reduce_t_kernel<16>, dim3(Cin_s / 64, Cout), dim3(1024), 0, stream, slab, bslab, dw, db, nsplit, Cout, Cin_s, accumulate);
+    else
+      hipLaunchKernelGGL(wgrad_reduce_t_kernel<4>, dim3(Cin_s / 64, Cout), dim3(256), 0, stream, slab, bslab, dw, db, nsplit, Cout, Cin_s, accumulate);
     OSVOS_LAUNCH_CHECK();
     return 0;
   }
