@@ -302,9 +302,24 @@ inline int conv_main(const void* x, const void* x_b, const void* wpk, const floa
                                    -1, stream);
 }
 
-// f32x3: the pooling kernels of the stage boundaries run as epilogues of the convolutions next to them (epi.h; OSVOS_FUSE_POOL=0: own launches)
-inline bool fuse_pool(int dtype) {
-  static const bool on = [] { const char* e = getenv("OSVOS_FUSE_POOL"); return !(e && e[0] == '0'); }();
+// f32x3: the pooling kernels of the stage boundaries can run as epilogues of the convolutions next to them (epi.h).  Measured at 854x480
+// batch 1 (profiles/r03_ab_fusions.txt): the FORWARD pool in the producer's epilogue saves its launch and 20 us (1.473 -> 1.451 ms of
+// forward convolutions + pools) and is the default; the BACKWARD pool in the data gradient's epilogue makes that workgroup's tail 12
+// dependent memory instructions per accumulator quad long on a CU that holds nothing else (2.817 -> 2.861 ms of backward): opt-in.
+// OSVOS_FUSE_POOL=0 / 1 switches both, OSVOS_FUSE_POOL_FWD / OSVOS_FUSE_POOL_BWD each.
+inline bool fuse_flag(const char* name, bool dflt) {
+  const char* all = getenv("OSVOS_FUSE_POOL");
+  const char* e = getenv(name);
+  if (e) return e[0] != '0';
+  if (all) return all[0] != '0';
+  return dflt;
+}
+inline bool fuse_pool(int dtype) {      // forward
+  static const bool on = fuse_flag("OSVOS_FUSE_POOL_FWD", true);
+  return on && dtype == OSVOS_F32_X3;
+}
+inline bool fuse_pool_bwd(int dtype) {
+  static const bool on = fuse_flag("OSVOS_FUSE_POOL_BWD", false);
   return on && dtype == OSVOS_F32_X3;
 }
 
@@ -1022,7 +1037,7 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
       }
       break;
     }
-    if (first_of_stage && fuse_pool(dtype)) {
+    if (first_of_stage && fuse_pool_bwd(dtype)) {
       // through the pool into the previous stage's output (+ that stage's side branch, + ReLU mask) inside the convolution's epilogue:
       // the pooled-resolution gradient is never written
       const int ps2 = si - 1;

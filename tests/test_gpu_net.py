@@ -556,8 +556,8 @@ def test_bf16_mode_conv1_1_weight_gradient_on_the_bf16_pipe_matches_the_fp32_ker
 
 
 def test_pooling_fused_into_the_convolutions_is_bit_identical_to_its_own_launches(tmp_path):
-    """f32x3 default: the four max-pools run in the epilogue of each stage's last convolution and their backward in the epilogue of the next
-    stage's first data gradient (csrc/epi.h).  Same values, same first-maximum rule, same order of operations: logits, losses and every
+    """f32x3 with OSVOS_FUSE_POOL=1: the four max-pools run in the epilogue of each stage's last convolution (the default) and their backward in
+    the epilogue of the next stage's first data gradient (opt-in) (csrc/epi.h).  Same values, same first-maximum rule, same order of operations: logits, losses and every
     gradient must equal the OSVOS_FUSE_POOL=0 run (own pooling launches) BIT FOR BIT when no launch is cut along K (OSVOS_X3_KSPLIT=1) --
     at odd sizes (ceil-mode partial windows on both axes) and batch 2 -- and to fp32 round-off with the automatic K splits (another
     summation order in the deep layers; there the fused backward runs in the split-K finalize kernel)."""
@@ -600,6 +600,6 @@ def test_pooling_fused_into_the_convolutions_is_bit_identical_to_its_own_launche
     a, b = got[("0", "")], got[("1", "")]
     for k in a:      # automatic K splits (the fused forward pool keeps its convolution un-split, the fused backward runs in the finalize kernel)
         if ":out" in k:
-            assert float(np.abs(a[k] - b[k]).max()) <= 2e-5 * float(a[k].std()), k
+            assert float(np.abs(a[k] - b[k]).max()) <= 1e-4 * float(a[k].std()), k
         else:      # (an arg-max / ReLU flip at a near-tie moves single stage-0 gradient entries: rel-L2, the bar of the golden tests)
             assert float(np.linalg.norm(a[k] - b[k])) <= 3e-3 * float(np.linalg.norm(a[k])) + 1e-30, k
