@@ -690,7 +690,10 @@ def main():
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world, "rccl_ranks_seen": ranks_seen,
                        "gpus_requested": args.gpus,
                        "grad_allreduce": "per optimizer step (RCCL)" if dist is not None else "none",
-                       "loss_item_sync_each_iter": bool(args.item_sync)},
+                       "loss_item_sync_each_iter": bool(args.item_sync),
+                       # class-balance counts (osvos_layers.py:28-34) run over each rank's own batch: every rank's batch is its own reference batch
+                       # (weak scaling).  Sharding ONE batch over ranks needs parallel.global_class_counts / cbce_with_counts (tests/test_parallel_gloo.py)
+                       "loss_class_counts": "per-rank batch" if world > 1 else "whole batch"},
             "roofline": res["roofline"], "cpu_baseline": base,
             "sustained": res.get("sustained"),
             "timed_region_detail": res.get("timing_detail"),

@@ -227,19 +227,70 @@ class GradientAllReducer:
             flat.div_(self._world())
 
     def broadcast_parameters(self, src=0):
-        """Make every rank start from rank `src`'s weights."""
-        if self.comm is not None:      # the ABI has one collective: broadcast = sum with every other rank contributing zeros
-            if self.comm.world > 1:
-                with torch.no_grad():
-                    for p in self.params:
-                        if self.comm.rank != src:
-                            p.data.zero_()
-                        self.comm.all_reduce(p.data.view(-1))
+        """Make every rank start from rank `src`'s weights: ONE collective over a flat copy of all parameters (52 tensors, 61 MB) instead of
+        one per tensor.  torch.distributed: a broadcast; the C-ABI communicator has one collective, so the broadcast is a sum to which every
+        other rank contributes zeros."""
+        ps = [p for p in self.module.parameters()]
+        if not ps or not self._active_or_world():
             return
-        if not dist.is_initialized():
-            return
-        for p in self.params:
-            dist.broadcast(p.data, src=src, group=self.group)
+        with torch.no_grad():
+            flat = torch.cat([p.data.reshape(-1) for p in ps])
+            if self.comm is not None:
+                if self.comm.rank != src:
+                    flat.zero_()
+                self.comm.all_reduce(flat)
+            else:
+                dist.broadcast(flat, src=src, group=self.group)
+            off = 0
+            for p in ps:
+                n = p.numel()
+                p.data.copy_(flat[off:off + n].view_as(p.data))
+                off += n
+
+    def _active_or_world(self):
+        if self.comm is not None:
+            return self.comm.world > 1
+        return dist.is_initialized() and dist.get_world_size(self.group) > 1
+
+
+def global_class_counts(label, group=None, comm=None):
+    """The two numbers a batch that is SHARDED over ranks must exchange for the class-balanced loss to equal the single-process loss of the
+    whole batch (reference layers/osvos_layers.py:28-34 counts positives and negatives over the whole input tensor and :46 divides
+    by the batch size): returns (n_pos, n_total, n_images) of the GLOBAL batch as float64 tensors on the label's device -- one all-reduce of
+    three doubles.  Without a process group (or with one rank) these are the local counts.
+
+    Use: ``loss = cbce_with_counts(output, label, n_pos, n_total, n_images)`` on every rank, gradients summed over ranks -> exactly the
+    single-process batch loss.  The reference scripts train with batch 1 per micro-batch (per-frame class weights), where nothing needs
+    exchanging: this is for callers that shard ONE batch (bench.py --mode parent --batch B under data parallelism treats every rank's batch
+    as its own reference batch instead, and says so)."""
+    lab = (label >= 0.5)
+    t = torch.stack([lab.sum().double(), torch.tensor(float(label.numel()), device=label.device, dtype=torch.float64),
+                     torch.tensor(float(label.shape[0]), device=label.device, dtype=torch.float64)])
+    if comm is not None and comm.world > 1:
+        f = t.float()
+        comm.all_reduce(f)                       # (the ABI communicator sums fp32: exact for counts below 2^24 per image batch)
+        t = f.double()
+    elif comm is None and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(t, group=group)
+    return t[0], t[1], t[2]
+
+
+def cbce_with_counts(output, label, n_pos, n_total, n_images, size_average=False, batch_average=True):
+    """class_balanced_cross_entropy_loss (osvos_layers.py:19-48) of this rank's SHARD of a batch, weighted and normalised with the GLOBAL counts
+    of ``global_class_counts``: summed over the ranks it is the reference loss of the whole batch (same operation order per element; the class
+    weights stay float32 quotients like the reference's).  Plain torch ops (autograd-differentiable, any device): the exchange is a host-side
+    extension next to the reference API, not a hot-path kernel."""
+    labels = (label >= 0.5).float()
+    n_pos32, n_tot32 = n_pos.float(), n_total.float()
+    w_pos, w_neg = (n_tot32 - n_pos32) / n_tot32, n_pos32 / n_tot32
+    g = (output >= 0).float()
+    val = output * (labels - g) - torch.log(1 + torch.exp(output - 2 * output * g))
+    final = w_pos * (-(labels * val)).sum() + w_neg * (-((1.0 - labels) * val)).sum()
+    if size_average:
+        final = final / n_total.to(final.dtype)
+    elif batch_average:
+        final = final / n_images.to(final.dtype)
+    return final
 
 
 def shard_indices(n_items, rank, world_size):

@@ -88,3 +88,55 @@ def test_flat_gradient_arena_views_zero_and_reattach():
     assert torch.allclose(flat, torch.cat([r.flatten() for r in ref]))
     red.all_reduce()                                   # no process group: a no-op that leaves the arena attached
     assert [p.grad.data_ptr() for p in live] == ptrs
+
+
+def _count_worker(rank, world, port, out):
+    sys.path.insert(0, REPO)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from osvos_pytorch_amd.parallel import GradientAllReducer, cbce_with_counts, global_class_counts
+    g = torch.Generator().manual_seed(11)
+    logits = torch.randn(4, 1, 12, 16, generator=g, dtype=torch.float64) * 3
+    labels = (torch.rand(4, 1, 12, 16, generator=g) > 0.7).float()
+    labels[3] = 0                                        # one frame without positives: the counts must come from the whole batch
+    mine = slice(2 * rank, 2 * rank + 2)                 # this rank's half of the batch
+    x = logits[mine].clone().requires_grad_()
+    n_pos, n_tot, n_img = global_class_counts(labels[mine])
+    loss = cbce_with_counts(x, labels[mine], n_pos, n_tot, n_img)
+    loss.backward()
+    t = torch.stack([loss.detach()])
+    dist.all_reduce(t)
+    # broadcast_parameters: ONE flat collective
+    torch.manual_seed(100 + rank)                        # different weights per rank before the broadcast
+    model = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3), torch.nn.Conv2d(4, 2, 1))
+    GradientAllReducer(model).broadcast_parameters(0)
+    torch.save({"loss": t[0], "grad": x.grad, "counts": (float(n_pos), float(n_tot), float(n_img)),
+                "w": torch.cat([p.data.flatten() for p in model.parameters()])}, out + ".%d" % rank)
+    dist.destroy_process_group()
+
+
+def test_count_exchange_makes_a_sharded_batch_equal_the_single_process_batch_loss(tmp_path):
+    """SURVEY 8e row 3 / reference osvos_layers.py:28-34,46: the class weights are counted over the WHOLE batch tensor and the loss is divided
+    by the batch size -- two ranks holding half a batch each must exchange (n_pos, n_total, N) to reproduce it.  Also: broadcast_parameters
+    as one flat collective leaves every rank with rank 0's weights."""
+    sys.path.insert(0, REPO)
+    from oracle import torch_ref
+    out = str(tmp_path / "c")
+    port = 30500 + (os.getpid() % 2000)
+    mp.spawn(_count_worker, args=(2, port, out), nprocs=2, join=True)
+    r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
+    g = torch.Generator().manual_seed(11)
+    logits = torch.randn(4, 1, 12, 16, generator=g, dtype=torch.float64) * 3
+    labels = (torch.rand(4, 1, 12, 16, generator=g) > 0.7).float()
+    labels[3] = 0
+    x = logits.clone().requires_grad_()
+    ref = torch_ref.cbce_loss(x, labels, size_average=False)          # the reference formula on the whole batch
+    ref.backward()
+    assert r0["counts"] == r1["counts"] == (float((labels >= 0.5).sum()), float(labels.numel()), 4.0)
+    torch.testing.assert_close(r0["loss"], ref.detach(), rtol=1e-12, atol=0)
+    torch.testing.assert_close(torch.cat([r0["grad"], r1["grad"]]), x.grad, rtol=1e-12, atol=1e-15)
+    assert torch.equal(r0["w"], r1["w"])
+    torch.manual_seed(100)
+    model = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3), torch.nn.Conv2d(4, 2, 1))
+    assert torch.equal(r0["w"], torch.cat([p.data.flatten() for p in model.parameters()]))
