@@ -9,12 +9,11 @@
 //                             (0 / 2 / 4 bytes) would misalign a 16-byte read: ONE aligned 20-byte window is read per (row, k-step) and
 //                             the three shifted operands are formed in registers (s = 1: four v_alignbit, s = 0 / 2: selection).
 //                             64 couts x 64 cins x 9 taps per workgroup, wave (wc, wi) owns a 32 x 32 x 9 block = 9 accumulators.
-//   wgrad_bf16v2_kernel<W>    what runs for bf16 tensors (OSVOS_WGRAD_FORM 1 / 2): 16-byte item loads issued from inside the k-loop,
-//                             W = 8 waves on 128-cout tiles where Cout allows.  Same LDS image and k-loop as the first form.
-//   wgrad_bf16pm_kernel<W>    the default for bf16 tensors since round 2 (OSVOS_WGRAD_FORM=3): pixel-major LDS tiles gathered with ds_read_b64_tr_b16.
-//   wgrad_bf16dma_kernel<PP>  OSVOS_WGRAD_FORM=4 / 5: the pixel-major tiles filled by LDS-DMA (XOR-swizzled instead of padded, no staging registers,
-//                             one barrier per half patch); PP = 1 alternates gather and multiply segments between the two waves of a SIMD.
-//                             Same speed as the default within 1-2 % (the chip's clock, not the schedule, sets it): kept as measured options.
+//   wgrad_bf16pm_kernel<W>    the default for bf16 tensors (OSVOS_WGRAD_FORM=3): pixel-major LDS tiles gathered with ds_read_b64_tr_b16; W = 8 waves on
+//                             128-cout tiles where Cout allows.  OSVOS_WGRAD_FORM=0 runs the first form on bf16 tensors as well.
+//   The item-load forms (1 / 2: wgrad_bf16v2_kernel) and the LDS-DMA forms (4 / 5: wgrad_bf16dma_kernel, plain / ping-pong) were measured level
+//   with or slower than the default in rounds 1-2 (the chip's clock, not the schedule, sets the rate) and are no longer part of the library:
+//   tools/native/wgrad_bf16_forms.inc, built into the probe harness only (tools/native/build.sh, -DOSVOS_WGRAD_ALL_FORMS).
 // All forms produce bit-identical weight gradients (same patches, splits and k-order).  Probe builds (-DOSVOS_WGRAD_PROF, -DOSVOS_WGRAD_ABL=n:
 // tools/native/) add s_memtime phase marks and timing ablations; the shipped library compiles none of that.
 #include "common.h"
@@ -323,287 +322,11 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WbArgs a) {
 }
 
 
-// ---------------------------------------------------------------------------------------------------------------------------------
-// bf16-in-HBM staging, second form (tools/native/wgrad_probe: the first form spends 34-37 % of a wave's life ISSUING the next patch's
-// 32 buffer_load_b64 -- a wave-level load costs the CU ~32-38 cycles whatever its width or lane pattern, i.e. 13 B/clk/CU with
-// 8-byte lanes -- and the MFMA pipe idles meanwhile: one wave per SIMD, and a wave held in a vmem issue cannot issue MFMAs):
-//   * item = 8 pixels x 8 channels: eight 16-byte loads (one pixel's channel octet each), 24 per thread and patch instead of 32;
-//     eight consecutive lanes hold two octets x four pixel groups, so the transposing ds_write_b128 are 2-way conflicted at worst
-//     (13 issue cycles hide 16 array cycles) and the fragment reads stay conflict-free
-//   * the loads of patch p+1 are issued from inside the (fully unrolled) k-loop of patch p, three per two k-steps, so they drain
-//     behind 18 MFMAs instead of in front of them
-// Measured and dropped (profiles/r01_wgrad_bf16_forms.txt): line-contiguous lanes with skewed channel rows (same time: the address
-// pattern is not what limits the loads); twelve waves with the tap rows cut across waves (3 accumulators per wave, three waves per
-// SIMD), single and double buffered; separate producer and consumer waves over two 6-row tile buffers.  All land within 3 % of
-// this form: what they share is the 76 KB a workgroup streams per 18.9 MFLOP patch, ~8 B/clk/CU sustained -- the tile, not the
-// schedule, is the limit, and 144 accumulator registers per wave leave no room for a bigger one.
-// WAVES = 4: 64 couts x 64 cins per workgroup, one wave per SIMD.  WAVES = 8: 128 couts x 64 cins -- the register budget of two waves
-// per SIMD (256) holds 144 accumulators + ONE dY and ONE X item of staging: a wave stuck in a vmem issue or in the transposing stores
-// leaves the matrix pipe to its neighbour, and a patch costs 16 loads per 144 MFMAs instead of 24
-template <int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void wgrad_bf16v2_kernel(WbArgs a) {
-  constexpr int BCOT = 16 * WAVES, OCT = BCOT / 8, NXI = WAVES == 4 ? 2 : 1, NLD = 8 + 8 * NXI, DYT_BYTES = BCOT * DY_CSTRIDE;
-  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* dYs = smem;
-  char* Xs = smem + DYT_BYTES;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int li = lane & 31, lh = lane >> 5;
-  const int wc = wave >> 1, wi = wave & 1;
-
-  int id = blockIdx.x;
-  if (a.map == 1) id = (id & 7) * (gridDim.x >> 3) + (id >> 3);
-  const int cit = id % a.nci_t;
-  id /= a.nci_t;
-  const int cot = id % a.nco_t;
-  const int split = id / a.nco_t;
-  const int co0 = cot * BCOT, ci0 = cit * BCI;
-  const int p_begin = split * a.per_split, p_end = min(p_begin + a.per_split, a.npatches);
-
-  // items: (pixel group of 8 along x, channel octet).  dY: 32 groups x 8 octets = one per thread; X halo: 50 x 8 = 400, two slots per thread
-  // (tid bits, low to high: octet bit 0, group bits 0-1, the other octet bits, the other group bits)
-  const int so = WAVES == 4 ? (tid & 1) | ((tid >> 2) & 6) : (tid & 1) | ((tid >> 2) & 0xe);                 // dY item: octet 0..OCT-1
-  const int sg = WAVES == 4 ? ((tid >> 1) & 3) | ((tid >> 3) & 0x1c) : ((tid >> 1) & 3) | ((tid >> 4) & 0x1c);   // and pixel group 0..31
-  const int xo = (tid & 1) | ((tid >> 2) & 6);                                                               // X item(s): octet 0..7
-  const int xg = ((tid >> 1) & 3) | ((tid >> 3) & (WAVES == 4 ? 0x1c : 0x3c));       // group 0..31 (a second item is group + 32) / 0..63
-  constexpr unsigned OOB = 0x80000000u;
-  u32x4 rdy[8], rx[NXI][8];
-  float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  const bool want_bias = a.bslab != nullptr && cit == 0;
-  int dy_c0 = (co0 + 8 * so < a.Cout) ? (sg & 3) * 8 : -1000000;              // first column of the item inside the patch
-#ifdef OSVOS_WGRAD_PROF
-  if (a.dbg >= 2) dy_c0 = -1000000;
+#ifdef OSVOS_WGRAD_ALL_FORMS      // forms 1 / 2 (probe builds only: tools/native/wgrad_bf16_forms.inc)
+#define OSVOS_WGRAD_FORMS_PART 1
+#include "../../tools/native/wgrad_bf16_forms.inc"
+#undef OSVOS_WGRAD_FORMS_PART
 #endif
-  const unsigned dy_rel = (unsigned)((((sg >> 2) * a.W + (sg & 3) * 8) * a.Cout_s + co0 + 8 * so) * 2);
-  unsigned x_rel[NXI];
-  int x_c0[NXI];
-#pragma unroll
-  for (int u = 0; u < NXI; ++u) {
-    const int g = xg + 32 * u, hy = g / 5, hg = g % 5;
-    x_rel[u] = (unsigned)(((hy * a.W + hg * 8) * a.Cin_s + ci0 + 8 * xo) * 2);
-    x_c0[u] = (g < XROWS * 5 && ci0 + 8 * xo < a.Cin_s) ? hg * 8 : -1000000;
-#ifdef OSVOS_WGRAD_PROF
-    if (a.dbg >= 1) x_c0[u] = -1000000;
-#endif
-  }
-  const int img_dy_bytes = a.H * a.W * a.Cout_s * 2, img_x_bytes = a.H * a.W * a.Cin_s * 2;
-  const unsigned dy_pix = (unsigned)(a.Cout_s * 2), x_pix = (unsigned)(a.Cin_s * 2);
-
-  struct Patch { __amdgpu_buffer_rsrc_t drs, xrs; unsigned dy_base, x_base; int x0; };
-  auto locate = [&](int p, bool live) -> Patch {
-    const int px = p % a.npx;
-    int t = p / a.npx;
-    const int py = t % a.npy;
-    const int n = live ? t / a.npy : 0;
-    Patch q;
-    q.x0 = live ? px * PW : 0x40000000;            // dead patch (past the split's last): every column test fails -> all loads out of range
-    const int y0 = py * PH;
-    q.drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(a.dy)) + (size_t)n * img_dy_bytes, 0, img_dy_bytes, 0x00020000);
-    q.xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(a.x)) + (size_t)n * img_x_bytes, 0, img_x_bytes, 0x00020000);
-    q.dy_base = (unsigned)((y0 * a.W + px * PW) * a.Cout_s * 2);
-    q.x_base = (unsigned)(((y0 - 1) * a.W + (px * PW - 1)) * a.Cin_s * 2);       // may be "negative": wraps out of range
-    return q;
-  };
-  // load number i of a patch: 0-7 dY pixel i; 8.. X item (i-8)/8 pixel (i-8)%8; past the last: nothing
-  auto issue = [&](const Patch& q, int i) {
-    if (i >= NLD) return;
-    if (i < 8) {
-      const unsigned off = (q.x0 + dy_c0 + i < a.W && dy_c0 >= 0) ? dy_rel + q.dy_base + (unsigned)i * dy_pix : OOB;
-      rdy[i] = __builtin_amdgcn_raw_buffer_load_b128(q.drs, off, 0, 0);
-    } else {
-      const int u = (i - 8) >> 3, j = (i - 8) & 7;
-      const bool ok = x_c0[u] >= 0 && x_c0[u] + j < PW + 2 && (unsigned)(q.x0 - 1 + x_c0[u] + j) < (unsigned)a.W;
-      const unsigned off = ok ? x_rel[u] + q.x_base + (unsigned)j * x_pix : OOB;
-      rx[u][j] = __builtin_amdgcn_raw_buffer_load_b128(q.xrs, off, 0, 0);
-    }
-  };
-  // 8 pixels x 8 channels in registers -> per channel one 16-byte row piece of 8 pixels (v_perm_b32 picks the two bf16 of a pixel pair)
-  auto transpose_store = [&](const u32x4 (&r)[8], char* row0, int row_stride) {
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const unsigned sel = (c & 1) ? 0x07060302u : 0x05040100u;
-      uint4 v;
-      v.x = __builtin_amdgcn_perm(r[1][c >> 1], r[0][c >> 1], sel);
-      v.y = __builtin_amdgcn_perm(r[3][c >> 1], r[2][c >> 1], sel);
-      v.z = __builtin_amdgcn_perm(r[5][c >> 1], r[4][c >> 1], sel);
-      v.w = __builtin_amdgcn_perm(r[7][c >> 1], r[6][c >> 1], sel);
-      *reinterpret_cast<uint4*>(row0 + c * row_stride) = v;
-    }
-  };
-  char* const dy_dst = dYs + (8 * so) * DY_CSTRIDE + sg * 16;
-  char* const x_dst = Xs + (8 * xo) * X_CSTRIDE + xg * 16;
-  auto store_patch = [&]() {
-    if (want_bias) {                                  // bias gradient: fp32 column sums of the (bf16) dY
-#pragma unroll
-      for (int j = 0; j < 8; ++j)
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-          bsum[2 * d] += __uint_as_float(rdy[j][d] << 16);
-          bsum[2 * d + 1] += __uint_as_float(rdy[j][d] & 0xffff0000u);
-        }
-    }
-    transpose_store(rdy, dy_dst, DY_CSTRIDE);
-    if (xg < XROWS * 5) transpose_store(rx[0], x_dst, X_CSTRIDE);
-    if constexpr (NXI == 2) {
-      if (xg + 32 < XROWS * 5) transpose_store(rx[NXI - 1], x_dst + 32 * 16, X_CSTRIDE);
-    }
-  };
-
-  f32x16 acc[9];
-#pragma unroll
-  for (int t = 0; t < 9; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-
-  const int ca = wc * 32 + li, cb = wi * 32 + li;
-  const char* a_base = dYs + ca * DY_CSTRIDE + lh * 16;
-  const char* b_base = Xs + cb * X_CSTRIDE + lh * 16;
-
-#ifdef OSVOS_WGRAD_PROF
-  unsigned long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tp = __builtin_amdgcn_s_memtime(), tq;
-  const unsigned long long t_begin = tp;
-#endif
-  {
-    const Patch q = locate(p_begin, p_begin < p_end);
-#pragma unroll
-    for (int i = 0; i < NLD; ++i) issue(q, i);
-  }
-  WPROF(0);
-  for (int p = p_begin; p < p_end; ++p) {
-    __syncthreads();
-    WPROF(1);
-#ifdef OSVOS_WGRAD_PROF
-    __builtin_amdgcn_s_waitcnt(0x0f70);
-    WPROF(2);
-#endif
-    store_patch();
-    WPROF(3);
-    __syncthreads();
-    WPROF(4);
-    const Patch nx = locate(p + 1, p + 1 < p_end);
-    WPROF(5);
-    struct Frag { uint4 a0; uint4 w0[3]; unsigned w4[3]; };
-    auto ldk = [&](int ks, Frag& f) {
-#if defined(OSVOS_WGRAD_ABL) && OSVOS_WGRAD_ABL == 2
-      if (ks > 1) return;                                  // ablation: no LDS fragment reads after the first two k-steps
-#endif
-      const int row = ks >> 1, kx = ks & 1;
-      f.a0 = *reinterpret_cast<const uint4*>(a_base + (row * PW + kx * 16) * 2);
-#pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        const char* src = b_base + ((row + r) * XPITCH + kx * 16) * 2;
-        f.w0[r] = *reinterpret_cast<const uint4*>(src);
-        f.w4[r] = reinterpret_cast<const uint4*>(src + 16)->x;
-      }
-    };
-    // rows of taps; `mid` (a load number or -1) is issued after the first row's three MFMAs
-    auto mm = [&](const Frag& f, int mid) {
-#pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        uint4 b[3];
-        b[0] = f.w0[r];
-        b[1].x = __builtin_amdgcn_alignbit(f.w0[r].y, f.w0[r].x, 16);
-        b[1].y = __builtin_amdgcn_alignbit(f.w0[r].z, f.w0[r].y, 16);
-        b[1].z = __builtin_amdgcn_alignbit(f.w0[r].w, f.w0[r].z, 16);
-        b[1].w = __builtin_amdgcn_alignbit(f.w4[r], f.w0[r].w, 16);
-        b[2].x = f.w0[r].y; b[2].y = f.w0[r].z; b[2].z = f.w0[r].w; b[2].w = f.w4[r];
-#pragma unroll
-        for (int s = 0; s < 3; ++s) {
-#if defined(OSVOS_WGRAD_ABL) && OSVOS_WGRAD_ABL == 1
-          acc[r * 3 + s][0] += __uint_as_float(b[s].x ^ b[s].y ^ b[s].z ^ b[s].w ^ f.a0.x ^ f.a0.w);      // ablation: no MFMA
-#else
-          const bf16x8_t bb = __builtin_bit_cast(bf16x8_t, b[s]);
-          acc[r * 3 + s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bb, __builtin_bit_cast(bf16x8_t, f.a0), acc[r * 3 + s], 0, 0, 0);
-#endif
-        }
-        if (r == 0 && mid >= 0) {
-          __builtin_amdgcn_sched_barrier(0);
-#if !(defined(OSVOS_WGRAD_ABL) && OSVOS_WGRAD_ABL == 3)
-          issue(nx, mid);
-#endif
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-    };
-    if constexpr (WAVES == 8) {
-      // two waves per SIMD cover each other's LDS latency: ONE fragment set (19 registers less than the ping-pong below -- the
-      // difference between fitting 256 registers and spilling the staging registers to scratch, whose in-order vmcnt waits would
-      // then wait for the next patch's global loads as well)
-      Frag f;
-#pragma unroll
-      for (int ks = 0; ks < PH * 2; ++ks) {
-        ldk(ks, f);
-#if !(defined(OSVOS_WGRAD_ABL) && OSVOS_WGRAD_ABL == 3)
-        issue(nx, ks);
-#endif
-        __builtin_amdgcn_sched_barrier(0);
-        mm(f, -1);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    } else {
-    Frag f0, f1;
-      ldk(0, f0);
-  #pragma unroll
-      for (int it = 0; it < PH; ++it) {                     // two k-steps and NLD / 8 (three or two) loads of the next patch per turn
-        constexpr int LPT = NLD / PH;
-        ldk(2 * it + 1, f1);
-  #if !(defined(OSVOS_WGRAD_ABL) && OSVOS_WGRAD_ABL == 3)
-        issue(nx, LPT * it);
-  #endif
-        __builtin_amdgcn_sched_barrier(0);
-        mm(f0, LPT == 3 ? LPT * it + 2 : -1);
-        __builtin_amdgcn_sched_barrier(0);
-        ldk((2 * it + 2) & (PH * 2 - 1), f0);
-  #if !(defined(OSVOS_WGRAD_ABL) && OSVOS_WGRAD_ABL == 3)                // ablation 3: no vmem instruction inside the k-loop
-        issue(nx, LPT * it + 1);
-  #endif
-        __builtin_amdgcn_sched_barrier(0);
-        mm(f1, -1);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    WPROF(6);
-  }
-  __syncthreads();
-
-  {   // slab epilogue, as in the first form
-    const size_t slab_elems = (size_t)9 * a.Cout * a.Cin_s;
-    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(a.slab + (size_t)split * slab_elems, 0, (int)(slab_elems * 4), 0x00020000);
-    const int co = co0 + wc * 32 + li;
-    const int cib = ci0 + wi * 32 + 4 * lh;
-    const unsigned row = co < a.Cout ? (unsigned)(co * a.Cin_s) * 4u : OOB;
-    const unsigned tap_stride = (unsigned)(a.Cout * a.Cin_s) * 4u;
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int ci = cib + 8 * q;
-        const unsigned off = ci < a.Cin_s ? row + (unsigned)t * tap_stride + (unsigned)ci * 4u : OOB;
-        const f32x4 v = {acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]};
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), srs, off, 0, 0);
-      }
-  }
-#ifdef OSVOS_WGRAD_PROF
-  WPROF(7);
-  if (a.prof != nullptr && lane == 0) {
-    unsigned long long* q = a.prof + ((size_t)blockIdx.x * WAVES + wave) * 10;
-    for (int k = 0; k < 8; ++k) q[k] = pt[k];
-    q[8] = t_begin;
-    q[9] = tp;
-  }
-#endif
-  if (want_bias) {
-    float* red = reinterpret_cast<float*>(smem);          // [32 pixel groups][OCT octets][8 channels]
-#pragma unroll
-    for (int c = 0; c < 8; ++c) red[(sg * OCT + so) * 8 + c] = bsum[c];
-    __syncthreads();
-    if (tid < BCOT) {
-      float sum = 0.f;
-      for (int g = 0; g < 32; ++g) sum += red[g * BCOT + tid];
-      if (co0 + tid < a.Cout) a.bslab[(size_t)split * a.Cout + co0 + tid] = sum;
-    }
-  }
-}
 
 // ---------------------------------------------------------------------------------------------------------------------------------
 // OSVOS_WGRAD_FORM=3 (the default since round 2: bit-identical to the other forms, 1.6 % faster on configs[2]): pixel-major tiles.  The tiles stay the way they lie in HBM -- [pixel][channel], one
@@ -842,323 +565,15 @@ __global__ __launch_bounds__(64 * WAVES) void wgrad_bf16pm_kernel(WbArgs a) {
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------------
-// OSVOS_WGRAD_FORM=4: pixel-major tiles filled by LDS-DMA (buffer_load_dwordx4 ... lds), eight waves, 128-cout tiles.
-// The pixel-major kernel above stops all waves twice per patch (barrier - 14 ds_write_b128 per thread - barrier: 15-20 % of a wave's life,
-// tools/native/wgrad_probe) and, with 56 staging registers next to 144 accumulators, has room for ONE fragment set, so every stage waits
-// out its own LDS latency.  Here nothing is staged through registers:
-//   * a patch is worked as two HALF patches of 32 x 4 pixels over two LDS buffers; while the MFMAs read half patch u from buffer u & 1 each
-//     wave issues its 8 DMA instructions for half patch u + 1 (one every second stage, between the MFMAs) into the other buffer; s_waitcnt vmcnt(0)
-//     + ONE barrier per half patch
-//   * the DMA writes lane l's 16 bytes at base + 16 l, so the tiles cannot be padded; instead of the +64-byte pixel pitch the 16-byte
-//     channel octets are XOR-swizzled with the pixel index (dY: octet ^ 4 (pixel & 3), 256-byte pixels; X: octet ^ 4 ((column >> 1) & 1),
-//     128-byte pixels, halo rows of 36 pixels): the four pixel rows of a ds_read_b64_tr_b16 fall on disjoint quarters of the 64 banks for
-//     every tap shift.  The swizzle is applied on the GLOBAL side (which octet a lane fetches); on the read side it is a per-lane constant
-//     for dY and one of three per-lane constants (column shift 0 / 1 / 2) for X -- every fragment address is base register + immediate
-//   * 144 accumulators + two fragment sets (stage st + 1 is gathered while stage st multiplies) + addresses: no spills at 256 registers
-//   * bias gradient: fp32 sums of the dY fragments the waves (wi = 0) hold anyway -- deterministic, a different summation order than the
-//     register-staged forms (the weight gradient itself is bit-identical to them: same patches, splits and k-order)
-struct DM {
-  static constexpr int WAVES = 8, BCOT = 128, HP = 4;
-  static constexpr int DYP = BCOT * 2, XP = BCI * 2;                        // pixel pitches in bytes: 256 and 128 (no padding)
-  static constexpr int XW = 36, XPIX = (HP + 2) * XW;                       // halo rows of 36 pixels (34 used), 216 halo pixels
-  static constexpr int X_B = XPIX * XP, DY_B = HP * PW * DYP;               // 27648 and 32768 bytes
-  static constexpr int X_OFF = 0, DY_OFF = 2 * X_B;                         // LDS: [X buf 0][X buf 1][dY buf 0][dY buf 1] -- every read offset fits 16 bits
-  static constexpr int NDY = DY_B / 1024 / WAVES, XI = X_B / 1024, NX = (XI + WAVES - 1) / WAVES, NDMA = NDY + NX;      // 4 + 4 DMA instructions per wave
-  static constexpr int NST = HP * 2 * 3;                                    // stages per half patch: 8 k-steps x 3 tap rows
-  static constexpr size_t LDS = (size_t)2 * X_B + 2 * DY_B;                 // 120832 bytes
-  static constexpr int GAP = 2;                                             // one DMA instruction every second stage
-  static_assert(DY_B % (1024 * WAVES) == 0 && X_B % 1024 == 0 && NDMA * GAP <= NST, "DMA instruction counts");
-};
-
-// PP = 1 (OSVOS_WGRAD_FORM=5): ping-pong -- the two waves of a SIMD alternate between a GATHER segment (the 20 ds_read_b64_tr_b16 of one k-step + two DMA
-// instructions) and a MULTIPLY segment (that k-step's 9 MFMAs back to back), one raw s_barrier per segment, waves 4-7 one segment behind waves 0-3: a SIMD's
-// matrix pipe always sees ONE wave's uninterrupted MFMA run while the partner gathers (MI355X_MICROARCH.md, "Two waves per SIMD").
-// Measured (profiles/r02_wgrad_bf16_dma_forms.txt, 12 x 120 x 214, 256 -> 256, rocprofv3 PMC): pixel-major form 58.8 % matrix-pipe occupancy at 1.88 GHz,
-// this kernel 60.8 % at 1.83 GHz, ping-pong 60.2 % at 1.81-1.94 GHz -- 325-335 us per launch all three (also with fragments two stages ahead, static wave
-// priorities and de-phased partner waves: removed again); the chip holds ~1.8 GHz on toggling bf16 operands whatever the schedule
-// (tools/native/mfma_probe: 1.83 PFLOP/s register-only at 1.81 GHz, 2.48 at 2.37 GHz on all-zero operands).
-template <int PP>
-__global__ __launch_bounds__(512) void wgrad_bf16dma_kernel(WbArgs a) {
-  using G = DM;
-  constexpr int GAP = G::GAP, PF = 1;
-  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-  typedef int i32x4 __attribute__((ext_vector_type(4)));
-  typedef short s16x4 __attribute__((ext_vector_type(4)));
-  typedef short s16x8 __attribute__((ext_vector_type(8)));
-  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);    // wave-uniform by construction; a scalar for m0 and for the branches
-  const int wc = wv >> 1, wi = wv & 1;
-  constexpr unsigned OOB = 0x80000000u;
-
-  int id = blockIdx.x;
-  if (a.map == 1) id = (id & 7) * (gridDim.x >> 3) + (id >> 3);
-  const int cit = id % a.nci_t;
-  id /= a.nci_t;
-  const int cot = id % a.nco_t;
-  const int split = id / a.nco_t;
-  const int co0 = cot * G::BCOT, ci0 = cit * BCI;
-  const int p_begin = split * a.per_split, p_end = min(p_begin + a.per_split, a.npatches);
-  const bool want_bias = a.bslab != nullptr && cit == 0 && wi == 0;
-  float bsum = 0.f;
-
-  // ---- DMA side.  dY instruction i of wave wv fills slots 64 (wv + 8 i) + lane of the dY tile: pixel (row i, column 4 wv + lane / 16),
-  // slot lane % 16 of that pixel = channel octet (lane % 16) ^ 4 (column & 3).  X instruction j fills slots 64 (wv + 8 j) + lane of the X tile:
-  // halo pixel hp = slot / 8 = (row hp / 36, column hp % 36), slot % 8 = octet (slot % 8) ^ 4 ((column >> 1) & 1).
-  const int dcol = 4 * wv + (lane >> 4);
-  const int doct = (lane & 15) ^ (4 * (dcol & 3));
-  const bool dy_ch_ok = co0 + 8 * doct < a.Cout;
-  const unsigned dy_rel = (unsigned)((dcol * a.Cout_s + co0 + 8 * doct) * 2);
-  unsigned xrel[G::NX];
-  int xcol[G::NX], xrow[G::NX];
-#pragma unroll
-  for (int j = 0; j < G::NX; ++j) {
-    const int e = 64 * (wv + G::WAVES * j) + lane, hp = e >> 3, hy = hp / G::XW, hx = hp - hy * G::XW;
-    const int oct = (e & 7) ^ (4 * ((hx >> 1) & 1));
-    xrel[j] = (unsigned)(((hy * a.W + hx) * a.Cin_s + ci0 + 8 * oct) * 2);
-    xcol[j] = (hx < PW + 2 && ci0 + 8 * oct < a.Cin_s) ? hx - 1 : 0x40000000;            // dead slot: the column test below always fails
-    xrow[j] = hy - 1;
-  }
-  const int img_dy_bytes = a.H * a.W * a.Cout_s * 2, img_x_bytes = a.H * a.W * a.Cin_s * 2;
-  const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem;
-  // hidden from the compiler (inline asm): it would put s_waitcnt vmcnt(0) in front of the next LDS read otherwise; the ordering is kept
-  // by hand -- vmcnt(0) + barrier at the end of every half patch
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Winline-asm"
-  auto dma16 = [](const i32x4& rs, unsigned lds_addr, unsigned voff) {
-    asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(lds_addr), "v"(voff), "s"(rs) : "m0", "memory");
-  };
-#pragma clang diagnostic pop
-  struct Patch { i32x4 drs, xrs; int x0, y0; bool live; };
-  auto locate = [&](int p) -> Patch {
-    const int px = p % a.npx;
-    int t = p / a.npx;
-    const int py = t % a.npy;
-    Patch q;
-    q.live = p < p_end;
-    const int n = q.live ? t / a.npy : 0;
-    q.x0 = px * PW;
-    q.y0 = py * PH;
-    const unsigned long long dv = reinterpret_cast<unsigned long long>(a.dy) + (unsigned long long)n * (unsigned)img_dy_bytes;
-    const unsigned long long xv = reinterpret_cast<unsigned long long>(a.x) + (unsigned long long)n * (unsigned)img_x_bytes;
-    q.drs = i32x4{(int)(unsigned)dv, (int)(unsigned)(dv >> 32), img_dy_bytes, 0x00020000};
-    q.xrs = i32x4{(int)(unsigned)xv, (int)(unsigned)(xv >> 32), img_x_bytes, 0x00020000};
-    return q;
-  };
-  // the d-th DMA instruction of this wave for (patch q, half h) into buffer buf (d, h, buf: compile-time constants after unrolling)
-  auto dma_one = [&](const Patch& q, int h, int buf, int d) {
-    if (!q.live) return;                              // wave-uniform
-    if (d < G::NDY) {
-      const int y = q.y0 + G::HP * h + d;
-      const unsigned off = (dy_ch_ok && q.x0 + dcol < a.W && y < a.H) ? dy_rel + (unsigned)(y * a.W + q.x0) * (unsigned)(a.Cout_s * 2) : OOB;
-#if defined(OSVOS_WGRAD_ABL) && OSVOS_WGRAD_ABL == 5
-      dma16(q.drs, lds0 + (unsigned)(G::DY_OFF + buf * G::DY_B + (wv + G::WAVES * d) * 1024), OOB | (off & 0xf0));      // ablation 5: the instruction without the data
-#else
-      dma16(q.drs, lds0 + (unsigned)(G::DY_OFF + buf * G::DY_B + (wv + G::WAVES * d) * 1024), off);
+#ifdef OSVOS_WGRAD_ALL_FORMS      // forms 4 / 5 (probe builds only)
+#define OSVOS_WGRAD_FORMS_PART 2
+#include "../../tools/native/wgrad_bf16_forms.inc"
+#undef OSVOS_WGRAD_FORMS_PART
 #endif
-    } else {
-      const int j = d - G::NDY;
-      if (wv + G::WAVES * j >= G::XI) return;         // wave-uniform: past the X tile
-      const int yb = q.y0 + G::HP * h;                // halo row hy = image row yb + hy - 1
-      const bool ok = (unsigned)(q.x0 + xcol[j]) < (unsigned)a.W && (unsigned)(yb + xrow[j]) < (unsigned)a.H;
-      const unsigned off = ok ? (unsigned)((yb - 1) * a.W + q.x0 - 1) * (unsigned)(a.Cin_s * 2) + xrel[j] : OOB;
-#if defined(OSVOS_WGRAD_ABL) && OSVOS_WGRAD_ABL == 5
-      dma16(q.xrs, lds0 + (unsigned)(G::X_OFF + buf * G::X_B + (wv + G::WAVES * j) * 1024), OOB | (off & 0xf0));
-#else
-      dma16(q.xrs, lds0 + (unsigned)(G::X_OFF + buf * G::X_B + (wv + G::WAVES * j) * 1024), off);
-#endif
-    }
-  };
 
-  f32x16 acc[9];
-#pragma unroll
-  for (int t = 0; t < 9; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-
-  // ---- fragment side: lane (i = lane & 15, g = (lane >> 4) & 1, lh = lane >> 5) addresses pixel 8 lh + i / 4 (+4 for the second read),
-  // channels 16 g + 4 (i % 4) .. +3 of its wave's 32-channel block = 8 bytes inside octet 4 w + 2 g + (i % 4) / 2, swizzled with the pixel
-  const int fi = lane & 15, fg = (lane >> 4) & 1, lh = lane >> 5;
-  const int fp = fi >> 2, fo = 2 * fg + ((fi & 3) >> 1), fb = (fi & 1) * 8;
-  const char* const a_base = smem + G::DY_OFF + (8 * lh + fp) * G::DYP + ((4 * wc + fo) ^ (4 * (fp & 3))) * 16 + fb;
-  const char* b_base[3];
-#pragma unroll
-  for (int s2 = 0; s2 < 3; ++s2) b_base[s2] = smem + G::X_OFF + (8 * lh + fp) * G::XP + ((4 * wi + fo) ^ (4 * (((fp + s2) >> 1) & 1))) * 16 + fb;
-  auto tr8 = [&](const char* p, int pitch) -> s16x8 {
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 4 * pitch));
-    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-  };
-
-#ifdef OSVOS_WGRAD_PROF
-  unsigned long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tp = __builtin_amdgcn_s_memtime(), tq;
-  const unsigned long long t_begin = tp;
-#endif
-  Patch q = locate(p_begin);
-  {
-#pragma unroll
-    for (int d = 0; d < G::NDMA; ++d) dma_one(q, 0, 0, d);
-  }
-  WPROF(0);
-  __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): this wave's part of half patch 0 has landed ...
-  __syncthreads();                                     // ... and everybody's has
-  WPROF(1);
-
-  // one half patch: 24 stages = 8 k-steps x 3 tap rows out of buffer B; the DMA of the NEXT half patch (patch nq, half nh) goes to buffer 1 - B
-  constexpr int NBF = PF + 1;
-  s16x8 af[2], bfr[NBF][3];
-  auto half_patch = [&](auto Bc, const Patch& nq, auto NHc) {
-    constexpr int B = decltype(Bc)::value, NH = decltype(NHc)::value;
-    auto lda = [&](int ks) {
-#if defined(OSVOS_WGRAD_ABL) && OSVOS_WGRAD_ABL == 2
-      if (ks > 1) return;
-#endif
-      af[ks & 1] = tr8(a_base + B * G::DY_B + ((ks >> 1) * PW + (ks & 1) * 16) * G::DYP, G::DYP);
-    };
-    auto ldb = [&](int st) {
-      const int ks = st / 3, r = st % 3;
-#if defined(OSVOS_WGRAD_ABL) && OSVOS_WGRAD_ABL == 2
-      if (st > 2) return;
-#endif
-#pragma unroll
-      for (int s2 = 0; s2 < 3; ++s2)
-        bfr[st % NBF][s2] = tr8(b_base[s2] + B * G::X_B + (((ks >> 1) + r) * G::XW + (ks & 1) * 16 + s2) * G::XP, G::XP);
-    };
-    lda(0);
-#pragma unroll
-    for (int i = 0; i < PF; ++i) ldb(i);
-#pragma unroll
-    for (int st = 0; st < G::NST; ++st) {
-      const int ks = st / 3, r = st % 3;
-      if (r == 3 - PF && ks + 1 < G::NST / 3) lda(ks + 1);        // the next k-step's dY fragment, PF stages ahead of its first use
-      if (st + PF < G::NST) ldb(st + PF);
-#if !(defined(OSVOS_WGRAD_ABL) && OSVOS_WGRAD_ABL == 3)                  // ablation 3: no DMA inside the k-loop
-      if (st % GAP == 0 && st / GAP < G::NDMA) dma_one(nq, NH, 1 - B, st / GAP);
-#endif
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int s2 = 0; s2 < 3; ++s2)
-#if defined(OSVOS_WGRAD_ABL) && OSVOS_WGRAD_ABL == 1
-        acc[r * 3 + s2][0] += __uint_as_float((unsigned)(bfr[st % NBF][s2][0] ^ bfr[st % NBF][s2][7] ^ af[ks & 1][0] ^ af[ks & 1][7]));      // ablation 1: no MFMA
-#else
-        acc[r * 3 + s2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, bfr[st % NBF][s2]),
-                                                                __builtin_bit_cast(bf16x8_t, af[ks & 1]), acc[r * 3 + s2], 0, 0, 0);
-#endif
-      if (r == 0 && want_bias) {                      // wave-uniform: fp32 sum of this lane's 8 pixels of its cout
-        const u32x4 v = __builtin_bit_cast(u32x4, af[ks & 1]);
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-          bsum += __uint_as_float(v[d] << 16);
-          bsum += __uint_as_float(v[d] & 0xffff0000u);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  };
-
-  // ---- ping-pong form of the same half patch: per k-step one gather segment and one multiply segment, a raw s_barrier after each
-  s16x8 paf, pbf[9];
-  auto half_patch_pp = [&](auto Bc, const Patch& nq, auto NHc) {
-    constexpr int B = decltype(Bc)::value, NH = decltype(NHc)::value;
-#pragma unroll
-    for (int ks = 0; ks < G::NST / 3; ++ks) {
-      // gather: the dY fragment and the nine shifted X fragments of k-step ks; the DMA of the next half patch rides in the first four gathers
-      paf = tr8(a_base + B * G::DY_B + ((ks >> 1) * PW + (ks & 1) * 16) * G::DYP, G::DYP);
-#pragma unroll
-      for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int s2 = 0; s2 < 3; ++s2)
-          pbf[r * 3 + s2] = tr8(b_base[s2] + B * G::X_B + (((ks >> 1) + r) * G::XW + (ks & 1) * 16 + s2) * G::XP, G::XP);
-      if (2 * ks + 1 < G::NDMA) {
-        dma_one(nq, NH, 1 - B, 2 * ks);
-        dma_one(nq, NH, 1 - B, 2 * ks + 1);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      if (ks == G::NST / 3 - 1) __builtin_amdgcn_s_waitcnt(0x0070);      // last gather of the half patch: the next one's DMA (this wave's part) has landed
-      else __builtin_amdgcn_s_waitcnt(0xC07F);                            // lgkmcnt(0): the fragments are in; the multiply segment starts without a wait
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      // multiply: 9 MFMAs back to back while the partner wave gathers
-#pragma unroll
-      for (int t = 0; t < 9; ++t)
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, pbf[t]), __builtin_bit_cast(bf16x8_t, paf), acc[t], 0, 0, 0);
-      if (want_bias) {
-        const u32x4 v = __builtin_bit_cast(u32x4, paf);
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-          bsum += __uint_as_float(v[d] << 16);
-          bsum += __uint_as_float(v[d] & 0xffff0000u);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  };
-  if constexpr (PP) {
-    if (wv >= 4) __builtin_amdgcn_s_barrier();          // waves 4-7 run one segment behind
-    for (int p = p_begin; p < p_end; ++p) {
-      half_patch_pp(std::integral_constant<int, 0>(), q, std::integral_constant<int, 1>());
-      const Patch nq = locate(p + 1);
-      half_patch_pp(std::integral_constant<int, 1>(), nq, std::integral_constant<int, 0>());
-      q = nq;
-    }
-    if (wv < 4) __builtin_amdgcn_s_barrier();
-    WPROF(6);
-  } else
-  for (int p = p_begin; p < p_end; ++p) {
-    half_patch(std::integral_constant<int, 0>(), q, std::integral_constant<int, 1>());
-    WPROF(6);
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    __syncthreads();
-    WPROF(1);
-    const Patch nq = locate(p + 1);
-    half_patch(std::integral_constant<int, 1>(), nq, std::integral_constant<int, 0>());
-    WPROF(6);
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    __syncthreads();
-    WPROF(1);
-    q = nq;
-  }
-
-  {   // slab epilogue, as in the other forms
-    const int li = lane & 31;
-    const size_t slab_elems = (size_t)9 * a.Cout * a.Cin_s;
-    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(a.slab + (size_t)split * slab_elems, 0, (int)(slab_elems * 4), 0x00020000);
-    const int co = co0 + wc * 32 + li;
-    const int cib = ci0 + wi * 32 + 4 * lh;
-    const unsigned row = co < a.Cout ? (unsigned)(co * a.Cin_s) * 4u : OOB;
-    const unsigned tap_stride = (unsigned)(a.Cout * a.Cin_s) * 4u;
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-      for (int qd = 0; qd < 4; ++qd) {
-        const int ci = cib + 8 * qd;
-        const unsigned off = ci < a.Cin_s ? row + (unsigned)t * tap_stride + (unsigned)ci * 4u : OOB;
-        const f32x4 v = {acc[t][4 * qd], acc[t][4 * qd + 1], acc[t][4 * qd + 2], acc[t][4 * qd + 3]};
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), srs, off, 0, 0);
-      }
-  }
-#ifdef OSVOS_WGRAD_PROF
-  WPROF(7);
-  if (a.prof != nullptr && lane == 0) {
-    unsigned long long* qq = a.prof + ((size_t)blockIdx.x * G::WAVES + wv) * 10;
-    for (int k = 0; k < 8; ++k) qq[k] = pt[k];
-    qq[8] = t_begin;
-    qq[9] = tp;
-  }
-#endif
-  if (a.bslab != nullptr && cit == 0) {                  // workgroup-uniform
-    float* red = reinterpret_cast<float*>(smem);         // [128 couts][2 pixel halves]; every fragment read is behind the last barrier
-    if (wi == 0) red[(32 * wc + 16 * fg + fi) * 2 + lh] = bsum;
-    __syncthreads();
-    if (tid < G::BCOT && co0 + tid < a.Cout) a.bslab[(size_t)split * a.Cout + co0 + tid] = red[2 * tid] + red[2 * tid + 1];
-  }
-}
-
+#ifdef OSVOS_WGRAD_ALL_FORMS
 constexpr size_t kLdsV2 = (size_t)DY_BYTES + X_BYTES, kLdsV2w = (size_t)2 * DY_BYTES + X_BYTES;
+#endif
 
 constexpr int kDefaultMap = 1;      // bf16-input form: XCD-local split order (L2 hit rate 38 % -> 77 %, HBM reads / 3; OSVOS_WGRAD_MAP=0 turns it off)
 constexpr int kDefaultForm = 3;     // bf16-input kernel: 0 = first staging form, 1 = second (wgrad_bf16v2_kernel<4>), 2 = second with eight waves / 128-cout
@@ -1214,7 +629,11 @@ int osvos_conv3x3_wgrad_bf16mfma_io(const void* x, const void* dy, int xb, void*
   OSVOS_ARG_CHECK(osvos_wgrad_bf16_applicable(Cin_s, Cout) && Cin == Cin_s && Cout_s % 4 == 0, "wgrad bf16: unsupported shape");
   OSVOS_ARG_CHECK((long)H * W * Cin_s < (1L << 29) && (long)H * W * Cout_s < (1L << 29), "wgrad bf16: image too large for 31-bit byte offsets");
   static const int form_env = getenv("OSVOS_WGRAD_FORM") ? atoi(getenv("OSVOS_WGRAD_FORM")) : -1;
+#ifdef OSVOS_WGRAD_ALL_FORMS
   const int form = xb ? (form_env >= 0 ? form_env : kDefaultForm) : 0;
+#else      // the shipped library holds two forms: 0 (first staging form; the only one for fp32 tensors) and 3 (pixel-major, the default for bf16 tensors)
+  const int form = xb ? ((form_env == 0) ? 0 : kDefaultForm) : 0;
+#endif
   const bool wide = form >= kWideForm && Cout % 128 == 0;        // eight-wave form: 128-cout tiles
   WbPlan p = make_plan(N, H, W, Cin_s, Cout, wide ? 128 : BCO);
   WbArgs a;
@@ -1240,6 +659,7 @@ int osvos_conv3x3_wgrad_bf16mfma_io(const void* x, const void* dy, int xb, void*
     attr_set = true;
   }
   const int phase = osvos_wgrad_phase();
+#ifdef OSVOS_WGRAD_ALL_FORMS
   if (phase != 2 && form >= 4 && wide) {                // LDS-DMA forms: 4 fragments one stage ahead, 5 ping-pong segments
     static bool attr4_set_dev[OSVOS_MAX_DEVICES] = {};
     bool& attr4_set = attr4_set_dev[osvos_current_device()];
@@ -1252,7 +672,9 @@ int osvos_conv3x3_wgrad_bf16mfma_io(const void* x, const void* dy, int xb, void*
     if (form == 5) hipLaunchKernelGGL(wgrad_bf16dma_kernel<1>, dim3((unsigned)blocks), dim3(512), lds_dma, stream, a);
     else hipLaunchKernelGGL(wgrad_bf16dma_kernel<0>, dim3((unsigned)blocks), dim3(512), lds_dma, stream, a);
     OSVOS_LAUNCH_CHECK();
-  } else if (phase != 2 && form >= 3) {
+  } else
+#endif
+  if (phase != 2 && form >= 3) {
     static bool attr3_set_dev[OSVOS_MAX_DEVICES] = {};      // per device, like every other kernel attribute
     bool& attr3_set = attr3_set_dev[osvos_current_device()];
     constexpr size_t lds4 = PM<4>::LDS, lds8 = PM<8>::LDS;
@@ -1264,6 +686,7 @@ int osvos_conv3x3_wgrad_bf16mfma_io(const void* x, const void* dy, int xb, void*
     if (wide) hipLaunchKernelGGL(wgrad_bf16pm_kernel<8>, dim3((unsigned)blocks), dim3(512), lds8, stream, a);
     else hipLaunchKernelGGL(wgrad_bf16pm_kernel<4>, dim3((unsigned)blocks), dim3(256), lds4, stream, a);
     OSVOS_LAUNCH_CHECK();
+#ifdef OSVOS_WGRAD_ALL_FORMS
   } else if (phase != 2 && form != 0) {
     static bool attr2_set_dev[OSVOS_MAX_DEVICES] = {};
     bool& attr2_set = attr2_set_dev[osvos_current_device()];
@@ -1275,6 +698,7 @@ int osvos_conv3x3_wgrad_bf16mfma_io(const void* x, const void* dy, int xb, void*
     if (wide) hipLaunchKernelGGL(wgrad_bf16v2_kernel<8>, dim3((unsigned)blocks), dim3(512), kLdsV2w, stream, a);
     else hipLaunchKernelGGL(wgrad_bf16v2_kernel<4>, dim3((unsigned)blocks), dim3(256), kLdsV2, stream, a);
     OSVOS_LAUNCH_CHECK();
+#endif
   } else if (phase != 2) {
     if (xb) hipLaunchKernelGGL(wgrad_bf16_kernel<1>, dim3((unsigned)blocks), dim3(256), lds, stream, a);
     else hipLaunchKernelGGL(wgrad_bf16_kernel<0>, dim3((unsigned)blocks), dim3(256), lds, stream, a);

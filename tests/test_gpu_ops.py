@@ -690,9 +690,10 @@ def test_result_writer_bytes_png_and_jaccard(tmp_path):
 
 @pytest.mark.gpu
 def test_wgrad_bf16_forms_are_bit_identical(tmp_path):
-    """OSVOS_WGRAD_FORM 0 / 1 / 3 / 4 / 5 (first staging form, four-wave item form, pixel-major tiles read with
-    ds_read_b64_tr_b16, the same filled by LDS-DMA, LDS-DMA with ping-pong gather / multiply segments) against the eight-wave item form: same patches, same splits, same k-order -> the weight gradient must be
-    bit-identical, the bias gradient equal up to fp32 summation order.  Shapes cover ragged right / bottom edges, one and two
+    """The two forms of the bf16 weight gradient that ship (OSVOS_WGRAD_FORM 0: first staging form, four waves / 64-cout tiles; 3, the default:
+    pixel-major tiles read with ds_read_b64_tr_b16, eight waves / 128-cout tiles where Cout allows): same patches, same k-order -> the weight
+    gradient must be bit-identical, the bias gradient equal up to fp32 summation order.  (The retired forms 1, 2, 4, 5 live in
+    tools/native/wgrad_bf16_forms.inc and are built into the probe harness only.)  Shapes cover ragged right / bottom edges, one and two
     128-cout tiles, 64-cout tiles and several images.  The switch is read once per process: every form runs in a subprocess."""
     import os, subprocess, sys, textwrap
     code = textwrap.dedent('''
@@ -710,12 +711,12 @@ def test_wgrad_bf16_forms_are_bit_identical(tmp_path):
         np.savez(sys.argv[1], **res)
     ''') % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),)
     got = {}
-    for form in ("2", "0", "1", "3", "4", "5"):
+    for form in ("3", "0"):
         out = str(tmp_path / ("f%s.npz" % form))
         subprocess.run([sys.executable, "-c", code, out], check=True, env=dict(os.environ, OSVOS_WGRAD_FORM=form), timeout=600)
         got[form] = dict(np.load(out))
-    for form in ("0", "1", "3", "4", "5"):
-        for k, ref in got["2"].items():
+    for form in ("0",):
+        for k, ref in got["3"].items():
             if k.startswith("dw_"):
                 assert np.array_equal(got[form][k], ref), (form, k)
             else:

@@ -7,7 +7,7 @@ mkdir -p bin
 C=../../osvos-pytorch_amd/csrc
 ABL=${1:-0}
 OUT=bin/wgrad_probe; [ "$ABL" != "0" ] && OUT=bin/wgrad_probe_abl$ABL
-/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -Wno-unused-function -DOSVOS_WGRAD_PROF -DOSVOS_WGRAD_ABL=$ABL \
+/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -Wno-unused-function -DOSVOS_WGRAD_PROF -DOSVOS_WGRAD_ALL_FORMS -DOSVOS_WGRAD_ABL=$ABL \
   $C/wgrad_bf16.hip $C/wgrad_f32.hip $C/wgrad_small_f32.hip -x hip $C/errors.cpp wgrad_probe.cpp -o $OUT
 # convolution probe (production kernels, no instrumentation); X3ABL=n builds bin/conv_probe_x3abl<n> with the f32x3 K-loop ablation n
 XABL=${X3ABL:-0}
