@@ -215,6 +215,8 @@ class Workload(object):
         self.net, self.x, self.gt = synth_problem(batch, height, width, device, seed=rank)
         self.net.set_precision(precision)
         self.net.set_inplace_grad_accumulation(True)      # what osvos_pytorch_amd.train_common.TrainLoop (the scripts' loop) does
+        if os.environ.get("OSVOS_DEFER_JOIN", "0") == "1":
+            self.net.set_deferred_backward_join(True)     # (TrainLoop reads the same switch)
         from osvos_pytorch_amd.train_common import make_sgd      # the scripts' own parameter groups (train_online.py:79-88 / train_parent.py:87-103)
         self.opt = make_sgd(self.net, "online" if mode == "infer" else mode)
         comm = None
@@ -333,6 +335,7 @@ class Workload(object):
         self.ave += 1
         self.nsteps += 1
         if self.ave % self.n_ave == 0:
+            self.net.join_backward()
             if self.reducer is not None:
                 self.reducer.all_reduce()
             self.opt.step()

@@ -32,6 +32,11 @@ extern "C" {
                                             upscale[i].weight is NOT diagonal with one shared filter -> the generic transposed-convolution head
                                             (head_generic.hip) runs instead of the commuted one, and gradients of upscale / upscale_ weights
                                             are written when their grads[] entries (0..7) are non-NULL */
+#define OSVOS_FLAG_DEFER_JOIN 0x200      /* OR-ed into the dtype of osvos_net_backward: do NOT make `stream` wait for the weight-gradient work still
+                                            running on aux_stream / aux2_stream when the call returns (the data-gradient chain, dx and everything the
+                                            caller's next forward needs ARE complete in stream order).  The caller owes one osvos_net_join before it reads
+                                            a parameter gradient on `stream` (optimizer step, all-reduce) and must keep `ws` alive until then.  Lets the
+                                            tail of the weight gradients run under the next micro-batch's forward (gradient-accumulation loops). */
 #define OSVOS_F32_X3 3        /* fp32 tensors, fp32 parameters and fp32 weight packs exactly as OSVOS_F32; the wide 3x3 convolutions
                                  (forward, data gradient) run on the bf16 matrix pipe with three-way split operands (six bf16
                                  products per fp32 product, fp32 accumulate): fp32-grade results, see osvos_conv3x3 below */
@@ -236,6 +241,9 @@ int osvos_net_forward(const float* x_nchw, const void* wbuf, void* ws, float* co
 int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, float* const* grads,
                        float* dx_nchw, int N, int H, int W, int dtype, int accumulate, void* stream, void* aux_stream,
                        void* aux2_stream);
+/* makes `stream` wait for everything enqueued so far on aux_stream / aux2_stream (NULL = skip): the join a backward with
+ * OSVOS_FLAG_DEFER_JOIN left out */
+int osvos_net_join(void* stream, void* aux_stream, void* aux2_stream);
 /* Gradient-ready events for overlapping the data-parallel all-reduce with the rest of the backward (extends
  * train_parent.py:163-172; SURVEY 8e "overlap with the last micro-batch's backward, bucket order = reverse layer order").
  * Arms the NEXT osvos_net_backward call made by THIS host thread: events[k] (hipEvent_t handles owned by the caller, k < 7) is

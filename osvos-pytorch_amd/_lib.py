@@ -19,6 +19,7 @@ _lock = threading.Lock()
 _lib = None
 
 F32, BF16, F32_BF16MFMA, F32_X3 = 0, 1, 2, 3
+DEFER_JOIN = 0x200         # OSVOS_FLAG_DEFER_JOIN: osvos_net_backward leaves the side streams un-joined (autograd.NetRuntime.join_backward)
 GENERIC_DECONV = 0x100      # OSVOS_FLAG_GENERIC_DECONV: OR-ed into the dtype of the osvos_net_* calls
 NPARAMS = 52
 
@@ -79,6 +80,7 @@ PROTOTYPES = {
     "osvos_net_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "osvos_net_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "osvos_net_arm_grad_events": (_i, [_vp, _i]),
+    "osvos_net_join": (_i, [_vp, _vp, _vp]),
     "osvos_comm_unique_id": (_i, [_vp]),
     "osvos_comm_init": (_i, [_vp, _i, _i, _vp]),
     "osvos_comm_allreduce_f32": (_i, [_vp, _vp, _sz, _vp]),

@@ -8,7 +8,7 @@ import os
 
 import torch
 
-from ._lib import F32, F32_BF16MFMA, F32_X3, GENERIC_DECONV, NPARAMS, check, lib, ptr_array
+from ._lib import DEFER_JOIN, F32, F32_BF16MFMA, F32_X3, GENERIC_DECONV, NPARAMS, check, lib, ptr_array
 
 # indices (state_dict order) of the frozen transposed-conv weights: lr 0 in both reference
 # scripts (train_online.py:84-85, train_parent.py:99-100); their gradients are never formed
@@ -41,6 +41,12 @@ class NetRuntime:
         self.generic_head = False     # upscale[i].weight not diagonal / shared-filter: generic transposed-convolution head
         self.grad_events = None       # hipEvent_t handles for the NEXT backward (GradientAllReducer.arm), consumed by it
         self.grad_events_recorded = False     # did the last backward record them (it does only when it accumulated in place)
+        # Deferred join (opt-in, gradient-accumulation loops: TrainLoop / bench.py with OSVOS_DEFER_JOIN=1): a backward that accumulates in
+        # place returns as soon as its data-gradient chain is enqueued and leaves the weight-gradient tail running on the side streams --
+        # under the NEXT micro-batch's forward, whose 256-pixel tiles leave ~18 % of the CUs idle at batch 1.  `join_backward` must run
+        # before anything reads a parameter gradient on the main stream (optimizer step, all-reduce).
+        self.defer_join = False
+        self.pending_join = None              # device of the un-joined backward
 
     # The side streams are shared by every OSVOS module of the process (one set per device).  ROCm maps HIP streams onto a handful
     # of hardware queues (GPU_MAX_HW_QUEUES); a second module with three more streams of its own ends up sharing queues with the
@@ -53,8 +59,22 @@ class NetRuntime:
         key = (device.type, device.index if device.index is not None else torch.cuda.current_device(), name)
         st = cls._shared_streams.get(key)
         if st is None:
-            st = cls._shared_streams[key] = torch.cuda.Stream(device=device)
+            prio = os.environ.get("OSVOS_AUX_PRIORITY", "")       # tuning: HIP priority of the weight-gradient / reduce streams (lower = more urgent)
+            try:
+                st = torch.cuda.Stream(device=device, priority=int(prio)) if prio and name in ("wgrad", "reduce") else torch.cuda.Stream(device=device)
+            except Exception:
+                st = torch.cuda.Stream(device=device)
+            cls._shared_streams[key] = st
         return st
+
+    def join_backward(self):
+        """Make the current stream wait for the weight-gradient work a deferred-join backward left on the side streams."""
+        if self.pending_join is None:
+            return
+        dev, self.pending_join = self.pending_join, None
+        with torch.cuda.device(dev):
+            check(lib().osvos_net_join(_stream(), C.c_void_p(self.aux_stream.cuda_stream) if self.aux_stream is not None else None,
+                                       C.c_void_p(self.aux2_stream.cuda_stream) if self.aux2_stream is not None else None), "net_join")
 
     def aux(self, device):
         if not self.two_streams:
@@ -202,11 +222,24 @@ class OSVOSNetFunction(torch.autograd.Function):
         rt.grad_events_recorded = bool(ev and inplace)
         if ev and inplace:         # data-parallel overlap (parallel.GradientAllReducer.arm): one ready-event per completion group
             check(l.osvos_net_arm_grad_events(ptr_array(ev), len(ev)), "net_arm_grad_events")
+        aux, aux2 = rt.aux(dev), rt.aux2(dev)
+        # deferred join: only when nothing of this call is handed back to autograd (in-place accumulation) and no ready-events are armed
+        defer = bool(rt.defer_join and inplace and not ev and aux is not None)
         check(l.osvos_net_backward(C.c_void_p(rt.wbuf.data_ptr()), C.c_void_p(ws.data_ptr()),
                                    ptr_array([None if g is None else g.data_ptr() for g in d]),
                                    ptr_array([None if g is None else g.data_ptr() for g in targets]),
                                    C.c_void_p(dx.data_ptr()) if dx is not None else None,
-                                   n, h, w, ctx.cdtype, 1 if inplace else 0, _stream(), rt.aux(dev), rt.aux2(dev)), "net_backward")
+                                   n, h, w, ctx.cdtype | (DEFER_JOIN if defer else 0), 1 if inplace else 0, _stream(), aux, aux2), "net_backward")
+        if defer:
+            # the side streams still read the workspace (activations, upstream gradients, slabs) and write the scratch halves: the caching
+            # allocator must not hand that memory out again before they are done with it
+            for st in (rt.aux_stream, rt.aux2_stream):
+                if st is not None:
+                    ws.record_stream(st)
+                    for t in targets:
+                        if t is not None:
+                            t.record_stream(st)
+            rt.pending_join = dev
         ctx.params = None
         ctx.ws = None
         return (None, dx) + tuple(grads)

@@ -436,7 +436,7 @@ int forward_p3(const float* x_nchw, const void* wbuf, void* ws, float* const* ou
 
 // the trunk + side_prep half of the backward (everything behind the head's dprep[i]); streams, events and hazards as in the fp32 form
 int backward_trunk_p3(const void* wbuf, void* ws, float* const* grads, float* dx_nchw, int N, int H, int W, int dtype, int accumulate,
-                      hipStream_t stream, hipStream_t aux, hipStream_t aux2, const GradEvents& gev, bool dprep3_ready) {
+                      hipStream_t stream, hipStream_t aux, hipStream_t aux2, const GradEvents& gev, bool dprep3_ready, bool defer_join) {
   const bool two = aux != stream, three = aux2 != aux;
   const WbufLayout P = wbuf_layout(dtype);
   const WsLayout L = ws_layout(N, H, W, dtype);
@@ -448,6 +448,7 @@ int backward_trunk_p3(const void* wbuf, void* ws, float* const* grads, float* dx
     return 0;
   };
   auto join = [&]() -> int {
+    if (defer_join) return 0;
     if (two) {
       hipEvent_t e = evp.next();
       if (!e) return -1;
@@ -539,7 +540,7 @@ int backward_trunk_p3(const void* wbuf, void* ws, float* const* grads, float* dx
   for (int l = kNumTrunk - 1; l >= 0; --l) {
     const int si = d[l].stage, h = L.hs[si], w = L.ws[si];
     const bool first_of_stage = (l == 0) || d[l - 1].stage != si;
-    const bool tail_on_main = l == 0 && two;      // conv1_1's weight gradient: on the main stream behind the input gradient (see the fp32 form)
+    const bool tail_on_main = l == 0 && two && !defer_join;      // conv1_1's weight gradient: on the main stream behind the input gradient (see the fp32 form)
     if (grads[d[l].w_param] != nullptr && !tail_on_main) {
       if ((rc = signal())) return rc;
       if ((rc = wgrad(l, h, w))) return rc;
@@ -780,6 +781,19 @@ int osvos_net_forward(const float* x_nchw, const void* wbuf, void* ws, float* co
                              &L.hs[1], &L.ws[1], stream);
 }
 
+int osvos_net_join(void* stream_, void* aux_, void* aux2_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EventPool& evp = event_pool();
+  for (void* a : {aux_, aux2_}) {
+    if (a == nullptr || a == stream_) continue;
+    hipEvent_t e = evp.next();
+    if (!e) return -1;
+    OSVOS_HIP_CHECK(hipEventRecord(e, (hipStream_t)a));
+    OSVOS_HIP_CHECK(hipStreamWaitEvent(stream, e, 0));
+  }
+  return 0;
+}
+
 int osvos_net_arm_grad_events(void* const* events, int n) {
   OSVOS_ARG_CHECK(n >= 0 && n <= OSVOS_NGRAD_GROUPS && (n == 0 || events != nullptr), "arm_grad_events: n = %d (0..%d)", n, OSVOS_NGRAD_GROUPS);
   GradEvents& g = grad_events();
@@ -798,6 +812,8 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
   hipStream_t aux2 = aux2_stream_ ? (hipStream_t)aux2_stream_ : aux;
   const GradEvents gev = grad_events();      // armed for this call only
   grad_events().n = 0;
+  // deferred join (OSVOS_FLAG_DEFER_JOIN): not with armed gradient-ready events (their last group is recorded behind the join)
+  const bool defer_join = (dtype_ & OSVOS_FLAG_DEFER_JOIN) != 0 && gev.n == 0 && aux != stream;
   auto ready = [&](int group, hipStream_t st) -> int {      // group's gradients are complete once `st` gets here
     if (group < gev.n && gev.ev[group] != nullptr) OSVOS_HIP_CHECK(hipEventRecord(gev.ev[group], st));
     return 0;
@@ -822,6 +838,7 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
   // together they keep the matrix pipes busier than either does alone.
   EventPool& evp = event_pool();
   auto join = [&]() -> int {
+    if (defer_join) return 0;            // the caller joins (osvos_net_join) before it touches a parameter gradient
     if (two) {
       hipEvent_t e = evp.next();
       if (!e) return -1;
@@ -952,7 +969,7 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
   }
   if ((rc = ready(0, stream))) return rc;      // score_dsn + fuse gradients
 
-  if (p3) return backward_trunk_p3(wbuf, ws, grads, dx_nchw, N, H, W, dtype, accumulate, stream, aux, aux2, gev, /*dprep3_ready=*/!generic);
+  if (p3) return backward_trunk_p3(wbuf, ws, grads, dx_nchw, N, H, W, dtype, accumulate, stream, aux, aux2, gev, /*dprep3_ready=*/!generic, defer_join);
 
   // ---- data-gradient chain on `stream`, weight gradients trailing on `aux` ----------------------
   // ready[k]: event recorded on `stream` when the k-th upstream gradient tensor is complete
@@ -1012,7 +1029,7 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
     const void* g_b = sh(L.dy_b[l]);
     // conv1_1's weight gradient is the LAST piece of work of the step and the weight-gradient stream is the one that finishes last (conv1_2's
     // gradient is still running when the data-gradient chain ends): it goes on the main stream, behind the input gradient, beside conv1_2's
-    const bool tail_on_main = l == 0 && two;
+    const bool tail_on_main = l == 0 && two && !defer_join;      // (deferred join: everything gradient-related stays on the side streams)
     if (grads[d[l].w_param] != nullptr && !tail_on_main) {
       if ((rc = signal())) return rc;   // dy[l] ready -> its weight gradient may start on aux
       rc = wgrad(xin, g, l, h, w);

@@ -87,6 +87,17 @@ class OSVOS(nn.Module):
         self._runtime.inplace_accumulate = bool(on)
         return self
 
+    def set_deferred_backward_join(self, on=True):
+        """Opt in (together with in-place gradient accumulation) to backwards that return before their weight-gradient tail has finished
+        on the side streams; call ``join_backward()`` before reading any ``.grad`` (TrainLoop does, before the optimizer step).  Not part
+        of the reference's API."""
+        self._runtime.defer_join = bool(on)
+        return self
+
+    def join_backward(self):
+        self._runtime.join_backward()
+        return self
+
     def invalidate_packed_weights(self):
         """Force a re-pack of the parameters on the next forward.  Needed only after writing parameters through ``.data``
         (``p.data.copy_(...)``, ``dist.broadcast(p.data)``): such writes do not bump ``p._version``, which keys the cache."""

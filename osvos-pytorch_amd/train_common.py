@@ -75,6 +75,8 @@ class TrainLoop(object):
         self.steps = 0
         if hasattr(net, 'set_inplace_grad_accumulation'):
             net.set_inplace_grad_accumulation(True)      # every backward of this loop is loss.backward()
+        if hasattr(net, 'set_deferred_backward_join') and os.environ.get("OSVOS_DEFER_JOIN", "0") == "1":
+            net.set_deferred_backward_join(True)         # the weight-gradient tail of micro-batch k runs under the forward of k + 1
         self._dev = next(net.parameters()).device
         self._nloss = 5 if mode == 'parent' else 1
         self._running = {}                                # epoch -> [device scalars]: a step window may hold frames of two epochs
@@ -132,6 +134,8 @@ class TrainLoop(object):
         self.ave += 1
         stepped = False
         if will_step:
+            if hasattr(self.net, 'join_backward'):
+                self.net.join_backward()           # (deferred join: the gradients are complete on the main stream from here on)
             if self.reducer is not None:
                 self.reducer.all_reduce()
             self.opt.step()
@@ -143,6 +147,11 @@ class TrainLoop(object):
             self.steps += 1
             stepped = True
         return stepped
+
+    def finish(self):
+        """Join anything a deferred-join backward left running (call before reading gradients outside an optimizer step)."""
+        if hasattr(self.net, 'join_backward'):
+            self.net.join_backward()
 
     def pop_running(self, epoch=None):
         """Running loss sums (host floats) of `epoch` (default: everything accumulated so far) and forget them."""

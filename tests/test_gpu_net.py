@@ -603,3 +603,41 @@ def test_pooling_fused_into_the_convolutions_is_bit_identical_to_its_own_launche
             assert float(np.abs(a[k] - b[k]).max()) <= 1e-4 * float(a[k].std()), k
         else:      # (an arg-max / ReLU flip at a near-tie moves single stage-0 gradient entries: rel-L2, the bar of the golden tests)
             assert float(np.linalg.norm(a[k] - b[k])) <= 3e-3 * float(np.linalg.norm(a[k])) + 1e-30, k
+
+
+def test_deferred_backward_join_changes_nothing_but_the_schedule(tmp_path):
+    """OSVOS_DEFER_JOIN=1 (opt-in): backwards return before their weight-gradient tail has finished on the side streams and the next forward
+    runs under it; TrainLoop joins before every optimizer step.  Same kernels, same accumulation order: the weights after two optimizer
+    steps (2 x nAveGrad micro-batches of the parent loop, all five heads) must be BIT-IDENTICAL to the default schedule.  A race on the
+    workspace (freed while the side streams still read it) or a missing join would show up here."""
+    import os, subprocess, sys, textwrap
+    code = textwrap.dedent('''
+        import sys, numpy as np, torch
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        import test_gpu_net as T
+        from oracle import synth
+        from osvos_pytorch_amd.train_common import TrainLoop, make_sgd
+        n_ave = 3
+        frames = [synth.calibrated_problem(1, 96, 160, seed=5 + k) for k in range(2)]
+        net = T.build_net(frames[0][0], "fp32x3")
+        loop = TrainLoop(net, make_sgd(net, "parent", lr=1e-9), mode="parent", n_ave_grad=n_ave)
+        for it in range(4 * n_ave):
+            _, x, m = frames[it %% 2]
+            junk = torch.empty(1 << 26, device="cuda")       # allocator churn between micro-batches: a workspace released too early gets reused
+            junk.fill_(float(it))
+            del junk
+            loop.micro_batch(torch.from_numpy(x).cuda().requires_grad_(), torch.from_numpy(m).cuda(), epoch=it)
+        loop.finish()
+        torch.cuda.synchronize()
+        assert loop.steps == 4
+        np.savez(sys.argv[1], **{k: v.cpu().numpy() for k, v in net.state_dict().items()})
+    ''') % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    got = {}
+    for flag in ("0", "1"):
+        out = str(tmp_path / ("d%s.npz" % flag))
+        subprocess.run([sys.executable, "-c", code, out], check=True, env=dict(os.environ, OSVOS_DEFER_JOIN=flag), timeout=900)
+        got[flag] = dict(np.load(out))
+    changed = 0
+    for k in got["0"]:
+        assert np.array_equal(got["0"][k], got["1"][k]), k
+    assert len(got["0"]) == 52
