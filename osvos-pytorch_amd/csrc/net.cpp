@@ -329,6 +329,14 @@ inline bool use_dgrad_c3() {
   return on;
 }
 
+// TIMING ABLATIONS (wrong results; tools/ablate_step.sh): OSVOS_DBG_SKIP bit 1 = no slab reduces, 2 = no pool backward kernels, 8 = no side_prep data
+// gradients, 16 = no side_prep weight gradients, 32 = no input gradient, 64 = no conv1_1 weight gradient.  What a step costs WITHOUT a piece of work
+// bounds what any rewrite of that piece can give.
+inline int dbg_skip() {
+  static const int v = [] { const char* e = getenv("OSVOS_DBG_SKIP"); return e ? atoi(e) : 0; }();
+  return v;
+}
+
 // gradient-ready events armed for the next backward of this host thread (osvos_net_arm_grad_events)
 struct GradEvents { hipEvent_t ev[OSVOS_NGRAD_GROUPS]; int n = 0; };
 GradEvents& grad_events() {
@@ -875,7 +883,7 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
     osvos_wgrad_set_phase(1);
     r = wgrad_launch(xin, g, l, h, w, aux);
     osvos_wgrad_set_phase(0);
-    if (r) return r;
+    if (r || (dbg_skip() & 1)) return r;
     hipEvent_t e = evp.next();
     if (!e) return -1;
     OSVOS_HIP_CHECK(hipEventRecord(e, aux));
@@ -1000,7 +1008,7 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
   for (int i = 0; i < 4; ++i) {
     const int si = i + 1, sl = kNumTrunk + i, h = L.hs[si], w = L.ws[si];
     const int lx = last_of_stage(si);
-    if (grads[d[sl].w_param] != nullptr) {
+    if (grads[d[sl].w_param] != nullptr && !(dbg_skip() & 16)) {
       const void* dp = store ? at(ws, L.dprep_b[i]) : at(ws, L.dprep[i]);      // (store mode: bf16 x and bf16 dprep)
       rc = side_aux2 ? wgrad_launch(at(ws, L.act[lx]), dp, sl, h, w, aux2) : wgrad(at(ws, L.act[lx]), dp, sl, h, w);
       if (rc) return rc;
@@ -1014,6 +1022,7 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
     // upstream gradient of conv5_3; stages 1-3 are merged in maxpool2x2_bwd below
     void* dst = (i == 3) ? f32(L.dy[lx]) : f32(L.dside[i]);
     void* dst_b = (i == 3) ? sh(L.dy_b[lx]) : (store ? at(ws, L.dside_b[i]) : nullptr);
+    if (dbg_skip() & 8) continue;
     rc = conv_main(at(ws, L.dprep[i]), store ? at(ws, L.dprep_b[i]) : nullptr, at(wbuf, P.dgrad[sl]), nullptr, (i == 3) ? mk32(L.act[lx]) : nullptr,
                    (i == 3) ? mk16(L.act_b[lx]) : nullptr, dst, dst_b, N, h, w, 16, d[sl].cin, d[sl].cin, 0, dtype, nullptr, stream,
                    P.dgrad3[sl] != (size_t)-1 ? at(wbuf, P.dgrad3[sl]) : nullptr);
@@ -1037,7 +1046,8 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
     }
     if (first_of_stage && !tail_on_main && (rc = ready(2 + (4 - si), aux2))) return rc;      // stage si complete (its first conv is the last one processed)
     if (l == 0) {
-      if (dx_nchw != nullptr && (dtype == OSVOS_F32 || dtype == OSVOS_F32_X3) && use_dgrad_c3()) {
+      if (dbg_skip() & 32) {
+      } else if (dx_nchw != nullptr && (dtype == OSVOS_F32 || dtype == OSVOS_F32_X3) && use_dgrad_c3()) {
         rc = osvos_conv3x3_dgrad_c3_f32(reinterpret_cast<const float*>(g), reinterpret_cast<const float*>(at(wbuf, P.dgrad[0])), dx_nchw, N, h, w, d[0].cout, stream);
         if (rc) return rc;
       } else if (dx_nchw != nullptr) {
@@ -1048,7 +1058,7 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
         if (rc) return rc;
       }
       if (tail_on_main) {
-        if (grads[d[0].w_param] != nullptr && (rc = wgrad_launch(xin, g, 0, h, w, stream))) return rc;
+        if (grads[d[0].w_param] != nullptr && !(dbg_skip() & 64) && (rc = wgrad_launch(xin, g, 0, h, w, stream))) return rc;
         if ((rc = join())) return rc;
         return ready(2 + 4, stream);      // stage 0 complete: conv1_2's reduce (aux2, joined) and conv1_1's (main)
       }
@@ -1073,6 +1083,7 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
       if (rc) return rc;
       const int ps2 = si - 1;
       const void* dside = ps2 >= 1 ? at(ws, L.dside[ps2 - 1]) : nullptr;
+      if (dbg_skip() & 2) continue;
       if (store)
         rc = osvos_maxpool2x2_bwd_bf16(at(ws, L.act_b[l - 1]), at(ws, L.dpool_b[si]), dside, at(ws, L.dy_b[l - 1]), N, L.hs[ps2], L.ws[ps2],
                                        kStageC[ps2], stream);

@@ -21,10 +21,10 @@ for step in "$@"; do
     smoke) timeout 300 python __graft_entry__.py smoke > $O/smoke.log 2>&1; tail -2 $O/smoke.log ;;
     bench) timeout 900 python bench.py $arg > $O/bench.log 2>$O/bench.err; tail -c 3000 $O/bench.log; tail -5 $O/bench.err ;;
     prof) (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof -o bench -- python $R/bench.py $arg > $O/rocprof.log 2>&1); DB=$(find $O/prof -name "*.db" | head -1); python tools/prof_summary.py $DB ${PROF_STEPS:-25} $O/kernel_stats.txt "python bench.py $arg" > /dev/null 2>&1; head -40 $O/kernel_stats.txt ;;
-    layers) # per-layer table (tools/layer_table.py): arg = "bf16 12" or "x3 1"
-       set -- $arg; M=$1; B=$2
-       timeout 300 python tools/layer_table.py run --mode $M --batch $B | tail -1 > $O/layers_$M.json
-       (cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/layers_pmc_$M -o p --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -- python $R/tools/layer_table.py run --mode $M --batch $B > $O/layers_pmc_$M.log 2>&1)
+    layers) # per-layer table (tools/layer_table.py): arg = "bf16 12" or "x3 1" (+ " --all")
+       set -- $arg; M=$1; B=$2; X=${3:-}
+       timeout 300 python tools/layer_table.py run --mode $M --batch $B $X | tail -1 > $O/layers_$M.json
+       (cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/layers_pmc_$M -o p --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -- python $R/tools/layer_table.py run --mode $M --batch $B $X > $O/layers_pmc_$M.log 2>&1)
        python tools/layer_table.py report $O/layers_pmc_$M $O/layers_$M.json > $O/layer_table_$M.txt 2>&1; cat $O/layer_table_$M.txt ;;
     cmd) timeout 900 bash -c "$arg" > $O/cmd_$t0.log 2>&1; tail -40 $O/cmd_$t0.log ;;
     *) echo "unknown step $step" ;;

@@ -20,6 +20,8 @@ import sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 LAYERS = [("conv3_2", 120, 214, 256, 256), ("conv4_2", 60, 107, 512, 512)]
+ALL_LAYERS = [("conv1_2", 480, 854, 64, 64), ("conv2_1", 240, 427, 64, 128), ("conv2_2", 240, 427, 128, 128), ("conv3_1", 120, 214, 128, 256),
+              ("conv3_2", 120, 214, 256, 256), ("conv4_1", 60, 107, 256, 512), ("conv4_2", 60, 107, 512, 512), ("conv5_2", 30, 54, 512, 512)]
 REPS = 3
 
 
@@ -44,7 +46,7 @@ def run(args):
             best = min(best, a.elapsed_time(b))
         return best
     manifest = []
-    for name, h, w, cin, cout in LAYERS:
+    for name, h, w, cin, cout in (ALL_LAYERS if args.all else LAYERS):
         gf = 2.0 * n * h * w * cout * 9 * cin / 1e9
         g = torch.Generator(device="cuda").manual_seed(3)
         x = torch.relu(torch.randn(n, h, w, cin, device="cuda", generator=g))
@@ -123,6 +125,7 @@ if __name__ == "__main__":
     r = sub.add_parser("run")
     r.add_argument("--mode", default="bf16", choices=["bf16", "x3"])
     r.add_argument("--batch", type=int, default=12)
+    r.add_argument("--all", action="store_true", help="every distinct wide trunk shape instead of conv3_2 / conv4_2")
     p = sub.add_parser("report")
     p.add_argument("dir")
     p.add_argument("manifest")
