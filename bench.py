@@ -449,16 +449,42 @@ def timed_region(wl, steps, dist, device, prof_lib=None):
     return elapsed, (list(ms), list(fl), list(cnt)), (n_prof if prof_lib is not None else 0)
 
 
-def measure(wl, steps, warmup, min_seconds, world, dist, device, use_prof=True):
-    """W warm-up steps, EXACTLY `steps` timed steps (headline), then a sustained region of >= min_seconds."""
+def measure(wl, steps, warmup, min_seconds, world, dist, device, use_prof=True, settle_seconds=0.0):
+    """Device settle (setup), W warm-up steps, EXACTLY `steps` timed steps (headline), then a sustained region of >= min_seconds."""
     from osvos_pytorch_amd import _lib
     lib = _lib.lib()
+    # setup, before the W warm-up steps: bring the device out of its idle power state.  A process that starts stepping on an idle MI355X runs
+    # its first ~6 steps at 5.3 -> 4.4 ms and needs ~30 more to reach its steady 4.1 ms (memory / fabric clocks ramp under load; the same curve
+    # reappears after one second of idling in the SAME process and a register-only MFMA loop does not remove it: tools/step_curve.py,
+    # profiles/r03_step_curve.txt).  With --warmup 5 --steps 20 the timed region would sit entirely inside that ramp; the line says how many
+    # settle steps ran (`setup_settle_steps`; --settle-seconds 0 turns them off).
+    settle_done = 0
+    if settle_seconds > 0:
+        unit = wl.n_ave if wl.mode != "infer" else 1          # whole optimizer steps
+        for _ in range(unit):                                  # (first launches: packs, workspaces, kernel attributes)
+            wl.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(unit):
+            wl.step()
+        torch.cuda.synchronize()
+        per = max((time.perf_counter() - t0) / unit, 1e-5)
+        n = int(math.ceil(settle_seconds / per / unit)) * unit
+        if dist is not None:                                   # the same count on every rank: the steps contain the collectives
+            t = torch.tensor([n], device=device, dtype=torch.int64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            n = int(t.item())
+        for _ in range(n):
+            wl.step()
+        settle_done = n + 2 * unit
+    res_settle = settle_done
     for _ in range(warmup):
         wl.step()
     prof = use_prof and not (wl.mode == "infer" and wl.graph) and not getattr(wl, "graph_train", False)
     elapsed, (ms, fl, cnt), n_prof = timed_region(wl, steps, dist, device, lib if prof else None)
     frames = steps * wl.batch * world
-    res = {"value": frames / elapsed, "ms_per_step": elapsed / steps * 1e3, "elapsed": elapsed, "timing_detail": dict(TIMING_DETAIL)}
+    res = {"value": frames / elapsed, "ms_per_step": elapsed / steps * 1e3, "elapsed": elapsed, "timing_detail": dict(TIMING_DETAIL),
+           "settle_steps": res_settle}
     if min_seconds > 0:
         n2 = max(steps, int(math.ceil(min_seconds / max(elapsed / steps, 1e-6))))
         n2 = -(-n2 // wl.n_ave) * wl.n_ave if wl.mode != "infer" else n2     # whole optimizer steps
@@ -586,6 +612,8 @@ def main():
     ap.add_argument("--min-seconds", type=float, default=2.0, help="length of the additional `sustained` timed region (0 = skip)")
     ap.add_argument("--force-dist", action="store_true", help="initialise the nccl (RCCL) process group and run the gradient "
                     "all-reduce even with one rank (single-GPU check of the multi-GPU path)")
+    ap.add_argument("--settle-seconds", type=float, default=1.0, help="untimed SETUP before the --warmup steps: run the workload this long (whole "
+                    "optimizer steps) to bring the device out of its idle power state; the step count is reported as setup_settle_steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip extra_configs (configs[2], configs[4]) and the item-sync figure")
@@ -622,7 +650,8 @@ def main():
         ranks_seen = int(t.item())
     wl = Workload(args.mode, args.precision, args.height, args.width, args.batch, args.graph, args.n_ave_grad, args.item_sync,
                   device, rank, dist, args.force_dist, graph_train=args.graph_train)
-    res = measure(wl, args.steps, args.warmup, args.min_seconds, world, dist, device, use_prof=not args.no_prof)
+    res = measure(wl, args.steps, args.warmup, args.min_seconds, world, dist, device, use_prof=not args.no_prof, settle_seconds=args.settle_seconds)
+    settle = res["settle_steps"]
     default_workload = (args.mode, args.precision, args.height, args.width, args.batch, args.item_sync) == ("online", "fp32x3", 480, 854, 1, 0)
     extras, item_line = None, None
     if world == 1 and dist is None and default_workload and not args.no_extra:
@@ -657,7 +686,8 @@ def main():
                 out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
                 d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
                 extras.append({"config": name, "command": "python bench.py " + " ".join(cmd[2:]), "workload": d["config"]["workload"],
-                               "value": d["value"], "unit": d["unit"], "steps": d["steps"], "ms_per_step": d["ms_per_step"], "dtype": d["dtype"],
+                               "value": d["value"], "unit": d["unit"], "steps": d["steps"], "setup_settle_steps": d.get("setup_settle_steps"),
+                               "ms_per_step": d["ms_per_step"], "dtype": d["dtype"],
                                "sustained": d.get("sustained"), "roofline": d.get("roofline")})
             except Exception as e:  # the headline must still be reported
                 extras.append({"config": name, "error": repr(e)})
@@ -686,6 +716,7 @@ def main():
                        "frames/sec (fwd+bwd) OSVOS-VGG16 %dx%d" % (args.width, args.height)) if args.mode != "infer" else
                       "frames/sec (forward only) OSVOS-VGG16 %dx%d" % (args.width, args.height),
             "value": round(res["value"], 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "setup_settle_steps": settle,      # untimed SETUP steps before the warm-up (device out of its idle power state; --settle-seconds)
             "ms_per_step": round(res["ms_per_step"], 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": DTYPE_NAME[args.precision],
             "data": "synthetic",

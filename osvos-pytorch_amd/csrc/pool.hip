@@ -7,7 +7,7 @@
 // ONE output row (block -> (image, output row, segment): three block-uniform divisions, everything per lane is 32-bit shifts and adds),
 // so a wave's loads are the contiguous even / odd pixels of two input rows and every load of a thread's items is in flight before the
 // first one is used.  (The first form flattened (n, oy, ox, c) into one 64-bit index and divided it three times per lane: ~600 VALU
-// instructions per 208 bytes moved, a third of the kernel's time at 2.5 TB/s -- profiles/r03_pool_kernels.txt.)
+// instructions per 208 bytes moved, a third of the kernel's time at 2.5 TB/s -- profiles/r03_ab_glue_kernels.txt.)
 #include "common.h"
 
 namespace {

@@ -322,6 +322,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 // NW waves per workgroup: 4 where the grid is large (deep layers: few splits, thousands of workgroups), 16 where it is not -- conv1_2 has
 // 256 splits and ONE channel tile pair: 64 workgroups each walking 64 x 9 dependent 256-byte loads per wave took 46 us at the very end
 // of the step (the last slab reduce is exposed: nothing is left to run beside it).
+// (A float4-load form with 18 KB in flight per wave and an in-place fold pass for the many-split layers was built and dropped in round 3:
+//  beside the matrix kernels it always shares the chip with, its launches took as long as these and the step was 2 % slower -- what a
+//  side-stream bandwidth kernel costs is the CU time it holds, not its stand-alone bandwidth; profiles/r03_ab_glue_kernels.txt.)
 template <int NW>
 __global__ __launch_bounds__(64 * NW) void wgrad_reduce_t_kernel(const float* __restrict__ slab, const float* __restrict__ bslab,
                                                                  float* __restrict__ dw, float* __restrict__ db,
