@@ -200,7 +200,7 @@ def cpu_baseline(h, w, mode, n_ave, budget_s=20.0):
 class Workload(object):
     """One benchmark configuration: builds the net + synthetic batch, exposes step()."""
 
-    def __init__(self, mode, precision, height, width, batch, graph, n_ave, item_sync, device, rank, dist, force_dist, graph_train=0):
+    def __init__(self, mode, precision, height, width, batch, graph, n_ave, item_sync, device, rank, dist, force_dist, graph_train=0, comm=None):
         from layers.osvos_layers import class_balanced_cross_entropy_loss as cbce
         from osvos_pytorch_amd.layers.osvos_layers import class_balanced_cross_entropy_loss_step as cbce_step
         from osvos_pytorch_amd.parallel import GradientAllReducer
@@ -219,10 +219,6 @@ class Workload(object):
             self.net.set_deferred_backward_join(True)     # (TrainLoop reads the same switch)
         from osvos_pytorch_amd.train_common import make_sgd      # the scripts' own parameter groups (train_online.py:79-88 / train_parent.py:87-103)
         self.opt = make_sgd(self.net, "online" if mode == "infer" else mode)
-        comm = None
-        if dist is not None and os.environ.get("OSVOS_DP_BACKEND", "torch") == "abi":      # gradients through osvos_comm_* (RCCL via the C ABI)
-            from osvos_pytorch_amd.parallel import AbiCommunicator
-            comm = AbiCommunicator(int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), device)
         self.reducer = GradientAllReducer(self.net, average=True, always=force_dist, comm=comm) if dist is not None else None
         self.running = torch.zeros((), device=device)
         self.ave, self.epoch, self.nsteps = 0, 0, 0
@@ -400,11 +396,57 @@ def load_traffic():
         return None
 
 
-def timed_region(wl, steps, dist, device, prof_lib=None):
+class TorchCtl:
+    """bench.py's own control plane (barriers, max over ranks of the elapsed time / a step count) on torch.distributed's nccl (= RCCL) group."""
+
+    def __init__(self, dist, device):
+        self.dist, self.device = dist, device
+        self.world, self.rank = dist.get_world_size(), dist.get_rank()
+
+    def barrier(self):
+        self.dist.barrier()
+
+    def max(self, value):
+        t = torch.tensor([float(value)], device=self.device, dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def close(self):
+        self.dist.destroy_process_group()
+
+
+class AbiCtl:
+    """The same on the library's own communicator (OSVOS_DP_BACKEND=abi: osvos_comm_*, RCCL through the C ABI) -- NO torch.distributed process
+    group in the process.  The ABI has one collective, a float32 sum: a barrier is a one-element sum + synchronize, a max over ranks is a
+    sum of a vector in which every rank fills its own slot.  (A gloo group for this was tried first: a gloo barrier issued between runs of
+    steps leaves the following steps 25-35 % slower on the GPU side -- profiles/r03_dp_backends.txt -- so the control plane stays off it.)"""
+
+    def __init__(self, comm, device):
+        self.comm, self.device, self.world, self.rank = comm, device, comm.world, comm.rank
+
+    def barrier(self):
+        t = torch.zeros(1, device=self.device)
+        self.comm.all_reduce(t)
+        torch.cuda.synchronize()
+
+    def max(self, value):
+        # float32 carries 24 bits: seconds are sent as (whole milliseconds, remainder) -- exact to well below a microsecond -- and counts as they are
+        ms = math.floor(float(value) * 1e3)
+        t = torch.zeros(2 * self.world, device=self.device)
+        t[2 * self.rank], t[2 * self.rank + 1] = float(ms), float(value) * 1e3 - ms
+        self.comm.all_reduce(t)
+        v = t.double().view(self.world, 2)
+        return float((v[:, 0] + v[:, 1]).max().item()) / 1e3
+
+    def close(self):
+        self.comm.close()
+
+
+def timed_region(wl, steps, ctl, device, prof_lib=None):
     """barrier + synchronize, `steps` x step(), synchronize + barrier; returns (seconds [max over ranks], prof tuple)."""
     from osvos_pytorch_amd import _lib
-    if dist is not None:
-        dist.barrier()
+    if ctl is not None:
+        ctl.barrier()
     torch.cuda.synchronize()
     # launch events: every PROF_EVERY-th step of the region is instrumented (an event pair around each of its ~56 conv launches / regions);
     # the others run exactly as they would without bench.py looking.  Events are created and first-recorded before t0.
@@ -430,8 +472,8 @@ def timed_region(wl, steps, dist, device, prof_lib=None):
     t_host = time.perf_counter()
     torch.cuda.synchronize()
     t_sync = time.perf_counter()
-    if dist is not None:
-        dist.barrier()
+    if ctl is not None:
+        ctl.barrier()
     elapsed = time.perf_counter() - t0
     if gc_was:
         gc.enable()
@@ -442,14 +484,12 @@ def timed_region(wl, steps, dist, device, prof_lib=None):
     cnt = (C.c_long * 4)()
     if prof_lib is not None:
         _lib.check(prof_lib.osvos_prof_stop(ms, fl, cnt), "prof_stop")
-    if dist is not None:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    if ctl is not None:
+        elapsed = ctl.max(elapsed)
     return elapsed, (list(ms), list(fl), list(cnt)), (n_prof if prof_lib is not None else 0)
 
 
-def measure(wl, steps, warmup, min_seconds, world, dist, device, use_prof=True, settle_seconds=0.0):
+def measure(wl, steps, warmup, min_seconds, world, ctl, device, use_prof=True, settle_seconds=0.0):
     """Device settle (setup), W warm-up steps, EXACTLY `steps` timed steps (headline), then a sustained region of >= min_seconds."""
     from osvos_pytorch_amd import _lib
     lib = _lib.lib()
@@ -470,10 +510,8 @@ def measure(wl, steps, warmup, min_seconds, world, dist, device, use_prof=True, 
         torch.cuda.synchronize()
         per = max((time.perf_counter() - t0) / unit, 1e-5)
         n = int(math.ceil(settle_seconds / per / unit)) * unit
-        if dist is not None:                                   # the same count on every rank: the steps contain the collectives
-            t = torch.tensor([n], device=device, dtype=torch.int64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            n = int(t.item())
+        if ctl is not None:                                    # the same count on every rank: the steps contain the collectives
+            n = int(round(ctl.max(n)))
         for _ in range(n):
             wl.step()
         settle_done = n + 2 * unit
@@ -481,14 +519,14 @@ def measure(wl, steps, warmup, min_seconds, world, dist, device, use_prof=True, 
     for _ in range(warmup):
         wl.step()
     prof = use_prof and not (wl.mode == "infer" and wl.graph) and not getattr(wl, "graph_train", False)
-    elapsed, (ms, fl, cnt), n_prof = timed_region(wl, steps, dist, device, lib if prof else None)
+    elapsed, (ms, fl, cnt), n_prof = timed_region(wl, steps, ctl, device, lib if prof else None)
     frames = steps * wl.batch * world
     res = {"value": frames / elapsed, "ms_per_step": elapsed / steps * 1e3, "elapsed": elapsed, "timing_detail": dict(TIMING_DETAIL),
            "settle_steps": res_settle}
     if min_seconds > 0:
         n2 = max(steps, int(math.ceil(min_seconds / max(elapsed / steps, 1e-6))))
         n2 = -(-n2 // wl.n_ave) * wl.n_ave if wl.mode != "infer" else n2     # whole optimizer steps
-        e2, _, _ = timed_region(wl, n2, dist, device, None)
+        e2, _, _ = timed_region(wl, n2, ctl, device, None)
         res["sustained"] = {"seconds": round(e2, 3), "steps": n2, "value": round(n2 * wl.batch * world / e2, 3),
                             "ms_per_step": round(e2 / n2 * 1e3, 4)}
     gf_fwd = conv_gflop_forward(wl.h, wl.w) * wl.batch
@@ -626,35 +664,42 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 or args.force_dist:
-        import torch.distributed as dist
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        world = dist.get_world_size()          # n_gpus of the JSON line = the process group's size, not an environment variable
-    else:
-        dist = None
-    ranks_seen = 1
+    abi = os.environ.get("OSVOS_DP_BACKEND", "torch") == "abi"      # gradients AND control plane through osvos_comm_* (RCCL via the C ABI, csrc/comm.cpp)
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
-
-    if dist is not None:       # bring the process group's communicator up before anything is timed (its first collective initialises RCCL)
-        for _ in range(2):
-            dist.barrier()
-        t = torch.ones(1, device=device, dtype=torch.float64)
-        dist.all_reduce(t)                      # = number of ranks RCCL actually reaches
+    ctl, comm, ranks_seen = None, None, 1
+    if world > 1 or args.force_dist:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        # The communicator is the FIRST thing that touches the device: an RCCL communicator initialised after the process has already
+        # allocated / launched on the GPU leaves every later step 30 % slower on the GPU side (232 -> 162 frames/s with one rank, either
+        # backend; profiles/r03_dp_backends.txt).  Scripts do the same (train_common.init_distributed / make_reducer run before the net exists).
+        if abi:      # ONE RCCL communicator in the process, the library's; the 128-byte id travels through a TCPStore (parallel.AbiCommunicator)
+            from osvos_pytorch_amd.parallel import AbiCommunicator
+            comm = AbiCommunicator(rank, world, device)
+            ctl = AbiCtl(comm, device)
+            t = torch.ones(1, device=device, dtype=torch.float32)
+            comm.all_reduce(t)
+        else:
+            import torch.distributed as dist
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+            ctl = TorchCtl(dist, device)
+            for _ in range(2):      # bring the communicator up before anything is timed (its first collective initialises RCCL)
+                dist.barrier()
+            t = torch.ones(1, device=device, dtype=torch.float32)
+            dist.all_reduce(t)
         torch.cuda.synchronize()
-        ranks_seen = int(t.item())
+        world = ctl.world                       # n_gpus of the JSON line = the communicator's size, not an environment variable
+        ranks_seen = int(t.item())              # = number of ranks RCCL actually reaches
     wl = Workload(args.mode, args.precision, args.height, args.width, args.batch, args.graph, args.n_ave_grad, args.item_sync,
-                  device, rank, dist, args.force_dist, graph_train=args.graph_train)
-    res = measure(wl, args.steps, args.warmup, args.min_seconds, world, dist, device, use_prof=not args.no_prof, settle_seconds=args.settle_seconds)
+                  device, rank, ctl, args.force_dist, graph_train=args.graph_train, comm=comm)
+    res = measure(wl, args.steps, args.warmup, args.min_seconds, world, ctl, device, use_prof=not args.no_prof, settle_seconds=args.settle_seconds)
     settle = res["settle_steps"]
     default_workload = (args.mode, args.precision, args.height, args.width, args.batch, args.item_sync) == ("online", "fp32x3", 480, 854, 1, 0)
     extras, item_line = None, None
-    if world == 1 and dist is None and default_workload and not args.no_extra:
+    if world == 1 and ctl is None and default_workload and not args.no_extra:
         # the headline loop with the reference's per-iteration loss.item() left in (train_online.py:128)
         wl.item_sync = 1
         r = measure(wl, args.steps, 2, 0.0, 1, None, device, use_prof=False)
@@ -723,7 +768,7 @@ def main():
             "config": {"workload": workload,
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world, "rccl_ranks_seen": ranks_seen,
                        "gpus_requested": args.gpus,
-                       "grad_allreduce": "per optimizer step (RCCL)" if dist is not None else "none",
+                       "grad_allreduce": ("per optimizer step (RCCL through %s)" % ("the C ABI, osvos_comm_*" if abi else "torch.distributed")) if ctl is not None else "none",
                        "loss_item_sync_each_iter": bool(args.item_sync),
                        # class-balance counts (osvos_layers.py:28-34) run over each rank's own batch: every rank's batch is its own reference batch
                        # (weak scaling).  Sharding ONE batch over ranks needs parallel.global_class_counts / cbce_with_counts (tests/test_parallel_gloo.py)
@@ -736,8 +781,8 @@ def main():
             "running_loss": running_loss,
         }
         print(json.dumps(line))
-    if dist is not None:
-        dist.destroy_process_group()
+    if ctl is not None:
+        ctl.close()
 
 
 if __name__ == "__main__":

@@ -235,8 +235,19 @@ def epoch_plan(n_items, epoch, n_ave_grad, rank=0, world=1, seed=0, shuffle=True
     return [(idx, g0 + j) for j, idx in enumerate(perm) if (g0 + j) % world == rank]
 
 
-def init_distributed():
-    """One process per GPU (torchrun / torch.distributed.run).  Returns (rank, world, device)."""
+_ABI_COMM = None      # the process's AbiCommunicator (OSVOS_DP_BACKEND=abi), created by init_distributed, used by make_reducer
+
+
+def init_distributed(collectives=True):
+    """One process per GPU (torchrun / torch.distributed.run).  Returns (rank, world, device).
+
+    With more than one rank and `collectives` the RCCL communicator is brought up HERE, before the process allocates or launches anything on
+    the GPU: a communicator initialised after the first device activity leaves every later step ~30 % slower on the GPU side (measured with
+    one rank through both backends: 232 -> 162 frames/s on the headline loop; profiles/r03_dp_backends.txt).  torch.distributed creates its
+    communicator eagerly when init_process_group is given `device_id`; the C-ABI communicator (OSVOS_DP_BACKEND=abi) is created right away
+    and NO torch.distributed process group is opened then (one RCCL instance per process; gradients and epoch statistics use osvos_comm_*).
+    `collectives=False` (train_online.py: every rank fine-tunes its own sequences, nothing is exchanged) opens nothing."""
+    global _ABI_COMM
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
@@ -245,20 +256,25 @@ def init_distributed():
         device = torch.device('cuda', local)
     else:
         device = torch.device('cpu')
-    if world > 1:
+    if world > 1 and collectives:
         import torch.distributed as dist
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl' if torch.cuda.is_available() else 'gloo')
+        if device.type != 'cuda':
+            dist.init_process_group('gloo')
+        elif os.environ.get('OSVOS_DP_BACKEND', 'torch') == 'abi':
+            from .parallel import AbiCommunicator
+            _ABI_COMM = AbiCommunicator(rank, world, device)
+        else:
+            dist.init_process_group('nccl', device_id=device)
+            dist.barrier()          # (first collective: RCCL's own lazy initialisation happens now, not inside the first optimizer step)
     return rank, world, device
 
 
 def make_reducer(net, world, average=False):
     """The gradient exchange of the data-parallel loop: torch.distributed ('nccl' = RCCL) by default, RCCL through the library's own C ABI
-    with OSVOS_DP_BACKEND=abi (osvos_comm_*: no process group needed for the gradients; the chunked overlap is cheap there)."""
+    with OSVOS_DP_BACKEND=abi (osvos_comm_*: no process group at all; the chunked overlap is cheap there).  Either communicator was brought up by
+    init_distributed, before the network existed."""
     if world <= 1:
         return None
-    comm = None
-    if os.environ.get('OSVOS_DP_BACKEND', 'torch') == 'abi' and torch.cuda.is_available():
-        from .parallel import AbiCommunicator
-        comm = AbiCommunicator(int(os.environ.get('RANK', '0')), world, torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0'))))
+    comm = _ABI_COMM          # OSVOS_DP_BACKEND=abi: created by init_distributed before anything touched the device
     return GradientAllReducer(net, average=average, comm=comm)

@@ -59,6 +59,12 @@ def run(dev, use_reducer, n_ave, epochs, data, sd0, overlap=True, comm=None):
 def main():
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
+    # both communicators come up BEFORE anything else touches the device: an RCCL communicator initialised after the first allocations /
+    # launches leaves every later step ~30 % slower (profiles/r03_dp_backends.txt) -- the timing lines below would measure that instead
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    dist.barrier()
+    from osvos_pytorch_amd.parallel import AbiCommunicator
+    comm = AbiCommunicator(0, 1, dev)                      # RCCL through the C ABI (osvos_comm_*), one rank
     h, w = int(os.environ.get("DP_H", "120")), int(os.environ.get("DP_W", "214"))
     data = frames(6, h, w, dev)
     from bench import synth_problem               # He-init weights with calibrated heads (logit maps ~ N(-1, 3^2)): finite, well-scaled gradients
@@ -70,8 +76,7 @@ def main():
         run(dev, False, 5, 2, data, sd0)
         t0 = time.perf_counter()
         run(dev, False, 5, 10, data, sd0)
-        print("timing, no reducer, NO process group: %.3f ms per micro-batch (60 micro-batches, nAveGrad 5, incl. building the net)" % ((time.perf_counter() - t0) / 60 * 1e3))
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        print("timing, no reducer: %.3f ms per micro-batch (60 micro-batches, nAveGrad 5, incl. building the net)" % ((time.perf_counter() - t0) / 60 * 1e3))
     blocking, loop_b, red_b, t_block = run(dev, True, 3, 3, data, sd0, overlap=False)
     forced, loop_f, red, t_forced = run(dev, True, 3, 3, data, sd0)
     ok = True
@@ -86,8 +91,6 @@ def main():
     report("blocking one-rank all-reduce vs no process group", blocking, plain)
     report("overlapped chunked all-reduce vs no process group", forced, plain)
     report("overlapped vs blocking", forced, blocking)
-    from osvos_pytorch_amd.parallel import AbiCommunicator
-    comm = AbiCommunicator(0, 1, dev)                      # RCCL through the C ABI (osvos_comm_*), one rank
     abi_b, loop_ab, red_ab, t_ab = run(dev, True, 3, 3, data, sd0, overlap=False, comm=comm)
     abi_o, loop_ao, red_ao, t_ao = run(dev, True, 3, 3, data, sd0, overlap=True, comm=comm)
     report("C-ABI RCCL, blocking all-reduce vs no process group", abi_b, plain)
@@ -110,11 +113,13 @@ def main():
     print("wall time of the loop: %.3f s without a process group, %.3f s with the forced one-rank all-reduce (%dx%d, 18 micro-batches)" % (t_plain, t_forced, w, h))
     if os.environ.get("DP_TIME", "0") == "1":      # per-micro-batch cost of the three variants at this size (process group still up)
         big = frames(6, h, w, dev)
-        for tag, kw in (("no reducer (process group initialised)", dict(use_reducer=False)), ("blocking all-reduce", dict(use_reducer=True, overlap=False)),
-                        ("overlapped chunked all-reduce", dict(use_reducer=True, overlap=True))):
-            _, lp, _, _ = run(dev, kw["use_reducer"], 5, 2, big, sd0, overlap=kw.get("overlap", True))       # warm
+        for tag, kw in (("no reducer (communicators up)", dict(use_reducer=False)), ("torch.distributed, blocking all-reduce", dict(use_reducer=True, overlap=False)),
+                        ("torch.distributed, overlapped chunked all-reduce", dict(use_reducer=True, overlap=True)),
+                        ("C-ABI RCCL, blocking all-reduce", dict(use_reducer=True, overlap=False, comm=comm)),
+                        ("C-ABI RCCL, overlapped chunked all-reduce", dict(use_reducer=True, overlap=True, comm=comm))):
+            _, lp, _, _ = run(dev, kw["use_reducer"], 5, 2, big, sd0, overlap=kw.get("overlap", True), comm=kw.get("comm"))       # warm
             t0 = time.perf_counter()
-            _, lp, _, _ = run(dev, kw["use_reducer"], 5, 10, big, sd0, overlap=kw.get("overlap", True))
+            _, lp, _, _ = run(dev, kw["use_reducer"], 5, 10, big, sd0, overlap=kw.get("overlap", True), comm=kw.get("comm"))
             dt = time.perf_counter() - t0
             print("timing, %s: %.3f ms per micro-batch (60 micro-batches, nAveGrad 5, incl. building the net)" % (tag, dt / 60 * 1e3))
     comm.close()

@@ -15,7 +15,26 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 grp = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(dev)
-wl = bench.Workload("online", os.environ.get("OSVOS_PRECISION", "fp32x3"), 480, 854, 1, 0, 0, 0, dev, 0, None, False)
+dist, comm = None, None
+if os.environ.get("DP", "") in ("abi", "torch"):      # one-rank data-parallel exchange forced on (bench.py --force-dist)
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29577")
+    if os.environ["DP"] == "abi":
+        dist.init_process_group("gloo", rank=0, world_size=1)
+        from osvos_pytorch_amd.parallel import AbiCommunicator
+        if os.environ.get("BARRIER") == "1":
+            dist.barrier(); dist.barrier()
+        comm = AbiCommunicator(0, 1, dev)
+        if os.environ.get("TINY") == "1":
+            t = torch.ones(1, device=dev)
+            comm.all_reduce(t)
+            torch.cuda.synchronize()
+            print("tiny all-reduce:", t.item())
+    else:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        dist.barrier()
+wl = bench.Workload("online", os.environ.get("OSVOS_PRECISION", "fp32x3"), 480, 854, 1, 0, 0, 0, dev, 0, dist, dist is not None, comm=comm)
 if os.environ.get("PROBE_FIRST") == "1":
     print("pipe probe first:", bench.pipe_sustained_tflops(dev))
 for rnd in range(int(os.environ.get("ROUNDS", "1"))):

@@ -126,7 +126,7 @@ def main():
     ap.add_argument('--precision', default=os.environ.get('OSVOS_PRECISION', 'fp32x3'), choices=['fp32', 'fp32x3', 'bf16'])
     args = ap.parse_args()
 
-    rank, world, device = init_distributed()
+    rank, world, device = init_distributed(collectives=False)      # sequences are sharded over the ranks: nothing is exchanged
     seqs = os.environ.get('SEQ_NAME', 'blackswan').split(',')
     save_dir = Path.save_root_dir()
     os.makedirs(save_dir, exist_ok=True)

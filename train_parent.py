@@ -165,11 +165,15 @@ def main(argv=None, build_net=None, loss_fn=None):
         for e in epochs:
             pending.remove(e)
             running, count = loop.pop_running(e), loop.pop_count(e)
-            if reducer is not None:
+            if reducer is not None and reducer.comm is not None:      # OSVOS_DP_BACKEND=abi: the one collective of the C ABI, a float32 sum
+                t = torch.tensor(running + [float(count)], device=device, dtype=torch.float32)
+                reducer.comm.all_reduce(t)
+            elif reducer is not None:
                 import torch.distributed as dist
                 t = torch.tensor(running + [float(count)], device=device, dtype=torch.float64)
                 dist.all_reduce(t)
-                running, count = t[:-1].tolist(), int(t[-1].item())
+            if reducer is not None:
+                running, count = t[:-1].tolist(), int(round(float(t[-1].item())))
             if rank == 0:
                 print('[Epoch: %d, numImages: %5d]' % (e, count))
                 for l, v in enumerate(running):
