@@ -9,6 +9,7 @@
 //     and the L2->LDS weight stream, not the matrix pipe, are what has to be rationed
 //   * numerics equal a bf16-activation pipeline: rounding happens right before the MFMA either way
 #include "common.h"
+#include "maskbits.h"
 #include <type_traits>
 #include "kernels.h"
 
@@ -28,6 +29,8 @@ struct ConvArgsB {
   int N, H, W, Cin, CinP, Cout, CoutP, y_cs;
   int tiles_x, tiles_y, nct, nsp, map;
   int relu, mask_bf16;
+  const unsigned* mask_bits;   // ReLU mask as ONE BIT per element ([N][H][W][y_cs / 32] words, bit = channel % 32; maskbits.h): takes precedence over `mask`
+  unsigned* y_bits;            // optional: the same for the result (written next to y / ybf by the forward of a layer whose output is a later mask)
   unsigned long long* prof;   // phase cycle counters (only read by builds with -DOSVOS_CONV_PROF; tools/conv_phase_probe.py)
 };
 
@@ -256,6 +259,13 @@ __global__ __launch_bounds__(C::NT, C::OCC) void conv3x3_bf16_kernel(ConvArgsB a
                                                                          a.bias != nullptr ? a.Cout * 4 : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(a.ybf != nullptr ? (void*)(a.ybf + n * img_elems) : anyp, 0,
                                                                          a.ybf != nullptr ? (int)(img_elems * 2) : 0, 0x00020000);
+    // one-bit masks (maskbits.h): words per pixel = y_cs / 32
+    const int bw = a.y_cs >> 5;
+    const size_t img_words = (size_t)a.H * a.W * bw;
+    const __amdgpu_buffer_rsrc_t mbrs = __builtin_amdgcn_make_buffer_rsrc(a.mask_bits != nullptr ? (void*)const_cast<unsigned*>(a.mask_bits + n * img_words) : anyp, 0,
+                                                                          a.mask_bits != nullptr ? (int)(img_words * 4) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ybrs = __builtin_amdgcn_make_buffer_rsrc(a.y_bits != nullptr ? (void*)(a.y_bits + n * img_words) : anyp, 0,
+                                                                          a.y_bits != nullptr ? (int)(img_words * 4) : 0, 0x00020000);
 #pragma unroll
     for (int ni = 0; ni < C::WN; ++ni) {
       const int cb = co0 + (wn * C::WN + ni) * 32 + 4 * lh;
@@ -269,6 +279,9 @@ __global__ __launch_bounds__(C::NT, C::OCC) void conv3x3_bf16_kernel(ConvArgsB a
         const int ox = x0 + (mb % C::TBX) * C::RBW + li % C::RBW;
         const unsigned pix = (oy < a.H && ox < a.W) ? (unsigned)((oy * a.W + ox) * a.y_cs) * 4u : OOB;
         uint2 hb[4];               // bf16 copy: couts 8q + 4lh + (0..3) of this lane, packed
+        const unsigned bitoff = (pix != OOB && cb - 4 * lh < a.Cout) ? (unsigned)(oy * a.W + ox) * (unsigned)(bw * 4) + (unsigned)((cb - 4 * lh) >> 5) * 4u : OOB;
+        const unsigned mword = mb_load(mbrs, bitoff);      // (an absent tensor's descriptor drops the access)
+        unsigned ybits = 0;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int co = cb + 8 * q;
@@ -279,7 +292,10 @@ __global__ __launch_bounds__(C::NT, C::OCC) void conv3x3_bf16_kernel(ConvArgsB a
             v[e] = acc[mi][ni][4 * q + e] + bv[q][e];
             if (a.relu) v[e] = v[e] > 0.f ? v[e] : 0.f;
           }
-          if (a.mask != nullptr) {
+          if (a.mask_bits != nullptr) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = mb_test(mword, q, lh, e) ? v[e] : 0.f;
+          } else if (a.mask != nullptr) {
             if (a.mask_bf16) {       // post-ReLU activations stored as bf16: > 0 <=> the 16-bit pattern is a positive integer
               typedef short s16x4 __attribute__((ext_vector_type(4)));
               const s16x4 m = __builtin_bit_cast(s16x4, __builtin_amdgcn_raw_buffer_load_b64(mrs, off >> 1, 0, 0));
@@ -295,7 +311,9 @@ __global__ __launch_bounds__(C::NT, C::OCC) void conv3x3_bf16_kernel(ConvArgsB a
           bf16x4_t h;
           h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
           hb[q] = __builtin_bit_cast(uint2, h);
+          ybits |= a.ybf != nullptr ? mb_bits_bf16(hb[q], q) : mb_bits_f32(v, q);      // (the stored value decides: bf16 when that is what is kept)
         }
+        if (a.y_bits != nullptr) mb_store(ybrs, bitoff, ybits, lh);
         if (a.ybf != nullptr) {
           // lanes l and l+32 hold the two halves of every 8-cout group: v_permlane32_swap trades the odd-q quad of the
           // lower lane for the even-q quad of the upper one, after which each lane owns 8 consecutive couts
@@ -477,7 +495,15 @@ extern "C" void osvos_debug_set_conv_prof(void* p) { g_conv_prof = (unsigned lon
 // xb = 0: x fp32, xb = 1: x bf16; ybf (optional) receives a bf16 copy of y
 int osvos_conv3x3_bf16mfma_io(const void* x, int xb, const void* wpk, const float* bias, const void* mask, int mask_bf16, float* y, void* ybf,
                               int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int tile, hipStream_t stream) {
+  return osvos_conv3x3_bf16mfma_bits(x, xb, wpk, bias, mask, mask_bf16, nullptr, y, ybf, nullptr, N, H, W, Cin, Cout, y_cs, relu, tile, stream);
+}
+
+// mask_bits: the ReLU mask as one bit per element (maskbits.h; takes precedence over `mask`); y_bits: sign bits of the result, written beside it
+int osvos_conv3x3_bf16mfma_bits(const void* x, int xb, const void* wpk, const float* bias, const void* mask, int mask_bf16, const unsigned* mask_bits,
+                                float* y, void* ybf, unsigned* y_bits, int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int tile,
+                                hipStream_t stream) {
   OSVOS_ARG_CHECK(x && wpk && (y || ybf), "conv3x3 bf16: null pointer");
+  OSVOS_ARG_CHECK((mask_bits == nullptr && y_bits == nullptr) || (Cout % 32 == 0 && y_cs == Cout), "conv3x3 bf16: one-bit masks need Cout %% 32 == 0 and a dense result (Cout %d, stride %d)", Cout, y_cs);
   OSVOS_ARG_CHECK((Cout % 4 == 0 && y_cs % 4 == 0) || (y != nullptr && !(mask && mask_bf16)),
                   "conv3x3 bf16: ragged channel counts (Cout %d, stride %d) support fp32 outputs and masks only", Cout, y_cs);
   OSVOS_ARG_CHECK(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv3x3 bf16: bad shape");
@@ -489,6 +515,7 @@ int osvos_conv3x3_bf16mfma_io(const void* x, int xb, const void* wpk, const floa
   ConvArgsB a;
   a.x = x; a.wpk = reinterpret_cast<const uint4*>(wpk); a.bias = bias; a.mask = mask; a.mask_bf16 = mask_bf16 ? 1 : 0; a.y = y;
   a.ybf = reinterpret_cast<bf16_t*>(ybf);
+  a.mask_bits = mask_bits; a.y_bits = y_bits;
   a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.CinP = (Cin + 31) / 32 * 32; a.Cout = Cout; a.CoutP = osvos_cout_pad(Cout); a.y_cs = y_cs;
   a.relu = relu;
   a.prof = g_conv_prof;
@@ -510,7 +537,7 @@ int osvos_conv3x3_bf16mfma_io(const void* x, int xb, const void* wpk, const floa
   tile %= 100;
   if (xb && tile >= 30 && tile <= 35) {      // LDS-DMA staged kernel
     OSVOS_ARG_CHECK(osvos_conv3x3_bf16_dma_applicable(Cin, Cout, y_cs), "conv3x3 bf16: tile %d (DMA staging) needs Cin %% 16 == 0, Cout, y_cs %% 8 == 0", tile);
-    return osvos_conv3x3_bf16_dma(x, wpk, bias, mask, mask_bf16, y, ybf, N, H, W, Cin, Cout, y_cs, relu, tile - 30, a.map, stream);
+    return osvos_conv3x3_bf16_dma(x, wpk, bias, mask, mask_bf16, mask_bits, y, ybf, y_bits, N, H, W, Cin, Cout, y_cs, relu, tile - 30, a.map, stream);
   }
   if (xb) {
     switch (tile) {

@@ -13,6 +13,7 @@
 // LDS: 3 x 48 KB (NB = 4) -> one workgroup per CU, one wave per SIMD; latency is hidden by the DMA distance (two chunks)
 // and by software-pipelined fragment reads.  Needs Cin % 16 == 0 (every layer but conv1_1).
 #include "common.h"
+#include "maskbits.h"
 
 namespace {
 
@@ -30,6 +31,8 @@ struct DmaArgs {
   int N, H, W, Cin, CinP, Cout, CoutP, y_cs;
   int tiles_x, tiles_y, nct, nsp, map, ntiles;
   int relu, mask_bf16;
+  const unsigned* mask_bits;   // one-bit-per-element ReLU mask (maskbits.h); takes precedence over `mask`
+  unsigned* y_bits;            // optional: sign bits of the result
 };
 
 constexpr int TW = 32, HWD = TW + 2;
@@ -257,6 +260,13 @@ __global__ __launch_bounds__(64 * 2 * WGM, WGM == 4 ? 2 : 1) void conv3x3_bf16_d
                                                                          a.bias != nullptr ? a.Cout * 4 : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(a.ybf != nullptr ? (void*)(a.ybf + n * img_elems) : anyp, 0,
                                                                          a.ybf != nullptr ? (int)(img_elems * 2) : 0, 0x00020000);
+    // one-bit masks (maskbits.h): words per pixel = y_cs / 32
+    const int bw = a.y_cs >> 5;
+    const size_t img_words = (size_t)a.H * a.W * bw;
+    const __amdgpu_buffer_rsrc_t mbrs = __builtin_amdgcn_make_buffer_rsrc(a.mask_bits != nullptr ? (void*)const_cast<unsigned*>(a.mask_bits + n * img_words) : anyp, 0,
+                                                                          a.mask_bits != nullptr ? (int)(img_words * 4) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ybrs = __builtin_amdgcn_make_buffer_rsrc(a.y_bits != nullptr ? (void*)(a.y_bits + n * img_words) : anyp, 0,
+                                                                          a.y_bits != nullptr ? (int)(img_words * 4) : 0, 0x00020000);
 #pragma unroll
     for (int ni = 0; ni < C::WN; ++ni) {
       const int cb = co0 + (wn * C::WN + ni) * 32 + 4 * lh;
@@ -268,6 +278,9 @@ __global__ __launch_bounds__(64 * 2 * WGM, WGM == 4 ? 2 : 1) void conv3x3_bf16_d
         const int oy = y0 + wm * C::WM + mi, ox = x0 + li;
         const unsigned pix = (oy < a.H && ox < a.W) ? (unsigned)((oy * a.W + ox) * a.y_cs) * 4u : OOB;
         uint2 hb[4];
+        const unsigned bitoff = (pix != OOB && cb - 4 * lh < a.Cout) ? (unsigned)(oy * a.W + ox) * (unsigned)(bw * 4) + (unsigned)((cb - 4 * lh) >> 5) * 4u : OOB;
+        const unsigned mword = mb_load(mbrs, bitoff);      // (an absent tensor's descriptor drops the access)
+        unsigned ybits = 0;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int co = cb + 8 * q;
@@ -278,7 +291,10 @@ __global__ __launch_bounds__(64 * 2 * WGM, WGM == 4 ? 2 : 1) void conv3x3_bf16_d
             v[e] = acc[mi][ni][4 * q + e] + bv[q][e];
             if (a.relu) v[e] = v[e] > 0.f ? v[e] : 0.f;
           }
-          if (a.mask != nullptr) {
+          if (a.mask_bits != nullptr) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = mb_test(mword, q, lh, e) ? v[e] : 0.f;
+          } else if (a.mask != nullptr) {
             if (a.mask_bf16) {
               typedef short s16x4 __attribute__((ext_vector_type(4)));
               const s16x4 m = __builtin_bit_cast(s16x4, __builtin_amdgcn_raw_buffer_load_b64(mrs, off >> 1, 0, 0));
@@ -294,7 +310,9 @@ __global__ __launch_bounds__(64 * 2 * WGM, WGM == 4 ? 2 : 1) void conv3x3_bf16_d
           bf16x4_t h;
           h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
           hb[q] = __builtin_bit_cast(uint2, h);
+          ybits |= a.ybf != nullptr ? mb_bits_bf16(hb[q], q) : mb_bits_f32(v, q);      // (the stored value decides: bf16 when that is what is kept)
         }
+        if (a.y_bits != nullptr) mb_store(ybrs, bitoff, ybits, lh);
         if (a.ybf != nullptr) {
 #pragma unroll
           for (int pq = 0; pq < 2; ++pq) {
@@ -356,8 +374,8 @@ bool osvos_conv3x3_bf16_dma_applicable(int Cin, int Cout, int y_cs) { return Cin
 // variant 0: 256 px x 128 couts (4 waves), 1: 256 px x 64 couts (4 waves), 2: 512 px x 128 couts (8 waves), 3: 512 px x 64 couts (8 waves),
 // 4 / 5: variants 0 / 2 as persistent workgroups (one per CU, tiles pipelined back to back);
 // map = 1: XCD-local spatial block order
-int osvos_conv3x3_bf16_dma(const void* x, const void* wpk, const float* bias, const void* mask, int mask_bf16, float* y, void* ybf,
-                           int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int variant, int map, hipStream_t stream) {
+int osvos_conv3x3_bf16_dma(const void* x, const void* wpk, const float* bias, const void* mask, int mask_bf16, const unsigned* mask_bits, float* y, void* ybf,
+                           unsigned* y_bits, int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int variant, int map, hipStream_t stream) {
   OSVOS_ARG_CHECK(x && wpk && (y || ybf), "conv3x3 bf16 dma: null pointer");
   OSVOS_ARG_CHECK(N > 0 && H > 0 && W > 0 && osvos_conv3x3_bf16_dma_applicable(Cin, Cout, y_cs) && y_cs >= Cout,
                   "conv3x3 bf16 dma: needs Cin %% 16 == 0, Cout %% 8 == 0, y_cs %% 8 == 0 (got %d, %d, %d)", Cin, Cout, y_cs);
@@ -365,6 +383,7 @@ int osvos_conv3x3_bf16_dma(const void* x, const void* wpk, const float* bias, co
   DmaArgs a;
   a.x = reinterpret_cast<const bf16_t*>(x); a.wpk = reinterpret_cast<const uint4*>(wpk); a.bias = bias; a.mask = mask; a.mask_bf16 = mask_bf16 ? 1 : 0;
   a.y = y; a.ybf = reinterpret_cast<bf16_t*>(ybf);
+  a.mask_bits = mask_bits; a.y_bits = y_bits;
   a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.CinP = (Cin + 31) / 32 * 32; a.Cout = Cout; a.CoutP = osvos_cout_pad(Cout); a.y_cs = y_cs;
   a.relu = relu; a.map = map ? 1 : 0;
   switch (variant) {

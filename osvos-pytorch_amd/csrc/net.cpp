@@ -119,12 +119,26 @@ struct WsLayout {
   // bf16 copies of the conv operands (dtype OSVOS_F32_BF16MFMA only): written by the producer's epilogue, read by the
   // consuming convolution instead of the fp32 tensor (half the bytes, no conversion while staging)
   size_t xin_b, act_b[kNumTrunk], pooled_b[5], dy_b[kNumTrunk], dpool_b[5], dside_b[4], dprep_b[4];
+  // sign bits of the activations that later serve as ReLU masks (maskbits.h; (size_t)-1 = none): [N][h][w][cout / 32] words
+  size_t bits[kNumTrunk];
   size_t fwd_total, total;
 };
+
+// One-bit ReLU masks (maskbits.h): the forward writes the sign bits of every activation a data gradient is later masked with, the data
+// gradient reads one word per (pixel, 32 channels) instead of the activation itself.  bf16-store mode (OSVOS_MASK_BITS=0: the activation).
+inline bool use_mask_bits(int dtype) {
+  static const bool on = [] { const char* e = getenv("OSVOS_MASK_BITS"); return !(e && e[0] == '0'); }();
+  return on && use_store(dtype);
+}
+// act[l] masks the data gradient of layer l + 1 when both are in the same stage; stage 4's last activation masks its side branch's
+inline bool act_is_a_mask(const ConvDesc* d, int l) {
+  return (l + 1 < kNumTrunk && d[l + 1].stage == d[l].stage) || l == kNumTrunk - 1;
+}
 
 WsLayout ws_layout(int N, int H, int W, int dtype) {
   WsLayout L;
   memset(&L, 0, sizeof(L));
+  for (int l = 0; l < kNumTrunk; ++l) L.bits[l] = (size_t)-1;
   const size_t es = osvos_elem(dtype);
   L.hs[0] = H; L.ws[0] = W;
   for (int i = 1; i < 5; ++i) { L.hs[i] = (L.hs[i - 1] + 1) / 2; L.ws[i] = (L.ws[i - 1] + 1) / 2; }
@@ -194,6 +208,7 @@ WsLayout ws_layout(int N, int H, int W, int dtype) {
     const size_t e = (size_t)N * L.hs[si] * L.ws[si] * d[l].cout;
     L.act[l] = take(te * e);
     L.act_b[l] = store ? L.act[l] : (shadow ? take(2 * e) : 0);
+    L.bits[l] = (use_mask_bits(dtype) && act_is_a_mask(d, l)) ? take(e / 8) : (size_t)-1;
   }
   for (int si = 1; si < 5; ++si) {
     const size_t e = (size_t)N * L.hs[si] * L.ws[si] * kStageC[si - 1];
@@ -289,7 +304,7 @@ inline bool use_presplit() {
 // (epi: fused pooling epilogues, f32x3 only -- fuse_pool() says when the caller may ask for them)
 inline int conv_main(const void* x, const void* x_b, const void* wpk, const float* bias, const void* mask, const void* mask_b, void* y, void* y_b,
                      int N, int h, int w, int cin, int cout, int y_cs, int relu, int dtype, void* part, hipStream_t stream, const void* wpk3 = nullptr,
-                     const ConvEpi* epi = nullptr) {
+                     const ConvEpi* epi = nullptr, const void* mask_bits = nullptr, void* y_bits = nullptr) {
   if (dtype == OSVOS_F32_X3 && osvos_conv3x3_f32x3_applicable(cin, cout, y_cs))      // three-way bf16 split on the bf16 matrix pipe
     // (with a pre-split pack the fp32 pack of the layer is not even built -- osvos_net_pack -- so it is not handed over either)
     return osvos_conv3x3_f32x3_epi((const float*)x, (use_presplit() && wpk3) ? nullptr : (const float*)wpk, use_presplit() ? wpk3 : nullptr, bias,
@@ -297,9 +312,8 @@ inline int conv_main(const void* x, const void* x_b, const void* wpk, const floa
   if (dtype == OSVOS_F32 || dtype == OSVOS_F32_X3)
     return osvos_conv3x3_f32_ws((const float*)x, (const float*)wpk, bias, (const float*)mask, (float*)y, N, h, w, cin, cout, y_cs,
                                 relu, -1, part, stream);
-  return osvos_conv3x3_bf16mfma_io(x_b ? x_b : x, x_b ? 1 : 0, wpk, bias, mask_b ? mask_b : mask, mask_b ? 1 : 0, (float*)y, y_b, N, h, w, cin,
-                                   cout, y_cs, relu,
-                                   -1, stream);
+  return osvos_conv3x3_bf16mfma_bits(x_b ? x_b : x, x_b ? 1 : 0, wpk, bias, mask_b ? mask_b : mask, mask_b ? 1 : 0, (const unsigned*)mask_bits, (float*)y, y_b,
+                                     (unsigned*)y_bits, N, h, w, cin, cout, y_cs, relu, -1, stream);
 }
 
 // f32x3: the pooling kernels of the stage boundaries can run as epilogues of the convolutions next to them (epi.h).  Measured at 854x480
@@ -738,7 +752,8 @@ int osvos_net_forward(const float* x_nchw, const void* wbuf, void* ws, float* co
         if (pool_here) epi.pooled = reinterpret_cast<float*>(at(ws, L.pooled[si + 1]));
         rc = conv_main(cur, cur_b, at(wbuf, P.fwd[l]), reinterpret_cast<const float*>(at(wbuf, P.bias[l])), nullptr, nullptr,
                        f32(L.act[l]), sh(L.act_b[l]), N, h, w, d[l].cin_s, d[l].cout, d[l].cout, 1, dtype, at(ws, L.conv_part), stream,
-                       P.fwd3[l] != (size_t)-1 ? at(wbuf, P.fwd3[l]) : nullptr, pool_here ? &epi : nullptr);
+                       P.fwd3[l] != (size_t)-1 ? at(wbuf, P.fwd3[l]) : nullptr, pool_here ? &epi : nullptr, nullptr,
+                       L.bits[l] != (size_t)-1 ? at(ws, L.bits[l]) : nullptr);
       }
       if (rc) return rc;
       cur = at(ws, L.act[l]);
@@ -1025,7 +1040,8 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
     if (dbg_skip() & 8) continue;
     rc = conv_main(at(ws, L.dprep[i]), store ? at(ws, L.dprep_b[i]) : nullptr, at(wbuf, P.dgrad[sl]), nullptr, (i == 3) ? mk32(L.act[lx]) : nullptr,
                    (i == 3) ? mk16(L.act_b[lx]) : nullptr, dst, dst_b, N, h, w, 16, d[sl].cin, d[sl].cin, 0, dtype, nullptr, stream,
-                   P.dgrad3[sl] != (size_t)-1 ? at(wbuf, P.dgrad3[sl]) : nullptr);
+                   P.dgrad3[sl] != (size_t)-1 ? at(wbuf, P.dgrad3[sl]) : nullptr, nullptr,
+                   (i == 3 && L.bits[lx] != (size_t)-1) ? at(ws, L.bits[lx]) : nullptr);
     if (rc) return rc;
   }
 
@@ -1094,7 +1110,8 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
       if (rc) return rc;
     } else {
       rc = conv_main(g, g_b, at(wbuf, P.dgrad[l]), nullptr, mk32(L.act[l - 1]), mk16(L.act_b[l - 1]), f32(L.dy[l - 1]), sh(L.dy_b[l - 1]), N, h, w,
-                     d[l].cout, d[l].cin, d[l].cin, 0, dtype, at(ws, L.conv_part), stream, P.dgrad3[l] != (size_t)-1 ? at(wbuf, P.dgrad3[l]) : nullptr);
+                     d[l].cout, d[l].cin, d[l].cin, 0, dtype, at(ws, L.conv_part), stream, P.dgrad3[l] != (size_t)-1 ? at(wbuf, P.dgrad3[l]) : nullptr,
+                     nullptr, L.bits[l - 1] != (size_t)-1 ? at(ws, L.bits[l - 1]) : nullptr);
       if (rc) return rc;
     }
   }

@@ -555,6 +555,47 @@ def test_bf16_mode_conv1_1_weight_gradient_on_the_bf16_pipe_matches_the_fp32_ker
         assert torch.equal(got[1][2], got[0][2])          # everything else in the network is untouched
 
 
+def test_one_bit_relu_masks_change_nothing_but_the_bytes_read(tmp_path):
+    """bf16-store mode: the forward also writes the sign bits of every activation that later masks a data gradient, and the data gradients
+    read one 32-bit word per (pixel, 32 channels) instead of the activation (csrc/maskbits.h).  Same predicate (stored bf16 value > 0), so
+    logits, losses, every parameter gradient and the input gradient must equal the OSVOS_MASK_BITS=0 run BIT FOR BIT -- odd sizes (partial
+    tiles on both axes), a batch, and the 107-pixel-wide shape whose conv4_x take the LDS-DMA kernel's epilogue."""
+    import os, subprocess, sys, textwrap
+    code = textwrap.dedent('''
+        import sys, numpy as np, torch
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        import test_gpu_net as T
+        from oracle import synth
+        from layers.osvos_layers import class_balanced_cross_entropy_loss as cbce
+        res = {}
+        for tag, (n, h, w) in {"a": (2, 37, 53), "b": (1, 120, 214), "c": (2, 240, 427)}.items():
+            wts, x, m = synth.calibrated_problem(n, h, w, seed=5)
+            net = T.build_net(wts, "bf16")
+            xg = torch.from_numpy(x).requires_grad_()
+            outs = net.forward(xg.cuda())
+            gt = torch.from_numpy(m).cuda()
+            losses = [cbce(o, gt, size_average=False) for o in outs]
+            (0.5 * sum(losses[:-1]) + losses[-1]).backward()
+            for i, o in enumerate(outs):
+                res["%%s:out%%d" %% (tag, i)] = o.detach().cpu().numpy()
+            for k, v in net.named_parameters():
+                if v.grad is not None:
+                    res["%%s:g:%%s" %% (tag, k)] = v.grad.cpu().numpy()
+            res[tag + ":dx"] = xg.grad.numpy()
+        np.savez(sys.argv[1], **res)
+    ''') % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    got = {}
+    for bits in ("0", "1"):
+        out = str(tmp_path / ("m%s.npz" % bits))
+        subprocess.run([sys.executable, "-c", code, out], check=True, env=dict(os.environ, OSVOS_MASK_BITS=bits), timeout=900)
+        got[bits] = dict(np.load(out))
+    a, b = got["0"], got["1"]
+    assert a.keys() == b.keys() and len(a) > 120
+    for k in a:
+        assert np.isfinite(b[k]).all(), k
+        assert np.array_equal(a[k], b[k]), (k, float(np.abs(a[k] - b[k]).max()))
+
+
 def test_pooling_fused_into_the_convolutions_is_bit_identical_to_its_own_launches(tmp_path):
     """f32x3 with OSVOS_FUSE_POOL=1: the four max-pools run in the epilogue of each stage's last convolution (the default) and their backward in
     the epilogue of the next stage's first data gradient (opt-in) (csrc/epi.h).  Same values, same first-maximum rule, same order of operations: logits, losses and every

@@ -61,13 +61,16 @@ def run(args):
                                                                        cout, cout, 1, -1, st()), "conv"),
                    "dgrad": lambda: _lib.check(lib.osvos_conv3x3_bf16io(vp(dyb.data_ptr()), 1, vp(wd.data_ptr()), None, vp(xb.data_ptr()), 1, None, vp(yb.data_ptr()), n, h,
                                                                          w, cout, cin, cin, 0, -1, st()), "dgrad"),
+                   "dgrad_nomask": lambda: _lib.check(lib.osvos_conv3x3_bf16io(vp(dyb.data_ptr()), 1, vp(wd.data_ptr()), None, None, 0, None, vp(yb.data_ptr()), n, h,
+                                                                                w, cout, cin, cin, 0, -1, st()), "dgrad"),
                    "wgrad": lambda: ops.conv3x3_wgrad_bf16act(xb, dyb, cin, cout)}
         else:
             w3, w3d = ops.pack_x3(wt), ops.pack_x3(wt, dgrad=True)
             fns = {"fwd": lambda: ops.conv3x3_x3(x, w3, None, cout, relu=True),
                    "dgrad": lambda: ops.conv3x3_x3(dy, w3d, None, cin, mask=x),
+                   "dgrad_nomask": lambda: ops.conv3x3_x3(dy, w3d, None, cin),
                    "wgrad": lambda: ops.conv3x3_wgrad(x, dy, cin, cout, dtype=_lib.F32_X3)}
-        for d in ("fwd", "dgrad", "wgrad"):
+        for d in (("fwd", "dgrad", "dgrad_nomask", "wgrad") if args.nomask else ("fwd", "dgrad", "wgrad")):
             manifest.append({"layer": name, "dir": d, "gflop": gf, "ms": timed(fns[d]), "launches": REPS + 1})
     # what the matrix pipe of this box sustains (register-only loop, noise operands)
     blocks, iters = 2048, 2000
@@ -104,7 +107,7 @@ def report(args):
         rows = disp[i:i + m["launches"]]
         i += m["launches"]
         tf = m["gflop"] / m["ms"]
-        line = "%-8s %-5s %8.2f %9.3f %9.1f | %8.3f %8.3f |" % (m["layer"], m["dir"], m["gflop"], m["ms"], tf, mult * tf / 2500.0, mult * tf / man["pipe_sustained_tflops"])
+        line = "%-8s %-12s %8.2f %9.3f %9.1f | %8.3f %8.3f |" % (m["layer"], m["dir"], m["gflop"], m["ms"], tf, mult * tf / 2500.0, mult * tf / man["pipe_sustained_tflops"])
         use = rows[1:]                      # (the first launch of each group is the warm-up)
         if use:
             us = sum(r[3] for r in use) / len(use)
@@ -125,6 +128,7 @@ if __name__ == "__main__":
     r = sub.add_parser("run")
     r.add_argument("--mode", default="bf16", choices=["bf16", "x3"])
     r.add_argument("--batch", type=int, default=12)
+    r.add_argument("--nomask", action="store_true", help="also time the data gradient without its ReLU mask (what the mask read costs)")
     r.add_argument("--all", action="store_true", help="every distinct wide trunk shape instead of conv3_2 / conv4_2")
     p = sub.add_parser("report")
     p.add_argument("dir")
