@@ -25,6 +25,7 @@
 #include "common.h"
 #include "kernels.h"
 #include "epi.h"
+#include "maskbits.h"
 
 namespace {
 
@@ -325,6 +326,13 @@ __global__ __launch_bounds__(C::NT, C::OCC) void conv3x3_f32x3_kernel(ConvArgsX 
   const bool use_mask = !split && a.mask != nullptr;
   const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(use_mask ? a.mask + n * img_elems : a.y), 0,
                                                                        use_mask ? (int)(img_elems * 4) : 0, 0x00020000);
+  const bool use_mbits = !split && a.epi.mask_bits != nullptr, put_bits = !split && a.epi.y_bits != nullptr;
+  const int bw = a.y_cs >> 5;
+  const size_t img_words = (size_t)a.H * a.W * bw;
+  const __amdgpu_buffer_rsrc_t mbrs = __builtin_amdgcn_make_buffer_rsrc(use_mbits ? (void*)const_cast<unsigned*>(a.epi.mask_bits + n * img_words) : (void*)a.y, 0,
+                                                                        use_mbits ? (int)(img_words * 4) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ybrs = __builtin_amdgcn_make_buffer_rsrc(put_bits ? (void*)(a.epi.y_bits + n * img_words) : (void*)a.y, 0,
+                                                                        put_bits ? (int)(img_words * 4) : 0, 0x00020000);
   const bool use_bias = !split && a.bias != nullptr;
   const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(use_bias ? a.bias : a.y), 0, use_bias ? a.Cout * 4 : 0, 0x00020000);
   const bool relu = !split && a.relu;
@@ -355,6 +363,9 @@ __global__ __launch_bounds__(C::NT, C::OCC) void conv3x3_f32x3_kernel(ConvArgsX 
       const int ox = x0 + (mb % C::TBX) * C::RBW + li % C::RBW;
       const bool inside = oy < a.H && ox < a.W;
       const unsigned pix = inside ? (unsigned)((oy * a.W + ox) * cs) * 4u : OOB;
+      const unsigned bitoff = (inside && cb - 4 * lh < a.Cout) ? (unsigned)(oy * a.W + ox) * (unsigned)(bw * 4) + (unsigned)((cb - 4 * lh) >> 5) * 4u : OOB;
+      const unsigned mword = mb_load(mbrs, bitoff);
+      unsigned ybits = 0;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int co = cb + 8 * q;
@@ -365,11 +376,15 @@ __global__ __launch_bounds__(C::NT, C::OCC) void conv3x3_f32x3_kernel(ConvArgsX 
           v[e] = acc[mi][ni][4 * q + e] + bv[q][e];
           if (relu) v[e] = v[e] > 0.f ? v[e] : 0.f;
         }
-        if (use_mask) {
+        if (use_mbits) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = mb_test(mword, q, lh, e) ? v[e] : 0.f;
+        } else if (use_mask) {
           const f32x4 m = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(mrs, off, 0, 0));
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = m[e] > 0.f ? v[e] : 0.f;
         }
+        ybits |= mb_bits_f32(v, q);
         if (pool_bwd) {
           epi_pool_bwd_quad(v, pxrs, psrs, pdrs, oy, ox, a.epi.pool_H, a.epi.pool_W, a.y_cs, co, inside && co < a.Cout);
         } else {
@@ -380,6 +395,7 @@ __global__ __launch_bounds__(C::NT, C::OCC) void conv3x3_f32x3_kernel(ConvArgsX 
           for (int e = 0; e < 4; ++e) keep[mi][q][e] = inside ? v[e] : 0.f;
         }
       }
+      if (put_bits) mb_store(ybrs, bitoff, ybits, lh);
     }
     if (pool_fwd) {
       // windows: RBW 32 -- M blocks 2j, 2j+1 of this wave are the two rows, lane ^ 1 the neighbouring column;
@@ -649,6 +665,9 @@ int osvos_conv3x3_f32x3_epi(const float* x, const float* wpk, const void* wpk3, 
     a.ksplit = ksplit > 0 ? ksplit : (env_ks > 0 && Cin >= 256 ? env_ks : pick_ksplit_x(kTilesX[tile], N, H, W, Cin, Cout, a.CoutP));
     if (a.ksplit < 1 || a.ksplit > 8 || a.ksplit > (Cin >> 4) || Cout % 4 != 0) a.ksplit = 1;
   }
+  if (epi != nullptr && (epi->mask_bits != nullptr || epi->y_bits != nullptr))
+    OSVOS_ARG_CHECK(Cout % 32 == 0 && y_cs == Cout && !pool_bwd, "conv3x3 f32x3: one-bit masks need a dense result with Cout %% 32 == 0 (Cout %d, stride %d)", Cout, y_cs);
+  if (epi != nullptr && epi->y_bits != nullptr) a.ksplit = 1;
   if (pool_fwd) {
     a.ksplit = 1;
     OSVOS_ARG_CHECK(tile == 10 || tile == 12 || tile == 14, "conv3x3 f32x3: fused pool forward is built for tiles 10, 12 and 14 (got %d)", tile);

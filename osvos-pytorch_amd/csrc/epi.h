@@ -16,6 +16,10 @@ struct ConvEpi {
   float* pool_dx = nullptr;            // backward: result; non-NULL selects the fused pool backward (y is then not written)
   int pool_H = 0, pool_W = 0;
   float* pooled = nullptr;             // forward: NHWC [N][ceil(H/2)][ceil(W/2)][Cout], written next to y
+  // one-bit ReLU masks (maskbits.h), [N][H][W][Cout / 32] words; dense results with Cout % 32 == 0 only
+  const unsigned* mask_bits = nullptr; // data gradient: used instead of the fp32 `mask` by launches that are not cut along K (the finalize kernel of a
+                                       // split launch reads `mask`: pass both)
+  unsigned* y_bits = nullptr;          // forward: sign bits of the result, written next to y (the launch is then never cut along K)
 };
 
 typedef unsigned int epi_u32x4 __attribute__((ext_vector_type(4)));

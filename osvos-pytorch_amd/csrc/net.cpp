@@ -128,11 +128,15 @@ struct WsLayout {
 // gradient reads one word per (pixel, 32 channels) instead of the activation itself.  bf16-store mode (OSVOS_MASK_BITS=0: the activation).
 inline bool use_mask_bits(int dtype) {
   static const bool on = [] { const char* e = getenv("OSVOS_MASK_BITS"); return !(e && e[0] == '0'); }();
-  return on && use_store(dtype);
+  return on && (use_store(dtype) || dtype == OSVOS_F32_X3);
 }
-// act[l] masks the data gradient of layer l + 1 when both are in the same stage; stage 4's last activation masks its side branch's
-inline bool act_is_a_mask(const ConvDesc* d, int l) {
-  return (l + 1 < kNumTrunk && d[l + 1].stage == d[l].stage) || l == kNumTrunk - 1;
+// act[l] masks the data gradient of layer l + 1 when both are in the same stage; stage 4's last activation masks its side branch's.
+// f32x3 (fp32 tensors; the P3 network keeps its own masks): only where the f32x3 kernel produces the activation in ONE launch -- not conv1_1
+// (exact kernel) and not stage 4, whose forward launches are cut along K (bits would pin them to one K range)
+inline bool act_is_a_mask(const ConvDesc* d, int l, int dtype) {
+  const bool is = (l + 1 < kNumTrunk && d[l + 1].stage == d[l].stage) || l == kNumTrunk - 1;
+  if (dtype == OSVOS_F32_X3) return is && l >= 1 && d[l].stage <= 3;
+  return is;
 }
 
 WsLayout ws_layout(int N, int H, int W, int dtype) {
@@ -208,7 +212,7 @@ WsLayout ws_layout(int N, int H, int W, int dtype) {
     const size_t e = (size_t)N * L.hs[si] * L.ws[si] * d[l].cout;
     L.act[l] = take(te * e);
     L.act_b[l] = store ? L.act[l] : (shadow ? take(2 * e) : 0);
-    L.bits[l] = (use_mask_bits(dtype) && act_is_a_mask(d, l)) ? take(e / 8) : (size_t)-1;
+    L.bits[l] = (use_mask_bits(dtype) && act_is_a_mask(d, l, dtype)) ? take(e / 8) : (size_t)-1;
   }
   for (int si = 1; si < 5; ++si) {
     const size_t e = (size_t)N * L.hs[si] * L.ws[si] * kStageC[si - 1];
@@ -305,10 +309,16 @@ inline bool use_presplit() {
 inline int conv_main(const void* x, const void* x_b, const void* wpk, const float* bias, const void* mask, const void* mask_b, void* y, void* y_b,
                      int N, int h, int w, int cin, int cout, int y_cs, int relu, int dtype, void* part, hipStream_t stream, const void* wpk3 = nullptr,
                      const ConvEpi* epi = nullptr, const void* mask_bits = nullptr, void* y_bits = nullptr) {
-  if (dtype == OSVOS_F32_X3 && osvos_conv3x3_f32x3_applicable(cin, cout, y_cs))      // three-way bf16 split on the bf16 matrix pipe
+  if (dtype == OSVOS_F32_X3 && osvos_conv3x3_f32x3_applicable(cin, cout, y_cs)) {    // three-way bf16 split on the bf16 matrix pipe
+    ConvEpi e2;
+    if (epi != nullptr) e2 = *epi;
+    e2.mask_bits = reinterpret_cast<const unsigned*>(mask_bits);
+    e2.y_bits = reinterpret_cast<unsigned*>(y_bits);
+    const bool any = epi != nullptr || mask_bits != nullptr || y_bits != nullptr;
     // (with a pre-split pack the fp32 pack of the layer is not even built -- osvos_net_pack -- so it is not handed over either)
     return osvos_conv3x3_f32x3_epi((const float*)x, (use_presplit() && wpk3) ? nullptr : (const float*)wpk, use_presplit() ? wpk3 : nullptr, bias,
-                                   (const float*)mask, (float*)y, N, h, w, cin, cout, y_cs, relu, -1, 0, part, epi, stream);
+                                   (const float*)mask, (float*)y, N, h, w, cin, cout, y_cs, relu, -1, 0, part, any ? &e2 : nullptr, stream);
+  }
   if (dtype == OSVOS_F32 || dtype == OSVOS_F32_X3)
     return osvos_conv3x3_f32_ws((const float*)x, (const float*)wpk, bias, (const float*)mask, (float*)y, N, h, w, cin, cout, y_cs,
                                 relu, -1, part, stream);

@@ -555,9 +555,11 @@ def test_bf16_mode_conv1_1_weight_gradient_on_the_bf16_pipe_matches_the_fp32_ker
         assert torch.equal(got[1][2], got[0][2])          # everything else in the network is untouched
 
 
-def test_one_bit_relu_masks_change_nothing_but_the_bytes_read(tmp_path):
-    """bf16-store mode: the forward also writes the sign bits of every activation that later masks a data gradient, and the data gradients
+@pytest.mark.parametrize("precision", ["bf16", "fp32x3"])
+def test_one_bit_relu_masks_change_nothing_but_the_bytes_read(tmp_path, precision):
+    """bf16-store mode and f32x3 (stages 1-3 there): the forward also writes the sign bits of every activation that later masks a data gradient, and the data gradients
     read one 32-bit word per (pixel, 32 channels) instead of the activation (csrc/maskbits.h).  Same predicate (stored bf16 value > 0), so
+    (stored fp32 value > 0 in f32x3), so
     logits, losses, every parameter gradient and the input gradient must equal the OSVOS_MASK_BITS=0 run BIT FOR BIT -- odd sizes (partial
     tiles on both axes), a batch, and the 107-pixel-wide shape whose conv4_x take the LDS-DMA kernel's epilogue."""
     import os, subprocess, sys, textwrap
@@ -570,7 +572,7 @@ def test_one_bit_relu_masks_change_nothing_but_the_bytes_read(tmp_path):
         res = {}
         for tag, (n, h, w) in {"a": (2, 37, 53), "b": (1, 120, 214), "c": (2, 240, 427)}.items():
             wts, x, m = synth.calibrated_problem(n, h, w, seed=5)
-            net = T.build_net(wts, "bf16")
+            net = T.build_net(wts, sys.argv[2])
             xg = torch.from_numpy(x).requires_grad_()
             outs = net.forward(xg.cuda())
             gt = torch.from_numpy(m).cuda()
@@ -587,7 +589,8 @@ def test_one_bit_relu_masks_change_nothing_but_the_bytes_read(tmp_path):
     got = {}
     for bits in ("0", "1"):
         out = str(tmp_path / ("m%s.npz" % bits))
-        subprocess.run([sys.executable, "-c", code, out], check=True, env=dict(os.environ, OSVOS_MASK_BITS=bits), timeout=900)
+        # (OSVOS_X3_KSPLIT=1: a layer that writes bits is never cut along K; the comparison run must sum in the same order)
+        subprocess.run([sys.executable, "-c", code, out, precision], check=True, env=dict(os.environ, OSVOS_MASK_BITS=bits, OSVOS_X3_KSPLIT="1"), timeout=900)
         got[bits] = dict(np.load(out))
     a, b = got["0"], got["1"]
     assert a.keys() == b.keys() and len(a) > 120
