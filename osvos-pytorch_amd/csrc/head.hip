@@ -50,42 +50,46 @@ struct UpArgs {
 
 // transposed conv (k = 2s, stride s, no padding) + center crop, gathered per output pixel:
 // out[Y,X] = sum_{y,x} in[y,x] * f[Yp - y*s][Xp - x*s],  Yp = Y + top, top = floor((Ho - H)/2)
-__global__ void head_upsample_kernel(UpArgs a) {
-  const long hw = (long)a.H * a.W;
-  const long total = (long)a.N * hw;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-    const int X = (int)(idx % a.W);
-    const int Y = (int)((idx / a.W) % a.H);
-    const long n = idx / hw;
-    float fused = a.fuse_bias[0];
+// (block = 256 consecutive pixels of ONE image: 32-bit index math; the first form divided a flat 64-bit index three times per pixel)
+__global__ __launch_bounds__(256) void head_upsample_kernel(UpArgs a) {
+  const unsigned hw = (unsigned)a.H * (unsigned)a.W;
+  const unsigned p = blockIdx.x * 256u + threadIdx.x;
+  if (p >= hw) return;
+  const unsigned n = blockIdx.y;
+  const int Y = (int)(p / (unsigned)a.W), X = (int)(p - (unsigned)Y * (unsigned)a.W);
+  const size_t idx = (size_t)n * hw + p;
+  float fused = a.fuse_bias[0];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int s = 2 << i, k = 2 * s;
-      const int h = a.hs[i], w = a.ws[i];
-      const int top = ((h + 1) * s - a.H) / 2, left = ((w + 1) * s - a.W) / 2;
-      const int Yp = Y + top, Xp = X + left;
-      const int yh = Yp / s, xh = Xp / s;
-      float side = 0.f, fu = 0.f;
+  for (int i = 0; i < 4; ++i) {
+    const int s = 2 << i, k = 2 * s;
+    const int h = a.hs[i], w = a.ws[i];
+    const int top = ((h + 1) * s - a.H) / 2, left = ((w + 1) * s - a.W) / 2;
+    const int Yp = Y + top, Xp = X + left;
+    const int yh = Yp / s, xh = Xp / s;
+    const float* sc = a.score[i] + (size_t)n * h * w;
+    const float* fp = a.fpart[i] + (size_t)n * h * w;
+    float side = 0.f, fu = 0.f;
 #pragma unroll
-      for (int ddy = 0; ddy < 2; ++ddy) {
-        const int y = yh - 1 + ddy;
-        if (y < 0 || y >= h) continue;
-        const int ky = Yp - y * s;
+    for (int ddy = 0; ddy < 2; ++ddy) {
+      const int y = yh - 1 + ddy;
+      const int yc = y < 0 ? 0 : (y >= h ? h - 1 : y);
+      const int ky = Yp - y * s;
 #pragma unroll
-        for (int ddx = 0; ddx < 2; ++ddx) {
-          const int x = xh - 1 + ddx;
-          if (x < 0 || x >= w) continue;
-          const int kx = Xp - x * s;
-          const long li = (n * h + y) * w + x;
-          side += a.score[i][li] * a.f1[i][ky * k + kx];
-          fu += a.fpart[i][li] * a.f16[i][ky * k + kx];
-        }
+      for (int ddx = 0; ddx < 2; ++ddx) {
+        const int x = xh - 1 + ddx;
+        const int xc = x < 0 ? 0 : (x >= w ? w - 1 : x);
+        const int kx = Xp - x * s;
+        const bool in = y == yc && x == xc;        // (ky, kx are inside the filter whenever the tap is inside the map)
+        const int li = yc * w + xc, t = in ? ky * k + kx : 0;
+        const float w1 = in ? a.f1[i][t] : 0.f, w16 = in ? a.f16[i][t] : 0.f;
+        side += sc[li] * w1;
+        fu += fp[li] * w16;
       }
-      a.outs[i][idx] = side;
-      fused += fu;
     }
-    a.outs[4][idx] = fused;
+    a.outs[i][idx] = side;
+    fused += fu;
   }
+  a.outs[4][idx] = fused;
 }
 
 struct HbArgs {
@@ -109,34 +113,56 @@ struct HbArgs {
 // partials, which are wave-reduced and pushed with one double atomic per wave per value.
 template <int TPP>
 __device__ __forceinline__ void head_bwd_body(const HbArgs& a, const unsigned bid, const unsigned nblocks, double (*red)[34]) {
-  const int k = 2 * a.s, kk = k * k;
-  const int top = ((a.h + 1) * a.s - a.H) / 2, left = ((a.w + 1) * a.s - a.W) / 2;
+  // the lane-group width fixes the scale: stride S = 2, 4, 8, 16 and K = 2 S taps per axis for TPP = 1, 4, 16, 64 -- every lane owns
+  // K * K / TPP = 16 taps (t = sub + j TPP), whose (ky, kx) are shifts of compile-time strides and whose filter values are loaded once per thread
+  constexpr int S = TPP == 1 ? 2 : (TPP == 4 ? 4 : (TPP == 16 ? 8 : 16)), K = 2 * S, TAPS = K * K / TPP;
+  static_assert(TAPS == 16, "16 taps per lane at every scale");
+  const int top = ((a.h + 1) * S - a.H) / 2, left = ((a.w + 1) * S - a.W) / 2;
   const int sub = threadIdx.x % TPP;
-  const long npix = (long)a.N * a.h * a.w;
-  const int groups_per_block = 256 / TPP;
+  const unsigned hw_lo = (unsigned)a.h * (unsigned)a.w;
+  const unsigned npix = (unsigned)a.N * hw_lo;              // (< 2^31: checked on the host)
+  constexpr unsigned groups_per_block = 256 / TPP;
+  const bool have_f = a.dfused != nullptr, have_s = a.dside != nullptr;
+  float w16[TAPS], w1[TAPS];
+#pragma unroll
+  for (int j = 0; j < TAPS; ++j) {
+    w16[j] = a.f16[sub + j * TPP];
+    w1[j] = a.f1[sub + j * TPP];
+  }
   float pwf[16], pwd[16], pbd = 0.f;
 #pragma unroll
   for (int c = 0; c < 16; ++c) { pwf[c] = 0.f; pwd[c] = 0.f; }
-  const long ngroups_total = (long)nblocks * groups_per_block;
-  const long iters = (npix + ngroups_total - 1) / ngroups_total;
-  for (long it = 0; it < iters; ++it) {
-    const long pix = it * ngroups_total + (long)bid * groups_per_block + threadIdx.x / TPP;
+  const unsigned ngroups_total = nblocks * groups_per_block;
+  const unsigned iters = (npix + ngroups_total - 1) / ngroups_total;
+  for (unsigned it = 0; it < iters; ++it) {
+    const unsigned pix = it * ngroups_total + bid * groups_per_block + threadIdx.x / TPP;
     const bool live = pix < npix;      // whole groups go dead together; shuffles stay wave-uniform
     float df = 0.f, ds = 0.f;
-    int x = 0, y = 0;
-    long n = 0;
+    unsigned n = 0;
     if (live) {
-      x = (int)(pix % a.w);
-      y = (int)((pix / a.w) % a.h);
-      n = pix / ((long)a.w * a.h);
-      for (int t = sub; t < kk; t += TPP) {
-        const int ky = t / k, kx = t % k;
-        const int Y = y * a.s + ky - top, X = x * a.s + kx - left;
-        if (Y >= 0 && Y < a.H && X >= 0 && X < a.W) {
-          const long o = (n * a.H + Y) * a.W + X;
-          if (a.dfused != nullptr) df += a.f16[t] * a.dfused[o];
-          if (a.dside != nullptr) ds += a.f1[t] * a.dside[o];
-        }
+      n = pix / hw_lo;
+      const unsigned r = pix - n * hw_lo;
+      const int y = (int)(r / (unsigned)a.w), x = (int)(r - (unsigned)y * (unsigned)a.w);
+      const int Y0 = y * S - top, X0 = x * S - left;
+      const float* fu = a.dfused + (size_t)n * a.H * a.W;
+      const float* sd = a.dside + (size_t)n * a.H * a.W;
+      // every tap's load is unconditional (clamped address, weight zeroed outside the frame): all 32 are in flight before the first multiply
+      float vf[TAPS], vs[TAPS];
+      bool in[TAPS];
+#pragma unroll
+      for (int j = 0; j < TAPS; ++j) {
+        const int t = sub + j * TPP;          // K is a power of two: shifts
+        const int Y = Y0 + t / K, X = X0 + t % K;
+        const int Yc = Y < 0 ? 0 : (Y >= a.H ? a.H - 1 : Y), Xc = X < 0 ? 0 : (X >= a.W ? a.W - 1 : X);
+        in[j] = Y == Yc && X == Xc;
+        const int o = Yc * a.W + Xc;
+        vf[j] = have_f ? fu[o] : 0.f;
+        vs[j] = have_s ? sd[o] : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < TAPS; ++j) {
+        df += (in[j] ? w16[j] : 0.f) * vf[j];
+        ds += (in[j] ? w1[j] : 0.f) * vs[j];
       }
     }
 #pragma unroll
@@ -147,7 +173,7 @@ __device__ __forceinline__ void head_bwd_body(const HbArgs& a, const unsigned bi
     if (live && sub == 0) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const f32x4 p = a.prep[pix * 4 + q];
+        const f32x4 p = a.prep[(size_t)pix * 4 + q];
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -156,11 +182,11 @@ __device__ __forceinline__ void head_bwd_body(const HbArgs& a, const unsigned bi
           pwf[c] += p[e] * df;
           pwd[c] += p[e] * ds;
         }
-        a.dprep[pix * 4 + q] = o;
+        a.dprep[(size_t)pix * 4 + q] = o;
         if (a.dprep_b != nullptr && a.b_p3) {
           uint2 ph, pm, pl;
           p3_split4(o, ph, pm, pl);
-          const long hw = (long)a.h * a.w, base = (n * 3 * hw + (pix - n * hw)) * 4 + q;      // uint2 units: 4 per pixel and plane
+          const size_t hw = hw_lo, base = ((size_t)n * 3 * hw + (pix - n * hw_lo)) * 4 + q;      // uint2 units: 4 per pixel and plane
           a.dprep_b[base] = ph;
           a.dprep_b[base + hw * 4] = pm;
           a.dprep_b[base + 2 * hw * 4] = pl;
@@ -168,7 +194,7 @@ __device__ __forceinline__ void head_bwd_body(const HbArgs& a, const unsigned bi
           typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
           bf16x4_t hb;
           hb[0] = (__bf16)o[0]; hb[1] = (__bf16)o[1]; hb[2] = (__bf16)o[2]; hb[3] = (__bf16)o[3];
-          a.dprep_b[pix * 4 + q] = __builtin_bit_cast(uint2, hb);
+          a.dprep_b[(size_t)pix * 4 + q] = __builtin_bit_cast(uint2, hb);
         }
       }
       pbd += ds;
@@ -273,7 +299,8 @@ extern "C" int osvos_head_upsample(const float* const* score, const float* const
   for (int i = 0; i < 5; ++i) a.outs[i] = outs[i];
   a.fuse_bias = fuse_bias;
   a.N = N; a.H = H; a.W = W;
-  hipLaunchKernelGGL(head_upsample_kernel, dim3(grid_for((long)N * H * W, 4096)), dim3(256), 0, (hipStream_t)stream, a);
+  OSVOS_ARG_CHECK((long)H * W < (1L << 31) && N <= 65535, "head_upsample: frame / batch too large (%d x %d x %d)", N, H, W);
+  hipLaunchKernelGGL(head_upsample_kernel, dim3((unsigned)(((long)H * W + 255) / 256), (unsigned)N), dim3(256), 0, (hipStream_t)stream, a);
   OSVOS_LAUNCH_CHECK();
   return 0;
 }

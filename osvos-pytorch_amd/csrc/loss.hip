@@ -17,10 +17,16 @@ struct Scratch {            // 32 bytes, zeroed per call
   double spare;
 };
 
+// (both sweeps read 16 bytes per lane and load: `n4` float4 groups, then the <= 3 leftover elements by the first lanes of workgroup 0)
 __global__ void cbce_count_kernel(const float* __restrict__ label, long count, Scratch* sc) {
   unsigned int c = 0;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x)
-    c += label[i] >= 0.5f ? 1u : 0u;
+  const long n4 = count >> 2;
+  const f32x4* l4 = reinterpret_cast<const f32x4*>(label);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const f32x4 v = l4[i];
+    c += (v[0] >= 0.5f ? 1u : 0u) + (v[1] >= 0.5f ? 1u : 0u) + (v[2] >= 0.5f ? 1u : 0u) + (v[3] >= 0.5f ? 1u : 0u);
+  }
+  if (blockIdx.x == 0 && (long)threadIdx.x < count - 4 * n4) c += label[4 * n4 + threadIdx.x] >= 0.5f ? 1u : 0u;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
   __shared__ unsigned int red[4];
@@ -32,29 +38,46 @@ __global__ void cbce_count_kernel(const float* __restrict__ label, long count, S
   }
 }
 
+// one element: accumulates the two loss sums, returns the gradient
+__device__ __forceinline__ float cbce_elem(float x, float lab, float wpos, float wneg, float inv_div, float gscale, bool want_grad, double& lpos, double& lneg) {
+  const float y = lab >= 0.5f ? 1.f : 0.f;
+  const float g = x >= 0.f ? 1.f : 0.f;
+  const float val = x * (y - g) - logf(1.f + expf(x - 2.f * x * g));
+  lpos += (double)(-y * val);
+  lneg += (double)(-(1.f - y) * val);
+  if (!want_grad) return 0.f;
+  // d(-val)/dx = (1 - 2g) * sigmoid(-|x|) - (y - g): the form autograd derives from the
+  // reference's expression; no cancellation for saturated logits (sigmoid(x) - y would lose it)
+  const float ez = expf(-fabsf(x));
+  const float sz = ez / (1.f + ez);
+  const float gi = (y > 0.5f ? wpos : wneg) * ((1.f - 2.f * g) * sz - (y - g)) * inv_div;
+  // gscale: the upstream gradient of the loss (1 / nAveGrad, times the side-head weight in the parent loop), applied to the
+  // ROUNDED per-pixel gradient -- the same two roundings as this kernel followed by osvos_scale (autograd's chain)
+  return gi * gscale;
+}
+
 __global__ void cbce_main_kernel(const float* __restrict__ out, const float* __restrict__ label,
                                  float* __restrict__ grad, long count, float inv_div, float gscale, Scratch* sc) {
   const float ntot = (float)count;
   const float npos = (float)sc->npos;
   const float wpos = (ntot - npos) / ntot, wneg = npos / ntot;
+  const bool want = grad != nullptr;
   double lpos = 0.0, lneg = 0.0;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
-    const float x = out[i];
-    const float y = label[i] >= 0.5f ? 1.f : 0.f;
-    const float g = x >= 0.f ? 1.f : 0.f;
-    const float val = x * (y - g) - logf(1.f + expf(x - 2.f * x * g));
-    lpos += (double)(-y * val);
-    lneg += (double)(-(1.f - y) * val);
-    if (grad != nullptr) {
-      // d(-val)/dx = (1 - 2g) * sigmoid(-|x|) - (y - g): the form autograd derives from the
-      // reference's expression; no cancellation for saturated logits (sigmoid(x) - y would lose it)
-      const float ez = expf(-fabsf(x));
-      const float sz = ez / (1.f + ez);
-      const float gi = (y > 0.5f ? wpos : wneg) * ((1.f - 2.f * g) * sz - (y - g)) * inv_div;
-      // gscale: the upstream gradient of the loss (1 / nAveGrad, times the side-head weight in the parent loop), applied to the
-      // ROUNDED per-pixel gradient -- the same two roundings as this kernel followed by osvos_scale (autograd's chain)
-      grad[i] = gi * gscale;
-    }
+  const long n4 = count >> 2;
+  const f32x4* o4 = reinterpret_cast<const f32x4*>(out);
+  const f32x4* l4 = reinterpret_cast<const f32x4*>(label);
+  f32x4* g4 = reinterpret_cast<f32x4*>(grad);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const f32x4 x = o4[i], lab = l4[i];
+    f32x4 g;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) g[e] = cbce_elem(x[e], lab[e], wpos, wneg, inv_div, gscale, want, lpos, lneg);
+    if (want) g4[i] = g;
+  }
+  if (blockIdx.x == 0 && (long)threadIdx.x < count - 4 * n4) {
+    const long i = 4 * n4 + threadIdx.x;
+    const float g = cbce_elem(out[i], label[i], wpos, wneg, inv_div, gscale, want, lpos, lneg);
+    if (want) grad[i] = g;
   }
   lpos = wave_sum(lpos);
   lneg = wave_sum(lneg);
@@ -113,11 +136,12 @@ extern "C" int osvos_cbce_step(const float* out, const float* label, float* loss
   hipStream_t stream = (hipStream_t)stream_;
   OSVOS_ARG_CHECK(out && label && loss && scratch && count > 0 && N > 0, "cbce: bad arguments");
   OSVOS_ARG_CHECK(mode >= 0 && mode <= 2, "cbce: mode %d", mode);
+  OSVOS_ARG_CHECK(((uintptr_t)out | (uintptr_t)label | (uintptr_t)grad) % 16 == 0, "cbce: out / label / grad must be 16-byte aligned (whole tensors are)");
   const float inv_div = mode == 0 ? 1.f / (float)count : (mode == 1 ? 1.f / (float)N : 1.f);
   Scratch* sc = reinterpret_cast<Scratch*>(scratch);
   OSVOS_HIP_CHECK(hipMemsetAsync(sc, 0, sizeof(Scratch), stream));
   // one double atomic pair per workgroup: few workgroups for a single frame (11 us), more for batches (94 -> ~25 us at batch 12)
-  const int g = grid_for(count, count > (1L << 21) ? 512 : 128);
+  const int g = grid_for(count >> 2, count > (1L << 21) ? 512 : 128);
   hipLaunchKernelGGL(cbce_count_kernel, dim3(g), dim3(256), 0, stream, label, count, sc);
   hipLaunchKernelGGL(cbce_main_kernel, dim3(g), dim3(256), 0, stream, out, label, grad, count, inv_div, grad_scale, sc);
   hipLaunchKernelGGL(cbce_final_kernel, dim3(1), dim3(1), 0, stream, sc, count, inv_div, loss, running);

@@ -1062,6 +1062,8 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
     const void* xin = first_of_stage ? (si == 0 ? at(ws, L.xin) : at(ws, L.pooled[si])) : at(ws, L.act[l - 1]);
     const void* g = at(ws, L.dy[l]);
     const void* g_b = sh(L.dy_b[l]);
+    // (Measured twice in round 3: conv1_1's weight gradient on the third stream BESIDE the input gradient instead of behind it is neutral at
+    //  batch 1 (f32x3) and 0.5-1 % slower at batch 12 (bf16) -- not built in.)
     // conv1_1's weight gradient is the LAST piece of work of the step and the weight-gradient stream is the one that finishes last (conv1_2's
     // gradient is still running when the data-gradient chain ends): it goes on the main stream, behind the input gradient, beside conv1_2's
     const bool tail_on_main = l == 0 && two && !defer_join;      // (deferred join: everything gradient-related stays on the side streams)
