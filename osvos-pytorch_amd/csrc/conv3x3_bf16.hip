@@ -399,6 +399,7 @@ using B8 = CfgB<32, 1, 8, 4, 2, 2, 0, 2, 2>;   // 256 px x 128 co, 4x2 accumulat
 using B9 = CfgB<32, 1, 8, 2, 2, 2, 1, 3, 2>;   // 256 px x  64 co, 16-channel chunks, three workgroups per CU (conv1_x)
 using B10 = CfgB<16, 1, 8, 4, 2, 2, 0, 2, 2>;  // B8 as a 16 x 16 pixel tile: 107- and 54-pixel wide maps lose 12 % to padding instead of 28 %
 using B11 = CfgB<16, 1, 8, 2, 2, 2, 1, 1, 4>;  // B1 as a 16 x 16 pixel tile
+// (B6 on 16-channel chunks with three workgroups per CU, tried for the K = 64 input gradient: 279 against 276 us at batch 12 -- not kept)
 // (tile ids in the round-1 profile files predate a clean-up: 20 -> 8, 23 -> 9, 28 -> 10, 29 -> 11; the 8-wave, row-re-use and
 //  interleaved-load variants 8-19 / 21-22 / 24-27 of those files were measured, lost, and are gone)
 constexpr int kNumTilesB = 12;
@@ -413,8 +414,11 @@ const TileInfoB kTilesB[kNumTilesB] = {infoB<B0>(), infoB<B1>(), infoB<B2>(), in
 // 64-cout layers and the frames that are too small for B8; tiny frames fall back to 128- and 64-pixel tiles.
 constexpr int kDmaMinCin = 512, kDmaTile = 32;      // auto rule for the LDS-DMA kernel (OSVOS_DMA_MIN_CIN / OSVOS_DMA_TILE override)
 
-int pick_tile_b(int N, int H, int W, int CoutP) {
+int pick_tile_b(int N, int H, int W, int CoutP, int Cin) {
   if (CoutP <= 32) return 6;
+  // one 16-channel K chunk (the side branches' data gradients, 16 -> C): all prologue and epilogue -- three small workgroups per CU cover each
+  // other's phases (B9: 166 / 80 / 52 us against 215 / 90 / 57 for the automatic choice at batch 12, tools/tune_skinny_bf16.py)
+  if (Cin <= 16) return 9;
   const int order[] = {8, 1, 5, 7};
   for (int k = 0; k < 4; ++k) {
     const TileInfoB& t = kTilesB[order[k]];
@@ -522,7 +526,7 @@ int osvos_conv3x3_bf16mfma_bits(const void* x, int xb, const void* wpk, const fl
   if (tile < 0) {
     OSVOS_ENV_INT(env_tile, "OSVOS_CONV_TILE_BF16", -1);
     const bool env = env_tile >= 0;
-    tile = env ? env_tile : pick_tile_b(N, H, W, a.CoutP);
+    tile = env ? env_tile : pick_tile_b(N, H, W, a.CoutP, Cin);
     if (!env && !xb && tile == 10) tile = 8;     // (the 16 x 16 form spills with fp32 staging registers)
     // bf16 activations, deep layers (K = 9 x 512): the LDS-DMA staged 512 px x 128 co kernel wins when it still fills the chip
     // (conv4_x 0.355 -> 0.331 ms, conv5_x 0.117 -> 0.098 ms at batch 12)
