@@ -203,6 +203,8 @@ class Workload(object):
     def __init__(self, mode, precision, height, width, batch, graph, n_ave, item_sync, device, rank, dist, force_dist, graph_train=0, comm=None):
         from layers.osvos_layers import class_balanced_cross_entropy_loss as cbce
         from osvos_pytorch_amd.layers.osvos_layers import class_balanced_cross_entropy_loss_step as cbce_step
+        from osvos_pytorch_amd.layers.osvos_layers import class_balanced_cross_entropy_loss_step_multi as cbce_step_multi
+        self.cbce_step_multi = cbce_step_multi
         from osvos_pytorch_amd.parallel import GradientAllReducer
         self.cbce_step = cbce_step
         # what TrainLoop (the scripts' loop) does by default: upstream gradient (1 / nAveGrad ...) and running-loss add inside the loss
@@ -305,10 +307,15 @@ class Workload(object):
             inv = np.float32(1.0) / np.float32(self.n_ave)
             heads = [outputs[-1]] if self.mode == "online" else list(outputs)
             scales = [inv] if self.mode == "online" else [np.float32(inv * np.float32(1 - self.epoch / 240))] * 4 + [inv]
-            grads = []
-            for k, (o, sc) in enumerate(zip(heads, scales)):
-                loss, g = self.cbce_step(o, self.gt, size_average=False, grad_scale=float(sc), running=self.running if k == len(heads) - 1 else None)
-                grads.append(g)
+            if len(heads) > 1 and os.environ.get('OSVOS_CBCE_MULTI', '1') != '0':      # the parent loop's five losses in one library call, as TrainLoop does
+                losses, grads = self.cbce_step_multi(heads, self.gt, size_average=False, grad_scales=[float(sc) for sc in scales],
+                                                     running=[None] * (len(heads) - 1) + [self.running])
+                loss = losses[-1]
+            else:
+                grads = []
+                for k, (o, sc) in enumerate(zip(heads, scales)):
+                    loss, g = self.cbce_step(o, self.gt, size_average=False, grad_scale=float(sc), running=self.running if k == len(heads) - 1 else None)
+                    grads.append(g)
             if self.item_sync:
                 loss.item()                               # train_online.py:128: D2H sync every iteration
             if arm:

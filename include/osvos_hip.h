@@ -211,6 +211,11 @@ int osvos_cbce(const float* out, const float* label, float* loss, float* grad, v
  * but without the separate scale / add / divide launches between the loss and the head's backward. */
 int osvos_cbce_step(const float* out, const float* label, float* loss, float* grad, void* scratch,
                     long count, int N, int mode, float grad_scale, float* running, void* stream);
+/* Several heads against ONE label (train_parent.py:143-147: the five losses of a micro-batch) in three launches instead of 3 per head: the class
+ * counts of the label are formed once.  outs / losses / grads / running: arrays of n_heads (1..8) device pointers (grads, running and their entries
+ * may be NULL); grad_scales: n_heads HOST floats; scratch: 32 x n_heads bytes, zeroed by this call.  Per head identical to osvos_cbce_step. */
+int osvos_cbce_step_multi(const float* const* outs, const float* label, float* const* losses, float* const* grads, void* scratch,
+                          long count, int N, int mode, int n_heads, const float* grad_scales, float* const* running, void* stream);
 /* y[i] = x[i] * (*scalar)   (loss.backward() chain rule with a device-resident upstream grad) */
 int osvos_scale(const float* x, const float* scalar, float* y, long count, void* stream);
 

@@ -72,6 +72,7 @@ PROTOTYPES = {
     "osvos_deconv_diag_check": (_i, [_vp, _i, _i, _vp, _vp]),
     "osvos_cbce": (_i, [_vp, _vp, _vp, _vp, _vp, _l, _i, _i, _vp]),
     "osvos_cbce_step": (_i, [_vp, _vp, _vp, _vp, _vp, _l, _i, _i, _f, _vp, _vp]),
+    "osvos_cbce_step_multi": (_i, [_vp, _vp, _vp, _vp, _vp, _l, _i, _i, _i, _vp, _vp, _vp]),
     "osvos_scale": (_i, [_vp, _vp, _vp, _l, _vp]),
     "osvos_net_wbuf_bytes": (_sz, [_i]),
     "osvos_net_ws_bytes": (_sz, [_i, _i, _i, _i]),

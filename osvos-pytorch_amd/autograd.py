@@ -302,3 +302,35 @@ def cbce_step(output, label, mode, grad_scale=1.0, running=None):
                                 C.c_void_p(scratch.data_ptr()), out.numel(), out.shape[0], int(mode), float(grad_scale),
                                 C.c_void_p(running.data_ptr()) if running is not None else None, _stream()), "cbce_step")
     return loss, grad.view_as(output)
+
+
+def cbce_step_multi(outputs, label, mode, grad_scales, runnings=None):
+    """``cbce_step`` for several heads against one label (the parent loop's five losses, train_parent.py:143-147) in ONE library call: the
+    label's class counts are formed once and the loss / gradient sweep of all heads is one launch.  Returns ``(losses, grads)``: ``losses`` a
+    float32 CUDA tensor of ``len(outputs)`` plain losses (detached), ``grads[k] = grad_scales[k] * dLoss_k/dOutput_k``; ``runnings`` (list of
+    0-dim fp32 CUDA tensors or Nones) get ``+= loss_k`` on the device.  Per head the arithmetic is ``cbce_step``'s."""
+    n = len(outputs)
+    if not (1 <= n <= 8) or len(grad_scales) != n or (runnings is not None and len(runnings) != n):
+        raise RuntimeError("cbce_step_multi: 1..8 heads with one grad_scale (and one running entry) each")
+    if not all(o.is_cuda for o in outputs):
+        raise RuntimeError("class_balanced_cross_entropy_loss (osvos_pytorch_amd) needs CUDA tensors; no CPU fallback")
+    outs = [o.detach().contiguous().float() for o in outputs]
+    dev = outs[0].device
+    lab = label.detach().to(device=dev, dtype=torch.float32).contiguous()
+    if any(o.numel() != lab.numel() for o in outs):
+        raise RuntimeError("every output and the label must have the same number of elements")
+    for r in (runnings or []):
+        if r is not None and not (r.is_cuda and r.dtype == torch.float32 and r.numel() == 1):
+            raise RuntimeError("running entries must be one-element float32 CUDA tensors")
+    losses = torch.empty(n, device=dev, dtype=torch.float32)
+    grads = [torch.empty_like(o) for o in outs]
+    scratch = torch.empty(4 * n, device=dev, dtype=torch.float64)
+    vp = C.c_void_p
+    a_out = (vp * n)(*[vp(o.data_ptr()) for o in outs])
+    a_loss = (vp * n)(*[vp(losses.data_ptr() + 4 * k) for k in range(n)])
+    a_grad = (vp * n)(*[vp(g.data_ptr()) for g in grads])
+    a_run = (vp * n)(*[vp(r.data_ptr()) if r is not None else None for r in (runnings or [None] * n)])
+    a_scale = (C.c_float * n)(*[float(s) for s in grad_scales])
+    check(lib().osvos_cbce_step_multi(a_out, vp(lab.data_ptr()), a_loss, a_grad, vp(scratch.data_ptr()), lab.numel(), outs[0].shape[0], int(mode), n,
+                                      a_scale, a_run, _stream()), "cbce_step_multi")
+    return losses, [g.view_as(o) for g, o in zip(grads, outputs)]

@@ -99,6 +99,66 @@ __global__ void cbce_final_kernel(const Scratch* sc, long count, float inv_div, 
   if (running != nullptr) running[0] += l;      // running_loss += loss (train_online.py:128) without a host round trip or an extra launch
 }
 
+// ---- several heads against ONE label in three launches (train_parent.py:145: five losses per micro-batch): the label's class counts are
+// formed once, the loss / gradient sweep runs with blockIdx.y = head, one thread per head finalises.  Same arithmetic per head as above.
+constexpr int kMaxHeads = 8;
+struct CbceHeads {
+  const float* out[kMaxHeads];
+  float* grad[kMaxHeads];
+  float* loss[kMaxHeads];
+  float* running[kMaxHeads];
+  float gscale[kMaxHeads];
+  int n;
+};
+
+__global__ void cbce_main_multi_kernel(CbceHeads hd, const float* __restrict__ label, long count, float inv_div, Scratch* sc) {
+  const int head = blockIdx.y;
+  const float ntot = (float)count;
+  const float npos = (float)sc[0].npos;
+  const float wpos = (ntot - npos) / ntot, wneg = npos / ntot;
+  const float* __restrict__ out = hd.out[head];
+  float* __restrict__ grad = hd.grad[head];
+  const float gscale = hd.gscale[head];
+  const bool want = grad != nullptr;
+  double lpos = 0.0, lneg = 0.0;
+  const long n4 = count >> 2;
+  const f32x4* o4 = reinterpret_cast<const f32x4*>(out);
+  const f32x4* l4 = reinterpret_cast<const f32x4*>(label);
+  f32x4* g4 = reinterpret_cast<f32x4*>(grad);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const f32x4 x = o4[i], lab = l4[i];
+    f32x4 g;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) g[e] = cbce_elem(x[e], lab[e], wpos, wneg, inv_div, gscale, want, lpos, lneg);
+    if (want) g4[i] = g;
+  }
+  if (blockIdx.x == 0 && (long)threadIdx.x < count - 4 * n4) {
+    const long i = 4 * n4 + threadIdx.x;
+    const float g = cbce_elem(out[i], label[i], wpos, wneg, inv_div, gscale, want, lpos, lneg);
+    if (want) grad[i] = g;
+  }
+  lpos = wave_sum(lpos);
+  lneg = wave_sum(lneg);
+  __shared__ double red[4][2];
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = lpos; red[threadIdx.x >> 6][1] = lneg; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(&sc[head].lpos, red[0][0] + red[1][0] + red[2][0] + red[3][0]);
+    atomicAdd(&sc[head].lneg, red[0][1] + red[1][1] + red[2][1] + red[3][1]);
+  }
+}
+
+__global__ void cbce_final_multi_kernel(CbceHeads hd, const Scratch* sc, long count, float inv_div) {
+  const int head = threadIdx.x;
+  if (head >= hd.n) return;
+  const float ntot = (float)count;
+  const float npos = (float)sc[0].npos;
+  const float wpos = (ntot - npos) / ntot, wneg = npos / ntot;
+  const float l = (float)(((double)wpos * sc[head].lpos + (double)wneg * sc[head].lneg) * (double)inv_div);
+  hd.loss[head][0] = l;
+  if (hd.running[head] != nullptr) hd.running[head][0] += l;
+}
+
 __global__ void scale_kernel(const float* __restrict__ x, const float* __restrict__ scalar, float* __restrict__ y, long count) {
   const float s = scalar[0];
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) y[i] = x[i] * s;
@@ -145,6 +205,37 @@ extern "C" int osvos_cbce_step(const float* out, const float* label, float* loss
   hipLaunchKernelGGL(cbce_count_kernel, dim3(g), dim3(256), 0, stream, label, count, sc);
   hipLaunchKernelGGL(cbce_main_kernel, dim3(g), dim3(256), 0, stream, out, label, grad, count, inv_div, grad_scale, sc);
   hipLaunchKernelGGL(cbce_final_kernel, dim3(1), dim3(1), 0, stream, sc, count, inv_div, loss, running);
+  OSVOS_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int osvos_cbce_step_multi(const float* const* outs, const float* label, float* const* losses, float* const* grads, void* scratch,
+                                     long count, int N, int mode, int n_heads, const float* grad_scales, float* const* running, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  OSVOS_ARG_CHECK(outs && label && losses && scratch && grad_scales && count > 0 && N > 0, "cbce_multi: bad arguments");
+  OSVOS_ARG_CHECK(n_heads >= 1 && n_heads <= kMaxHeads, "cbce_multi: %d heads (1..%d)", n_heads, kMaxHeads);
+  OSVOS_ARG_CHECK(mode >= 0 && mode <= 2, "cbce_multi: mode %d", mode);
+  CbceHeads hd;
+  hd.n = n_heads;
+  uintptr_t align = (uintptr_t)label;
+  for (int h = 0; h < kMaxHeads; ++h) {
+    const bool live = h < n_heads;
+    OSVOS_ARG_CHECK(!live || (outs[h] && losses[h]), "cbce_multi: head %d: null pointer", h);
+    hd.out[h] = live ? outs[h] : nullptr;
+    hd.grad[h] = live && grads ? grads[h] : nullptr;
+    hd.loss[h] = live ? losses[h] : nullptr;
+    hd.running[h] = live && running ? running[h] : nullptr;
+    hd.gscale[h] = live ? grad_scales[h] : 0.f;
+    if (live) align |= (uintptr_t)hd.out[h] | (uintptr_t)hd.grad[h];
+  }
+  OSVOS_ARG_CHECK(align % 16 == 0, "cbce_multi: out / label / grad must be 16-byte aligned (whole tensors are)");
+  const float inv_div = mode == 0 ? 1.f / (float)count : (mode == 1 ? 1.f / (float)N : 1.f);
+  Scratch* sc = reinterpret_cast<Scratch*>(scratch);      // n_heads x 32 bytes
+  OSVOS_HIP_CHECK(hipMemsetAsync(sc, 0, sizeof(Scratch) * n_heads, stream));
+  const int g = grid_for(count >> 2, count > (1L << 21) ? 512 : 128);
+  hipLaunchKernelGGL(cbce_count_kernel, dim3(g), dim3(256), 0, stream, label, count, sc);
+  hipLaunchKernelGGL(cbce_main_multi_kernel, dim3(g, n_heads), dim3(256), 0, stream, hd, label, count, inv_div, sc);
+  hipLaunchKernelGGL(cbce_final_multi_kernel, dim3(1), dim3(64), 0, stream, hd, sc, count, inv_div);
   OSVOS_LAUNCH_CHECK();
   return 0;
 }

@@ -8,7 +8,7 @@ from __future__ import division
 import numpy as np
 import torch
 
-from ..autograd import CBCELossFunction, cbce_step
+from ..autograd import CBCELossFunction, cbce_step, cbce_step_multi
 
 
 def logit(x):
@@ -34,6 +34,13 @@ def class_balanced_cross_entropy_loss_step(output, label, size_average=True, bat
     ``torch.autograd.backward([output], [grad])``.  An extension next to the reference's function above, not a replacement."""
     mode = 0 if size_average else (1 if batch_average else 2)
     return cbce_step(output, label, mode, grad_scale, running)
+
+
+def class_balanced_cross_entropy_loss_step_multi(outputs, label, size_average=True, batch_average=True, grad_scales=None, running=None):
+    """``class_balanced_cross_entropy_loss_step`` for all heads of a micro-batch in one call (the parent loop: train_parent.py:143-147):
+    ``(losses, grads)`` with ``losses`` a float32 tensor of the plain per-head losses."""
+    mode = 0 if size_average else (1 if batch_average else 2)
+    return cbce_step_multi(list(outputs), label, mode, list(grad_scales) if grad_scales is not None else [1.0] * len(outputs), running)
 
 
 def center_crop(x, height, width):

@@ -11,7 +11,8 @@ import torch.optim as optim
 
 import numpy as np
 
-from .layers.osvos_layers import class_balanced_cross_entropy_loss, class_balanced_cross_entropy_loss_step
+from .layers.osvos_layers import (class_balanced_cross_entropy_loss, class_balanced_cross_entropy_loss_step,
+                                  class_balanced_cross_entropy_loss_step_multi)
 from .parallel import GradientAllReducer
 
 
@@ -120,10 +121,15 @@ class TrainLoop(object):
         else:
             side = np.float32(inv * np.float32(1 - epoch / self.n_epochs))
             heads, scales = list(outputs), [side] * (len(outputs) - 1) + [inv]
-        grads, loss = [], None
-        for o, s, r in zip(heads, scales, running):
-            loss, g = class_balanced_cross_entropy_loss_step(o, gts, size_average=False, grad_scale=float(s), running=r)
-            grads.append(g)
+        if len(heads) > 1 and os.environ.get('OSVOS_CBCE_MULTI', '1') != '0':      # the parent loop's five losses: one library call (class counts formed once, one sweep)
+            losses, grads = class_balanced_cross_entropy_loss_step_multi(heads, gts, size_average=False, grad_scales=[float(s) for s in scales],
+                                                                         running=list(running))
+            loss = losses[-1]
+        else:
+            grads, loss = [], None
+            for o, s, r in zip(heads, scales, running):
+                loss, g = class_balanced_cross_entropy_loss_step(o, gts, size_average=False, grad_scale=float(s), running=r)
+                grads.append(g)
         will_step = (self.ave + 1) % self.local_ave == 0 and (self.max_steps is None or self.steps < self.max_steps)
         if self.reducer is not None and will_step:
             self.reducer.arm()

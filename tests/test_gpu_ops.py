@@ -805,3 +805,26 @@ def test_input_gradient_of_the_first_convolution(shape):
     assert dx.shape == (n, 3, h, w)
     emax, el2 = rel_err(dx.cpu(), ref)
     assert emax < 2e-5 and el2 < 1e-5, (shape, emax, el2)
+
+
+@pytest.mark.gpu
+def test_cbce_step_multi_equals_the_single_head_calls():
+    """osvos_cbce_step_multi (the parent loop's five losses in three launches, class counts formed once) against five osvos_cbce_step calls: the
+    per-head arithmetic is the same kernel body, so gradients are bit-identical and losses / running sums agree to the last float32 bit or
+    two (the double partial sums meet in another order); odd element counts (scalar tail) and a batch."""
+    from osvos_pytorch_amd.layers.osvos_layers import class_balanced_cross_entropy_loss_step as one
+    from osvos_pytorch_amd.layers.osvos_layers import class_balanced_cross_entropy_loss_step_multi as multi
+    g = torch.Generator(device="cuda").manual_seed(11)
+    for (n, h, w) in [(1, 37, 53), (2, 64, 66), (3, 16, 17)]:
+        outs = [torch.randn(n, 1, h, w, device="cuda", generator=g) * 3 - 1 for _ in range(5)]
+        lab = (torch.rand(n, 1, h, w, device="cuda", generator=g) > 0.8).float()
+        scales = [0.07, 0.07, 0.07, 0.07, 0.1]
+        r1 = [torch.full((), 2.5, device="cuda") for _ in range(5)]
+        r2 = [torch.full((), 2.5, device="cuda") for _ in range(5)]
+        ref = [one(o, lab, size_average=False, grad_scale=s, running=r) for o, s, r in zip(outs, scales, r1)]
+        losses, grads = multi(outs, lab, size_average=False, grad_scales=scales, running=r2)
+        torch.cuda.synchronize()
+        for k in range(5):
+            assert torch.equal(grads[k], ref[k][1]), k
+            assert abs(float(losses[k]) - float(ref[k][0])) <= 2e-7 * abs(float(ref[k][0])), k
+            assert abs(float(r2[k]) - float(r1[k])) <= 2e-7 * abs(float(r1[k])), k
