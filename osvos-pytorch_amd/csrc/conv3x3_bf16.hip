@@ -31,6 +31,7 @@ struct ConvArgsB {
   int relu, mask_bf16;
   const unsigned* mask_bits;   // ReLU mask as ONE BIT per element ([N][H][W][y_cs / 32] words, bit = channel % 32; maskbits.h): takes precedence over `mask`
   unsigned* y_bits;            // optional: the same for the result (written next to y / ybf by the forward of a layer whose output is a later mask)
+  bf16_t* pooled;              // optional: maxpool2x2 (ceil mode) of the bf16 result, [N][ceil(H/2)][ceil(W/2)][y_cs] (last convolution of a stage; needs ReLU)
   unsigned long long* prof;   // phase cycle counters (only read by builds with -DOSVOS_CONV_PROF; tools/conv_phase_probe.py)
 };
 
@@ -259,6 +260,10 @@ __global__ __launch_bounds__(C::NT, C::OCC) void conv3x3_bf16_kernel(ConvArgsB a
                                                                          a.bias != nullptr ? a.Cout * 4 : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(a.ybf != nullptr ? (void*)(a.ybf + n * img_elems) : anyp, 0,
                                                                          a.ybf != nullptr ? (int)(img_elems * 2) : 0, 0x00020000);
+    const bool pool_fwd = a.pooled != nullptr;
+    const int PHo = (a.H + 1) / 2, PWo = (a.W + 1) / 2;
+    const size_t poimg = (size_t)PHo * PWo * a.y_cs;
+    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(pool_fwd ? (void*)(a.pooled + n * poimg) : anyp, 0, pool_fwd ? (int)(poimg * 2) : 0, 0x00020000);
     // one-bit masks (maskbits.h): words per pixel = y_cs / 32
     const int bw = a.y_cs >> 5;
     const size_t img_words = (size_t)a.H * a.W * bw;
@@ -272,6 +277,7 @@ __global__ __launch_bounds__(C::NT, C::OCC) void conv3x3_bf16_kernel(ConvArgsB a
       f32x4 bv[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) bv[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brs, (cb + 8 * q) * 4, 0, 0));
+      u32x4 keep[C::WM][2];      // (pool forward only: the packed bf16 results of this wave, zero outside the image)
 #pragma unroll
       for (int mi = 0; mi < C::WM; ++mi) {
         const int mb = wm * C::WM + mi;
@@ -326,6 +332,40 @@ __global__ __launch_bounds__(C::NT, C::OCC) void conv3x3_bf16_kernel(ConvArgsB a
             const int co = co0 + (wn * C::WN + ni) * 32 + 16 * pq + 8 * lh;
             const unsigned off = co < a.Cout ? (pix >> 1) + (unsigned)co * 2u : OOB;       // (a.Cout % 8 == 0 checked on the host)
             __builtin_amdgcn_raw_buffer_store_b128(o, hrs, off, 0, 0);
+            if (pool_fwd) keep[mi][pq] = pix != OOB ? o : u32x4{0, 0, 0, 0};
+          }
+        }
+      }
+      if (pool_fwd) {
+        // fused forward pool (this launch is the last convolution of a stage): max over the 2 x 2 window of the packed bf16 results.  Post-ReLU
+        // values are >= 0, so positions outside the image count as 0 and 16-bit UNSIGNED integer max is the bf16 max.
+        // windows: RBW 32 -- M blocks 2j, 2j+1 of this wave are the two rows, lane ^ 1 the neighbouring column;
+        //          RBW 16 -- an M block holds both rows (lanes li and li ^ 16), lane ^ 1 the neighbouring column
+        typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+        constexpr int NP = (C::RBW == 32) ? C::WM / 2 : C::WM;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+          const int mb = wm * C::WM + (C::RBW == 32 ? 2 * j : j);
+          const int oy = y0 + (mb / C::TBX) * C::RBH, ox = x0 + (mb % C::TBX) * C::RBW + li % C::RBW;      // top row of the window pair
+          const bool writer = (li & 1) == 0 && ((C::RBW == 32) || li < 16) && oy < a.H && ox < a.W;
+          const unsigned ppix = writer ? (unsigned)(((oy >> 1) * PWo + (ox >> 1)) * a.y_cs) * 2u : OOB;
+#pragma unroll
+          for (int pq = 0; pq < 2; ++pq) {
+            u16x8 m;
+            if constexpr ((C::RBW == 32)) {
+              m = __builtin_elementwise_max(__builtin_bit_cast(u16x8, keep[2 * j][pq]), __builtin_bit_cast(u16x8, keep[2 * j + 1][pq]));
+            } else {
+              const u32x4 t = keep[j][pq];
+              const u32x4 u = {(unsigned)__shfl_xor((int)t[0], 16, 64), (unsigned)__shfl_xor((int)t[1], 16, 64), (unsigned)__shfl_xor((int)t[2], 16, 64),
+                               (unsigned)__shfl_xor((int)t[3], 16, 64)};
+              m = __builtin_elementwise_max(__builtin_bit_cast(u16x8, t), __builtin_bit_cast(u16x8, u));
+            }
+            const u32x4 t = __builtin_bit_cast(u32x4, m);
+            const u32x4 u = {(unsigned)__shfl_xor((int)t[0], 1, 64), (unsigned)__shfl_xor((int)t[1], 1, 64), (unsigned)__shfl_xor((int)t[2], 1, 64),
+                             (unsigned)__shfl_xor((int)t[3], 1, 64)};
+            m = __builtin_elementwise_max(m, __builtin_bit_cast(u16x8, u));
+            const int co = co0 + (wn * C::WN + ni) * 32 + 16 * pq + 8 * lh;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, m), prs, (co < a.Cout && ppix != OOB) ? ppix + (unsigned)co * 2u : OOB, 0, 0);
           }
         }
       }
@@ -499,13 +539,17 @@ extern "C" void osvos_debug_set_conv_prof(void* p) { g_conv_prof = (unsigned lon
 // xb = 0: x fp32, xb = 1: x bf16; ybf (optional) receives a bf16 copy of y
 int osvos_conv3x3_bf16mfma_io(const void* x, int xb, const void* wpk, const float* bias, const void* mask, int mask_bf16, float* y, void* ybf,
                               int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int tile, hipStream_t stream) {
-  return osvos_conv3x3_bf16mfma_bits(x, xb, wpk, bias, mask, mask_bf16, nullptr, y, ybf, nullptr, N, H, W, Cin, Cout, y_cs, relu, tile, stream);
+  return osvos_conv3x3_bf16mfma_bits(x, xb, wpk, bias, mask, mask_bf16, nullptr, y, ybf, nullptr, nullptr, N, H, W, Cin, Cout, y_cs, relu, tile, stream);
 }
 
 // mask_bits: the ReLU mask as one bit per element (maskbits.h; takes precedence over `mask`); y_bits: sign bits of the result, written beside it
+// pooled_bf16 (optional; needs ybf, ReLU, a dense result with Cout % 8 == 0): maxpool2x2 (ceil mode) of the bf16 result, written by the same launch
+// ([N][ceil(H/2)][ceil(W/2)][Cout]; the 8 x 8-pixel tile cannot hold whole windows per wave: there the pooling kernel is launched behind the convolution)
 int osvos_conv3x3_bf16mfma_bits(const void* x, int xb, const void* wpk, const float* bias, const void* mask, int mask_bf16, const unsigned* mask_bits,
-                                float* y, void* ybf, unsigned* y_bits, int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int tile,
+                                float* y, void* ybf, unsigned* y_bits, void* pooled_bf16, int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int tile,
                                 hipStream_t stream) {
+  OSVOS_ARG_CHECK(pooled_bf16 == nullptr || (ybf != nullptr && relu && mask == nullptr && mask_bits == nullptr && Cout % 8 == 0 && y_cs == Cout),
+                  "conv3x3 bf16: the fused forward pool needs a bf16 result, ReLU, no mask and a dense Cout %% 8 == 0 (Cout %d, stride %d)", Cout, y_cs);
   OSVOS_ARG_CHECK(x && wpk && (y || ybf), "conv3x3 bf16: null pointer");
   OSVOS_ARG_CHECK((mask_bits == nullptr && y_bits == nullptr) || (Cout % 32 == 0 && y_cs == Cout), "conv3x3 bf16: one-bit masks need Cout %% 32 == 0 and a dense result (Cout %d, stride %d)", Cout, y_cs);
   OSVOS_ARG_CHECK((Cout % 4 == 0 && y_cs % 4 == 0) || (y != nullptr && !(mask && mask_bf16)),
@@ -519,7 +563,7 @@ int osvos_conv3x3_bf16mfma_bits(const void* x, int xb, const void* wpk, const fl
   ConvArgsB a;
   a.x = x; a.wpk = reinterpret_cast<const uint4*>(wpk); a.bias = bias; a.mask = mask; a.mask_bf16 = mask_bf16 ? 1 : 0; a.y = y;
   a.ybf = reinterpret_cast<bf16_t*>(ybf);
-  a.mask_bits = mask_bits; a.y_bits = y_bits;
+  a.mask_bits = mask_bits; a.y_bits = y_bits; a.pooled = reinterpret_cast<bf16_t*>(pooled_bf16);
   a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.CinP = (Cin + 31) / 32 * 32; a.Cout = Cout; a.CoutP = osvos_cout_pad(Cout); a.y_cs = y_cs;
   a.relu = relu;
   a.prof = g_conv_prof;
@@ -541,7 +585,12 @@ int osvos_conv3x3_bf16mfma_bits(const void* x, int xb, const void* wpk, const fl
   tile %= 100;
   if (xb && tile >= 30 && tile <= 35) {      // LDS-DMA staged kernel
     OSVOS_ARG_CHECK(osvos_conv3x3_bf16_dma_applicable(Cin, Cout, y_cs), "conv3x3 bf16: tile %d (DMA staging) needs Cin %% 16 == 0, Cout, y_cs %% 8 == 0", tile);
-    return osvos_conv3x3_bf16_dma(x, wpk, bias, mask, mask_bf16, mask_bits, y, ybf, y_bits, N, H, W, Cin, Cout, y_cs, relu, tile - 30, a.map, stream);
+    return osvos_conv3x3_bf16_dma(x, wpk, bias, mask, mask_bf16, mask_bits, y, ybf, y_bits, pooled_bf16, N, H, W, Cin, Cout, y_cs, relu, tile - 30, a.map, stream);
+  }
+  if (a.pooled != nullptr && !(xb && tile != 7 && tile >= 0 && tile < kNumTilesB)) {      // a tile whose waves do not hold whole windows: separate pooling launch
+    a.pooled = nullptr;
+    const int rc = osvos_conv3x3_bf16mfma_bits(x, xb, wpk, bias, mask, mask_bf16, mask_bits, y, ybf, y_bits, nullptr, N, H, W, Cin, Cout, y_cs, relu, tile + 100 * a.map, stream);
+    return rc ? rc : osvos_maxpool2x2_bf16(ybf, pooled_bf16, N, H, W, Cout, stream);
   }
   if (xb) {
     switch (tile) {

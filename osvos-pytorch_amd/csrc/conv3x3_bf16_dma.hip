@@ -33,6 +33,7 @@ struct DmaArgs {
   int relu, mask_bf16;
   const unsigned* mask_bits;   // one-bit-per-element ReLU mask (maskbits.h); takes precedence over `mask`
   unsigned* y_bits;            // optional: sign bits of the result
+  bf16_t* pooled;              // optional: maxpool2x2 (ceil mode) of the bf16 result, [N][ceil(H/2)][ceil(W/2)][y_cs] (last convolution of a stage; needs ReLU)
 };
 
 constexpr int TW = 32, HWD = TW + 2;
@@ -260,6 +261,10 @@ __global__ __launch_bounds__(64 * 2 * WGM, WGM == 4 ? 2 : 1) void conv3x3_bf16_d
                                                                          a.bias != nullptr ? a.Cout * 4 : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(a.ybf != nullptr ? (void*)(a.ybf + n * img_elems) : anyp, 0,
                                                                          a.ybf != nullptr ? (int)(img_elems * 2) : 0, 0x00020000);
+    const bool pool_fwd = a.pooled != nullptr;
+    const int PHo = (a.H + 1) / 2, PWo = (a.W + 1) / 2;
+    const size_t poimg = (size_t)PHo * PWo * a.y_cs;
+    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(pool_fwd ? (void*)(a.pooled + n * poimg) : anyp, 0, pool_fwd ? (int)(poimg * 2) : 0, 0x00020000);
     // one-bit masks (maskbits.h): words per pixel = y_cs / 32
     const int bw = a.y_cs >> 5;
     const size_t img_words = (size_t)a.H * a.W * bw;
@@ -273,6 +278,7 @@ __global__ __launch_bounds__(64 * 2 * WGM, WGM == 4 ? 2 : 1) void conv3x3_bf16_d
       f32x4 bv[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) bv[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brs, (cb + 8 * q) * 4, 0, 0));
+      u32x4 keep[C::WM][2];      // (pool forward only: the packed bf16 results of this wave, zero outside the image)
 #pragma unroll
       for (int mi = 0; mi < C::WM; ++mi) {
         const int oy = y0 + wm * C::WM + mi, ox = x0 + li;
@@ -322,6 +328,39 @@ __global__ __launch_bounds__(64 * 2 * WGM, WGM == 4 ? 2 : 1) void conv3x3_bf16_d
             const int co = co0 + (wn * C::WN + ni) * 32 + 16 * pq + 8 * lh;
             const unsigned off = co < a.Cout ? (pix >> 1) + (unsigned)co * 2u : OOB;
             __builtin_amdgcn_raw_buffer_store_b128(o, hrs, off, 0, 0);
+            if (pool_fwd) keep[mi][pq] = pix != OOB ? o : u32x4{0, 0, 0, 0};
+          }
+        }
+      }
+      if (pool_fwd) {
+        // fused forward pool (this launch is the last convolution of a stage): max over the 2 x 2 window of the packed bf16 results.  Post-ReLU
+        // values are >= 0, so positions outside the image count as 0 and 16-bit UNSIGNED integer max is the bf16 max.
+        // windows: RBW 32 -- M blocks 2j, 2j+1 of this wave are the two rows, lane ^ 1 the neighbouring column;
+        //          RBW 16 -- an M block holds both rows (lanes li and li ^ 16), lane ^ 1 the neighbouring column
+        typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+        constexpr int NP = true ? C::WM / 2 : C::WM;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+          const int oy = y0 + wm * C::WM + 2 * j, ox = x0 + li;      // top row of the window pair
+          const bool writer = (li & 1) == 0 && (true || li < 16) && oy < a.H && ox < a.W;
+          const unsigned ppix = writer ? (unsigned)(((oy >> 1) * PWo + (ox >> 1)) * a.y_cs) * 2u : OOB;
+#pragma unroll
+          for (int pq = 0; pq < 2; ++pq) {
+            u16x8 m;
+            if constexpr (true) {
+              m = __builtin_elementwise_max(__builtin_bit_cast(u16x8, keep[2 * j][pq]), __builtin_bit_cast(u16x8, keep[2 * j + 1][pq]));
+            } else {
+              const u32x4 t = keep[j][pq];
+              const u32x4 u = {(unsigned)__shfl_xor((int)t[0], 16, 64), (unsigned)__shfl_xor((int)t[1], 16, 64), (unsigned)__shfl_xor((int)t[2], 16, 64),
+                               (unsigned)__shfl_xor((int)t[3], 16, 64)};
+              m = __builtin_elementwise_max(__builtin_bit_cast(u16x8, t), __builtin_bit_cast(u16x8, u));
+            }
+            const u32x4 t = __builtin_bit_cast(u32x4, m);
+            const u32x4 u = {(unsigned)__shfl_xor((int)t[0], 1, 64), (unsigned)__shfl_xor((int)t[1], 1, 64), (unsigned)__shfl_xor((int)t[2], 1, 64),
+                             (unsigned)__shfl_xor((int)t[3], 1, 64)};
+            m = __builtin_elementwise_max(m, __builtin_bit_cast(u16x8, u));
+            const int co = co0 + (wn * C::WN + ni) * 32 + 16 * pq + 8 * lh;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, m), prs, (co < a.Cout && ppix != OOB) ? ppix + (unsigned)co * 2u : OOB, 0, 0);
           }
         }
       }
@@ -375,7 +414,7 @@ bool osvos_conv3x3_bf16_dma_applicable(int Cin, int Cout, int y_cs) { return Cin
 // 4 / 5: variants 0 / 2 as persistent workgroups (one per CU, tiles pipelined back to back);
 // map = 1: XCD-local spatial block order
 int osvos_conv3x3_bf16_dma(const void* x, const void* wpk, const float* bias, const void* mask, int mask_bf16, const unsigned* mask_bits, float* y, void* ybf,
-                           unsigned* y_bits, int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int variant, int map, hipStream_t stream) {
+                           unsigned* y_bits, void* pooled_bf16, int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int variant, int map, hipStream_t stream) {
   OSVOS_ARG_CHECK(x && wpk && (y || ybf), "conv3x3 bf16 dma: null pointer");
   OSVOS_ARG_CHECK(N > 0 && H > 0 && W > 0 && osvos_conv3x3_bf16_dma_applicable(Cin, Cout, y_cs) && y_cs >= Cout,
                   "conv3x3 bf16 dma: needs Cin %% 16 == 0, Cout %% 8 == 0, y_cs %% 8 == 0 (got %d, %d, %d)", Cin, Cout, y_cs);
@@ -383,7 +422,7 @@ int osvos_conv3x3_bf16_dma(const void* x, const void* wpk, const float* bias, co
   DmaArgs a;
   a.x = reinterpret_cast<const bf16_t*>(x); a.wpk = reinterpret_cast<const uint4*>(wpk); a.bias = bias; a.mask = mask; a.mask_bf16 = mask_bf16 ? 1 : 0;
   a.y = y; a.ybf = reinterpret_cast<bf16_t*>(ybf);
-  a.mask_bits = mask_bits; a.y_bits = y_bits;
+  a.mask_bits = mask_bits; a.y_bits = y_bits; a.pooled = reinterpret_cast<bf16_t*>(pooled_bf16);
   a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.CinP = (Cin + 31) / 32 * 32; a.Cout = Cout; a.CoutP = osvos_cout_pad(Cout); a.y_cs = y_cs;
   a.relu = relu; a.map = map ? 1 : 0;
   switch (variant) {

@@ -90,7 +90,7 @@ int osvos_conv3x3_bf16mfma(const float* x, const void* wpk, const float* bias, c
 int osvos_conv3x3_bf16mfma_num_tiles(void);
 // xb = 1: x is bf16 NHWC; ybf (optional): bf16 copy of y
 int osvos_conv3x3_bf16mfma_bits(const void* x, int xb, const void* wpk, const float* bias, const void* mask, int mask_bf16, const unsigned* mask_bits,
-                                float* y, void* ybf, unsigned* y_bits, int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int tile,
+                                float* y, void* ybf, unsigned* y_bits, void* pooled_bf16, int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int tile,
                                 hipStream_t stream);
 int osvos_conv3x3_bf16mfma_io(const void* x, int xb, const void* wpk, const float* bias, const void* mask, int mask_bf16, float* y, void* ybf,
                               int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int tile, hipStream_t stream);
@@ -98,7 +98,7 @@ int osvos_conv3x3_bf16mfma_xb_tiles(int* tiles, int max);
 // LDS-DMA staged variant (bf16 activations only): conv3x3_bf16_dma.hip; reached through tile ids 30..33 (256 px x 128 / 64 co with 4 waves, 512 px x 128 / 64 co with 8 waves)
 bool osvos_conv3x3_bf16_dma_applicable(int Cin, int Cout, int y_cs);
 int osvos_conv3x3_bf16_dma(const void* x, const void* wpk, const float* bias, const void* mask, int mask_bf16, const unsigned* mask_bits, float* y, void* ybf,
-                           unsigned* y_bits, int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int variant, int map, hipStream_t stream);
+                           unsigned* y_bits, void* pooled_bf16, int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int variant, int map, hipStream_t stream);
 
 // bf16-operand weight gradient (fp32 tensors): wgrad_bf16.hip
 bool osvos_wgrad_bf16_applicable(int Cin_s, int Cout);

@@ -308,7 +308,7 @@ inline bool use_presplit() {
 // (epi: fused pooling epilogues, f32x3 only -- fuse_pool() says when the caller may ask for them)
 inline int conv_main(const void* x, const void* x_b, const void* wpk, const float* bias, const void* mask, const void* mask_b, void* y, void* y_b,
                      int N, int h, int w, int cin, int cout, int y_cs, int relu, int dtype, void* part, hipStream_t stream, const void* wpk3 = nullptr,
-                     const ConvEpi* epi = nullptr, const void* mask_bits = nullptr, void* y_bits = nullptr) {
+                     const ConvEpi* epi = nullptr, const void* mask_bits = nullptr, void* y_bits = nullptr, void* pooled_b = nullptr) {
   if (dtype == OSVOS_F32_X3 && osvos_conv3x3_f32x3_applicable(cin, cout, y_cs)) {    // three-way bf16 split on the bf16 matrix pipe
     ConvEpi e2;
     if (epi != nullptr) e2 = *epi;
@@ -323,7 +323,7 @@ inline int conv_main(const void* x, const void* x_b, const void* wpk, const floa
     return osvos_conv3x3_f32_ws((const float*)x, (const float*)wpk, bias, (const float*)mask, (float*)y, N, h, w, cin, cout, y_cs,
                                 relu, -1, part, stream);
   return osvos_conv3x3_bf16mfma_bits(x_b ? x_b : x, x_b ? 1 : 0, wpk, bias, mask_b ? mask_b : mask, mask_b ? 1 : 0, (const unsigned*)mask_bits, (float*)y, y_b,
-                                     (unsigned*)y_bits, N, h, w, cin, cout, y_cs, relu, -1, stream);
+                                     (unsigned*)y_bits, pooled_b, N, h, w, cin, cout, y_cs, relu, -1, stream);
 }
 
 // f32x3: the pooling kernels of the stage boundaries can run as epilogues of the convolutions next to them (epi.h).  Measured at 854x480
@@ -338,9 +338,9 @@ inline bool fuse_flag(const char* name, bool dflt) {
   if (all) return all[0] != '0';
   return dflt;
 }
-inline bool fuse_pool(int dtype) {      // forward
+inline bool fuse_pool(int dtype) {      // forward: f32x3 (fp32 tensors) and the bf16-store mode (bf16 tensors; conv3x3_bf16*.hip)
   static const bool on = fuse_flag("OSVOS_FUSE_POOL_FWD", true);
-  return on && dtype == OSVOS_F32_X3;
+  return on && (dtype == OSVOS_F32_X3 || use_store(dtype));
 }
 inline bool fuse_pool_bwd(int dtype) {
   static const bool on = fuse_flag("OSVOS_FUSE_POOL_BWD", false);
@@ -743,7 +743,7 @@ int osvos_net_forward(const float* x_nchw, const void* wbuf, void* ws, float* co
     const int h = L.hs[si], w = L.ws[si];
     if (si > 0 && fuse_pool(dtype)) {      // pooled[si] was written by the previous stage's last convolution
       cur = at(ws, L.pooled[si]);
-      cur_b = nullptr;
+      cur_b = store ? at(ws, L.pooled_b[si]) : nullptr;
     } else if (si > 0) {
       if (store)
         rc = osvos_maxpool2x2_bf16(cur_b, at(ws, L.pooled_b[si]), N, L.hs[si - 1], L.ws[si - 1], kStageC[si - 1], stream);
@@ -759,11 +759,11 @@ int osvos_net_forward(const float* x_nchw, const void* wbuf, void* ws, float* co
         ProfScope ps(OSVOS_PROF_CONV_FWD, conv_flops(N, h, w, d[l].cin, d[l].cout), stream);
         ConvEpi epi;
         const bool pool_here = fuse_pool(dtype) && si < 4 && j == kStageN[si] - 1;      // last convolution of stages 0-3: + the pooled tensor
-        if (pool_here) epi.pooled = reinterpret_cast<float*>(at(ws, L.pooled[si + 1]));
+        if (pool_here && !store) epi.pooled = reinterpret_cast<float*>(at(ws, L.pooled[si + 1]));
         rc = conv_main(cur, cur_b, at(wbuf, P.fwd[l]), reinterpret_cast<const float*>(at(wbuf, P.bias[l])), nullptr, nullptr,
                        f32(L.act[l]), sh(L.act_b[l]), N, h, w, d[l].cin_s, d[l].cout, d[l].cout, 1, dtype, at(ws, L.conv_part), stream,
-                       P.fwd3[l] != (size_t)-1 ? at(wbuf, P.fwd3[l]) : nullptr, pool_here ? &epi : nullptr, nullptr,
-                       L.bits[l] != (size_t)-1 ? at(ws, L.bits[l]) : nullptr);
+                       P.fwd3[l] != (size_t)-1 ? at(wbuf, P.fwd3[l]) : nullptr, (pool_here && !store) ? &epi : nullptr, nullptr,
+                       L.bits[l] != (size_t)-1 ? at(ws, L.bits[l]) : nullptr, (pool_here && store) ? at(ws, L.pooled_b[si + 1]) : nullptr);
       }
       if (rc) return rc;
       cur = at(ws, L.act[l]);

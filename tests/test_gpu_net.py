@@ -587,16 +587,20 @@ def test_one_bit_relu_masks_change_nothing_but_the_bytes_read(tmp_path, precisio
         np.savez(sys.argv[1], **res)
     ''') % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     got = {}
-    for bits in ("0", "1"):
-        out = str(tmp_path / ("m%s.npz" % bits))
+    variants = {"0": dict(OSVOS_MASK_BITS="0"), "1": dict(OSVOS_MASK_BITS="1")}
+    if precision == "bf16":      # the same for the forward pool fused into the bf16 convolutions' epilogue (max of the same stored bf16 values)
+        variants["nopool"] = dict(OSVOS_MASK_BITS="1", OSVOS_FUSE_POOL_FWD="0")
+    for tag, env in variants.items():
+        out = str(tmp_path / ("m%s.npz" % tag))
         # (OSVOS_X3_KSPLIT=1: a layer that writes bits is never cut along K; the comparison run must sum in the same order)
-        subprocess.run([sys.executable, "-c", code, out, precision], check=True, env=dict(os.environ, OSVOS_MASK_BITS=bits, OSVOS_X3_KSPLIT="1"), timeout=900)
-        got[bits] = dict(np.load(out))
-    a, b = got["0"], got["1"]
-    assert a.keys() == b.keys() and len(a) > 120
-    for k in a:
-        assert np.isfinite(b[k]).all(), k
-        assert np.array_equal(a[k], b[k]), (k, float(np.abs(a[k] - b[k]).max()))
+        subprocess.run([sys.executable, "-c", code, out, precision], check=True, env=dict(os.environ, OSVOS_X3_KSPLIT="1", **env), timeout=900)
+        got[tag] = dict(np.load(out))
+    for other in [t for t in variants if t != "1"]:
+        a, b = got[other], got["1"]
+        assert a.keys() == b.keys() and len(a) > 120
+        for k in a:
+            assert np.isfinite(b[k]).all(), k
+            assert np.array_equal(a[k], b[k]), (other, k, float(np.abs(a[k] - b[k]).max()))
 
 
 def test_pooling_fused_into_the_convolutions_is_bit_identical_to_its_own_launches(tmp_path):
