@@ -84,10 +84,11 @@ def conv_gflop_parts(h, w):
 
 
 # f32x3: which passes still run on the EXACT fp32 MFMA kernels (1 executed FLOP per algorithmic FLOP, not 6): conv1_1's forward (Cin = 3) and
-# weight gradient, and the side_prep (Cout = 16) weight gradients unless OSVOS_X3_SIDE_WGRAD puts them on the bf16 pipe (csrc/net.cpp)
-def x3_exact_gflop(h, w, side_wgrad_exact=True):
+# weight gradient, its input gradient on the fp32 FMA kernel (dgrad_c3.hip, unless OSVOS_DGRAD_C3=0), and the side_prep (Cout = 16) weight
+# gradients unless OSVOS_X3_SIDE_WGRAD puts them on the bf16 pipe (csrc/net.cpp)
+def x3_exact_gflop(h, w, side_wgrad_exact=True, input_grad_exact=True):
     c11, side = conv_gflop_parts(h, w)
-    return {"fwd": c11, "bwd": c11 + (side if side_wgrad_exact else 0.0)}
+    return {"fwd": c11, "bwd": c11 + (c11 if input_grad_exact else 0.0) + (side if side_wgrad_exact else 0.0)}
 
 
 def synth_problem(n, h, w, device, seed):
@@ -546,7 +547,8 @@ def measure(wl, steps, warmup, min_seconds, world, ctl, device, use_prof=True, s
     # gradient; the side_prep weight gradients unless they run on the bf16 pipe) -- per family, from the layers' own FLOP shares
     mult_f = mult_b = mult_s = 1.0
     if x3:
-        ex = x3_exact_gflop(wl.h, wl.w, side_wgrad_exact=os.environ.get("OSVOS_X3_SIDE_WGRAD", "1") == "0")
+        ex = x3_exact_gflop(wl.h, wl.w, side_wgrad_exact=os.environ.get("OSVOS_X3_SIDE_WGRAD", "1") == "0",
+                            input_grad_exact=os.environ.get("OSVOS_DGRAD_C3", "1") != "0" and wl.mode != "infer")
         gf1 = conv_gflop_forward(wl.h, wl.w)
         mult_f = 6.0 - 5.0 * ex["fwd"] / gf1
         mult_b = 6.0 - 5.0 * ex["bwd"] / (2.0 * gf1)
