@@ -566,8 +566,8 @@ def measure(wl, steps, warmup, min_seconds, world, ctl, device, use_prof=True, s
             return {}
         return {"executed_over_algorithmic": round(m, 4), "algorithmic_tflops": round(alg_tflops, 2),
                 "algorithmic_over_fp32_mfma_peak": round(alg_tflops / FP32_MFMA_PEAK_TFLOPS, 4),
-                "note": "f32x3: 6 bf16 MFMA products per fp32 product; the passes that stay on the exact fp32 kernels (conv1_1 forward / weight "
-                        "gradient%s) are counted at 1x" % ("" if os.environ.get("OSVOS_X3_SIDE_WGRAD", "1") != "0" else ", side_prep weight gradients")}
+                "note": "f32x3: 6 bf16 MFMA products per fp32 product; the passes that stay on fp32 kernels (conv1_1 forward / weight "
+                        "gradient / input gradient%s) are counted at 1x" % ("" if os.environ.get("OSVOS_X3_SIDE_WGRAD", "1") != "0" else ", side_prep weight gradients")}
     if wl.mode == "infer" and wl.graph:
         # one captured graph per step: the family is the whole forward (17 conv launches + glue)
         ach = mult_f * gf_fwd / 1e3 / (elapsed / steps)
