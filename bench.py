@@ -450,25 +450,37 @@ class AbiCtl:
         self.comm.close()
 
 
-def timed_region(wl, steps, ctl, device, prof_lib=None):
-    """barrier + synchronize, `steps` x step(), synchronize + barrier; returns (seconds [max over ranks], prof tuple)."""
+def prepare_region(steps, prof_lib=None):
+    """Everything a timed region needs that takes host time while the GPU idles -- the launch events of the instrumented steps (created and
+    first-recorded here), a full cyclic-GC pass -- done BEFORE the warm-up steps, so that nothing but barrier + synchronize stands between the last
+    warm-up step and t0.  (With this work between warm-up and t0 the device sat idle for tens of milliseconds and the 0.09 s region started on a
+    device that had begun to leave its loaded power state again: `value` read 4-5 % under `sustained` however long the settle phase was --
+    tools/ab_settle.sh, profiles/r03_step_curve.txt.)"""
     from osvos_pytorch_amd import _lib
-    if ctl is not None:
-        ctl.barrier()
-    torch.cuda.synchronize()
-    # launch events: every PROF_EVERY-th step of the region is instrumented (an event pair around each of its ~56 conv launches / regions);
-    # the others run exactly as they would without bench.py looking.  Events are created and first-recorded before t0.
     every = PROF_EVERY if steps >= 2 * PROF_EVERY else 1
     n_prof = (steps + every - 1) // every
     if prof_lib is not None:
         _lib.check(prof_lib.osvos_prof_start(n_prof * 64 + 64), "prof_start")
         prof_lib.osvos_prof_pause(1)
         torch.cuda.synchronize()
+    gc.collect()
+
+
+def timed_region(wl, steps, ctl, device, prof_lib=None):
+    """barrier + synchronize, `steps` x step(), synchronize + barrier; returns (seconds [max over ranks], prof tuple).  prepare_region() ran
+    before the warm-up steps."""
+    from osvos_pytorch_amd import _lib
+    # launch events: every PROF_EVERY-th step of the region is instrumented (an event pair around each of its ~56 conv launches / regions);
+    # the others run exactly as they would without bench.py looking.
+    every = PROF_EVERY if steps >= 2 * PROF_EVERY else 1
+    n_prof = (steps + every - 1) // every
     # host hygiene for a region that may be only 0.1 s long: no cyclic-GC pass in the middle of it (a generation-2 collection of a
     # process that has imported torch costs tens of milliseconds)
-    gc.collect()
     gc_was = gc.isenabled()
     gc.disable()
+    if ctl is not None:
+        ctl.barrier()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(steps):
         if prof_lib is not None and i % every == 0:
@@ -506,6 +518,8 @@ def measure(wl, steps, warmup, min_seconds, world, ctl, device, use_prof=True, s
     # reappears after one second of idling in the SAME process and a register-only MFMA loop does not remove it: tools/step_curve.py,
     # profiles/r03_step_curve.txt).  With --warmup 5 --steps 20 the timed region would sit entirely inside that ramp; the line says how many
     # settle steps ran (`setup_settle_steps`; --settle-seconds 0 turns them off).
+    prof = use_prof and not (wl.mode == "infer" and wl.graph) and not getattr(wl, "graph_train", False)
+    prepare_region(steps, lib if prof else None)      # (host-side preparation of the timed region: before ANY of the steps below)
     settle_done = 0
     if settle_seconds > 0:
         unit = wl.n_ave if wl.mode != "infer" else 1          # whole optimizer steps
@@ -526,7 +540,6 @@ def measure(wl, steps, warmup, min_seconds, world, ctl, device, use_prof=True, s
     res_settle = settle_done
     for _ in range(warmup):
         wl.step()
-    prof = use_prof and not (wl.mode == "infer" and wl.graph) and not getattr(wl, "graph_train", False)
     elapsed, (ms, fl, cnt), n_prof = timed_region(wl, steps, ctl, device, lib if prof else None)
     frames = steps * wl.batch * world
     res = {"value": frames / elapsed, "ms_per_step": elapsed / steps * 1e3, "elapsed": elapsed, "timing_detail": dict(TIMING_DETAIL),
