@@ -225,7 +225,8 @@ int osvos_scale(const float* x, const float* scalar, float* y, long count, void*
  *   wbuf:   persistent buffer of osvos_net_wbuf_bytes(): packed weights (refresh with
  *           osvos_net_pack whenever a parameter changed, e.g. after optimizer.step())
  *   ws:     per-call workspace of osvos_net_ws_bytes(); forward leaves the activations the
- *           backward needs in it
+ *           backward needs in it (and, in the bf16-store and f32x3 modes, the SIGN BITS of the activations that mask a later data
+ *           gradient -- one 32-bit word per pixel and 32 channels, csrc/maskbits.h -- so the same ws must go to the backward untouched)
  *   outs:   host array of 5 device pointers, fp32 [N,1,H,W] */
 size_t osvos_net_wbuf_bytes(int dtype);
 size_t osvos_net_ws_bytes(int N, int H, int W, int dtype);
