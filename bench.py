@@ -84,9 +84,8 @@ def conv_gflop_parts(h, w):
 
 
 # f32x3: which passes still run on the EXACT fp32 MFMA kernels (1 executed FLOP per algorithmic FLOP, not 6): conv1_1's forward (Cin = 3) and
-# weight gradient, its input gradient on the fp32 FMA kernel (dgrad_c3.hip, unless OSVOS_DGRAD_C3=0), and the side_prep (Cout = 16) weight
-# gradients unless OSVOS_X3_SIDE_WGRAD puts them on the bf16 pipe (csrc/net.cpp)
-def x3_exact_gflop(h, w, side_wgrad_exact=True, input_grad_exact=True):
+# weight gradient and its input gradient on the fp32 FMA kernel (dgrad_c3.hip).  (The side_prep weight gradients run on the bf16 pipe: S16 form.)
+def x3_exact_gflop(h, w, side_wgrad_exact=False, input_grad_exact=True):
     c11, side = conv_gflop_parts(h, w)
     return {"fwd": c11, "bwd": c11 + (c11 if input_grad_exact else 0.0) + (side if side_wgrad_exact else 0.0)}
 
@@ -556,12 +555,11 @@ def measure(wl, steps, warmup, min_seconds, world, ctl, device, use_prof=True, s
     # bounds those kernels is the bf16 dense peak; `achieved` counts the EXECUTED bf16 FLOPs (6 x algorithmic), the algorithmic rate
     # and its ratio to the fp32-MFMA peak (the roofline of the exact kernels, which this mode is free to exceed) are given next to it.
     x3 = wl.precision == "fp32x3"
-    # executed / algorithmic FLOPs: 6 where a pass runs as f32x3, 1 where it stays on the exact fp32 kernel (conv1_1 forward and weight
-    # gradient; the side_prep weight gradients unless they run on the bf16 pipe) -- per family, from the layers' own FLOP shares
+    # executed / algorithmic FLOPs: 6 where a pass runs as f32x3, 1 where it stays on the exact fp32 kernel (conv1_1 forward, weight
+    # gradient and input gradient) -- per family, from the layers' own FLOP shares
     mult_f = mult_b = mult_s = 1.0
     if x3:
-        ex = x3_exact_gflop(wl.h, wl.w, side_wgrad_exact=os.environ.get("OSVOS_X3_SIDE_WGRAD", "1") == "0",
-                            input_grad_exact=os.environ.get("OSVOS_DGRAD_C3", "1") != "0" and wl.mode != "infer")
+        ex = x3_exact_gflop(wl.h, wl.w, side_wgrad_exact=False, input_grad_exact=wl.mode != "infer")
         gf1 = conv_gflop_forward(wl.h, wl.w)
         mult_f = 6.0 - 5.0 * ex["fwd"] / gf1
         mult_b = 6.0 - 5.0 * ex["bwd"] / (2.0 * gf1)
@@ -580,7 +578,7 @@ def measure(wl, steps, warmup, min_seconds, world, ctl, device, use_prof=True, s
         return {"executed_over_algorithmic": round(m, 4), "algorithmic_tflops": round(alg_tflops, 2),
                 "algorithmic_over_fp32_mfma_peak": round(alg_tflops / FP32_MFMA_PEAK_TFLOPS, 4),
                 "note": "f32x3: 6 bf16 MFMA products per fp32 product; the passes that stay on fp32 kernels (conv1_1 forward / weight "
-                        "gradient / input gradient%s) are counted at 1x" % ("" if os.environ.get("OSVOS_X3_SIDE_WGRAD", "1") != "0" else ", side_prep weight gradients")}
+                        "gradient / input gradient) are counted at 1x"}
     if wl.mode == "infer" and wl.graph:
         # one captured graph per step: the family is the whole forward (17 conv launches + glue)
         ach = mult_f * gf_fwd / 1e3 / (elapsed / steps)

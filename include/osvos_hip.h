@@ -104,32 +104,6 @@ int osvos_conv3x3_splitk(const void* x, const void* wpk, const float* bias, cons
  * kernel (fp32 FMAs, filter through scalar loads) in place of a 32-cout MFMA tile that would waste 10x the matrix work. */
 int osvos_conv3x3_dgrad_c3(const float* dy, const float* wpk_dgrad, float* dx_nchw, int N, int H, int W, int Cout, void* stream);
 
-/* ---- P3 operand storage for the f32x3 arithmetic ------------------------------------------------------------------------
- * A "P3" tensor is an fp32 NHWC tensor held as its three bf16 pieces: [N][3][H][W][C] bf16, plane 0 = hi = bf16(v), plane 1 = mid =
- * bf16(v - hi), plane 2 = lo = bf16(v - hi - mid) (round-to-nearest-even; v = hi + mid + lo EXACTLY: a lossless 6-byte encoding).
- * It is what the f32x3 kernels multiply; with the pieces formed once in the producer's epilogue the consumers stage their operands
- * by LDS-DMA / plain copies.  osvos_net_* use it internally for dtype OSVOS_F32_X3 when OSVOS_X3_P3=1 (opt-in: measured 3-5 % slower than fp32 tensors split while staging).
- *   osvos_f32_to_p3_abi / osvos_p3_to_f32_abi: conversions (src channel stride cs, C channels copied, dst channel stride cd % 8 == 0,
- *     padding channels zero; the way back needs C % 4 == 0 and a dense source).
- *   osvos_conv3x3_p3_abi: y = epi(bias + conv3x3(x)) as osvos_conv3x3, x3 a P3 tensor (Cin % 16 == 0), wpk3 from
- *     osvos_pack_conv3x3_x3 (dgrad != 0: the data gradient's filter); results as fp32 NHWC (y, channel stride y_cs) and / or as a P3
- *     tensor (y3, channel stride y3_cs; needs Cout % 8 == 0) -- at least one; mask: fp32 NHWC, or (mask_is_p3) a P3 tensor whose plane 0
- *     is read, channel stride mask_cs; tile -1 = automatic, 0 .. osvos_conv3x3_p3_tiles()-1 (+100: XCD-local halo map); ksplit 0 =
- *     automatic, 1..8 with part_ws of osvos_conv3x3_p3_ws_bytes() (NULL = never split).
- *   osvos_conv3x3_wgrad_p3_abi: dW / db as osvos_conv3x3_wgrad from P3 x and P3 dy (wide layers: Cin_s, Cout multiples of 64);
- *     workspace of osvos_wgrad_ws_bytes(.., OSVOS_F32_X3).
- *   osvos_maxpool2x2_p3_abi: fp32 x -> P3 y3 (and fp32 y when non-NULL); osvos_maxpool2x2_bwd_p3_abi: the fused pool backward of
- *     osvos_maxpool2x2_bwd from fp32 x / dy / dside -> P3 dx3 (and fp32 dx when non-NULL).  C % 8 == 0. */
-int osvos_f32_to_p3_abi(const float* src, void* dst3, int N, int H, int W, int C, int cs, int cd, void* stream);
-int osvos_p3_to_f32_abi(const void* src3, float* dst, int N, int H, int W, int C, void* stream);
-int osvos_conv3x3_p3_tiles(void);
-size_t osvos_conv3x3_p3_ws_bytes(int N, int H, int W, int Cout);
-int osvos_conv3x3_p3_abi(const void* x3, const void* wpk3, const float* bias, const void* mask, int mask_is_p3, int mask_cs, float* y, int y_cs,
-                         void* y3, int y3_cs, int N, int H, int W, int Cin, int Cout, int relu, int tile, int ksplit, void* part_ws, void* stream);
-int osvos_conv3x3_wgrad_p3_abi(const void* x3, const void* dy3, void* ws, float* dw, float* db, int N, int H, int W, int Cin, int Cin_s,
-                               int Cout, int Cout_s, int accumulate, void* stream);
-int osvos_maxpool2x2_p3_abi(const float* x, float* y, void* y3, int N, int H, int W, int C, void* stream);
-int osvos_maxpool2x2_bwd_p3_abi(const float* x, const float* dy, const float* dside, float* dx, void* dx3, int N, int H, int W, int C, void* stream);
 
 /* ---- bf16 operand storage for the bf16-MFMA path (dtype OSVOS_F32_BF16MFMA) ------------------------------------------
  * The convolutions of that path round their operands to bf16 anyway; producers can hand the rounded tensor over
@@ -280,8 +254,7 @@ int osvos_comm_destroy(void* comm);
  * outputs, 13..16 pooled inputs of stages 1-4, 17..20 side_prep outputs, 21 NHWC input.  (fp32 elements; with dtype
  * OSVOS_F32_BF16MFMA the trunk tensors 0..16 are bf16 unless OSVOS_BF16_STORE=0.) */
 int osvos_net_ws_query(int N, int H, int W, int dtype, int which, size_t* offset, size_t* elems, int* channels, int* h, int* w);
-/* storage format of trunk tensor `which` (0..16) for `dtype`: 0 fp32 NHWC, 1 bf16 NHWC (OSVOS_F32_BF16MFMA store mode),
- * 2 P3 (OSVOS_F32_X3: [N][3][H][W][C] bf16 pieces, 6 bytes per element; stage 0 keeps fp32) */
+/* storage format of trunk tensor `which` (0..16) for `dtype`: 0 fp32 NHWC, 1 bf16 NHWC (OSVOS_F32_BF16MFMA store mode) */
 int osvos_net_ws_format(int dtype, int which);
 
 /* ---- training-time input pipeline (dataloaders/davis_2016.py:99-106 + custom_transforms.py: flip, ScaleNRotate, ToTensor) ------

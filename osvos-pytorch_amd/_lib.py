@@ -54,14 +54,6 @@ PROTOTYPES = {
     "osvos_maxpool2x2_bf16copy": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "osvos_maxpool2x2_bwd_bf16copy": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "osvos_conv3x3_dgrad_c3": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
-    "osvos_f32_to_p3_abi": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
-    "osvos_p3_to_f32_abi": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
-    "osvos_conv3x3_p3_tiles": (_i, []),
-    "osvos_conv3x3_p3_ws_bytes": (_sz, [_i, _i, _i, _i]),
-    "osvos_conv3x3_p3_abi": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
-    "osvos_conv3x3_wgrad_p3_abi": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
-    "osvos_maxpool2x2_p3_abi": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
-    "osvos_maxpool2x2_bwd_p3_abi": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "osvos_wgrad_ws_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "osvos_conv3x3_wgrad": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "osvos_maxpool2x2": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),

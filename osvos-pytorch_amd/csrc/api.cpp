@@ -147,30 +147,6 @@ int osvos_conv3x3_dgrad_c3(const float* dy, const float* wpk_dgrad, float* dx_nc
   return osvos_conv3x3_dgrad_c3_f32(dy, wpk_dgrad, dx_nchw, N, H, W, Cout, (hipStream_t)stream);
 }
 
-// ---- P3 storage of the f32x3 arithmetic (p3.h): fp32 tensors held as their three bf16 piece planes [N][3][H][W][C] ----
-int osvos_f32_to_p3_abi(const float* src, void* dst3, int N, int H, int W, int C, int cs, int cd, void* stream) {
-  return osvos_f32_to_p3(src, dst3, N, H, W, C, cs, cd, (hipStream_t)stream);
-}
-int osvos_p3_to_f32_abi(const void* src3, float* dst, int N, int H, int W, int C, void* stream) {
-  return osvos_p3_to_f32(src3, dst, N, H, W, C, (hipStream_t)stream);
-}
-int osvos_conv3x3_p3_tiles(void) { return osvos_conv3x3_p3_num_tiles(); }
-size_t osvos_conv3x3_p3_ws_bytes(int N, int H, int W, int Cout) { return osvos_conv3x3_p3_splitk_ws_bytes(N, H, W, Cout); }
-int osvos_conv3x3_p3_abi(const void* x3, const void* wpk3, const float* bias, const void* mask, int mask_is_p3, int mask_cs, float* y, int y_cs,
-                         void* y3, int y3_cs, int N, int H, int W, int Cin, int Cout, int relu, int tile, int ksplit, void* part_ws, void* stream) {
-  return osvos_conv3x3_p3(x3, wpk3, bias, mask, mask_is_p3, mask_cs, y, y_cs, y3, y3_cs, N, H, W, Cin, Cout, relu, tile, ksplit, part_ws,
-                          (hipStream_t)stream);
-}
-int osvos_conv3x3_wgrad_p3_abi(const void* x3, const void* dy3, void* ws, float* dw, float* db, int N, int H, int W, int Cin, int Cin_s,
-                               int Cout, int Cout_s, int accumulate, void* stream) {
-  return osvos_conv3x3_wgrad_p3(x3, dy3, ws, dw, db, N, H, W, Cin, Cin_s, Cout, Cout_s, accumulate, (hipStream_t)stream);
-}
-int osvos_maxpool2x2_p3_abi(const float* x, float* y, void* y3, int N, int H, int W, int C, void* stream) {
-  return osvos_maxpool2x2_p3(x, y, y3, N, H, W, C, (hipStream_t)stream);
-}
-int osvos_maxpool2x2_bwd_p3_abi(const float* x, const float* dy, const float* dside, float* dx, void* dx3, int N, int H, int W, int C, void* stream) {
-  return osvos_maxpool2x2_bwd_p3(x, dy, dside, dx, dx3, N, H, W, C, (hipStream_t)stream);
-}
 
 int osvos_head_lowres(const void* prep, const float* wd, const float* bd, const float* wf,
                       float* score, float* fpart, int N, int h, int w, int dtype, void* stream) {

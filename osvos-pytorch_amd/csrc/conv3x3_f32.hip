@@ -20,7 +20,6 @@
 //     on XCD b % 8) keeps re-using the same weight slice from its private L2
 #include "common.h"
 #include "kernels.h"
-#include "p3.h"
 
 namespace {
 
@@ -29,9 +28,7 @@ struct ConvArgs {
   const float* wpk;
   const float* bias;
   const float* mask;
-  float* y;           // may be NULL when y3 is given
-  bf16_t* y3;         // optional P3 form of the result (p3.h: [N][3][H][W][y3_cs] bf16 pieces), Cout % 8 == 0; not with split-K
-  int y3_cs;
+  float* y;
   int N, H, W, Cin, Cout, CoutP, y_cs;
   int tiles_x, tiles_y, nct;
   int relu, map, nsp;
@@ -231,18 +228,14 @@ __global__ __launch_bounds__(256) void conv3x3_f32_kernel(ConvArgs a) {
     const int cs = split ? a.Cout : a.y_cs;
     const size_t out_elems = (size_t)a.H * a.W * cs;
     float* const anyp = const_cast<float*>(a.wpk);
-    float* obase = split ? a.part + ((size_t)blockIdx.y * a.N + n) * out_elems : (a.y != nullptr ? a.y + n * out_elems : nullptr);
-    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(obase != nullptr ? obase : anyp, 0, obase != nullptr ? (int)(out_elems * 4) : 0, 0x00020000);
+    float* obase = split ? a.part + ((size_t)blockIdx.y * a.N + n) * out_elems : a.y + n * out_elems;
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(obase, 0, (int)(out_elems * 4), 0x00020000);
     const bool use_mask = !split && a.mask != nullptr;
     const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(use_mask ? a.mask + n * img_elems : anyp), 0,
                                                                          use_mask ? (int)(img_elems * 4) : 0, 0x00020000);
     const bool use_bias = !split && a.bias != nullptr;
     const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(use_bias ? a.bias : anyp), 0, use_bias ? a.Cout * 4 : 0, 0x00020000);
     const bool relu = !split && a.relu;
-    const bool want3 = !split && a.y3 != nullptr;
-    const unsigned y3_plane = (unsigned)a.H * a.W * a.y3_cs * 2u;
-    const __amdgpu_buffer_rsrc_t y3rs = __builtin_amdgcn_make_buffer_rsrc(want3 ? (void*)(a.y3 + (size_t)n * 3 * a.H * a.W * a.y3_cs) : (void*)anyp, 0,
-                                                                          want3 ? (int)(3u * y3_plane) : 0, 0x00020000);
 #pragma unroll
     for (int ni = 0; ni < C::WN; ++ni) {
       const int cb = co0 + (wn * C::WN + ni) * 32 + 4 * lh;
@@ -256,7 +249,6 @@ __global__ __launch_bounds__(256) void conv3x3_f32_kernel(ConvArgs a) {
         const int ox = x0 + (mb % C::TBX) * C::RBW + li % C::RBW;
         const bool inside = oy < a.H && ox < a.W;
         const unsigned pix = inside ? (unsigned)((oy * a.W + ox) * cs) * 4u : OOB;
-        f32x4 v4[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int co = cb + 8 * q;
@@ -272,11 +264,8 @@ __global__ __launch_bounds__(256) void conv3x3_f32_kernel(ConvArgs a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = m[e] > 0.f ? v[e] : 0.f;
           }
-          if (obase != nullptr) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, off, 0, 0);
-          v4[q] = v;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, off, 0, 0);
         }
-        if (want3)
-          p3_store32(v4, y3rs, inside ? (unsigned)((oy * a.W + ox) * a.y3_cs) * 2u : OOB, y3_plane, co0 + (wn * C::WN + ni) * 32, lh, a.Cout);
       }
     }
   } else {      // ragged channel counts (the 3-channel input gradient): element-wise
@@ -395,27 +384,6 @@ __global__ void conv_splitk_finalize_kernel(const float* __restrict__ part, cons
   }
 }
 
-// split-K finalize fused with the pool backward (epi.h): one thread per (pooled pixel, 4 channels) sums the K parts and routes the result
-// through the 2 x 2 window into dx at the pool's input resolution
-__global__ void conv_splitk_finalize_poolbwd_kernel(const float* __restrict__ part, ConvEpi epi, int N, int H, int W, int Cout, int ksplit) {
-  const int c4n = Cout / 4;
-  const long npix = (long)N * H * W, total = npix * c4n;
-  const size_t pimg = (size_t)epi.pool_H * epi.pool_W * Cout;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long pix = i / c4n;
-    const int c4 = (int)(i % c4n) * 4;
-    f32x4 s = *reinterpret_cast<const f32x4*>(part + pix * Cout + c4);
-    for (int k = 1; k < ksplit; ++k) s += *reinterpret_cast<const f32x4*>(part + ((size_t)k * npix + pix) * Cout + c4);
-    const int ox = (int)(pix % W), oy = (int)((pix / W) % H);
-    const long n = pix / ((long)W * H);
-    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(epi.pool_x) + n * pimg, 0, (int)(pimg * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(epi.pool_dside != nullptr ? epi.pool_dside : epi.pool_x) + n * pimg, 0,
-                                                                         epi.pool_dside != nullptr ? (int)(pimg * 4) : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(epi.pool_dx + n * pimg, 0, (int)(pimg * 4), 0x00020000);
-    epi_pool_bwd_quad(s, xrs, srs, drs, oy, ox, epi.pool_H, epi.pool_W, Cout, c4, true);
-  }
-}
-
 // how many K parts a launch should be cut into so the machine sees >= ~7 workgroups per CU (balance) without
 // drowning in partial-sum traffic; 1 for the big shallow layers
 int pick_ksplit(const TileInfo& t, int N, int H, int W, int Cin, int Cout, int CoutP, int y_cs) {
@@ -441,9 +409,6 @@ size_t osvos_conv3x3_splitk_ws_bytes_f32(int N, int H, int W, int Cout) {
 }
 
 // part_ws: NULL (never split) or a buffer of osvos_conv3x3_splitk_ws_bytes_f32() for the split-K partial sums
-int osvos_conv3x3_f32_ws(const float* x, const float* wpk, const float* bias, const float* mask, float* y,
-                         int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int tile, void* part_ws, hipStream_t stream);
-
 static unsigned long long* g_conv_prof_f32 = nullptr;
 extern "C" void osvos_debug_set_conv_prof_f32(void* p) { g_conv_prof_f32 = (unsigned long long*)p; }
 static thread_local int g_force_ksplit = 0;      // tests / tuning: osvos_conv3x3_splitk(..., ksplit > 0, ...)
@@ -456,28 +421,17 @@ int osvos_conv3x3_f32(const float* x, const float* wpk, const float* bias, const
 
 int osvos_conv3x3_f32_ws(const float* x, const float* wpk, const float* bias, const float* mask, float* y,
                          int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int tile, void* part_ws, hipStream_t stream) {
-  return osvos_conv3x3_f32_p3out(x, wpk, bias, mask, y, nullptr, 0, N, H, W, Cin, Cout, y_cs, relu, tile, part_ws, stream);
-}
-
-// y3 != NULL: the result also (or, with y == NULL, only) as a P3 tensor with channel stride y3_cs -- the exact fp32 kernel as the
-// producer of a P3 consumer (conv1_1 in the P3 storage mode of the f32x3 network); needs Cout % 8 == 0, never splits K
-int osvos_conv3x3_f32_p3out(const float* x, const float* wpk, const float* bias, const float* mask, float* y, void* y3, int y3_cs,
-                            int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int tile, void* part_ws, hipStream_t stream) {
-  OSVOS_ARG_CHECK(x && wpk && (y || y3), "conv3x3: null pointer");
-  OSVOS_ARG_CHECK(y3 == nullptr || (Cout % 8 == 0 && y3_cs % 8 == 0 && y3_cs >= Cout && (y_cs & 3) == 0 && (long)H * W * y3_cs * 6 < (1L << 31)),
-                  "conv3x3: P3 output needs Cout %% 8 == 0 and y3_cs %% 8 == 0 (%d, %d)", Cout, y3_cs);
-  if (y3 != nullptr) part_ws = nullptr;
+  OSVOS_ARG_CHECK(x && wpk && y, "conv3x3: null pointer");
   OSVOS_ARG_CHECK(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv3x3: bad shape");
   OSVOS_ARG_CHECK(Cin % 8 == 0, "conv3x3 f32: Cin (%d) must be a multiple of 8 (pad the input)", Cin);
   OSVOS_ARG_CHECK(y_cs >= Cout, "conv3x3: y channel stride %d < Cout %d", y_cs, Cout);
   OSVOS_ARG_CHECK((long)H * W * Cin < (1L << 29) && (long)H * W * y_cs < (1L << 29), "conv3x3: image too large for 31-bit byte offsets");
   // f32x3: the same fp32 problem on the bf16 matrix pipe with three-way split operands (conv3x3_f32x3.hip).  Tile ids
   // 200.. force it (tests, tuning); otherwise the process-wide mode decides (osvos_set_fp32_conv_mode / OSVOS_FP32_CONV).
-  if (y3 == nullptr && (tile >= 200 || (tile < 0 && osvos_fp32_conv_mode() == 1 && osvos_conv3x3_f32x3_applicable(Cin, Cout, y_cs))))
+  if ((tile >= 200 || (tile < 0 && osvos_fp32_conv_mode() == 1 && osvos_conv3x3_f32x3_applicable(Cin, Cout, y_cs))))
     return osvos_conv3x3_f32x3(x, wpk, bias, mask, y, N, H, W, Cin, Cout, y_cs, relu, tile >= 200 ? tile - 200 : -1, g_force_ksplit, part_ws, stream);
   ConvArgs a;
   a.x = x; a.wpk = wpk; a.bias = bias; a.mask = mask; a.y = y;
-  a.y3 = reinterpret_cast<bf16_t*>(y3); a.y3_cs = y3_cs;
   a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.CoutP = osvos_cout_pad(Cout); a.y_cs = y_cs;
   a.relu = relu;
   if (tile < 0) {
@@ -528,15 +482,6 @@ int osvos_conv3x3_splitk_finalize_f32(const float* part, const float* bias, cons
   long blocks = (npix * (Cout / 4) + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(conv_splitk_finalize_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, part, bias, mask, y, npix, Cout, y_cs, ksplit, relu);
-  OSVOS_LAUNCH_CHECK();
-  return 0;
-}
-
-int osvos_conv3x3_splitk_finalize_poolbwd_f32(const float* part, const ConvEpi* epi, int N, int H, int W, int Cout, int ksplit, hipStream_t stream) {
-  OSVOS_ARG_CHECK(part && epi && epi->pool_x && epi->pool_dx && Cout % 4 == 0 && ksplit >= 1, "splitk finalize (pool backward): bad arguments");
-  long blocks = ((long)N * H * W * (Cout / 4) + 255) / 256;
-  if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(conv_splitk_finalize_poolbwd_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, part, *epi, N, H, W, Cout, ksplit);
   OSVOS_LAUNCH_CHECK();
   return 0;
 }

@@ -336,14 +336,7 @@ __global__ __launch_bounds__(C::NT, C::OCC) void conv3x3_f32x3_kernel(ConvArgsX 
   const bool use_bias = !split && a.bias != nullptr;
   const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(use_bias ? a.bias : a.y), 0, use_bias ? a.Cout * 4 : 0, 0x00020000);
   const bool relu = !split && a.relu;
-  // fused pool backward (epi.h): this launch is the data gradient of the first convolution of a stage
-  const bool pool_bwd = !split && a.epi.pool_dx != nullptr;
-  const size_t pimg = (size_t)a.epi.pool_H * a.epi.pool_W * a.y_cs;
   float* const anyf = const_cast<float*>(a.wpk != nullptr ? a.wpk : reinterpret_cast<const float*>(a.wpk3));
-  const __amdgpu_buffer_rsrc_t pxrs = __builtin_amdgcn_make_buffer_rsrc(pool_bwd ? const_cast<float*>(a.epi.pool_x) + n * pimg : anyf, 0, pool_bwd ? (int)(pimg * 4) : 0, 0x00020000);
-  const bool have_ds = pool_bwd && a.epi.pool_dside != nullptr;
-  const __amdgpu_buffer_rsrc_t psrs = __builtin_amdgcn_make_buffer_rsrc(have_ds ? const_cast<float*>(a.epi.pool_dside) + n * pimg : anyf, 0, have_ds ? (int)(pimg * 4) : 0, 0x00020000);
-  const __amdgpu_buffer_rsrc_t pdrs = __builtin_amdgcn_make_buffer_rsrc(pool_bwd ? a.epi.pool_dx + n * pimg : anyf, 0, pool_bwd ? (int)(pimg * 4) : 0, 0x00020000);
   // fused pool forward: this launch is the last convolution of a stage (post-ReLU values >= 0, so positions outside the image count as 0)
   const bool pool_fwd = !split && a.epi.pooled != nullptr;
   const int PHo = (a.H + 1) / 2, PWo = (a.W + 1) / 2;
@@ -385,11 +378,7 @@ __global__ __launch_bounds__(C::NT, C::OCC) void conv3x3_f32x3_kernel(ConvArgsX 
           for (int e = 0; e < 4; ++e) v[e] = m[e] > 0.f ? v[e] : 0.f;
         }
         ybits |= mb_bits_f32(v, q);
-        if (pool_bwd) {
-          epi_pool_bwd_quad(v, pxrs, psrs, pdrs, oy, ox, a.epi.pool_H, a.epi.pool_W, a.y_cs, co, inside && co < a.Cout);
-        } else {
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, off, 0, 0);
-        }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, off, 0, 0);
         if (pool_fwd) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) keep[mi][q][e] = inside ? v[e] : 0.f;
@@ -627,18 +616,14 @@ int osvos_conv3x3_f32x3_ps(const float* x, const float* wpk, const void* wpk3, c
   return osvos_conv3x3_f32x3_epi(x, wpk, wpk3, bias, mask, y, N, H, W, Cin, Cout, y_cs, relu, tile, ksplit, part_ws, nullptr, stream);
 }
 
-// epi (may be NULL): fused pooling epilogues (epi.h).  epi->pool_dx: y may be NULL (the pooled-resolution gradient is not written);
-// epi->pooled: the launch never splits K and needs one of the eight-wave tiles whose waves hold whole 2 x 2 windows (10, 12, 14)
+// epi (may be NULL): fused epilogues (epi.h).  epi->pooled: the launch needs one of the eight-wave tiles whose waves hold whole 2 x 2
+// windows (10, 12, 14) and is never cut along K by partial-sum launches (the stream-K form keeps whole tiles in one workgroup's registers)
 int osvos_conv3x3_f32x3_epi(const float* x, const float* wpk, const void* wpk3, const float* bias, const float* mask, float* y,
                             int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int tile, int ksplit, void* part_ws, const ConvEpi* epi,
                             hipStream_t stream) {
-  const bool pool_bwd = epi != nullptr && epi->pool_dx != nullptr, pool_fwd = epi != nullptr && epi->pooled != nullptr;
-  OSVOS_ARG_CHECK(x && (wpk || wpk3) && (y || pool_bwd), "conv3x3 f32x3: null pointer");
-  OSVOS_ARG_CHECK(!pool_bwd || (epi->pool_x != nullptr && Cout % 4 == 0 && y_cs == Cout && (epi->pool_H + 1) / 2 == H && (epi->pool_W + 1) / 2 == W &&
-                                mask == nullptr && bias == nullptr && !relu && (long)epi->pool_H * epi->pool_W * y_cs < (1L << 29)),
-                  "conv3x3 f32x3: fused pool backward needs x, a dense Cout %% 4 == 0 result and pool_H/W = the pool's input size (%d x %d for %d x %d)",
-                  epi ? epi->pool_H : 0, epi ? epi->pool_W : 0, H, W);
-  OSVOS_ARG_CHECK(!pool_fwd || (relu && Cout % 4 == 0 && y_cs == Cout && !pool_bwd), "conv3x3 f32x3: fused pool forward needs ReLU and a dense Cout %% 4 == 0 result");
+  const bool pool_fwd = epi != nullptr && epi->pooled != nullptr;
+  OSVOS_ARG_CHECK(x && (wpk || wpk3) && y, "conv3x3 f32x3: null pointer");
+  OSVOS_ARG_CHECK(!pool_fwd || (relu && Cout % 4 == 0 && y_cs == Cout), "conv3x3 f32x3: fused pool forward needs ReLU and a dense Cout %% 4 == 0 result");
   OSVOS_ARG_CHECK(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv3x3 f32x3: bad shape");
   OSVOS_ARG_CHECK(osvos_conv3x3_f32x3_applicable(Cin, Cout, y_cs), "conv3x3 f32x3: needs Cin %% 16 == 0 (%d), y_cs %% 4 == 0 and >= Cout rounded up to 4 (%d, %d)",
                   Cin, Cout, y_cs);
@@ -666,7 +651,7 @@ int osvos_conv3x3_f32x3_epi(const float* x, const float* wpk, const void* wpk3, 
     if (a.ksplit < 1 || a.ksplit > 8 || a.ksplit > (Cin >> 4) || Cout % 4 != 0) a.ksplit = 1;
   }
   if (epi != nullptr && (epi->mask_bits != nullptr || epi->y_bits != nullptr))
-    OSVOS_ARG_CHECK(Cout % 32 == 0 && y_cs == Cout && !pool_bwd, "conv3x3 f32x3: one-bit masks need a dense result with Cout %% 32 == 0 (Cout %d, stride %d)", Cout, y_cs);
+    OSVOS_ARG_CHECK(Cout % 32 == 0 && y_cs == Cout, "conv3x3 f32x3: one-bit masks need a dense result with Cout %% 32 == 0 (Cout %d, stride %d)", Cout, y_cs);
   if (epi != nullptr && epi->y_bits != nullptr) a.ksplit = 1;
   if (pool_fwd) {
     a.ksplit = 1;
@@ -695,6 +680,5 @@ int osvos_conv3x3_f32x3_epi(const float* x, const float* wpk, const void* wpk3, 
     default: osvos_set_error("conv3x3 f32x3: unknown tile config %d", tile); return -1;
   }
   if (rc) return rc;
-  if (a.ksplit > 1 && pool_bwd) return osvos_conv3x3_splitk_finalize_poolbwd_f32(a.part, epi, N, H, W, Cout, a.ksplit, stream);
   return a.ksplit > 1 ? osvos_conv3x3_splitk_finalize_f32(a.part, bias, mask, y, (long)N * H * W, Cout, y_cs, a.ksplit, relu, stream) : 0;
 }

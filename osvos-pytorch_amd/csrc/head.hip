@@ -12,7 +12,6 @@
 // <= 2x2 taps per scale per output pixel.  The caller verifies the diagonal/shared-filter
 // precondition with osvos_deconv_diag_check and refuses to run otherwise.
 #include "kernels.h"
-#include "p3.h"
 
 namespace {
 
@@ -81,9 +80,10 @@ __global__ __launch_bounds__(256) void head_upsample_kernel(UpArgs a) {
         const int kx = Xp - x * s;
         const bool in = y == yc && x == xc;        // (ky, kx are inside the filter whenever the tap is inside the map)
         const int li = yc * w + xc, t = in ? ky * k + kx : 0;
-        const float w1 = in ? a.f1[i][t] : 0.f, w16 = in ? a.f16[i][t] : 0.f;
-        side += sc[li] * w1;
-        fu += fp[li] * w16;
+        // the load is unconditional (clamped address), the SELECT is on the accumulated result: a tap outside the map contributes nothing even
+        // when the clamped element is Inf / NaN (0 * Inf would poison the neighbours of a diverged border pixel; the reference never touches those taps)
+        side = in ? fmaf(sc[li], a.f1[i][t], side) : side;
+        fu = in ? fmaf(fp[li], a.f16[i][t], fu) : fu;
       }
     }
     a.outs[i][idx] = side;
@@ -101,8 +101,7 @@ struct HbArgs {
   const float* wd;
   const float* wf;
   f32x4* dprep;
-  uint2* dprep_b;   // optional bf16 copy of dprep (operand of the bf16 side_prep weight gradient); with b_p3: the P3 form [N][3][h][w][16]
-  int b_p3;         // (p3.h: operand of the f32x3 side_prep data gradient in the P3 storage mode)
+  uint2* dprep_b;   // optional bf16 copy of dprep (operand of the bf16 side_prep weight gradient)
   double* acc;   // per-workgroup partials [gridDim.x][34]: [0..15] dwf, [16..31] dwd, [32] dbd, [33] spare
   int N, H, W, h, w, s;
 };
@@ -146,7 +145,7 @@ __device__ __forceinline__ void head_bwd_body(const HbArgs& a, const unsigned bi
       const int Y0 = y * S - top, X0 = x * S - left;
       const float* fu = a.dfused + (size_t)n * a.H * a.W;
       const float* sd = a.dside + (size_t)n * a.H * a.W;
-      // every tap's load is unconditional (clamped address, weight zeroed outside the frame): all 32 are in flight before the first multiply
+      // every tap's load is unconditional (clamped address, the tap dropped by a select outside the frame): all 32 are in flight before the first multiply
       float vf[TAPS], vs[TAPS];
       bool in[TAPS];
 #pragma unroll
@@ -161,8 +160,8 @@ __device__ __forceinline__ void head_bwd_body(const HbArgs& a, const unsigned bi
       }
 #pragma unroll
       for (int j = 0; j < TAPS; ++j) {
-        df += (in[j] ? w16[j] : 0.f) * vf[j];
-        ds += (in[j] ? w1[j] : 0.f) * vs[j];
+        df = in[j] ? fmaf(w16[j], vf[j], df) : df;      // select on the result, not on the weight: a non-finite clamped element stays out
+        ds = in[j] ? fmaf(w1[j], vs[j], ds) : ds;
       }
     }
 #pragma unroll
@@ -183,14 +182,7 @@ __device__ __forceinline__ void head_bwd_body(const HbArgs& a, const unsigned bi
           pwd[c] += p[e] * ds;
         }
         a.dprep[(size_t)pix * 4 + q] = o;
-        if (a.dprep_b != nullptr && a.b_p3) {
-          uint2 ph, pm, pl;
-          p3_split4(o, ph, pm, pl);
-          const size_t hw = hw_lo, base = ((size_t)n * 3 * hw + (pix - n * hw_lo)) * 4 + q;      // uint2 units: 4 per pixel and plane
-          a.dprep_b[base] = ph;
-          a.dprep_b[base + hw * 4] = pm;
-          a.dprep_b[base + 2 * hw * 4] = pl;
-        } else if (a.dprep_b != nullptr) {
+        if (a.dprep_b != nullptr) {
           typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
           bf16x4_t hb;
           hb[0] = (__bf16)o[0]; hb[1] = (__bf16)o[1]; hb[2] = (__bf16)o[2]; hb[3] = (__bf16)o[3];
@@ -313,7 +305,7 @@ int osvos_head_bwd_blocks(int N, int h, int w, int scale_idx) {
 
 int osvos_head_bwd_f32(const float* prep, const float* dside, const float* dfused, const float* f1, const float* f16,
                        const float* wd, const float* wf, float* dprep, void* dprep_bf16, double* acc, int N, int H, int W, int h, int w,
-                       int scale_idx, hipStream_t stream, int b_p3) {
+                       int scale_idx, hipStream_t stream) {
   OSVOS_ARG_CHECK(prep && f1 && f16 && wd && wf && dprep && acc, "head_bwd: null pointer");
   OSVOS_ARG_CHECK(scale_idx >= 0 && scale_idx < 4 && N > 0 && H > 0 && W > 0 && h > 0 && w > 0, "head_bwd: bad shape");
   HbArgs a;
@@ -321,7 +313,6 @@ int osvos_head_bwd_f32(const float* prep, const float* dside, const float* dfuse
   a.dside = dside; a.dfused = dfused; a.f1 = f1; a.f16 = f16; a.wd = wd; a.wf = wf;
   a.dprep = reinterpret_cast<f32x4*>(dprep);
   a.dprep_b = reinterpret_cast<uint2*>(dprep_bf16);
-  a.b_p3 = b_p3;
   a.acc = acc;
   a.N = N; a.H = H; a.W = W; a.h = h; a.w = w; a.s = 2 << scale_idx;
   const int g = osvos_head_bwd_blocks(N, h, w, scale_idx);
@@ -338,7 +329,7 @@ int osvos_head_bwd_f32(const float* prep, const float* dside, const float* dfuse
 // all four scales in one launch: arrays indexed by scale; same partial layout per scale as osvos_head_bwd_f32 (acc[i]: osvos_head_bwd_blocks x 34)
 int osvos_head_bwd4_f32(const float* const* prep, const float* const* dside, const float* dfused, const float* const* f1, const float* const* f16,
                         const float* const* wd, const float* wf, float* const* dprep, void* const* dprep_bf16, double* const* acc,
-                        int N, int H, int W, const int* hs, const int* ws, hipStream_t stream, int b_p3) {
+                        int N, int H, int W, const int* hs, const int* ws, hipStream_t stream) {
   Hb4Args a;
   a.first[0] = 0;
   for (int i = 0; i < 4; ++i) {
@@ -348,7 +339,6 @@ int osvos_head_bwd4_f32(const float* const* prep, const float* const* dside, con
     q.dside = dside[i]; q.dfused = dfused; q.f1 = f1[i]; q.f16 = f16[i]; q.wd = wd[i]; q.wf = wf + 16 * i;
     q.dprep = reinterpret_cast<f32x4*>(dprep[i]);
     q.dprep_b = reinterpret_cast<uint2*>(dprep_bf16 ? dprep_bf16[i] : nullptr);
-    q.b_p3 = b_p3;
     q.acc = acc[i];
     q.N = N; q.H = H; q.W = W; q.h = hs[i]; q.w = ws[i]; q.s = 2 << i;
     a.first[i + 1] = a.first[i] + (unsigned)osvos_head_bwd_blocks(N, hs[i], ws[i], i);

@@ -9,8 +9,6 @@ size_t osvos_conv3x3_splitk_ws_bytes_f32(int N, int H, int W, int Cout);
 void osvos_conv3x3_force_ksplit(int k);
 int osvos_conv3x3_f32_ws(const float* x, const float* wpk, const float* bias, const float* mask, float* y,
                          int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int tile, void* part_ws, hipStream_t stream);
-int osvos_conv3x3_f32_p3out(const float* x, const float* wpk, const float* bias, const float* mask, float* y, void* y3, int y3_cs,
-                            int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int tile, void* part_ws, hipStream_t stream);
 int osvos_conv3x3_splitk_finalize_f32(const float* part, const float* bias, const float* mask, float* y, long npix, int Cout, int y_cs,
                                       int ksplit, int relu, hipStream_t stream);
 // f32x3 (conv3x3_f32x3.hip): fp32 tensors and fp32 packs, three-way bf16 split operands on the bf16 matrix pipe
@@ -25,18 +23,6 @@ bool osvos_wgrad_f32x3_skinny_applicable(int Cin, int Cin_s, int Cout, int Cout_
 size_t osvos_wgrad_f32x3_ws_bytes(int N, int H, int W, int Cin_s, int Cout);
 int osvos_conv3x3_wgrad_f32x3(const float* x, const float* dy, void* ws, float* dw, float* db,
                               int N, int H, int W, int Cin, int Cin_s, int Cout, int Cout_s, int accumulate, hipStream_t stream);
-int osvos_conv3x3_wgrad_p3(const void* x3, const void* dy3, void* ws, float* dw, float* db,
-                           int N, int H, int W, int Cin, int Cin_s, int Cout, int Cout_s, int accumulate, hipStream_t stream);
-// P3 storage of the f32x3 network (p3.h): conv3x3_p3.hip, p3_ops.hip
-bool osvos_conv3x3_p3_applicable(int Cin, int Cout, int y_cs, int y3_cs);
-int osvos_conv3x3_p3_num_tiles(void);
-size_t osvos_conv3x3_p3_splitk_ws_bytes(int N, int H, int W, int Cout);
-int osvos_conv3x3_p3(const void* x3, const void* wpk3, const float* bias, const void* mask, int mask_p3, int mask_cs, float* y, int y_cs,
-                     void* y3, int y3_cs, int N, int H, int W, int Cin, int Cout, int relu, int tile, int ksplit, void* part_ws, hipStream_t stream);
-int osvos_f32_to_p3(const float* src, void* dst3, int N, int H, int W, int C, int cs, int cd, hipStream_t stream);
-int osvos_p3_to_f32(const void* src3, float* dst, int N, int H, int W, int C, hipStream_t stream);
-int osvos_maxpool2x2_p3(const float* x, float* y, void* y3, int N, int H, int W, int C, hipStream_t stream);
-int osvos_maxpool2x2_bwd_p3(const float* x, const float* dy, const float* dside, float* dx, void* dx3, int N, int H, int W, int C, hipStream_t stream);
 size_t osvos_wpack_x3_bytes(int M, int K);
 #define OSVOS_PACK_MAX 40
 int osvos_pack_x3_multi(const float* const* ws, void* const* dsts, const int* Couts, const int* Cins, const int* dgrads, int n, hipStream_t stream);
@@ -46,7 +32,6 @@ int osvos_conv3x3_f32x3_ps(const float* x, const float* wpk, const void* wpk3, c
 int osvos_conv3x3_f32x3_epi(const float* x, const float* wpk, const void* wpk3, const float* bias, const float* mask, float* y,
                             int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int tile, int ksplit, void* part_ws, const ConvEpi* epi,
                             hipStream_t stream);
-int osvos_conv3x3_splitk_finalize_poolbwd_f32(const float* part, const ConvEpi* epi, int N, int H, int W, int Cout, int ksplit, hipStream_t stream);
 bool osvos_dgrad_c3_applicable(int Cin, int Cout);
 int osvos_conv3x3_dgrad_c3_f32(const float* dy, const float* wpk_dgrad, float* dx_nchw, int N, int H, int W, int Cout, hipStream_t stream);
 size_t osvos_wgrad_ws_bytes_f32(int N, int H, int W, int Cin_s, int Cout);
@@ -66,10 +51,10 @@ int osvos_head_lowres_f32(const float* prep, const float* wd, const float* bd, c
                           float* score, float* fpart, int N, int h, int w, hipStream_t stream);
 int osvos_head_bwd_f32(const float* prep, const float* dside, const float* dfused, const float* f1, const float* f16,
                        const float* wd, const float* wf, float* dprep, void* dprep_bf16, double* acc, int N, int H, int W, int h, int w,
-                       int scale_idx, hipStream_t stream, int b_p3 = 0);      // b_p3: dprep_bf16 is the P3 form [N][3][h][w][16] (p3.h)
+                       int scale_idx, hipStream_t stream);
 int osvos_head_bwd4_f32(const float* const* prep, const float* const* dside, const float* dfused, const float* const* f1, const float* const* f16,
                         const float* const* wd, const float* wf, float* const* dprep, void* const* dprep_bf16, double* const* acc,
-                        int N, int H, int W, const int* hs, const int* ws, hipStream_t stream, int b_p3 = 0);      // the four scales in one launch
+                        int N, int H, int W, const int* hs, const int* ws, hipStream_t stream);      // the four scales in one launch
 int osvos_head_bwd_blocks(int N, int h, int w, int scale_idx);   // workgroups (= partial rows of 34 doubles) head_bwd launches
 int osvos_sum_partials(const float* x, long count, double* part, int* nblocks, hipStream_t stream);
 // generic (non-diagonal upscale weights) head: head_generic.hip

@@ -89,28 +89,8 @@ inline bool use_store(int dtype) {
   return dtype == OSVOS_F32_BF16MFMA && on;
 }
 
-// P3 storage of the f32x3 mode (p3.h; OPT-IN with OSVOS_X3_P3=1 -- measured 3-5 % slower than fp32 tensors split while staging): the trunk
-// tensors (conv outputs, pooled tensors, their gradients) live in HBM as their three bf16 piece planes, formed once in the producer's
-// epilogue; the convolutions stage them by LDS-DMA (conv3x3_p3.hip), the weight gradients copy them (wgrad_f32x3.hip, P3IN).  fp32 copies
-// exist only where an fp32 consumer remains: the five stage outputs (pooling + arg-max recompute, side_prep's exact skinny weight
-// gradient), conv1_1's output (made by the exact kernel) and its gradient (conv1_1's exact weight gradient), the pooled / side gradients.
-inline bool use_p3(int dtype) {
-  static const bool on = [] { const char* e = getenv("OSVOS_X3_P3"); return e && e[0] == '1'; }();
-  return dtype == OSVOS_F32_X3 && on;
-}
-
-// first stage whose tensors are P3 (OSVOS_P3_FROM_STAGE, default 1; 0 = all of them).  Stage 0 (conv1_2: 64 -> 64 channels at full
-// resolution, K = 4 chunks) is bound by its 105 MB tensors, not by the matrix pipe: 6-byte elements cost it 25 % (0.220 vs 0.175 ms,
-// profiles/r03_tune_p3_first.txt), its only consumers are fp32 anyway (the pool pair) -- it keeps fp32 tensors and in-kernel splitting.
-inline int p3_first_stage() {
-  static const int v = [] { const char* e = getenv("OSVOS_P3_FROM_STAGE"); return e ? (atoi(e) <= 0 ? 0 : 1) : 1; }();
-  return v;
-}
-
 struct WsLayout {
   int hs[5], ws[5];
-  // P3 mode: byte offsets of the P3 tensors ((size_t)-1 = absent).  In that mode act[] / dy[] hold an fp32 tensor only where noted above.
-  size_t act3[kNumTrunk], pooled3[5], dy3[kNumTrunk], dprep3[4];
   size_t xin, act[kNumTrunk], pooled[5], prep[4], score[4], fpart[4];
   size_t conv_part;          // split-K partial sums of the small deep layers (forward prefix: inference uses it too)
   size_t side_part[4];       // the same for the side_prep convolutions, which run on the aux stream beside the trunk (own buffers)
@@ -131,7 +111,7 @@ inline bool use_mask_bits(int dtype) {
   return on && (use_store(dtype) || dtype == OSVOS_F32_X3);
 }
 // act[l] masks the data gradient of layer l + 1 when both are in the same stage; stage 4's last activation masks its side branch's.
-// f32x3 (fp32 tensors; the P3 network keeps its own masks): only where the f32x3 kernel produces the activation in ONE launch -- not conv1_1
+// f32x3 (fp32 tensors): only where the f32x3 kernel produces the activation in ONE launch -- not conv1_1
 // (exact kernel) and not stage 4, whose forward launches are cut along K (bits would pin them to one K range)
 inline bool act_is_a_mask(const ConvDesc* d, int l, int dtype) {
   const bool is = (l + 1 < kNumTrunk && d[l + 1].stage == d[l].stage) || l == kNumTrunk - 1;
@@ -150,59 +130,6 @@ WsLayout ws_layout(int N, int H, int W, int dtype) {
   auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
   ConvDesc d[kNumConv];
   conv_table(d);
-  if (use_p3(dtype)) {
-    auto stage_last = [&](int l) { return l + 1 == kNumTrunk || d[l + 1].stage != d[l].stage; };
-    L.xin = take(sizeof(float) * N * H * W * kInPad);
-    const int s0 = p3_first_stage();
-    for (int l = 0; l < kNumTrunk; ++l) {
-      const size_t e = (size_t)N * L.hs[d[l].stage] * L.ws[d[l].stage] * d[l].cout;
-      const bool fp32_stage = d[l].stage < s0;
-      L.act3[l] = fp32_stage ? (size_t)-1 : take(6 * e);
-      L.act[l] = (fp32_stage || stage_last(l)) ? take(4 * e) : (size_t)-1;
-    }
-    for (int si = 1; si < 5; ++si) {
-      L.pooled3[si] = take((size_t)6 * N * L.hs[si] * L.ws[si] * kStageC[si - 1]);
-      L.pooled[si] = (size_t)-1;
-    }
-    for (int i = 0; i < 4; ++i) {
-      const size_t npix = (size_t)N * L.hs[i + 1] * L.ws[i + 1];
-      L.prep[i] = take(sizeof(float) * npix * 16);
-      L.score[i] = take(sizeof(float) * npix);
-      L.fpart[i] = take(sizeof(float) * npix);
-    }
-    size_t mx = 0;
-    for (int l = 1; l < kNumTrunk; ++l)
-      if (d[l].cin >= 256) {
-        const size_t b = osvos_conv3x3_p3_splitk_ws_bytes(N, L.hs[d[l].stage], L.ws[d[l].stage], d[l].cout > d[l].cin ? d[l].cout : d[l].cin);
-        if (b > mx) mx = b;
-      }
-    L.conv_part = take(mx);
-    for (int i = 0; i < 4; ++i)
-      L.side_part[i] = kStageC[i + 1] >= 256 ? take(osvos_conv3x3_p3_splitk_ws_bytes(N, L.hs[i + 1], L.ws[i + 1], 16)) : (size_t)-1;
-    L.fwd_total = off;
-    for (int i = 0; i < 4; ++i) {
-      const size_t npix = (size_t)N * L.hs[i + 1] * L.ws[i + 1];
-      L.dprep[i] = take(sizeof(float) * npix * 16);
-      L.dprep3[i] = take((size_t)6 * npix * 16);
-      L.dside[i] = i < 3 ? take(sizeof(float) * npix * kStageC[i + 1]) : (size_t)-1;      // (stage 4's side gradient lands in dy3 directly)
-    }
-    for (int l = 0; l < kNumTrunk; ++l) {
-      const size_t e = (size_t)N * L.hs[d[l].stage] * L.ws[d[l].stage] * d[l].cout;
-      const bool fp32_stage = d[l].stage < s0;
-      L.dy3[l] = fp32_stage ? (size_t)-1 : take(6 * e);
-      L.dy[l] = (fp32_stage || l == 0) ? take(4 * e) : (size_t)-1;
-    }
-    for (int si = 1; si < 5; ++si) L.dpool[si] = take(sizeof(float) * N * L.hs[si] * L.ws[si] * kStageC[si - 1]);
-    for (int l = 0; l < kNumConv; ++l) {
-      const int si = d[l].stage;
-      L.wgrad[l] = take(osvos_wgrad_ws_bytes(N, L.hs[si], L.ws[si], d[l].cin_s, d[l].cout, dtype));
-    }
-    L.acc = take(sizeof(double) * (5 * OSVOS_HEAD_MAX_BLOCKS * 34));
-    L.dxin = take(sizeof(float) * N * H * W * 4);
-    for (int i = 0; i < 4; ++i) { const int k = 4 << i; L.gbuf[i] = take(sizeof(double) * 17 * k * k); }
-    L.total = off;
-    return L;
-  }
   const bool store = use_store(dtype), shadow = use_shadow(dtype) && !store;
   const size_t te = store ? 2 : es;          // element size of the trunk tensors
   L.xin = take(es * N * H * W * kInPad);
@@ -326,40 +253,25 @@ inline int conv_main(const void* x, const void* x_b, const void* wpk, const floa
                                      (unsigned*)y_bits, pooled_b, N, h, w, cin, cout, y_cs, relu, -1, stream);
 }
 
-// f32x3: the pooling kernels of the stage boundaries can run as epilogues of the convolutions next to them (epi.h).  Measured at 854x480
-// batch 1 (profiles/r03_ab_fusions.txt): the FORWARD pool in the producer's epilogue saves its launch and 20 us (1.473 -> 1.451 ms of
-// forward convolutions + pools) and is the default; the BACKWARD pool in the data gradient's epilogue makes that workgroup's tail 12
-// dependent memory instructions per accumulator quad long on a CU that holds nothing else (2.817 -> 2.861 ms of backward): opt-in.
-// OSVOS_FUSE_POOL=0 / 1 switches both, OSVOS_FUSE_POOL_FWD / OSVOS_FUSE_POOL_BWD each.
-inline bool fuse_flag(const char* name, bool dflt) {
-  const char* all = getenv("OSVOS_FUSE_POOL");
-  const char* e = getenv(name);
-  if (e) return e[0] != '0';
-  if (all) return all[0] != '0';
-  return dflt;
-}
-inline bool fuse_pool(int dtype) {      // forward: f32x3 (fp32 tensors) and the bf16-store mode (bf16 tensors; conv3x3_bf16*.hip)
-  static const bool on = fuse_flag("OSVOS_FUSE_POOL_FWD", true);
+// f32x3 and the bf16-store mode: the forward max-pool of a stage boundary runs as an epilogue of the stage's last convolution (epi.h).
+// Measured at 854x480 batch 1 (profiles/r03_ab_fusions.txt): saves its launch and 20 us (1.473 -> 1.451 ms of forward convolutions +
+// pools).  OSVOS_FUSE_POOL=0 (tests: bit-identity against the separate launches) turns it off.
+inline bool fuse_pool(int dtype) {
+  static const bool on = [] { const char* e = getenv("OSVOS_FUSE_POOL"); return !(e && e[0] == '0'); }();
   return on && (dtype == OSVOS_F32_X3 || use_store(dtype));
 }
-inline bool fuse_pool_bwd(int dtype) {
-  static const bool on = fuse_flag("OSVOS_FUSE_POOL_BWD", false);
-  return on && dtype == OSVOS_F32_X3;
-}
 
-// the 3-channel input gradient on its own bandwidth kernel (dgrad_c3.hip) instead of a 32-cout MFMA tile (OSVOS_DGRAD_C3=0: the MFMA tile)
-inline bool use_dgrad_c3() {
-  static const bool on = [] { const char* e = getenv("OSVOS_DGRAD_C3"); return !(e && e[0] == '0'); }();
-  return on;
-}
-
-// TIMING ABLATIONS (wrong results; tools/ablate_step.sh): OSVOS_DBG_SKIP bit 1 = no slab reduces, 2 = no pool backward kernels, 8 = no side_prep data
-// gradients, 16 = no side_prep weight gradients, 32 = no input gradient, 64 = no conv1_1 weight gradient.  What a step costs WITHOUT a piece of work
-// bounds what any rewrite of that piece can give.
+// TIMING ABLATIONS (wrong results; tools/ablate_step.sh) exist only in probe builds (make EXTRA=-DOSVOS_DBG_ABLATIONS): OSVOS_DBG_SKIP bit
+// 1 = no slab reduces, 2 = no pool backward kernels, 8 = no side_prep data gradients, 16 = no side_prep weight gradients, 32 = no input
+// gradient, 64 = no conv1_1 weight gradient.  The shipped library never skips work.
+#ifdef OSVOS_DBG_ABLATIONS
 inline int dbg_skip() {
   static const int v = [] { const char* e = getenv("OSVOS_DBG_SKIP"); return e ? atoi(e) : 0; }();
   return v;
 }
+#else
+constexpr int dbg_skip() { return 0; }
+#endif
 
 // gradient-ready events armed for the next backward of this host thread (osvos_net_arm_grad_events)
 struct GradEvents { hipEvent_t ev[OSVOS_NGRAD_GROUPS]; int n = 0; };
@@ -380,254 +292,6 @@ int osvos_gather_small(const float* const* srcs, const size_t* dst_off, const in
 int osvos_head_grads_finalize(const double* const* part, const int* nblk, const double* fb_part, int fb_nblk,
                               float* const* grads, int accumulate, int have_side, hipStream_t stream);
 
-// ---- the network on P3 trunk tensors (use_p3): same launches as the fp32 form below, the wide convolutions on conv3x3_p3 / wgrad P3 -----
-namespace {
-
-inline float* f32at(void* base, size_t off) { return off == (size_t)-1 ? nullptr : reinterpret_cast<float*>(at(base, off)); }
-
-int forward_p3(const float* x_nchw, const void* wbuf, void* ws, float* const* outs, int N, int H, int W, int dtype, bool generic,
-               hipStream_t stream, hipStream_t aux_all) {
-  const bool two = aux_all != stream;
-  EventPool& evp = event_pool();
-  const WbufLayout P = wbuf_layout(dtype);
-  const WsLayout L = ws_layout(N, H, W, dtype);
-  ConvDesc d[kNumConv];
-  conv_table(d);
-  auto bias = [&](int l) { return reinterpret_cast<const float*>(at(wbuf, P.bias[l])); };
-  int rc = osvos_nchw_to_nhwc_f32(x_nchw, f32at(ws, L.xin), nullptr, N, 3, H, W, kInPad, stream);
-  if (rc) return rc;
-  const int s0 = p3_first_stage();
-  {   // conv1_1 (Cin = 3) on the exact fp32 kernel; its epilogue forms the pieces when stage 0 is P3
-    ProfScope ps(OSVOS_PROF_CONV_FWD, conv_flops(N, H, W, d[0].cin, d[0].cout), stream);
-    rc = osvos_conv3x3_f32_p3out(f32at(ws, L.xin), reinterpret_cast<const float*>(at(wbuf, P.fwd[0])), bias(0), nullptr, f32at(ws, L.act[0]),
-                                 s0 == 0 ? at(ws, L.act3[0]) : nullptr, d[0].cout, N, H, W, d[0].cin_s, d[0].cout, d[0].cout, 1, -1, nullptr, stream);
-    if (rc) return rc;
-  }
-  const void* cur3 = s0 == 0 ? at(ws, L.act3[0]) : nullptr;
-  int l = 1;
-  if (s0 > 0) {   // conv1_2 on fp32 tensors (f32x3 with in-kernel splitting), like the fp32 form of the network
-    ProfScope ps(OSVOS_PROF_CONV_FWD, conv_flops(N, H, W, d[1].cin, d[1].cout), stream);
-    rc = osvos_conv3x3_f32x3_ps(f32at(ws, L.act[0]), nullptr, at(wbuf, P.fwd3[1]), bias(1), nullptr, f32at(ws, L.act[1]),
-                                N, H, W, d[1].cin, d[1].cout, d[1].cout, 1, -1, 0, nullptr, stream);
-    if (rc) return rc;
-    l = 2;
-  }
-  const float* score[4]; const float* fpart[4]; const float* f1[4]; const float* f16[4];
-  for (int si = 0; si < 5; ++si) {
-    const int h = L.hs[si], w = L.ws[si];
-    if (si > 0) {
-      rc = osvos_maxpool2x2_p3(f32at(ws, L.act[l - 1]), nullptr, at(ws, L.pooled3[si]), N, L.hs[si - 1], L.ws[si - 1], kStageC[si - 1], stream);
-      if (rc) return rc;
-      cur3 = at(ws, L.pooled3[si]);
-    }
-    for (int j = (si == 0 ? (s0 > 0 ? kStageN[0] : 1) : 0); j < kStageN[si]; ++j, ++l) {
-      ProfScope ps(OSVOS_PROF_CONV_FWD, conv_flops(N, h, w, d[l].cin, d[l].cout), stream);
-      rc = osvos_conv3x3_p3(cur3, at(wbuf, P.fwd3[l]), bias(l), nullptr, 0, 0, f32at(ws, L.act[l]), d[l].cout, at(ws, L.act3[l]), d[l].cout, N, h, w,
-                            d[l].cin, d[l].cout, 1, -1, 0, at(ws, L.conv_part), stream);
-      if (rc) return rc;
-      cur3 = at(ws, L.act3[l]);
-    }
-    if (si > 0) {
-      const int i = si - 1, sl = kNumTrunk + i;
-      hipStream_t aux = (si == 4) ? stream : aux_all;      // the last stage's side branch has nothing left to hide behind
-      if (two && aux != stream) {
-        hipEvent_t e = evp.next();
-        if (!e) return -1;
-        OSVOS_HIP_CHECK(hipEventRecord(e, stream));
-        OSVOS_HIP_CHECK(hipStreamWaitEvent(aux, e, 0));
-      }
-      {
-        ProfScope ps(OSVOS_PROF_OTHER, conv_flops(N, h, w, d[sl].cin, 16), aux);
-        rc = osvos_conv3x3_p3(cur3, at(wbuf, P.fwd3[sl]), bias(sl), nullptr, 0, 0, f32at(ws, L.prep[i]), 16, nullptr, 0, N, h, w, d[sl].cin, 16, 0, -1, 0,
-                              L.side_part[i] != (size_t)-1 ? at(ws, L.side_part[i]) : nullptr, aux);
-      }
-      if (rc) return rc;
-      float* sc = f32at(ws, L.score[i]);
-      float* fp = f32at(ws, L.fpart[i]);
-      rc = osvos_head_lowres(at(ws, L.prep[i]), reinterpret_cast<const float*>(at(wbuf, P.wd[i])), reinterpret_cast<const float*>(at(wbuf, P.bd[i])),
-                             reinterpret_cast<const float*>(at(wbuf, P.wf)) + 16 * i, sc, fp, N, h, w, dtype, aux);
-      if (rc) return rc;
-      score[i] = sc; fpart[i] = fp;
-      f1[i] = reinterpret_cast<const float*>(at(wbuf, P.f1[i]));
-      f16[i] = reinterpret_cast<const float*>(at(wbuf, P.f16[i]));
-    }
-  }
-  if (two) {
-    hipEvent_t e = evp.next();
-    if (!e) return -1;
-    OSVOS_HIP_CHECK(hipEventRecord(e, aux_all));
-    OSVOS_HIP_CHECK(hipStreamWaitEvent(stream, e, 0));
-  }
-  if (generic) {
-    const float* prep[4]; const float* weff[4];
-    for (int i = 0; i < 4; ++i) { prep[i] = f32at(ws, L.prep[i]); weff[i] = reinterpret_cast<const float*>(at(wbuf, P.weff[i])); }
-    return osvos_head_upsample_generic(score, prep, f1, weff, reinterpret_cast<const float*>(at(wbuf, P.bf)), outs, N, H, W, &L.hs[1], &L.ws[1], stream);
-  }
-  return osvos_head_upsample(score, fpart, f1, f16, reinterpret_cast<const float*>(at(wbuf, P.bf)), outs, N, H, W, &L.hs[1], &L.ws[1], stream);
-}
-
-// the trunk + side_prep half of the backward (everything behind the head's dprep[i]); streams, events and hazards as in the fp32 form
-int backward_trunk_p3(const void* wbuf, void* ws, float* const* grads, float* dx_nchw, int N, int H, int W, int dtype, int accumulate,
-                      hipStream_t stream, hipStream_t aux, hipStream_t aux2, const GradEvents& gev, bool dprep3_ready, bool defer_join) {
-  const bool two = aux != stream, three = aux2 != aux;
-  const WbufLayout P = wbuf_layout(dtype);
-  const WsLayout L = ws_layout(N, H, W, dtype);
-  ConvDesc d[kNumConv];
-  conv_table(d);
-  EventPool& evp = event_pool();
-  auto ready = [&](int group, hipStream_t st) -> int {
-    if (group < gev.n && gev.ev[group] != nullptr) OSVOS_HIP_CHECK(hipEventRecord(gev.ev[group], st));
-    return 0;
-  };
-  auto join = [&]() -> int {
-    if (defer_join) return 0;
-    if (two) {
-      hipEvent_t e = evp.next();
-      if (!e) return -1;
-      OSVOS_HIP_CHECK(hipEventRecord(e, aux));
-      OSVOS_HIP_CHECK(hipStreamWaitEvent(stream, e, 0));
-    }
-    if (three) {
-      hipEvent_t e = evp.next();
-      if (!e) return -1;
-      OSVOS_HIP_CHECK(hipEventRecord(e, aux2));
-      OSVOS_HIP_CHECK(hipStreamWaitEvent(stream, e, 0));
-    }
-    return 0;
-  };
-  auto signal = [&]() -> int {
-    if (!two) return 0;
-    hipEvent_t e = evp.next();
-    if (!e) return -1;
-    OSVOS_HIP_CHECK(hipEventRecord(e, stream));
-    OSVOS_HIP_CHECK(hipStreamWaitEvent(aux, e, 0));
-    return 0;
-  };
-  // weight gradient of layer l: wide layers from the P3 tensors, conv1_1 / side_prep on their exact skinny kernels from the fp32 ones
-  const int s0 = p3_first_stage();
-  auto wgrad_launch = [&](int l, int h, int w, hipStream_t st) -> int {
-    if (l >= 1 && l < kNumTrunk && d[l].stage < s0)      // fp32 stage: fp32-input f32x3 weight gradient
-      return osvos_conv3x3_wgrad(at(ws, L.act[l - 1]), at(ws, L.dy[l]), at(ws, L.wgrad[l]), grads[d[l].w_param], grads[d[l].b_param], N, h, w, d[l].cin,
-                                 d[l].cin_s, d[l].cout, d[l].cout, accumulate, dtype, st);
-    if (l >= 1 && l < kNumTrunk) {
-      const bool first_of_stage = d[l - 1].stage != d[l].stage;
-      const void* x3 = first_of_stage ? at(ws, L.pooled3[d[l].stage]) : at(ws, L.act3[l - 1]);
-      return osvos_conv3x3_wgrad_p3(x3, at(ws, L.dy3[l]), at(ws, L.wgrad[l]), grads[d[l].w_param], grads[d[l].b_param], N, h, w, d[l].cin, d[l].cin_s,
-                                    d[l].cout, d[l].cout, accumulate, st);
-    }
-    // side_prep (Cout = 16): on the bf16 pipe from the P3 stage output and the P3 head gradient (OSVOS_X3_SIDE_WGRAD=0: the exact fp32 skinny kernel)
-    if (l >= kNumTrunk && osvos_wgrad_f32x3_skinny_applicable(d[l].cin, d[l].cin_s, 16, 16))
-      return osvos_conv3x3_wgrad_p3(at(ws, L.act3[last_of_stage(d[l].stage)]), at(ws, L.dprep3[l - kNumTrunk]), at(ws, L.wgrad[l]), grads[d[l].w_param],
-                                    grads[d[l].b_param], N, h, w, d[l].cin, d[l].cin_s, 16, 16, accumulate, st);
-    const void* x = l == 0 ? at(ws, L.xin) : at(ws, L.act[last_of_stage(d[l].stage)]);
-    const void* g = l == 0 ? at(ws, L.dy[0]) : at(ws, L.dprep[l - kNumTrunk]);
-    return osvos_conv3x3_wgrad(x, g, at(ws, L.wgrad[l]), grads[d[l].w_param], grads[d[l].b_param], N, h, w, d[l].cin, d[l].cin_s, d[l].cout,
-                               d[l].cout, accumulate, dtype, st);
-  };
-  auto wgrad = [&](int l, int h, int w) -> int {
-    if (!three) return wgrad_launch(l, h, w, aux);
-    osvos_wgrad_set_phase(1);
-    int r = wgrad_launch(l, h, w, aux);
-    osvos_wgrad_set_phase(0);
-    if (r) return r;
-    hipEvent_t e = evp.next();
-    if (!e) return -1;
-    OSVOS_HIP_CHECK(hipEventRecord(e, aux));
-    OSVOS_HIP_CHECK(hipStreamWaitEvent(aux2, e, 0));
-    osvos_wgrad_set_phase(2);
-    r = wgrad_launch(l, h, w, aux2);
-    osvos_wgrad_set_phase(0);
-    return r;
-  };
-  int rc;
-  double bwd_flops = 0.0;
-  for (int l = 0; l < kNumConv; ++l) bwd_flops += 2.0 * conv_flops(N, L.hs[d[l].stage], L.ws[d[l].stage], d[l].cin, d[l].cout);
-  if (dx_nchw == nullptr) bwd_flops -= conv_flops(N, H, W, 3, d[0].cout);
-  ProfScope ps(OSVOS_PROF_CONV_BWD, bwd_flops, stream);
-  // the pieces of the four 16-channel head gradients (operands of the side_prep data gradients): written by the commuted head's
-  // backward itself; the generic head leaves fp32 only
-  for (int i = 0; i < 4 && !dprep3_ready; ++i) {
-    rc = osvos_f32_to_p3(f32at(ws, L.dprep[i]), at(ws, L.dprep3[i]), N, L.hs[i + 1], L.ws[i + 1], 16, 16, 16, stream);
-    if (rc) return rc;
-  }
-  if ((rc = signal())) return rc;       // dprep[0..3] ready
-  for (int i = 0; i < 4; ++i) {
-    const int si = i + 1, sl = kNumTrunk + i;
-    if (grads[d[sl].w_param] != nullptr && (rc = wgrad(sl, L.hs[si], L.ws[si]))) return rc;
-  }
-  if ((rc = ready(1, aux2))) return rc;
-  for (int i = 3; i >= 0; --i) {
-    const int si = i + 1, sl = kNumTrunk + i, h = L.hs[si], w = L.ws[si];
-    const int lx = last_of_stage(si);
-    // stage 4 has no pool after it: its ReLU mask is applied here and the result is conv5_3's upstream gradient; stages 1-3 are merged
-    // (fp32) in the pool backward below
-    if (i == 3)
-      rc = osvos_conv3x3_p3(at(ws, L.dprep3[i]), at(wbuf, P.dgrad3[sl]), nullptr, at(ws, L.act3[lx]), 1, d[sl].cin, nullptr, 0, at(ws, L.dy3[lx]), d[sl].cin,
-                            N, h, w, 16, d[sl].cin, 0, -1, 0, nullptr, stream);
-    else
-      rc = osvos_conv3x3_p3(at(ws, L.dprep3[i]), at(wbuf, P.dgrad3[sl]), nullptr, nullptr, 0, 0, f32at(ws, L.dside[i]), d[sl].cin, nullptr, 0, N, h, w, 16,
-                            d[sl].cin, 0, -1, 0, nullptr, stream);
-    if (rc) return rc;
-  }
-  for (int l = kNumTrunk - 1; l >= 0; --l) {
-    const int si = d[l].stage, h = L.hs[si], w = L.ws[si];
-    const bool first_of_stage = (l == 0) || d[l - 1].stage != si;
-    const bool tail_on_main = l == 0 && two && !defer_join;      // conv1_1's weight gradient: on the main stream behind the input gradient (see the fp32 form)
-    if (grads[d[l].w_param] != nullptr && !tail_on_main) {
-      if ((rc = signal())) return rc;
-      if ((rc = wgrad(l, h, w))) return rc;
-    }
-    if (first_of_stage && !tail_on_main && (rc = ready(2 + (4 - si), aux2))) return rc;
-    if (l == 0) {
-      if (dx_nchw != nullptr && use_dgrad_c3()) {
-        rc = osvos_conv3x3_dgrad_c3_f32(f32at(ws, L.dy[0]), reinterpret_cast<const float*>(at(wbuf, P.dgrad[0])), dx_nchw, N, h, w, d[0].cout, stream);
-        if (rc) return rc;
-      } else if (dx_nchw != nullptr) {
-        if (s0 > 0)
-          rc = osvos_conv3x3_f32x3_ps(f32at(ws, L.dy[0]), nullptr, at(wbuf, P.dgrad3[0]), nullptr, nullptr,
-                                      f32at(ws, L.dxin), N, h, w, d[0].cout, 3, 4, 0, -1, 0, nullptr, stream);
-        else
-          rc = osvos_conv3x3_p3(at(ws, L.dy3[0]), at(wbuf, P.dgrad3[0]), nullptr, nullptr, 0, 0, f32at(ws, L.dxin), 4, nullptr, 0, N, h, w, d[0].cout, 3, 0, -1, 0,
-                                nullptr, stream);
-        if (rc) return rc;
-        rc = osvos_nhwc_to_nchw(at(ws, L.dxin), dx_nchw, N, 3, H, W, 4, dtype, stream);
-        if (rc) return rc;
-      }
-      if (tail_on_main) {
-        if (grads[d[0].w_param] != nullptr && (rc = wgrad_launch(0, h, w, stream))) return rc;
-        if ((rc = join())) return rc;
-        return ready(2 + 4, stream);
-      }
-      break;
-    }
-    if (first_of_stage) {
-      // through the pool into the previous stage's output (+ that stage's side branch, + ReLU mask): fp32 in, P3 out
-      rc = osvos_conv3x3_p3(at(ws, L.dy3[l]), at(wbuf, P.dgrad3[l]), nullptr, nullptr, 0, 0, f32at(ws, L.dpool[si]), d[l].cin, nullptr, 0, N, h, w, d[l].cout,
-                            d[l].cin, 0, -1, 0, at(ws, L.conv_part), stream);
-      if (rc) return rc;
-      const int ps2 = si - 1;
-      if (ps2 < s0)      // into an fp32 stage
-        rc = osvos_maxpool2x2_bwd_f32(f32at(ws, L.act[l - 1]), f32at(ws, L.dpool[si]), ps2 >= 1 ? f32at(ws, L.dside[ps2 - 1]) : nullptr, f32at(ws, L.dy[l - 1]),
-                                      nullptr, N, L.hs[ps2], L.ws[ps2], kStageC[ps2], stream);
-      else
-        rc = osvos_maxpool2x2_bwd_p3(f32at(ws, L.act[l - 1]), f32at(ws, L.dpool[si]), ps2 >= 1 ? f32at(ws, L.dside[ps2 - 1]) : nullptr, nullptr,
-                                     at(ws, L.dy3[l - 1]), N, L.hs[ps2], L.ws[ps2], kStageC[ps2], stream);
-      if (rc) return rc;
-    } else if (si < s0) {      // fp32 stage: f32x3 data gradient with in-kernel splitting, fp32 mask
-      rc = osvos_conv3x3_f32x3_ps(f32at(ws, L.dy[l]), nullptr, at(wbuf, P.dgrad3[l]), nullptr,
-                                  f32at(ws, L.act[l - 1]), f32at(ws, L.dy[l - 1]), N, h, w, d[l].cout, d[l].cin, d[l].cin, 0, -1, 0, at(ws, L.conv_part), stream);
-      if (rc) return rc;
-    } else {
-      rc = osvos_conv3x3_p3(at(ws, L.dy3[l]), at(wbuf, P.dgrad3[l]), nullptr, at(ws, L.act3[l - 1]), 1, d[l].cin, l == 1 ? f32at(ws, L.dy[0]) : nullptr, d[l].cin,
-                            at(ws, L.dy3[l - 1]), d[l].cin, N, h, w, d[l].cout, d[l].cin, 0, -1, 0, at(ws, L.conv_part), stream);
-      if (rc) return rc;
-    }
-  }
-  return join();
-}
-
-}  // namespace
-
 extern "C" {
 
 size_t osvos_net_wbuf_bytes(int dtype) { return wbuf_layout(dtype & 0xff).total; }
@@ -641,9 +305,8 @@ int osvos_net_ws_query(int N, int H, int W, int dtype, int which, size_t* offset
   conv_table(d);
   int si, c;
   size_t off;
-  const bool p3 = use_p3(dtype & 0xff);      // P3 mode: the trunk tensors are P3 (osvos_net_ws_format)
-  if (which < 13) { si = d[which].stage; c = d[which].cout; off = (p3 && si >= p3_first_stage()) ? L.act3[which] : L.act[which]; }
-  else if (which < 17) { si = which - 12; c = kStageC[si - 1]; off = p3 ? L.pooled3[si] : L.pooled[si]; }
+  if (which < 13) { si = d[which].stage; c = d[which].cout; off = L.act[which]; }
+  else if (which < 17) { si = which - 12; c = kStageC[si - 1]; off = L.pooled[si]; }
   else if (which < 21) { si = which - 16; c = 16; off = L.prep[which - 17]; }
   else { si = 0; c = kInPad; off = L.xin; }
   *offset = off; *channels = c; *h = L.hs[si]; *w = L.ws[si];
@@ -651,14 +314,10 @@ int osvos_net_ws_query(int N, int H, int W, int dtype, int which, size_t* offset
   return 0;
 }
 
-// storage format of trunk tensor `which` (osvos_net_ws_query 0..16): 0 fp32 NHWC, 1 bf16 NHWC, 2 P3 ([N][3][H][W][C] bf16 pieces)
+// storage format of trunk tensor `which` (osvos_net_ws_query 0..16): 0 fp32 NHWC, 1 bf16 NHWC
 int osvos_net_ws_format(int dtype, int which) {
-  if (use_store(dtype & 0xff)) return 1;
-  if (!use_p3(dtype & 0xff) || which < 0 || which > 16) return 0;
-  if (which >= 13) return 2;
-  ConvDesc d[kNumConv];
-  conv_table(d);
-  return d[which].stage >= p3_first_stage() ? 2 : 0;
+  (void)which;
+  return use_store(dtype & 0xff) ? 1 : 0;
 }
 
 int osvos_net_pack(const float* const* params, void* wbuf, int dtype_, int with_dgrad, void* stream_) {
@@ -725,7 +384,6 @@ int osvos_net_forward(const float* x_nchw, const void* wbuf, void* ws, float* co
   OSVOS_ARG_CHECK(osvos_dtype_built(dtype), "net_forward: dtype %d not built", dtype);
   OSVOS_ARG_CHECK(N > 0 && H > 0 && W > 0, "net_forward: bad shape %dx%dx%d", N, H, W);
   for (int i = 0; i < 5; ++i) OSVOS_ARG_CHECK(outs[i] != nullptr, "net_forward: outs[%d] is null", i);
-  if (use_p3(dtype)) return forward_p3(x_nchw, wbuf, ws, outs, N, H, W, dtype, generic, stream, aux_all);
   const WbufLayout P = wbuf_layout(dtype);
   const WsLayout L = ws_layout(N, H, W, dtype);
   ConvDesc d[kNumConv];
@@ -860,7 +518,6 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
   ConvDesc d[kNumConv];
   conv_table(d);
   const bool store = use_store(dtype), shadow = use_shadow(dtype) && !store;
-  const bool p3 = use_p3(dtype);
   auto sh = [&](size_t off) -> void* { return (shadow || store) ? at(ws, off) : nullptr; };
   auto f32 = [&](size_t off) -> void* { return store ? nullptr : at(ws, off); };
   auto mk32 = [&](size_t off) -> const void* { return store ? nullptr : at(ws, off); };           // ReLU mask operand: fp32 ...
@@ -908,7 +565,8 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
     osvos_wgrad_set_phase(1);
     r = wgrad_launch(xin, g, l, h, w, aux);
     osvos_wgrad_set_phase(0);
-    if (r || (dbg_skip() & 1)) return r;
+    if (r) return r;
+    if (dbg_skip() & 1) return 0;
     hipEvent_t e = evp.next();
     if (!e) return -1;
     OSVOS_HIP_CHECK(hipEventRecord(e, aux));
@@ -927,8 +585,7 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
   const float* dfused = douts[4];
 
   // ---- head: upstream full-resolution gradients -> dprep[i] (+ score_dsn / fuse gradients) ----
-  static const bool merged_head = [] { const char* e = getenv("OSVOS_HEAD_BWD_MERGED"); return !(e && e[0] == '0'); }();
-  if (!generic && merged_head) {        // the four scales in one launch (as four ~20 us launches they sit back to back on the critical path)
+  if (!generic) {        // the four scales in one launch (as four ~20 us launches they sit back to back on the critical path)
     const float *prep4[4], *f1_4[4], *f16_4[4], *wd4[4];
     float* dprep4[4];
     void* dprepb4[4];
@@ -939,13 +596,13 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
       f16_4[i] = reinterpret_cast<const float*>(at(wbuf, P.f16[i]));
       wd4[i] = reinterpret_cast<const float*>(at(wbuf, P.wd[i]));
       dprep4[i] = reinterpret_cast<float*>(at(ws, L.dprep[i]));
-      dprepb4[i] = store ? at(ws, L.dprep_b[i]) : (p3 ? at(ws, L.dprep3[i]) : nullptr);
+      dprepb4[i] = store ? at(ws, L.dprep_b[i]) : nullptr;
       acc4[i] = acc + (size_t)i * OSVOS_HEAD_MAX_BLOCKS * 34;
       part[i] = acc4[i];
       nblk[i] = osvos_head_bwd_blocks(N, L.hs[i + 1], L.ws[i + 1], i);
     }
     rc = osvos_head_bwd4_f32(prep4, douts, dfused, f1_4, f16_4, wd4, reinterpret_cast<const float*>(at(wbuf, P.wf)), dprep4, dprepb4, acc4, N, H, W,
-                             &L.hs[1], &L.ws[1], stream, p3 ? 1 : 0);
+                             &L.hs[1], &L.ws[1], stream);
     if (rc) return rc;
   } else
   for (int i = 0; i < 4; ++i) {
@@ -959,8 +616,8 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
       rc = osvos_head_bwd_f32(reinterpret_cast<const float*>(at(ws, L.prep[i])), douts[i], dfused, reinterpret_cast<const float*>(at(wbuf, P.f1[i])),
                         reinterpret_cast<const float*>(at(wbuf, P.f16[i])), reinterpret_cast<const float*>(at(wbuf, P.wd[i])),
                         reinterpret_cast<const float*>(at(wbuf, P.wf)) + 16 * i, reinterpret_cast<float*>(at(ws, L.dprep[i])),
-                        store ? at(ws, L.dprep_b[i]) : (p3 ? at(ws, L.dprep3[i]) : nullptr), acc + (size_t)i * OSVOS_HEAD_MAX_BLOCKS * 34,
-                        N, H, W, L.hs[si], L.ws[si], i, stream, p3 ? 1 : 0);
+                        store ? at(ws, L.dprep_b[i]) : nullptr, acc + (size_t)i * OSVOS_HEAD_MAX_BLOCKS * 34,
+                        N, H, W, L.hs[si], L.ws[si], i, stream);
     if (rc) return rc;
     part[i] = acc + (size_t)i * OSVOS_HEAD_MAX_BLOCKS * 34;
     nblk[i] = osvos_head_bwd_blocks(N, L.hs[si], L.ws[si], i);
@@ -1002,8 +659,6 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
   }
   if ((rc = ready(0, stream))) return rc;      // score_dsn + fuse gradients
 
-  if (p3) return backward_trunk_p3(wbuf, ws, grads, dx_nchw, N, H, W, dtype, accumulate, stream, aux, aux2, gev, /*dprep3_ready=*/!generic, defer_join);
-
   // ---- data-gradient chain on `stream`, weight gradients trailing on `aux` ----------------------
   // ready[k]: event recorded on `stream` when the k-th upstream gradient tensor is complete
   double bwd_flops = 0.0;
@@ -1019,23 +674,14 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
     return 0;
   };
   if ((rc = signal())) return rc;       // dprep[0..3] ready
-  // The four skinny side_prep weight gradients (~65 us each at 854x480, bandwidth- and latency-bound) head the weight-gradient stream and push every
-  // trunk weight gradient back by their sum.  OSVOS_SIDE_WGRAD_AUX2=1 puts them, kernel and slab reduce both, on the third stream beside the first
-  // trunk gradients (each layer has its own slabs).  Measured on the headline: +0.1-0.25 %, inside the noise -- off by default.
-  static const bool side_on_aux2 = [] { const char* e = getenv("OSVOS_SIDE_WGRAD_AUX2"); return e && e[0] == '1'; }();
-  const bool side_aux2 = three && side_on_aux2;
-  if (side_aux2) {
-    hipEvent_t e = evp.next();
-    if (!e) return -1;
-    OSVOS_HIP_CHECK(hipEventRecord(e, stream));
-    OSVOS_HIP_CHECK(hipStreamWaitEvent(aux2, e, 0));
-  }
+  // the four skinny side_prep weight gradients head the weight-gradient stream (on the third stream beside the first trunk gradients they
+  // measured +0.1-0.25 %, inside the noise: round 3)
   for (int i = 0; i < 4; ++i) {
     const int si = i + 1, sl = kNumTrunk + i, h = L.hs[si], w = L.ws[si];
     const int lx = last_of_stage(si);
     if (grads[d[sl].w_param] != nullptr && !(dbg_skip() & 16)) {
       const void* dp = store ? at(ws, L.dprep_b[i]) : at(ws, L.dprep[i]);      // (store mode: bf16 x and bf16 dprep)
-      rc = side_aux2 ? wgrad_launch(at(ws, L.act[lx]), dp, sl, h, w, aux2) : wgrad(at(ws, L.act[lx]), dp, sl, h, w);
+      rc = wgrad(at(ws, L.act[lx]), dp, sl, h, w);
       if (rc) return rc;
     }
   }
@@ -1075,7 +721,7 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
     if (first_of_stage && !tail_on_main && (rc = ready(2 + (4 - si), aux2))) return rc;      // stage si complete (its first conv is the last one processed)
     if (l == 0) {
       if (dbg_skip() & 32) {
-      } else if (dx_nchw != nullptr && (dtype == OSVOS_F32 || dtype == OSVOS_F32_X3) && use_dgrad_c3()) {
+      } else if (dx_nchw != nullptr && (dtype == OSVOS_F32 || dtype == OSVOS_F32_X3)) {
         rc = osvos_conv3x3_dgrad_c3_f32(reinterpret_cast<const float*>(g), reinterpret_cast<const float*>(at(wbuf, P.dgrad[0])), dx_nchw, N, h, w, d[0].cout, stream);
         if (rc) return rc;
       } else if (dx_nchw != nullptr) {
@@ -1092,19 +738,7 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
       }
       break;
     }
-    if (first_of_stage && fuse_pool_bwd(dtype)) {
-      // through the pool into the previous stage's output (+ that stage's side branch, + ReLU mask) inside the convolution's epilogue:
-      // the pooled-resolution gradient is never written
-      const int ps2 = si - 1;
-      ConvEpi epi;
-      epi.pool_x = reinterpret_cast<const float*>(at(ws, L.act[l - 1]));
-      epi.pool_dside = ps2 >= 1 ? reinterpret_cast<const float*>(at(ws, L.dside[ps2 - 1])) : nullptr;
-      epi.pool_dx = reinterpret_cast<float*>(at(ws, L.dy[l - 1]));
-      epi.pool_H = L.hs[ps2]; epi.pool_W = L.ws[ps2];
-      rc = conv_main(g, g_b, at(wbuf, P.dgrad[l]), nullptr, nullptr, nullptr, nullptr, nullptr, N, h, w, d[l].cout, d[l].cin, d[l].cin, 0, dtype,
-                     at(ws, L.conv_part), stream, P.dgrad3[l] != (size_t)-1 ? at(wbuf, P.dgrad3[l]) : nullptr, &epi);
-      if (rc) return rc;
-    } else if (first_of_stage) {
+    if (first_of_stage) {
       // through the pool into the previous stage's output (+ that stage's side branch, + ReLU mask)
       rc = conv_main(g, g_b, at(wbuf, P.dgrad[l]), nullptr, nullptr, nullptr, f32(L.dpool[si]), store ? at(ws, L.dpool_b[si]) : nullptr, N, h, w,
                      d[l].cout, d[l].cin, d[l].cin, 0, dtype, at(ws, L.conv_part), stream, P.dgrad3[l] != (size_t)-1 ? at(wbuf, P.dgrad3[l]) : nullptr);

@@ -15,13 +15,8 @@
 //   * per (k-step, tap row): 3 tap columns x 3 pieces of X gathered (18 reads) -> 18 MFMAs; fragment sets double buffered
 //   * the next patch's fp32 pieces are loaded from INSIDE the k-loop (one item per stage) and split / written after the barrier
 //   * deterministic: fixed patch -> split assignment, fp32 slabs [split][tap][co][ci] + the shared slab reduce (wgrad_f32.hip)
-//
-// P3IN = 1 (the P3 storage mode of the network, p3.h): x and dy arrive as their three bf16 piece planes, formed once by the producers'
-// epilogues -- staging is three 16-byte loads and three 16-byte LDS writes per item, no conversion or subtraction between the barriers
-// (the fp32 form spends 44 VALU operations per 8 values there, with the matrix pipe of its one-wave-per-SIMD workgroup idle).
 #include "common.h"
 #include "kernels.h"
-#include "p3.h"
 
 namespace {
 
@@ -36,7 +31,7 @@ constexpr int PW = 16;
 
 // S16 = 1: the skinny shape of side_prep (Cout = 16; reference vgg_osvos.py:41): the four waves take four 32-cin blocks of ONE 32-cout block
 // whose upper 16 couts are zero rows of the dY tile (2x padding instead of the 4x a 64-cout tile would spend): 128 cins x 16 couts per
-// workgroup.  The exact-fp32 skinny kernel it replaces in the P3 mode runs at 26 TFLOP/s (263 us per step, VERDICT r02 "furthest below any roofline").
+// workgroup.  The exact-fp32 skinny kernel it replaces runs at 26 TFLOP/s (263 us per step, VERDICT r02 "furthest below any roofline").
 // WAVES = 4: 64 couts x 64 cins per workgroup, one wave per SIMD, double-buffered fragment sets.  WAVES = 8 (Cout % 128 == 0): 128 couts x
 // 64 cins, TWO waves per SIMD (<= 256 registers each: one fragment set, the partner wave covers the gather latency) -- the X tile and its
 // 54 gathers per k-step are shared by twice the MFMAs.
@@ -61,8 +56,8 @@ struct G3 {
 };
 
 struct W3Args {
-  const void* x;       // fp32 NHWC, or (P3IN) P3 [N][3][H][W][Cin_s]
-  const void* dy;      // fp32 NHWC, or (P3IN) P3 [N][3][H][W][Cout_s]
+  const void* x;       // fp32 NHWC [N][H][W][Cin_s]
+  const void* dy;      // fp32 NHWC [N][H][W][Cout_s]
   float* slab;
   float* bslab;
   int N, H, W, Cin_s, Cout, Cout_s;
@@ -113,7 +108,7 @@ __device__ __forceinline__ void stage_groups() {
 // ILV = 1 (four-wave forms): the next stage's 18-24 fragment gathers and the staging loads are INTERLEAVED with the stage's 18 MFMAs (one
 // gather per MFMA, sched_group_barrier) instead of being issued as a block in front of them: with one wave per SIMD nothing else covers
 // the ~150-250 cycles that block takes while the matrix pipe drains (576 cycles of MFMA per stage; the pipe was busy 51 % of the time).
-template <int PH, int WAVES, int P3IN, int S16 = 0, int ILV = 0>
+template <int PH, int WAVES, int S16 = 0, int ILV = 0>
 __global__ __launch_bounds__(64 * WAVES) void wgrad_f32x3_kernel(W3Args a) {
   using G = G3<PH, WAVES, S16>;
   constexpr int NT = G::NT, BCO = G::BCO, BCI = G::BCI;
@@ -137,14 +132,10 @@ __global__ __launch_bounds__(64 * WAVES) void wgrad_f32x3_kernel(W3Args a) {
   const int doct = tid % G::DOCT, dpg = tid / G::DOCT;      // dY: BCO / 8 octets per pixel
   const int xoct = tid % G::XOCT, xpg = tid / G::XOCT;      // X: BCI / 8 octets per pixel
   const bool dy_ch_ok = co0 + 8 * doct < a.Cout, x_ch_ok = ci0 + 8 * xoct < a.Cin_s;
-  constexpr int NR = P3IN ? 3 : 2, ES = P3IN ? 2 : 4;        // registers per staged item (P3: one per piece), element size in HBM
-  u32x4 rdy[G::NDY][NR], rx[G::NX][NR];
+  u32x4 rdy[G::NDY][2], rx[G::NX][2];
   float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const bool want_bias = a.bslab != nullptr && cit == 0;
-  // P3: the image's three planes sit in ONE buffer range, so a row outside the image must be pushed out explicitly (it would alias
-  // the neighbouring plane); the fp32 form lets such rows fall out of the per-image range by themselves
-  const unsigned dy_plane = (unsigned)a.H * a.W * a.Cout_s * 2u, x_plane = (unsigned)a.H * a.W * a.Cin_s * 2u;
-  const int img_dy_bytes = P3IN ? (int)(3u * dy_plane) : a.H * a.W * a.Cout_s * 4, img_x_bytes = P3IN ? (int)(3u * x_plane) : a.H * a.W * a.Cin_s * 4;
+  const int img_dy_bytes = a.H * a.W * a.Cout_s * 4, img_x_bytes = a.H * a.W * a.Cin_s * 4;
 
   struct Patch { __amdgpu_buffer_rsrc_t drs, xrs; int x0, y0; };
   auto locate = [&](int p, bool live) -> Patch {
@@ -164,50 +155,29 @@ __global__ __launch_bounds__(64 * WAVES) void wgrad_f32x3_kernel(W3Args a) {
   auto issue = [&](const Patch& q, int it) {      // it: compile-time item index (dY items first)
     if (it < G::NDY) {
       const int p = dpg + G::DPG * it, py = p / PW, pxx = p - py * PW;
-      const bool ok = dy_ch_ok && (G::DY_ITEMS % NT == 0 || p < G::PPIX) && q.x0 + pxx < a.W && (!P3IN || q.y0 + py < a.H);
-      const unsigned off = ok ? (unsigned)((((q.y0 + py) * a.W + q.x0 + pxx) * a.Cout_s + co0 + 8 * doct) * ES) : OOB;
-      if constexpr (P3IN != 0) {
-#pragma unroll
-        for (int pc = 0; pc < 3; ++pc) rdy[it][pc] = __builtin_amdgcn_raw_buffer_load_b128(q.drs, ok ? off + pc * dy_plane : OOB, 0, 0);
-      } else {
-        rdy[it][0] = __builtin_amdgcn_raw_buffer_load_b128(q.drs, off, 0, 0);
-        rdy[it][1] = __builtin_amdgcn_raw_buffer_load_b128(q.drs, off + 16u, 0, 0);
-      }
+      const bool ok = dy_ch_ok && (G::DY_ITEMS % NT == 0 || p < G::PPIX) && q.x0 + pxx < a.W;
+      const unsigned off = ok ? (unsigned)((((q.y0 + py) * a.W + q.x0 + pxx) * a.Cout_s + co0 + 8 * doct) * 4) : OOB;
+      rdy[it][0] = __builtin_amdgcn_raw_buffer_load_b128(q.drs, off, 0, 0);
+      rdy[it][1] = __builtin_amdgcn_raw_buffer_load_b128(q.drs, off + 16u, 0, 0);
     } else if (it < G::NIT) {
       const int j = it - G::NDY;
       const int hp = xpg + G::XPG * j, hy = hp / G::HW_, hx = hp - hy * G::HW_;
-      const bool ok = x_ch_ok && hp < G::XPIX && (unsigned)(q.x0 - 1 + hx) < (unsigned)a.W && (!P3IN || (unsigned)(q.y0 - 1 + hy) < (unsigned)a.H);
-      const unsigned off = ok ? (unsigned)((((q.y0 - 1 + hy) * a.W + q.x0 - 1 + hx) * a.Cin_s + ci0 + 8 * xoct) * ES) : OOB;
-      if constexpr (P3IN != 0) {
-#pragma unroll
-        for (int pc = 0; pc < 3; ++pc) rx[j][pc] = __builtin_amdgcn_raw_buffer_load_b128(q.xrs, ok ? off + pc * x_plane : OOB, 0, 0);
-      } else {
-        rx[j][0] = __builtin_amdgcn_raw_buffer_load_b128(q.xrs, off, 0, 0);
-        rx[j][1] = __builtin_amdgcn_raw_buffer_load_b128(q.xrs, off + 16u, 0, 0);
-      }
+      const bool ok = x_ch_ok && hp < G::XPIX && (unsigned)(q.x0 - 1 + hx) < (unsigned)a.W;
+      const unsigned off = ok ? (unsigned)((((q.y0 - 1 + hy) * a.W + q.x0 - 1 + hx) * a.Cin_s + ci0 + 8 * xoct) * 4) : OOB;
+      rx[j][0] = __builtin_amdgcn_raw_buffer_load_b128(q.xrs, off, 0, 0);
+      rx[j][1] = __builtin_amdgcn_raw_buffer_load_b128(q.xrs, off + 16u, 0, 0);
     }
   };
   auto store_patch = [&]() {
 #pragma unroll
     for (int i = 0; i < G::NDY; ++i) {
       u32x4 p0, p1, p2;
-      if constexpr (P3IN != 0) {
-        p0 = rdy[i][0]; p1 = rdy[i][1]; p2 = rdy[i][2];
-        if (want_bias) {                            // bias gradient: exact fp32 column sums of dY = hi + mid + lo (zeros outside the image)
+      if (want_bias) {                            // bias gradient: exact fp32 column sums of dY (zeros outside the image)
+        const f32x4 lo = __builtin_bit_cast(f32x4, rdy[i][0]), hi = __builtin_bit_cast(f32x4, rdy[i][1]);
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            bsum[2 * c] += p3_join((unsigned short)(p0[c] & 0xffffu), (unsigned short)(p1[c] & 0xffffu), (unsigned short)(p2[c] & 0xffffu));
-            bsum[2 * c + 1] += p3_join((unsigned short)(p0[c] >> 16), (unsigned short)(p1[c] >> 16), (unsigned short)(p2[c] >> 16));
-          }
-        }
-      } else {
-        if (want_bias) {                            // bias gradient: exact fp32 column sums of dY (zeros outside the image)
-          const f32x4 lo = __builtin_bit_cast(f32x4, rdy[i][0]), hi = __builtin_bit_cast(f32x4, rdy[i][1]);
-#pragma unroll
-          for (int c = 0; c < 4; ++c) { bsum[c] += lo[c]; bsum[4 + c] += hi[c]; }
-        }
-        split8w(rdy[i][0], rdy[i][1], p0, p1, p2);
+        for (int c = 0; c < 4; ++c) { bsum[c] += lo[c]; bsum[4 + c] += hi[c]; }
       }
+      split8w(rdy[i][0], rdy[i][1], p0, p1, p2);
       const int p = dpg + G::DPG * i;
       if (G::DY_ITEMS % NT == 0 || p < G::PPIX) {
         char* d = dYs + p * G::DYP + doct * 16;
@@ -219,11 +189,7 @@ __global__ __launch_bounds__(64 * WAVES) void wgrad_f32x3_kernel(W3Args a) {
 #pragma unroll
     for (int j = 0; j < G::NX; ++j) {
       u32x4 p0, p1, p2;
-      if constexpr (P3IN != 0) {
-        p0 = rx[j][0]; p1 = rx[j][1]; p2 = rx[j][2];
-      } else {
-        split8w(rx[j][0], rx[j][1], p0, p1, p2);
-      }
+      split8w(rx[j][0], rx[j][1], p0, p1, p2);
       const int hp = xpg + G::XPG * j;
       if (G::X_ITEMS % NT == 0 || hp < G::XPIX) {
         char* d = Xs + hp * G::XP + xoct * 16;
@@ -303,7 +269,7 @@ __global__ __launch_bounds__(64 * WAVES) void wgrad_f32x3_kernel(W3Args a) {
                                                                   __builtin_bit_cast(bf16x8_t, af[ks & (NB - 1)][PD[t]]), acc[r * 3 + s], 0, 0, 0);
       if constexpr (ILV != 0) {
         // gathers of the NEXT stage (independent registers: the fragment sets are double buffered) and this stage's staging loads
-        constexpr int V = P3IN ? 3 : 2;
+        constexpr int V = 2;
         const bool last = st + 1 >= G::NST, wide = r == 2, vm = st < G::NIT;      // (compile-time after unrolling)
         if (last) { if (vm) stage_groups<0, V>(); else stage_groups<0, 0>(); }
         else if (wide) { if (vm) stage_groups<24, V>(); else stage_groups<24, 0>(); }
@@ -369,14 +335,11 @@ W3Plan make_plan3(int N, int H, int W, int Cin_s, int Cout) {
     p.bslab_floats = (size_t)p.nsplit * Cout;
     return p;
   }
-  OSVOS_ENV_INT(env_waves, "OSVOS_X3_WGRAD_WAVES", 0);
-  // measured (tools/gpu_r02_o.sh): the eight-wave tile is 3-4 % faster standalone on conv2_2 / conv3_2 (157 vs 165, 162 vs 168 us), level or
-  // slower elsewhere (twice the splits = twice the slab traffic), and the whole step is slower with it beside the data-gradient kernels
-  // (206 vs 210 frames/s): four waves stay the default, OSVOS_X3_WGRAD_WAVES=8 selects the other form
-  p.waves = env_waves == 8 ? 8 : 4;
-  if (Cout % 128 != 0) p.waves = 4;
+  // (An eight-wave 128 x 64-channel tile was measured in round 2: 3-4 % faster standalone on conv2_2 / conv3_2, level or slower elsewhere --
+  //  twice the splits = twice the slab traffic -- and the whole step slower beside the data-gradient kernels, 206 vs 210 frames/s: removed.)
+  p.waves = 4;
   p.bco = 16 * p.waves;
-  p.ph = p.waves == 8 ? 4 : ((ceil_div(H, 6) * 6 <= ceil_div(H, 4) * 4) ? 6 : 4);      // (the eight-wave tile fits the LDS with 16 x 4 patches only)
+  p.ph = (ceil_div(H, 6) * 6 <= ceil_div(H, 4) * 4) ? 6 : 4;
   p.nco_t = ceil_div(Cout, p.bco);
   p.nci_t = ceil_div(Cin_s, 64);
   p.npx = ceil_div(W, PW);
@@ -393,17 +356,17 @@ W3Plan make_plan3(int N, int H, int W, int Cin_s, int Cout) {
   return p;
 }
 
-template <int PH, int WAVES, int P3IN, int S16 = 0, int ILV = 0>
+template <int PH, int WAVES, int S16 = 0, int ILV = 0>
 int launch3(const W3Args& a, long blocks, hipStream_t stream) {
   static bool attr_set_dev[OSVOS_MAX_DEVICES] = {};
   bool& attr_set = attr_set_dev[osvos_current_device()];
   if (!attr_set) {
-    OSVOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_f32x3_kernel<PH, WAVES, P3IN, S16, ILV>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    OSVOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_f32x3_kernel<PH, WAVES, S16, ILV>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)G3<PH, WAVES, S16>::LDS));
     attr_set = true;
   }
   constexpr size_t lds = G3<PH, WAVES, S16>::LDS;
-  hipLaunchKernelGGL((wgrad_f32x3_kernel<PH, WAVES, P3IN, S16, ILV>), dim3((unsigned)blocks), dim3(64 * WAVES), lds, stream, a);
+  hipLaunchKernelGGL((wgrad_f32x3_kernel<PH, WAVES, S16, ILV>), dim3((unsigned)blocks), dim3(64 * WAVES), lds, stream, a);
   OSVOS_LAUNCH_CHECK();
   return 0;
 }
@@ -417,10 +380,9 @@ int osvos_wgrad_reduce_launch(const float* slab, const float* bslab, float* dw, 
 bool osvos_wgrad_f32x3_applicable(int Cin, int Cin_s, int Cout, int Cout_s) {
   return Cin == Cin_s && Cin_s % 64 == 0 && Cout % 64 == 0 && Cout_s % 4 == 0;
 }
-// side_prep's shape (Cout = 16): the S16 form (OSVOS_X3_SIDE_WGRAD=0 keeps the exact fp32 skinny kernel)
+// side_prep's shape (Cout = 16): the S16 form
 bool osvos_wgrad_f32x3_skinny_applicable(int Cin, int Cin_s, int Cout, int Cout_s) {
-  static const bool on = [] { const char* e = getenv("OSVOS_X3_SIDE_WGRAD"); return !(e && e[0] == '0'); }();
-  return on && Cout == 16 && Cout_s == 16 && Cin == Cin_s && Cin_s % 128 == 0;
+  return Cout == 16 && Cout_s == 16 && Cin == Cin_s && Cin_s % 128 == 0;
 }
 
 size_t osvos_wgrad_f32x3_ws_bytes(int N, int H, int W, int Cin_s, int Cout) {
@@ -429,20 +391,17 @@ size_t osvos_wgrad_f32x3_ws_bytes(int N, int H, int W, int Cin_s, int Cout) {
     return align_up((p.slab_floats + p.bslab_floats) * sizeof(float), 256);
   }
   if (Cin_s % 64 != 0 || Cout % 64 != 0) return 0;
-  // whichever form runs (OSVOS_X3_WGRAD_WAVES): the eight-wave tiles need up to twice the splits of the four-wave ones
   const W3Plan p = make_plan3(N, H, W, Cin_s, Cout);
-  const size_t nsplit_max = 256;
-  const size_t worst = (size_t)(p.nsplit * 2 < (int)nsplit_max ? p.nsplit * 2 : nsplit_max);
-  return align_up(((size_t)worst * 9 * Cout * Cin_s + worst * Cout) * sizeof(float), 256);
+  return align_up((p.slab_floats + p.bslab_floats) * sizeof(float), 256);
 }
 
 namespace {
-int wgrad3_run(const void* x, const void* dy, int p3in, void* ws, float* dw, float* db,
+int wgrad3_run(const void* x, const void* dy, void* ws, float* dw, float* db,
                int N, int H, int W, int Cin, int Cin_s, int Cout, int Cout_s, int accumulate, hipStream_t stream) {
   OSVOS_ARG_CHECK(x && dy && ws && dw, "wgrad f32x3: null pointer");
   OSVOS_ARG_CHECK(N > 0 && H > 0 && W > 0, "wgrad f32x3: bad shape");
   const bool skinny = Cout == 16 && Cout_s == 16 && Cin == Cin_s && Cin_s % 128 == 0;      // side_prep
-  OSVOS_ARG_CHECK(skinny || (osvos_wgrad_f32x3_applicable(Cin, Cin_s, Cout, Cout_s) && (!p3in || Cout_s % 8 == 0)),
+  OSVOS_ARG_CHECK(skinny || osvos_wgrad_f32x3_applicable(Cin, Cin_s, Cout, Cout_s),
                   "wgrad f32x3: unsupported shape (Cin %d/%d Cout %d/%d)", Cin, Cin_s, Cout, Cout_s);
   OSVOS_ARG_CHECK((long)H * W * Cin_s < (1L << 28) && (long)H * W * Cout_s < (1L << 28), "wgrad f32x3: image too large for 31-bit byte offsets");
   const W3Plan p = make_plan3(N, H, W, Cin_s, Cout);
@@ -457,20 +416,9 @@ int wgrad3_run(const void* x, const void* dy, int p3in, void* ws, float* dw, flo
   a.map = (map_env == 1 && blocks % 8 == 0) ? 1 : 0;
   const int phase = osvos_wgrad_phase();
   if (phase != 2) {
-    int rc;
-    OSVOS_ENV_INT(ilv, "OSVOS_WGRAD_ILV", 1);      // 1: gathers / staging loads interleaved with the MFMAs (four-wave forms); 0: issued as a block
-    if (skinny && p3in)
-      rc = ilv ? launch3<4, 4, 1, 1, 1>(a, blocks, stream) : launch3<4, 4, 1, 1, 0>(a, blocks, stream);
-    else if (skinny)
-      rc = ilv ? launch3<4, 4, 0, 1, 1>(a, blocks, stream) : launch3<4, 4, 0, 1, 0>(a, blocks, stream);
-    else if (p3in)
-      rc = p.waves == 8 ? launch3<4, 8, 1>(a, blocks, stream)
-                        : (p.ph == 6 ? (ilv ? launch3<6, 4, 1, 0, 1>(a, blocks, stream) : launch3<6, 4, 1, 0, 0>(a, blocks, stream))
-                                     : (ilv ? launch3<4, 4, 1, 0, 1>(a, blocks, stream) : launch3<4, 4, 1, 0, 0>(a, blocks, stream)));
-    else
-      rc = p.waves == 8 ? launch3<4, 8, 0>(a, blocks, stream)
-                        : (p.ph == 6 ? (ilv ? launch3<6, 4, 0, 0, 1>(a, blocks, stream) : launch3<6, 4, 0, 0, 0>(a, blocks, stream))
-                                     : (ilv ? launch3<4, 4, 0, 0, 1>(a, blocks, stream) : launch3<4, 4, 0, 0, 0>(a, blocks, stream)));
+    // gathers / staging loads interleaved with the MFMAs of the previous stage (round 3; the block-issue form measured level and is gone)
+    const int rc = skinny ? launch3<4, 4, 1, 1>(a, blocks, stream)
+                          : (p.ph == 6 ? launch3<6, 4, 0, 1>(a, blocks, stream) : launch3<4, 4, 0, 1>(a, blocks, stream));
     if (rc) return rc;
   }
   if (phase == 1) return 0;
@@ -480,11 +428,5 @@ int wgrad3_run(const void* x, const void* dy, int p3in, void* ws, float* dw, flo
 
 int osvos_conv3x3_wgrad_f32x3(const float* x, const float* dy, void* ws, float* dw, float* db,
                               int N, int H, int W, int Cin, int Cin_s, int Cout, int Cout_s, int accumulate, hipStream_t stream) {
-  return wgrad3_run(x, dy, 0, ws, dw, db, N, H, W, Cin, Cin_s, Cout, Cout_s, accumulate, stream);
-}
-
-// x3 / dy3: P3 tensors [N][3][H][W][Cin_s] / [N][3][H][W][Cout_s]; same workspace, slabs and reduce as the fp32 form
-int osvos_conv3x3_wgrad_p3(const void* x3, const void* dy3, void* ws, float* dw, float* db,
-                           int N, int H, int W, int Cin, int Cin_s, int Cout, int Cout_s, int accumulate, hipStream_t stream) {
-  return wgrad3_run(x3, dy3, 1, ws, dw, db, N, H, W, Cin, Cin_s, Cout, Cout_s, accumulate, stream);
+  return wgrad3_run(x, dy, ws, dw, db, N, H, W, Cin, Cin_s, Cout, Cout_s, accumulate, stream);
 }

@@ -283,72 +283,7 @@ def conv3x3_x3(x, wpk3, bias, cout, relu=False, mask=None, y_cs=None, tile=-1):
     return y
 
 
-# ---- P3 tensors (csrc/p3.h): an fp32 NHWC tensor as its three bf16 piece planes, torch.bfloat16 [N,3,H,W,C] ----------------------------
-def f32_to_p3(x, cd=None):
-    """fp32 [N,H,W,C] -> P3 [N,3,H,W,cd] (cd = C rounded up to 8 by default; padding channels zero)"""
-    _need_cuda(x)
-    n, h, w, c = x.shape
-    cd = cd or (c + 7) // 8 * 8
-    y = torch.empty((n, 3, h, w, cd), device=x.device, dtype=torch.bfloat16)
-    check(lib().osvos_f32_to_p3_abi(_p(x.contiguous()), _p(y), n, h, w, c, c, cd, _stream()), "f32_to_p3")
-    return y
 
-
-def p3_to_f32(x3):
-    _need_cuda(x3)
-    n, _, h, w, c = x3.shape
-    y = torch.empty((n, h, w, c), device=x3.device, dtype=torch.float32)
-    check(lib().osvos_p3_to_f32_abi(_p(x3), _p(y), n, h, w, c, _stream()), "p3_to_f32")
-    return y
-
-
-def conv3x3_p3(x3, wpk3, bias, cout, relu=False, mask=None, want_f32=True, want_p3=True, y_cs=None, tile=-1, ksplit=1):
-    """P3 convolution (pre-split weights from pack_x3): x3 [N,3,H,W,Cin] -> (y fp32 [N,H,W,y_cs] | None, y3 P3 [N,3,H,W,cout] | None).
-    mask: fp32 [N,H,W,cout] or a P3 tensor [N,3,H,W,cout].  ksplit: 1 = never split, 0 = automatic, 2..8 = forced."""
-    _need_cuda(x3, wpk3, bias, mask)
-    n, _, h, w, cin = x3.shape
-    y_cs = y_cs or (cout + 3) // 4 * 4
-    y = torch.zeros((n, h, w, y_cs), device=x3.device, dtype=torch.float32) if want_f32 else None
-    y3 = torch.zeros((n, 3, h, w, cout), device=x3.device, dtype=torch.bfloat16) if want_p3 else None
-    part = None
-    if ksplit != 1:
-        part = torch.empty(lib().osvos_conv3x3_p3_ws_bytes(n, h, w, cout), device=x3.device, dtype=torch.uint8)
-    mp3 = int(mask is not None and mask.dtype == torch.bfloat16)
-    mcs = int(mask.shape[-1]) if mask is not None else 0
-    check(lib().osvos_conv3x3_p3_abi(_p(x3), _p(wpk3), _p(bias), _p(mask), mp3, mcs, _p(y), y_cs, _p(y3), cout, n, h, w, cin, cout,
-                                     int(relu), tile, ksplit, _p(part), _stream()), "conv3x3_p3")
-    return y, y3
-
-
-def conv3x3_wgrad_p3(x3, dy3, cin, cout, want_bias=True):
-    """P3 x [N,3,H,W,cin], P3 dy [N,3,H,W,cout] -> (dW fp32 [cout,cin,3,3], db fp32 [cout])"""
-    _need_cuda(x3, dy3)
-    n, _, h, w, cin_s = x3.shape
-    ws = torch.empty(lib().osvos_wgrad_ws_bytes(n, h, w, cin_s, cout, F32_X3), device=x3.device, dtype=torch.uint8)
-    dw = torch.empty((cout, cin, 3, 3), device=x3.device, dtype=torch.float32)
-    db = torch.empty((cout,), device=x3.device, dtype=torch.float32) if want_bias else None
-    check(lib().osvos_conv3x3_wgrad_p3_abi(_p(x3), _p(dy3), _p(ws), _p(dw), _p(db), n, h, w, cin, cin_s, cout, int(dy3.shape[-1]), 0, _stream()), "wgrad_p3")
-    return dw, db
-
-
-def maxpool2x2_p3(x, want_f32=False):
-    """fp32 [N,H,W,C] -> (pooled fp32 | None, pooled P3)"""
-    _need_cuda(x)
-    n, h, w, c = x.shape
-    ho, wo = (h + 1) // 2, (w + 1) // 2
-    y = torch.empty((n, ho, wo, c), device=x.device, dtype=torch.float32) if want_f32 else None
-    y3 = torch.empty((n, 3, ho, wo, c), device=x.device, dtype=torch.bfloat16)
-    check(lib().osvos_maxpool2x2_p3_abi(_p(x), _p(y), _p(y3), n, h, w, c, _stream()), "maxpool_p3")
-    return y, y3
-
-
-def maxpool2x2_bwd_p3(x, dy, dside=None, want_f32=False):
-    _need_cuda(x, dy, dside)
-    n, h, w, c = x.shape
-    dx = torch.empty_like(x) if want_f32 else None
-    dx3 = torch.empty((n, 3, h, w, c), device=x.device, dtype=torch.bfloat16)
-    check(lib().osvos_maxpool2x2_bwd_p3_abi(_p(x), _p(dy), _p(dside), _p(dx), _p(dx3), n, h, w, c, _stream()), "maxpool_bwd_p3")
-    return dx, dx3
 
 
 def conv3x3_dgrad_c3(dy, w_oihw):

@@ -828,3 +828,26 @@ def test_cbce_step_multi_equals_the_single_head_calls():
             assert torch.equal(grads[k], ref[k][1]), k
             assert abs(float(losses[k]) - float(ref[k][0])) <= 2e-7 * abs(float(ref[k][0])), k
             assert abs(float(r2[k]) - float(r1[k])) <= 2e-7 * abs(float(r1[k])), k
+
+
+@pytest.mark.parametrize("shape", [(1, 24, 32, 128), (2, 17, 21, 256), (1, 30, 54, 512), (1, 7, 5, 128)])
+def test_skinny_side_prep_wgrad_on_the_bf16_pipe(shape):
+    """side_prep's weight gradient (Cout = 16; vgg_osvos.py:41) -- the S16 form of wgrad_f32x3.hip, what the default fp32x3 network runs --
+    against float64 and against the exact fp32 skinny kernel it replaced (0.17 of the fp32 roofline in round 2)"""
+    from osvos_pytorch_amd import ops
+    from osvos_pytorch_amd._lib import F32, F32_X3
+    n, h, w, cin = shape
+    cout = 16
+    g = torch.Generator().manual_seed(51 + h)
+    x = F.relu(torch.randn(n, cin, h, w, generator=g))
+    dy = torch.randn(n, cout, h, w, generator=g)
+    wt = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), wt, padding=1).backward(dy.double())
+    xd, dyd = x.permute(0, 2, 3, 1).contiguous().cuda(), dy.permute(0, 2, 3, 1).contiguous().cuda()
+    dw3, db3 = ops.conv3x3_wgrad(xd, dyd, cin, cout, dtype=F32_X3)
+    d = dw3.cpu().double() - wt.grad
+    emax, el2 = float(d.abs().max() / wt.grad.abs().max()), float(d.norm() / wt.grad.norm())
+    assert el2 < 1e-6 and emax < 1e-5, (shape, emax, el2)
+    torch.testing.assert_close(db3.cpu().double(), dy.double().sum((0, 2, 3)), rtol=1e-5, atol=1e-4)
+    dw, db = ops.conv3x3_wgrad(xd, dyd, cin, cout, dtype=F32)
+    assert float((dw3.double() - dw.double()).norm() / dw.double().norm()) < 1e-6, shape

@@ -1,5 +1,6 @@
 #!/bin/bash
 # What each piece of the backward costs at step level: bench.py with OSVOS_DBG_SKIP masks (csrc/net.cpp; results are WRONG, timing only).
+# Needs a probe build of the library: (cd osvos-pytorch_amd/csrc && make clean && make EXTRA=-DOSVOS_DBG_ABLATIONS)
 # usage: tools/ablate_step.sh "<bench args>" mask [mask ...]
 ARGS=$1; shift
 for m in "$@"; do

@@ -1,7 +1,7 @@
 #!/bin/bash
 # One parameterised runner for gpurun calls (replaces the per-experiment gpu_r02_*.sh scripts): runs the named steps in order, every step
 # under its own timeout, logs under gpurun_out/<tag>/.   usage: tools/gpu_run.sh <tag> <step> [<step> ...]
-#   steps: p3tests | tune_p3[:args] | pytest[:expr] | smoke | bench[:args] | prof[:args] | layers:<mode batch> | cmd:<shell command>
+#   steps: pytest[:expr] | smoke | bench[:args] | prof[:args] | layers:<mode batch> | cmd:<shell command>
 set -u
 TAG=$1; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -15,8 +15,6 @@ for step in "$@"; do
   name=${step%%:*}; arg=""; [[ "$step" == *:* ]] && arg=${step#*:}
   t0=$(date +%s)
   case $name in
-    p3tests) timeout 600 python -m pytest tests/test_gpu_p3.py -q --tb=short -p no:cacheprovider -x > $O/p3tests.log 2>&1; echo "exit $?" >> $O/p3tests.log; tail -15 $O/p3tests.log ;;
-    tune_p3) timeout 600 python tools/tune_p3.py $arg > $O/tune_p3.log 2>&1; tail -60 $O/tune_p3.log ;;
     pytest) timeout 1200 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider --durations=25 ${arg:+-k "$arg"} > $O/pytest_gpu.log 2>&1; echo "exit $?" >> $O/pytest_gpu.log; grep -E "passed|failed|FAILED|Error" $O/pytest_gpu.log | tail -25 ;;
     smoke) timeout 300 python __graft_entry__.py smoke > $O/smoke.log 2>&1; tail -2 $O/smoke.log ;;
     bench) timeout 900 python bench.py $arg > $O/bench.log 2>$O/bench.err; tail -c 3000 $O/bench.log; tail -5 $O/bench.err ;;
