@@ -89,6 +89,16 @@ int osvos_get_fp32_conv_mode(void);
  * osvos_conv3x3_x3: arguments as osvos_conv3x3 with dtype OSVOS_F32_X3; tile -1 or one of the eight-wave f32x3 tiles (10, 12, 14, 15). */
 size_t osvos_wpack_x3_bytes_abi(int Cout, int Cin, int dgrad);
 int osvos_pack_conv3x3_x3(const float* w_oihw, void* wpk3, int Cout, int Cin, int dgrad, void* stream);
+/* Stream-K form of osvos_conv3x3_x3 (round 4): one persistent workgroup per CU walks an even share of the launch's (tile, 16-channel K chunk)
+ * units; tiles whose K range is shared are summed by the last arriver in a fixed order (deterministic; no workgroup ever waits for another).
+ * sk_ws: caller-owned workspace of osvos_conv3x3_x3_streamk_ws_bytes(); its first osvos_conv3x3_x3_streamk_ticket_bytes() bytes must be ZERO
+ * before the first launch that uses the buffer (every launch leaves them zero); launches sharing one workspace must be stream-ordered.
+ * grid: 0 = automatic (stream-K only when a plain grid would leave CUs without a tile), > 0 = forced with that many workgroups (<= 256).
+ * pooled (optional): maxpool2x2_ceil(y) written next to y (needs relu, y_cs == Cout).  Tiles 10, 12, 14 (or -1); other tiles run plain. */
+size_t osvos_conv3x3_x3_streamk_ws_bytes(void);
+size_t osvos_conv3x3_x3_streamk_ticket_bytes(void);
+int osvos_conv3x3_x3_streamk(const void* x, const void* wpk3, const float* bias, const void* mask, void* y, void* pooled, int N, int H, int W, int Cin,
+                             int Cout, int y_cs, int relu, int tile, int grid, void* sk_ws, void* stream);
 int osvos_conv3x3_x3(const void* x, const void* wpk3, const float* bias, const void* mask, void* y,
                      int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int tile, void* stream);
 /* same convolution cut into `ksplit` parts along K = 9*Cin (0 = automatic, 1..8): layers too small to balance over
@@ -103,6 +113,8 @@ int osvos_conv3x3_splitk(const void* x, const void* wpk, const float* bias, cons
  * (Cout % 16 == 0), wpk_dgrad = osvos_pack_conv3x3_dgrad(w, .., Cout, 3, OSVOS_F32) -> dx_nchw fp32 [N][3][H][W] directly.  A bandwidth
  * kernel (fp32 FMAs, filter through scalar loads) in place of a 32-cout MFMA tile that would waste 10x the matrix work. */
 int osvos_conv3x3_dgrad_c3(const float* dy, const float* wpk_dgrad, float* dx_nchw, int N, int H, int W, int Cout, void* stream);
+/* the same from a bf16 dy (NHWC bf16: the bf16-store mode); wpk_dgrad is still the OSVOS_F32 pack, arithmetic fp32 */
+int osvos_conv3x3_dgrad_c3_bf16act(const void* dy_bf16, const float* wpk_dgrad, float* dx_nchw, int N, int H, int W, int Cout, void* stream);
 
 
 /* ---- bf16 operand storage for the bf16-MFMA path (dtype OSVOS_F32_BF16MFMA) ------------------------------------------

@@ -42,6 +42,9 @@ PROTOTYPES = {
     "osvos_wpack_x3_bytes_abi": (_sz, [_i, _i, _i]),
     "osvos_pack_conv3x3_x3": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "osvos_conv3x3_x3": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "osvos_conv3x3_x3_streamk_ws_bytes": (_sz, []),
+    "osvos_conv3x3_x3_streamk_ticket_bytes": (_sz, []),
+    "osvos_conv3x3_x3_streamk": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "osvos_get_fp32_conv_mode": (_i, []),
     "osvos_conv3x3_splitk_ws_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "osvos_conv3x3_splitk": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
@@ -54,6 +57,7 @@ PROTOTYPES = {
     "osvos_maxpool2x2_bf16copy": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "osvos_maxpool2x2_bwd_bf16copy": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "osvos_conv3x3_dgrad_c3": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "osvos_conv3x3_dgrad_c3_bf16act": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "osvos_wgrad_ws_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "osvos_conv3x3_wgrad": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "osvos_maxpool2x2": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),

@@ -65,6 +65,21 @@ int osvos_conv3x3_x3(const void* x, const void* wpk3, const float* bias, const v
                                 tile >= 200 ? tile - 200 : tile, 0, nullptr, (hipStream_t)stream);
 }
 
+// stream-K form of osvos_conv3x3_x3 (conv3x3_f32x3.hip): sk_ws of osvos_conv3x3_x3_streamk_ws_bytes() with its first
+// osvos_conv3x3_x3_streamk_ticket_bytes() bytes ZERO before the first use; grid 0 = automatic decision, > 0 = forced with that many workgroups
+size_t osvos_conv3x3_x3_streamk_ws_bytes(void) { return osvos_conv3x3_f32x3_streamk_ws_bytes(); }
+size_t osvos_conv3x3_x3_streamk_ticket_bytes(void) { return osvos_conv3x3_f32x3_streamk_ticket_bytes(); }
+int osvos_conv3x3_x3_streamk(const void* x, const void* wpk3, const float* bias, const void* mask, void* y, void* pooled, int N, int H, int W, int Cin,
+                             int Cout, int y_cs, int relu, int tile, int grid, void* sk_ws, void* stream) {
+  OSVOS_ARG_CHECK(wpk3 != nullptr && sk_ws != nullptr && grid >= 0, "conv3x3_x3_streamk: null pack / workspace");
+  ConvEpi epi;
+  epi.sk_ws = sk_ws;
+  epi.sk_grid = grid;
+  epi.pooled = reinterpret_cast<float*>(pooled);
+  return osvos_conv3x3_f32x3_epi((const float*)x, nullptr, wpk3, bias, (const float*)mask, (float*)y, N, H, W, Cin, Cout, y_cs, relu,
+                                 tile >= 200 ? tile - 200 : tile, 1, nullptr, &epi, (hipStream_t)stream);
+}
+
 // bf16-MFMA convolution with explicit operand / result formats: x fp32 (x_is_bf16 = 0) or bf16 NHWC; y fp32 and,
 // when y_bf16 != NULL, a bf16 copy of y with the same channel stride (the operand of the next convolution)
 int osvos_conv3x3_bf16io(const void* x, int x_is_bf16, const void* wpk, const float* bias, const void* mask, int mask_is_bf16, float* y,
@@ -145,6 +160,9 @@ int osvos_maxpool2x2_bwd_bf16copy(const float* x, const float* dy, const float* 
 
 int osvos_conv3x3_dgrad_c3(const float* dy, const float* wpk_dgrad, float* dx_nchw, int N, int H, int W, int Cout, void* stream) {
   return osvos_conv3x3_dgrad_c3_f32(dy, wpk_dgrad, dx_nchw, N, H, W, Cout, (hipStream_t)stream);
+}
+int osvos_conv3x3_dgrad_c3_bf16act(const void* dy_bf16, const float* wpk_dgrad, float* dx_nchw, int N, int H, int W, int Cout, void* stream) {
+  return osvos_conv3x3_dgrad_c3_bf16in(dy_bf16, wpk_dgrad, dx_nchw, N, H, W, Cout, (hipStream_t)stream);
 }
 
 

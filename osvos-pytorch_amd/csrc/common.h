@@ -44,6 +44,16 @@ static inline int osvos_current_device() {
   if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= OSVOS_MAX_DEVICES) d = 0;
   return d;
 }
+// compute units of the current device (cached per device)
+static inline int osvos_cu_count() {
+  static int cus[OSVOS_MAX_DEVICES] = {};
+  int& c = cus[osvos_current_device()];
+  if (c == 0) {
+    int v = 0;
+    c = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, osvos_current_device()) == hipSuccess && v > 0) ? v : 256;
+  }
+  return c;
+}
 // integer environment knob, read once per process (tuning / test switches must not cost a getenv per launch)
 #define OSVOS_ENV_INT(var, name, dflt) static const int var = [] { const char* e_ = getenv(name); return e_ ? atoi(e_) : (dflt); }()
 

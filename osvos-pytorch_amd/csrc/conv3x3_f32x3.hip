@@ -22,6 +22,19 @@
 //     step ahead and pinned with sched_barrier (hipcc otherwise sinks every ds_read to its first use)
 //   * epilogue identical to conv3x3_f32.hip (cout-major accumulators -> 16-byte buffer stores, bias / ReLU / ReLU-mask
 //     of the producer fused, split-K partial sums)
+//
+// STREAM-K form (SK = 1; round 4).  At batch 1 the 256-pixel tiles give 202-224 workgroups on 256 CUs (conv3_x / conv4_x), 420 on conv2_x:
+// one workgroup per CU (110-143 KB of LDS), so 12-18 % of the chip idles for lack of tiles and nothing runs beside the forward.  The SK kernel
+// is launched with one PERSISTENT workgroup per CU; the launch's work = ntiles x (Cin / 16) units (tile, 16-channel K chunk) in one linear
+// order is cut into gridDim.x equal contiguous shares.  A workgroup walks its share tile by tile; a tile whose K range it covers alone gets the
+// normal epilogue, otherwise the raw accumulators go to a partial slot in the workspace ([virtual workgroup][2] slots: a share has at most one
+// partial head and one partial tail), the workgroup takes a ticket on the tile, and the LAST arriver sums the parts IN CONTRIBUTOR ORDER (its
+// own from registers: the sum does not depend on who arrives last -> deterministic) and runs the epilogue.  No spin-waits: a workgroup never
+// waits for another one, so no residency assumption is made.  Cross-CU visibility follows MI355X_MICROARCH.md "Workgroup dispatch ...": plain
+// stores -> every wave drains its stores -> barrier -> lane 0: agent release fence + s_waitcnt vmcnt(0) + relaxed agent atomic; the last
+// arriver: agent acquire fence by lane 0 -> barrier -> plain loads.  Blocks are renumbered so that XCD b % 8 owns a CONTIGUOUS eighth of the
+// unit space: with the spatial tile as the fast index an XCD keeps one slice of the weights hot in its L2 (deep layers), with the Cout tile
+// as the fast index the Cout tiles of one halo run back to back in one workgroup (shallow layers).
 #include "common.h"
 #include "kernels.h"
 #include "epi.h"
@@ -46,6 +59,10 @@ struct ConvArgsX {
   int ksplit;
   float* part;
   ConvEpi epi;           // optional fused pooling epilogues (epi.h)
+  // stream-K kernels only
+  int sk_order;          // 0: Cout tile is the fast index of the tile order, 1: the spatial tile is
+  unsigned* sk_tickets;  // [ntiles], zero at launch; the last arriver of a tile zeroes its ticket again
+  float* sk_part;        // [gridDim.x][2] slots of NT * WM * WN * 16 floats (raw accumulators)
 };
 
 constexpr int cdivx(int a, int b) { return (a + b - 1) / b; }
@@ -73,7 +90,8 @@ struct CfgX {
   static constexpr int NBL = cdivx(B_ITEMS, NT);
   static constexpr int MB = TBX * TBY;
   static constexpr int WM = MB / WGM, WN = NB / WGN;
-  static constexpr size_t LDS_BYTES = (size_t)(BUF_U4 + 1) * 16;
+  static constexpr size_t LDS_BYTES = (size_t)(BUF_U4 + 2) * 16;      // (+ one slot of slack, + the stream-K ticket word)
+  static constexpr int SK_SLOT_F4 = NT * WM * WN * 4;       // float4 per stream-K partial slot
   static_assert(WGM * WGN == 4 || WGM * WGN == 8, "4 or 8 waves per workgroup");
   static_assert(MB % WGM == 0 && NB % WGN == 0, "wave grid must divide the tile");
   static_assert(LDS_BYTES <= 160 * 1024, "tile does not fit the 160 KB LDS of a gfx950 CU");
@@ -105,7 +123,7 @@ __device__ inline void split8(const u32x4& lo, const u32x4& hi, uint4& p0, uint4
 // PS = 1: the weights arrive PRE-SPLIT (three bf16 piece planes, made once per optimizer step by pack_x3_kernel): their staging is
 // a plain copy.  5 of the 7 items a thread stages per chunk are weights, re-split by every workgroup of every launch when PS = 0 --
 // 64 % of the VALU work between the two barriers of a chunk (profiles/r02_pmc_f32x3.txt).
-template <class C, int PS>
+template <class C, int PS, int SK>
 __global__ __launch_bounds__(C::NT, C::OCC) void conv3x3_f32x3_kernel(ConvArgsX a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint4* As = reinterpret_cast<uint4*>(smem);
@@ -113,16 +131,41 @@ __global__ __launch_bounds__(C::NT, C::OCC) void conv3x3_f32x3_kernel(ConvArgsX 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int wm = wave / C::WGN, wn = wave % C::WGN;
+  const int nch_all = a.Cin >> 4;
 
+  // stream-K: this workgroup's share [u, u_end) of the U = ntiles * nch_all units; vme = its index in unit order (XCD-contiguous)
+  unsigned u = 0, u_end = 0, vme = 0, sk_U = 0, my_first_tile = 0;
+  if constexpr (SK != 0) {
+    const unsigned G = gridDim.x;
+    vme = (G & 7u) == 0 ? (blockIdx.x & 7u) * (G >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    sk_U = (unsigned)(a.nct * a.nsp) * (unsigned)nch_all;
+    u = (unsigned)(((unsigned long long)vme * sk_U) / G);
+    u_end = (unsigned)(((unsigned long long)(vme + 1) * sk_U) / G);
+    my_first_tile = u / (unsigned)nch_all;
+  }
+ for (;;) {      // SK: one pass per (tile, K range) segment of the share; otherwise exactly one pass
   int sp, ct;
-  if (a.map == 0) {          // Cout tile in the low bits: XCD b % 8 keeps one weight slice hot in its L2
-    sp = blockIdx.x / a.nct;
-    ct = blockIdx.x % a.nct;
-  } else {                   // Cout tiles of one spatial tile on the same XCD: the halo is fetched from HBM once per XCD
-    const int j = blockIdx.x >> 3;
-    ct = j % a.nct;
-    sp = (j / a.nct) * 8 + (blockIdx.x & 7);
-    if (sp >= a.nsp) return;
+  int kc_begin, kc_end;
+  unsigned tile_id = 0;
+  if constexpr (SK != 0) {
+    if (u >= u_end) break;
+    tile_id = u / (unsigned)nch_all;
+    kc_begin = (int)(u - tile_id * (unsigned)nch_all);
+    kc_end = min(nch_all, kc_begin + (int)(u_end - u));
+    if (a.sk_order == 0) { sp = (int)(tile_id / (unsigned)a.nct); ct = (int)(tile_id % (unsigned)a.nct); }
+    else { ct = (int)(tile_id / (unsigned)a.nsp); sp = (int)(tile_id % (unsigned)a.nsp); }
+  } else {
+    if (a.map == 0) {          // Cout tile in the low bits: XCD b % 8 keeps one weight slice hot in its L2
+      sp = blockIdx.x / a.nct;
+      ct = blockIdx.x % a.nct;
+    } else {                   // Cout tiles of one spatial tile on the same XCD: the halo is fetched from HBM once per XCD
+      const int j = blockIdx.x >> 3;
+      ct = j % a.nct;
+      sp = (j / a.nct) * 8 + (blockIdx.x & 7);
+      if (sp >= a.nsp) return;
+    }
+    kc_begin = (int)((long)nch_all * blockIdx.y / a.ksplit);
+    kc_end = (int)((long)nch_all * (blockIdx.y + 1) / a.ksplit);
   }
   const int tx = sp % a.tiles_x;
   sp /= a.tiles_x;
@@ -243,9 +286,6 @@ __global__ __launch_bounds__(C::NT, C::OCC) void conv3x3_f32x3_kernel(ConvArgsX 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-  const int nch_all = a.Cin >> 4;
-  const int kc_begin = (int)((long)nch_all * blockIdx.y / a.ksplit);
-  const int kc_end = (int)((long)nch_all * (blockIdx.y + 1) / a.ksplit);
   // probe builds (tools/native/build.sh, -DOSVOS_X3_ABL=n; wrong results, timing only): 1 no MFMA, 2 no fragment reads after the first step,
   // 3 no global loads inside the K loop, 4 tiles stored once (no split / ds_write per chunk), 5 no barriers
   load_chunk(kc_begin);
@@ -315,6 +355,69 @@ __global__ __launch_bounds__(C::NT, C::OCC) void conv3x3_f32x3_kernel(ConvArgsX 
     }
   }
 
+  if constexpr (SK != 0) {
+    u += (unsigned)(kc_end - kc_begin);
+    if (!(kc_begin == 0 && kc_end == nch_all)) {      // this tile's K range is shared with other workgroups
+      const unsigned G = gridDim.x, nch = (unsigned)nch_all;
+      const unsigned vf = ((tile_id * nch + 1u) * G - 1u) / sk_U;        // owner of the tile's first unit ...
+      const unsigned vl = ((tile_id + 1u) * nch * G - 1u) / sk_U;        // ... and of its last one: contributors vf .. vl, in K order
+      const unsigned nparts = vl - vf + 1u, cme = vme - vf;
+      f32x4* const slots = reinterpret_cast<f32x4*>(a.sk_part);
+      f32x4* const mine = slots + (size_t)(2u * vme + (tile_id == my_first_tile ? 0u : 1u)) * C::SK_SLOT_F4;
+#pragma unroll
+      for (int mi = 0; mi < C::WM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < C::WN; ++ni)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            mine[((mi * C::WN + ni) * 4 + q) * C::NT + tid] = f32x4{acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]};
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's part has left the CU
+      __syncthreads();
+      unsigned* const flag = reinterpret_cast<unsigned*>(As + C::BUF_U4 + 1);
+      if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (the compiler may drop its own wait after buffer_wbl2: MI355X_MICROARCH.md, compiler hazard)
+        *flag = __hip_atomic_fetch_add(a.sk_tickets + tile_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __syncthreads();
+      if (*flag != nparts - 1u) continue;                   // not the last arriver: on to the next segment (uniform)
+      if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        a.sk_tickets[tile_id] = 0u;                          // ready for the next launch that uses the workspace
+      }
+      __syncthreads();
+      // sum of the parts in contributor (= K) order, this workgroup's own part taken from its registers: the same bits whoever arrives last
+      f32x16 own[C::WM][C::WN];
+#pragma unroll
+      for (int mi = 0; mi < C::WM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < C::WN; ++ni) own[mi][ni] = acc[mi][ni];
+      for (unsigned j = 0; j < nparts; ++j) {
+        const bool is_me = j == cme;
+        const unsigned vo = vf + j;
+        const unsigned first_tile_o = (unsigned)(((unsigned long long)vo * sk_U) / G) / nch;
+        const f32x4* const src = slots + (size_t)(2u * vo + (tile_id == first_tile_o ? 0u : 1u)) * C::SK_SLOT_F4;
+        f32x4 part[C::WM][C::WN][4];
+#pragma unroll
+        for (int mi = 0; mi < C::WM; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < C::WN; ++ni)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              if (is_me) part[mi][ni][q] = f32x4{own[mi][ni][4 * q], own[mi][ni][4 * q + 1], own[mi][ni][4 * q + 2], own[mi][ni][4 * q + 3]};
+              else part[mi][ni][q] = src[((mi * C::WN + ni) * 4 + q) * C::NT + tid];
+            }
+#pragma unroll
+        for (int mi = 0; mi < C::WM; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < C::WN; ++ni)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) acc[mi][ni][4 * q + e] = j == 0 ? part[mi][ni][q][e] : acc[mi][ni][4 * q + e] + part[mi][ni][q][e];
+      }
+    }
+  }
   // ---- epilogue (same as conv3x3_f32.hip): D = [cout rows][pixel columns], lane (li, lh) holds pixel li of its M block
   // and couts 8 q + 4 lh + (0..3) in registers 4q..4q+3 = one 16-byte store
   const size_t img_elems = (size_t)a.H * a.W * a.y_cs;
@@ -416,14 +519,21 @@ __global__ __launch_bounds__(C::NT, C::OCC) void conv3x3_f32x3_kernel(ConvArgsX 
       }
     }
   }
+  if constexpr (SK == 0) break;
+ }
 }
 
-template <class C, int PS>
-int launch_x2(const ConvArgsX& a0, hipStream_t stream) {
+constexpr int kSkMaxGrid = 256, kSkMaxTiles = 8192;       // stream-K: workgroups (= CUs of an MI355X) and tickets the workspace is sized for
+constexpr size_t kSkSlotBytes = 128 * 1024;               // the largest tile's accumulators (256 pixels x 128 couts fp32)
+constexpr size_t kSkTicketBytes = (size_t)kSkMaxTiles * 4;
+
+// sk_grid > 0: the stream-K kernel with that many persistent workgroups (the caller has checked that the tile order has >= sk_grid units)
+template <class C, int PS, int SK>
+int launch_x2(const ConvArgsX& a0, int sk_grid, hipStream_t stream) {
   static bool attr_set_dev[OSVOS_MAX_DEVICES] = {};      // hipFuncSetAttribute is per device
   bool& attr_set = attr_set_dev[osvos_current_device()];
   if (!attr_set) {
-    OSVOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f32x3_kernel<C, PS>),
+    OSVOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f32x3_kernel<C, PS, SK>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
     attr_set = true;
   }
@@ -432,20 +542,32 @@ int launch_x2(const ConvArgsX& a0, hipStream_t stream) {
   a.tiles_y = ceil_div(a.H, C::TH);
   a.nct = ceil_div(a.CoutP, C::BN);
   a.nsp = a.tiles_x * a.tiles_y * a.N;
-  const long blocks = a.map == 0 ? (long)a.nct * a.nsp : (long)a.nct * ((a.nsp + 7) / 8) * 8;
-  OSVOS_ARG_CHECK(blocks > 0 && blocks < (1L << 31), "conv3x3 f32x3: grid of %ld blocks", blocks);
-  hipLaunchKernelGGL((conv3x3_f32x3_kernel<C, PS>), dim3((unsigned)blocks, (unsigned)a.ksplit), dim3(C::NT), C::LDS_BYTES, stream, a);
+  if constexpr (SK != 0) {
+    static_assert((size_t)C::SK_SLOT_F4 * 16 <= kSkSlotBytes, "stream-K partial slot larger than the workspace's");
+    const long ntiles = (long)a.nct * a.nsp, units = ntiles * (a.Cin >> 4);
+    OSVOS_ARG_CHECK(sk_grid > 0 && sk_grid <= kSkMaxGrid && ntiles <= kSkMaxTiles && units >= sk_grid && a.sk_tickets && a.sk_part && a.ksplit == 1,
+                    "conv3x3 f32x3 stream-K: %ld tiles, %ld units on %d workgroups", ntiles, units, sk_grid);
+    hipLaunchKernelGGL((conv3x3_f32x3_kernel<C, PS, SK>), dim3((unsigned)sk_grid), dim3(C::NT), C::LDS_BYTES, stream, a);
+  } else {
+    const long blocks = a.map == 0 ? (long)a.nct * a.nsp : (long)a.nct * ((a.nsp + 7) / 8) * 8;
+    OSVOS_ARG_CHECK(blocks > 0 && blocks < (1L << 31), "conv3x3 f32x3: grid of %ld blocks", blocks);
+    hipLaunchKernelGGL((conv3x3_f32x3_kernel<C, PS, SK>), dim3((unsigned)blocks, (unsigned)a.ksplit), dim3(C::NT), C::LDS_BYTES, stream, a);
+  }
   OSVOS_LAUNCH_CHECK();
   return 0;
 }
-// the pre-split form is built for the production tiles (eight waves, in-loop staging); the others take the fp32 pack
-template <class C>
-int launch_x(const ConvArgsX& a, hipStream_t stream) {
+// the pre-split form is built for the production tiles (eight waves, in-loop staging); the others take the fp32 pack.  Stream-K: the
+// pre-split production tiles of the wide layers (SKT)
+template <class C, bool SKT = false>
+int launch_x(const ConvArgsX& a, int sk_grid, hipStream_t stream) {
   if constexpr (C::ILV != 0 && C::NT == 512) {
-    if (a.wpk3 != nullptr) return launch_x2<C, 1>(a, stream);
+    if constexpr (SKT) {
+      if (a.wpk3 != nullptr && sk_grid > 0) return launch_x2<C, 1, 1>(a, sk_grid, stream);
+    }
+    if (a.wpk3 != nullptr) return launch_x2<C, 1, 0>(a, 0, stream);
   }
   OSVOS_ARG_CHECK(a.wpk != nullptr, "conv3x3 f32x3: this tile config has no pre-split form and no fp32 pack was given");
-  return launch_x2<C, 0>(a, stream);
+  return launch_x2<C, 0, 0>(a, 0, stream);
 }
 
 struct TileInfoX { int tw, th, bn, nt; size_t lds; };
@@ -600,6 +722,11 @@ int osvos_pack_x3(const float* w, void* wpk3, int Cout, int Cin, int dgrad, hipS
 
 int osvos_conv3x3_f32x3_num_tiles(void) { return kNumTilesX; }
 
+// stream-K workspace (ConvEpi::sk_ws): tickets (must be ZERO before the first launch that uses the buffer; every launch leaves them zero) +
+// two partial slots per persistent workgroup.  Independent of the layer's shape; launches that share it must be stream-ordered.
+size_t osvos_conv3x3_f32x3_streamk_ws_bytes(void) { return kSkTicketBytes + (size_t)kSkMaxGrid * 2 * kSkSlotBytes; }
+size_t osvos_conv3x3_f32x3_streamk_ticket_bytes(void) { return kSkTicketBytes; }
+
 // Cout may be ragged (the 3-channel input gradient) as long as the output has room for the rounded-up channel quad: the pack's
 // padded couts carry zero weights, so the extra channel is written as 0
 bool osvos_conv3x3_f32x3_applicable(int Cin, int Cout, int y_cs) { return Cin % 16 == 0 && y_cs % 4 == 0 && ((Cout + 3) & ~3) <= y_cs; }
@@ -657,26 +784,47 @@ int osvos_conv3x3_f32x3_epi(const float* x, const float* wpk, const void* wpk3, 
     a.ksplit = 1;
     OSVOS_ARG_CHECK(tile == 10 || tile == 12 || tile == 14, "conv3x3 f32x3: fused pool forward is built for tiles 10, 12 and 14 (got %d)", tile);
   }
+  // stream-K (kernel header): taken when the caller hands a workspace and the plain grid would leave a sizeable part of the chip without a
+  // tile -- one workgroup per CU, so a grid of `ntiles` runs in ceil(ntiles / CUs) rounds and loses 1 - ntiles / (rounds x CUs) of them
+  // (conv3_x at 854x480 batch 1: 210 tiles, 18 %) -- or would need partial-sum launches + a finalize kernel to fill it (conv5_x)
+  int sk_grid = 0;
+  a.sk_order = 0; a.sk_tickets = nullptr; a.sk_part = nullptr;
+  if (epi != nullptr && epi->sk_ws != nullptr && wpk3 != nullptr && (tile == 10 || tile == 12 || tile == 14) && Cout % 4 == 0) {
+    const long ntiles = tiles_of(kTilesX[tile], N, H, W, a.CoutP), units = ntiles * (Cin >> 4);
+    OSVOS_ENV_INT(env_grid, "OSVOS_X3_STREAMK_GRID", 0);            // tuning: persistent workgroups (default: the CU count)
+    OSVOS_ENV_INT(env_loss, "OSVOS_X3_STREAMK_MIN_LOSS", 6);        // tuning: percent of the chip a plain grid must leave idle
+    int g = epi->sk_grid > 0 ? epi->sk_grid : (env_grid > 0 ? env_grid : osvos_cu_count());
+    if (g > kSkMaxGrid) g = kSkMaxGrid;
+    const long rounds = (ntiles * a.ksplit + g - 1) / g;
+    const bool lossy = a.ksplit > 1 || (rounds * g - ntiles) * 100 >= (long)env_loss * rounds * g;
+    if (ntiles <= kSkMaxTiles && units >= g && (epi->sk_grid > 0 || lossy)) {
+      sk_grid = g;
+      a.ksplit = 1;
+      a.sk_order = a.map ? 0 : 1;      // activations > weights: Cout tiles of one halo back to back; else one weight slice per XCD
+      a.sk_tickets = reinterpret_cast<unsigned*>(epi->sk_ws);
+      a.sk_part = reinterpret_cast<float*>(reinterpret_cast<char*>(epi->sk_ws) + kSkTicketBytes);
+    }
+  }
   int rc;
   switch (tile) {
-    case 0: rc = launch_x<X0>(a, stream); break;
-    case 1: rc = launch_x<X1>(a, stream); break;
-    case 2: rc = launch_x<X2>(a, stream); break;
-    case 3: rc = launch_x<X3>(a, stream); break;
-    case 4: rc = launch_x<X4>(a, stream); break;
-    case 5: rc = launch_x<X5>(a, stream); break;
-    case 6: rc = launch_x<X6>(a, stream); break;
-    case 7: rc = launch_x<X7>(a, stream); break;
-    case 8: rc = launch_x<X8>(a, stream); break;
-    case 9: rc = launch_x<X9>(a, stream); break;
-    case 10: rc = launch_x<X10>(a, stream); break;
-    case 11: rc = launch_x<X11>(a, stream); break;
-    case 12: rc = launch_x<X12>(a, stream); break;
-    case 13: rc = launch_x<X13>(a, stream); break;
-    case 14: rc = launch_x<X14>(a, stream); break;
-    case 15: rc = launch_x<X15>(a, stream); break;
-    case 16: rc = launch_x<X16>(a, stream); break;
-    case 17: rc = launch_x<X17>(a, stream); break;
+    case 0: rc = launch_x<X0>(a, 0, stream); break;
+    case 1: rc = launch_x<X1>(a, 0, stream); break;
+    case 2: rc = launch_x<X2>(a, 0, stream); break;
+    case 3: rc = launch_x<X3>(a, 0, stream); break;
+    case 4: rc = launch_x<X4>(a, 0, stream); break;
+    case 5: rc = launch_x<X5>(a, 0, stream); break;
+    case 6: rc = launch_x<X6>(a, 0, stream); break;
+    case 7: rc = launch_x<X7>(a, 0, stream); break;
+    case 8: rc = launch_x<X8>(a, 0, stream); break;
+    case 9: rc = launch_x<X9>(a, 0, stream); break;
+    case 10: rc = launch_x<X10, true>(a, sk_grid, stream); break;
+    case 11: rc = launch_x<X11>(a, 0, stream); break;
+    case 12: rc = launch_x<X12, true>(a, sk_grid, stream); break;
+    case 13: rc = launch_x<X13>(a, 0, stream); break;
+    case 14: rc = launch_x<X14, true>(a, sk_grid, stream); break;
+    case 15: rc = launch_x<X15>(a, 0, stream); break;
+    case 16: rc = launch_x<X16>(a, 0, stream); break;
+    case 17: rc = launch_x<X17>(a, 0, stream); break;
     default: osvos_set_error("conv3x3 f32x3: unknown tile config %d", tile); return -1;
   }
   if (rc) return rc;

@@ -14,4 +14,7 @@ struct ConvEpi {
   const unsigned* mask_bits = nullptr; // data gradient: used instead of the fp32 `mask` by launches that are not cut along K (the finalize kernel of a
                                        // split launch reads `mask`: pass both)
   unsigned* y_bits = nullptr;          // forward: sign bits of the result, written next to y (the launch is then never cut along K by partial-sum launches)
+  // stream-K (conv3x3_f32x3.hip): workspace of osvos_conv3x3_f32x3_streamk_ws_bytes(), tickets zeroed once by the caller; NULL = plain grids only
+  void* sk_ws = nullptr;
+  int sk_grid = 0;                     // 0: automatic (taken when the plain grid would idle CUs); > 0: forced, that many workgroups (tests)
 };

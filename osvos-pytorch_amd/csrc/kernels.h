@@ -15,6 +15,8 @@ int osvos_conv3x3_splitk_finalize_f32(const float* part, const float* bias, cons
 int osvos_fp32_conv_mode();          // 0 exact fp32 MFMA, 1 f32x3
 bool osvos_conv3x3_f32x3_applicable(int Cin, int Cout, int y_cs);
 int osvos_conv3x3_f32x3_num_tiles(void);
+size_t osvos_conv3x3_f32x3_streamk_ws_bytes(void);
+size_t osvos_conv3x3_f32x3_streamk_ticket_bytes(void);
 int osvos_conv3x3_f32x3(const float* x, const float* wpk, const float* bias, const float* mask, float* y,
                         int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int tile, int ksplit, void* part_ws, hipStream_t stream);
 // f32x3 weight gradient (wgrad_f32x3.hip): fp32 x / dy, three-way bf16 split, fp32 slabs + the shared reduce
@@ -34,6 +36,7 @@ int osvos_conv3x3_f32x3_epi(const float* x, const float* wpk, const void* wpk3, 
                             hipStream_t stream);
 bool osvos_dgrad_c3_applicable(int Cin, int Cout);
 int osvos_conv3x3_dgrad_c3_f32(const float* dy, const float* wpk_dgrad, float* dx_nchw, int N, int H, int W, int Cout, hipStream_t stream);
+int osvos_conv3x3_dgrad_c3_bf16in(const void* dy_bf16, const float* wpk_dgrad, float* dx_nchw, int N, int H, int W, int Cout, hipStream_t stream);
 size_t osvos_wgrad_ws_bytes_f32(int N, int H, int W, int Cin_s, int Cout);
 int osvos_conv3x3_wgrad_f32(const float* x, const float* dy, void* ws, float* dw, float* db,
                             int N, int H, int W, int Cin, int Cin_s, int Cout, int Cout_s,

@@ -39,6 +39,7 @@ int last_of_stage(int si) {
 
 struct WbufLayout {
   size_t fwd[kNumConv], dgrad[kNumConv], bias[kNumConv];
+  size_t dgrad0_f32;         // bf16 mode: fp32 data-gradient pack of conv1_1 for the input-gradient kernel (dgrad_c3.hip, bf16 dy in); (size_t)-1 = none
   size_t fwd3[kNumConv], dgrad3[kNumConv];      // OSVOS_F32_X3: pre-split bf16x3 packs of the layers the f32x3 kernels take ((size_t)-1: none)
   size_t wd[4], bd[4], wf, bf, f1[4], f16[4];
   size_t weff[4];            // generic head only: Weff_i[16][k*k] (head_generic.hip)
@@ -62,6 +63,7 @@ WbufLayout wbuf_layout(int dtype) {
       if (d[l].cout % 16 == 0) L.dgrad3[l] = take(osvos_wpack_x3_bytes(d[l].cin, d[l].cout));
     }
   }
+  L.dgrad0_f32 = dtype == OSVOS_F32_BF16MFMA ? take(osvos_wpack_dgrad_bytes(d[0].cout, d[0].cin, OSVOS_F32)) : (size_t)-1;
   for (int i = 0; i < 4; ++i) { L.wd[i] = take(16 * sizeof(float)); L.bd[i] = take(sizeof(float)); }
   L.wf = take(64 * sizeof(float));
   L.bf = take(sizeof(float));
@@ -93,6 +95,7 @@ struct WsLayout {
   int hs[5], ws[5];
   size_t xin, act[kNumTrunk], pooled[5], prep[4], score[4], fpart[4];
   size_t conv_part;          // split-K partial sums of the small deep layers (forward prefix: inference uses it too)
+  size_t sk_ws;              // f32x3: stream-K workspace of the main-stream convolutions (tickets + partial slots; (size_t)-1 = none)
   size_t side_part[4];       // the same for the side_prep convolutions, which run on the aux stream beside the trunk (own buffers)
   size_t dy[kNumTrunk], dpool[5], dside[4], dprep[4], wgrad[kNumConv], acc, dxin;
   size_t gbuf[4];            // generic head only: tap-indexed reductions G_i[16][k*k] + G1_i[k*k], doubles
@@ -160,6 +163,7 @@ WsLayout ws_layout(int N, int H, int W, int dtype) {
         if (b > mx) mx = b;
       }
     L.conv_part = take(mx);
+    L.sk_ws = dtype == OSVOS_F32_X3 ? take(osvos_conv3x3_f32x3_streamk_ws_bytes()) : (size_t)-1;
     // side_prep[i]: Cout = 16 on a small frame is a handful of workgroups walking K = 9 Cin serially (88 us for 0.24 GFLOP at
     // 30 x 54) -- and the last one sits exposed between conv5_3 and the head.  K splits turn it into a full-chip launch.
     for (int i = 0; i < 4; ++i)
@@ -235,13 +239,14 @@ inline bool use_presplit() {
 // (epi: fused pooling epilogues, f32x3 only -- fuse_pool() says when the caller may ask for them)
 inline int conv_main(const void* x, const void* x_b, const void* wpk, const float* bias, const void* mask, const void* mask_b, void* y, void* y_b,
                      int N, int h, int w, int cin, int cout, int y_cs, int relu, int dtype, void* part, hipStream_t stream, const void* wpk3 = nullptr,
-                     const ConvEpi* epi = nullptr, const void* mask_bits = nullptr, void* y_bits = nullptr, void* pooled_b = nullptr) {
+                     const ConvEpi* epi = nullptr, const void* mask_bits = nullptr, void* y_bits = nullptr, void* pooled_b = nullptr, void* sk_ws = nullptr) {
   if (dtype == OSVOS_F32_X3 && osvos_conv3x3_f32x3_applicable(cin, cout, y_cs)) {    // three-way bf16 split on the bf16 matrix pipe
     ConvEpi e2;
     if (epi != nullptr) e2 = *epi;
     e2.mask_bits = reinterpret_cast<const unsigned*>(mask_bits);
     e2.y_bits = reinterpret_cast<unsigned*>(y_bits);
-    const bool any = epi != nullptr || mask_bits != nullptr || y_bits != nullptr;
+    e2.sk_ws = sk_ws;
+    const bool any = epi != nullptr || mask_bits != nullptr || y_bits != nullptr || sk_ws != nullptr;
     // (with a pre-split pack the fp32 pack of the layer is not even built -- osvos_net_pack -- so it is not handed over either)
     return osvos_conv3x3_f32x3_epi((const float*)x, (use_presplit() && wpk3) ? nullptr : (const float*)wpk, use_presplit() ? wpk3 : nullptr, bias,
                                    (const float*)mask, (float*)y, N, h, w, cin, cout, y_cs, relu, -1, 0, part, any ? &e2 : nullptr, stream);
@@ -259,6 +264,14 @@ inline int conv_main(const void* x, const void* x_b, const void* wpk, const floa
 inline bool fuse_pool(int dtype) {
   static const bool on = [] { const char* e = getenv("OSVOS_FUSE_POOL"); return !(e && e[0] == '0'); }();
   return on && (dtype == OSVOS_F32_X3 || use_store(dtype));
+}
+
+// f32x3 stream-K (conv3x3_f32x3.hip): OSVOS_X3_STREAMK = 0 off, 1 (default) the forward's main-stream convolutions -- nothing runs beside them at
+// batch 1, the CUs a plain grid leaves without a tile just idle --, 2 also the data-gradient chain (whose idle CUs the weight-gradient stream
+// already fills)
+inline int streamk_mode() {
+  static const int v = [] { const char* e = getenv("OSVOS_X3_STREAMK"); return e ? atoi(e) : 1; }();
+  return v;
 }
 
 // TIMING ABLATIONS (wrong results; tools/ablate_step.sh) exist only in probe builds (make EXTRA=-DOSVOS_DBG_ABLATIONS): OSVOS_DBG_SKIP bit
@@ -352,6 +365,10 @@ int osvos_net_pack(const float* const* params, void* wbuf, int dtype_, int with_
     const int rc = osvos_pack_x3_multi(xw, xd, xco, xci, xdg, nx, stream);
     if (rc) return rc;
   }
+  if (with_dgrad && L.dgrad0_f32 != (size_t)-1) {
+    const int rc = osvos_pack_conv3x3_dgrad(params[d[0].w_param], at(wbuf, L.dgrad0_f32), d[0].cout, d[0].cin, OSVOS_F32, stream);
+    if (rc) return rc;
+  }
   for (int i = 0; i < 4; ++i) {
     const int k = 4 << i;
     srcs[ns] = params[42 + 2 * i]; dsts[ns] = L.wd[i]; counts[ns] = 16; ++ns;
@@ -393,6 +410,10 @@ int osvos_net_forward(const float* x_nchw, const void* wbuf, void* ws, float* co
   auto f32 = [&](size_t off) -> void* { return store ? nullptr : at(ws, off); };                  // fp32 trunk tensor (absent in store mode)
   int rc = osvos_nchw_to_nhwc_f32(x_nchw, reinterpret_cast<float*>(at(ws, L.xin)), sh(L.xin_b), N, 3, H, W, kInPad, stream);
   if (rc) return rc;
+  // stream-K workspace of the main-stream convolutions: the tickets must be zero before the first launch (every launch leaves them zero; the
+  // workspace itself arrives uninitialised from the caller, so they are cleared once per forward -- a 32 KB memset node, capturable)
+  void* const sk_ws = (L.sk_ws != (size_t)-1 && streamk_mode() >= 1) ? at(ws, L.sk_ws) : nullptr;
+  if (sk_ws != nullptr) OSVOS_HIP_CHECK(hipMemsetAsync(sk_ws, 0, osvos_conv3x3_f32x3_streamk_ticket_bytes(), stream));
   const void* cur = at(ws, L.xin);
   const void* cur_b = sh(L.xin_b);
   int l = 0;
@@ -421,7 +442,7 @@ int osvos_net_forward(const float* x_nchw, const void* wbuf, void* ws, float* co
         rc = conv_main(cur, cur_b, at(wbuf, P.fwd[l]), reinterpret_cast<const float*>(at(wbuf, P.bias[l])), nullptr, nullptr,
                        f32(L.act[l]), sh(L.act_b[l]), N, h, w, d[l].cin_s, d[l].cout, d[l].cout, 1, dtype, at(ws, L.conv_part), stream,
                        P.fwd3[l] != (size_t)-1 ? at(wbuf, P.fwd3[l]) : nullptr, (pool_here && !store) ? &epi : nullptr, nullptr,
-                       L.bits[l] != (size_t)-1 ? at(ws, L.bits[l]) : nullptr, (pool_here && store) ? at(ws, L.pooled_b[si + 1]) : nullptr);
+                       L.bits[l] != (size_t)-1 ? at(ws, L.bits[l]) : nullptr, (pool_here && store) ? at(ws, L.pooled_b[si + 1]) : nullptr, sk_ws);
       }
       if (rc) return rc;
       cur = at(ws, L.act[l]);
@@ -702,6 +723,8 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
   }
 
   // trunk, deepest layer first; dy[l] = dLoss/d(conv l output), ReLU mask already applied
+  // (stream-K for the data-gradient chain only with OSVOS_X3_STREAMK=2; the workspace's tickets are zero: every launch leaves them so)
+  void* const sk_bwd = (L.sk_ws != (size_t)-1 && streamk_mode() >= 2) ? at(ws, L.sk_ws) : nullptr;
   for (int l = kNumTrunk - 1; l >= 0; --l) {
     const int si = d[l].stage, h = L.hs[si], w = L.ws[si];
     const bool first_of_stage = (l == 0) || d[l - 1].stage != si;
@@ -724,6 +747,9 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
       } else if (dx_nchw != nullptr && (dtype == OSVOS_F32 || dtype == OSVOS_F32_X3)) {
         rc = osvos_conv3x3_dgrad_c3_f32(reinterpret_cast<const float*>(g), reinterpret_cast<const float*>(at(wbuf, P.dgrad[0])), dx_nchw, N, h, w, d[0].cout, stream);
         if (rc) return rc;
+      } else if (dx_nchw != nullptr && store && P.dgrad0_f32 != (size_t)-1) {      // bf16 trunk tensors: the same bandwidth kernel, bf16 dy in
+        rc = osvos_conv3x3_dgrad_c3_bf16in(g, reinterpret_cast<const float*>(at(wbuf, P.dgrad0_f32)), dx_nchw, N, h, w, d[0].cout, stream);
+        if (rc) return rc;
       } else if (dx_nchw != nullptr) {
         rc = conv_main(g, g_b, at(wbuf, P.dgrad[0]), nullptr, nullptr, nullptr, at(ws, L.dxin), nullptr, N, h, w, d[0].cout, 3, 4, 0, dtype,
                        nullptr, stream, P.dgrad3[0] != (size_t)-1 ? at(wbuf, P.dgrad3[0]) : nullptr);
@@ -741,7 +767,8 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
     if (first_of_stage) {
       // through the pool into the previous stage's output (+ that stage's side branch, + ReLU mask)
       rc = conv_main(g, g_b, at(wbuf, P.dgrad[l]), nullptr, nullptr, nullptr, f32(L.dpool[si]), store ? at(ws, L.dpool_b[si]) : nullptr, N, h, w,
-                     d[l].cout, d[l].cin, d[l].cin, 0, dtype, at(ws, L.conv_part), stream, P.dgrad3[l] != (size_t)-1 ? at(wbuf, P.dgrad3[l]) : nullptr);
+                     d[l].cout, d[l].cin, d[l].cin, 0, dtype, at(ws, L.conv_part), stream, P.dgrad3[l] != (size_t)-1 ? at(wbuf, P.dgrad3[l]) : nullptr,
+                     nullptr, nullptr, nullptr, nullptr, sk_bwd);
       if (rc) return rc;
       const int ps2 = si - 1;
       const void* dside = ps2 >= 1 ? at(ws, L.dside[ps2 - 1]) : nullptr;
@@ -757,7 +784,7 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
     } else {
       rc = conv_main(g, g_b, at(wbuf, P.dgrad[l]), nullptr, mk32(L.act[l - 1]), mk16(L.act_b[l - 1]), f32(L.dy[l - 1]), sh(L.dy_b[l - 1]), N, h, w,
                      d[l].cout, d[l].cin, d[l].cin, 0, dtype, at(ws, L.conv_part), stream, P.dgrad3[l] != (size_t)-1 ? at(wbuf, P.dgrad3[l]) : nullptr,
-                     nullptr, L.bits[l - 1] != (size_t)-1 ? at(ws, L.bits[l - 1]) : nullptr);
+                     nullptr, L.bits[l - 1] != (size_t)-1 ? at(ws, L.bits[l - 1]) : nullptr, nullptr, nullptr, sk_bwd);
       if (rc) return rc;
     }
   }

@@ -286,10 +286,37 @@ def conv3x3_x3(x, wpk3, bias, cout, relu=False, mask=None, y_cs=None, tile=-1):
 
 
 
+_SK_WS = {}
+
+
+def streamk_workspace(device):
+    """per-device stream-K workspace (tickets zeroed once; every launch leaves them zero)"""
+    key = str(device)
+    if key not in _SK_WS:
+        ws = torch.empty(lib().osvos_conv3x3_x3_streamk_ws_bytes(), device=device, dtype=torch.uint8)
+        ws[:lib().osvos_conv3x3_x3_streamk_ticket_bytes()].zero_()
+        _SK_WS[key] = ws
+    return _SK_WS[key]
+
+
+def conv3x3_x3_streamk(x, wpk3, bias, cout, relu=False, mask=None, tile=-1, grid=0, want_pooled=False):
+    """stream-K form of conv3x3_x3 (grid 0 = automatic, > 0 = that many persistent workgroups); returns y or (y, pooled)"""
+    _need_cuda(x, wpk3, bias, mask)
+    n, h, w, cin = x.shape
+    y = torch.empty((n, h, w, cout), device=x.device, dtype=torch.float32)
+    pooled = torch.empty((n, (h + 1) // 2, (w + 1) // 2, cout), device=x.device, dtype=torch.float32) if want_pooled else None
+    check(lib().osvos_conv3x3_x3_streamk(_p(x), _p(wpk3), _p(bias), _p(mask), _p(y), _p(pooled), n, h, w, cin, cout, cout, int(relu), tile, grid,
+                                         _p(streamk_workspace(x.device)), _stream()), "conv3x3_x3_streamk")
+    return (y, pooled) if want_pooled else y
+
+
 def conv3x3_dgrad_c3(dy, w_oihw):
     """input gradient of a 3-input-channel convolution: dy fp32 [N,H,W,Cout], filter [Cout,3,3,3] -> dx fp32 NCHW [N,3,H,W]"""
     _need_cuda(dy, w_oihw)
     n, h, w, cout = dy.shape
     dx = torch.empty((n, 3, h, w), device=dy.device, dtype=torch.float32)
-    check(lib().osvos_conv3x3_dgrad_c3(_p(dy.contiguous()), _p(pack_dgrad(w_oihw)), _p(dx), n, h, w, cout, _stream()), "dgrad_c3")
+    if dy.dtype == torch.bfloat16:      # bf16 dy (the bf16-store mode's trunk tensors); fp32 filter pack and arithmetic
+        check(lib().osvos_conv3x3_dgrad_c3_bf16act(_p(dy.contiguous()), _p(pack_dgrad(w_oihw)), _p(dx), n, h, w, cout, _stream()), "dgrad_c3 (bf16 in)")
+    else:
+        check(lib().osvos_conv3x3_dgrad_c3(_p(dy.contiguous()), _p(pack_dgrad(w_oihw)), _p(dx), n, h, w, cout, _stream()), "dgrad_c3")
     return dx

@@ -805,6 +805,12 @@ def test_input_gradient_of_the_first_convolution(shape):
     assert dx.shape == (n, 3, h, w)
     emax, el2 = rel_err(dx.cpu(), ref)
     assert emax < 2e-5 and el2 < 1e-5, (shape, emax, el2)
+    # bf16 dy (the bf16-store mode): exact products of the bf16 values with the fp32 filter, fp32 accumulation
+    dyb = dy.bfloat16()
+    refb = F.conv_transpose2d(dyb.double(), wt.double(), padding=1)
+    dxb = ops.conv3x3_dgrad_c3(dyb.permute(0, 2, 3, 1).contiguous().cuda(), wt.cuda())
+    emax, el2 = rel_err(dxb.cpu(), refb)
+    assert emax < 2e-5 and el2 < 1e-5, (shape, "bf16 in", emax, el2)
 
 
 @pytest.mark.gpu
@@ -851,3 +857,61 @@ def test_skinny_side_prep_wgrad_on_the_bf16_pipe(shape):
     torch.testing.assert_close(db3.cpu().double(), dy.double().sum((0, 2, 3)), rtol=1e-5, atol=1e-4)
     dw, db = ops.conv3x3_wgrad(xd, dyd, cin, cout, dtype=F32)
     assert float((dw3.double() - dw.double()).norm() / dw.double().norm()) < 1e-6, shape
+
+
+SK_CASES = [
+    # N, H, W, Cin, Cout, tile, grid   (grid 0 = automatic; small forced grids cut every tile into several parts)
+    (1, 37, 53, 64, 64, 12, 5),
+    (1, 37, 53, 64, 64, 12, 7),
+    (2, 30, 54, 512, 512, 12, 256),
+    (2, 30, 54, 512, 512, 14, 256),
+    (1, 61, 107, 256, 512, 14, 256),
+    (1, 120, 214, 256, 256, 10, 256),
+    (1, 120, 214, 256, 256, 10, 240),
+    (1, 96, 160, 128, 128, 10, 13),
+    (1, 30, 54, 512, 512, -1, 0),
+    (1, 120, 214, 128, 256, -1, 0),
+]
+
+
+@pytest.mark.parametrize("case", SK_CASES)
+def test_conv3x3_f32x3_streamk(case):
+    """stream-K form of the f32x3 convolution (conv3x3_f32x3.hip): persistent workgroups walk equal shares of the (tile, K chunk) units,
+    shared tiles are summed by the last arriver in contributor order.  Held to the float64 bars of the plain kernel, within fp32 summation
+    order of it, DETERMINISTIC (two runs bit-equal, also under a different arrival order: another launch running beside it), the fused
+    pool equal to the pooling kernel on the same y, ReLU mask / no-bias forms included."""
+    ops = _ops()
+    n, h, w, cin, cout, tile, grid = case
+    g = torch.Generator().manual_seed(cin + cout + h)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)
+    b = torch.randn(cout, generator=g)
+    ref = F.relu(F.conv2d(x.double(), wt.double(), b.double(), padding=1))
+    xg, pk3 = nhwc(x), ops.pack_x3(wt.cuda())
+    y, pooled = ops.conv3x3_x3_streamk(xg, pk3, b.cuda(), cout, relu=True, tile=tile, grid=grid, want_pooled=True)
+    emax, el2 = rel_err(nchw(y), ref)
+    assert emax < 2e-5 and el2 < 1e-5, (case, emax, el2)
+    plain = ops.conv3x3_x3(xg, pk3, b.cuda(), cout, relu=True, tile=tile)
+    assert float((y - plain).abs().max()) <= 4e-6 * float(plain.abs().max()), case
+    assert torch.equal(pooled, ops.maxpool2x2(y)), case
+    # determinism: same bits again, and with a second stream keeping part of the chip busy (another arrival order)
+    side = torch.cuda.Stream()
+    junk = torch.randn(4096, 4096, device="cuda")
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            junk = junk @ junk * 1e-3
+    y2 = ops.conv3x3_x3_streamk(xg, pk3, b.cuda(), cout, relu=True, tile=tile, grid=grid)
+    torch.cuda.synchronize()
+    assert torch.equal(y, y2), case
+    y3 = ops.conv3x3_x3_streamk(xg, pk3, b.cuda(), cout, relu=True, tile=tile, grid=grid)
+    assert torch.equal(y, y3), case
+    # data-gradient form: rotated pack, ReLU mask of the producer, no bias
+    dy = torch.randn(n, cout, h, w, generator=g)
+    m = torch.randn(n, cin, h, w, generator=g)
+    dpk3 = ops.pack_x3(wt.cuda(), dgrad=True)
+    dx = ops.conv3x3_x3_streamk(nhwc(dy), dpk3, None, cin, mask=nhwc(m), tile=tile, grid=grid)
+    ref_dx = torch.nn.grad.conv2d_input(x.shape, wt.double(), dy.double(), padding=1) * (m > 0)
+    assert rel_err(nchw(dx), ref_dx)[0] < 3e-5, case
+    # the tickets are back at zero: the workspace is ready for the next launch
+    ws = ops.streamk_workspace(xg.device)
+    assert int(ws[:ops.lib().osvos_conv3x3_x3_streamk_ticket_bytes()].view(torch.int32).abs().max()) == 0
