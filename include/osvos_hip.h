@@ -187,7 +187,7 @@ int osvos_deconv_diag_check(const float* w, int C, int k, float* out2, void* str
 /* ---- class-balanced BCE with logits (osvos_layers.py:19-48) ------------------------------
  * out/label fp32, `count` elements over N images.  mode 0: size_average, 1: batch_average,
  * 2: neither.  loss: fp32[1]; grad: fp32[count] = dLoss/dOut (upstream 1) or NULL;
- * scratch: 32 bytes, zeroed by this call. */
+ * scratch: 32 bytes, zeroed by this call.  Tensors that are not 16-byte aligned (offset views) are swept element-wise: slower, same numbers. */
 int osvos_cbce(const float* out, const float* label, float* loss, float* grad, void* scratch,
                long count, int N, int mode, void* stream);
 /* The same loss as one step of the training loops sees it (train_online.py:127-141, train_parent.py:143-163): `loss` is the plain
@@ -202,6 +202,20 @@ int osvos_cbce_step(const float* out, const float* label, float* loss, float* gr
  * may be NULL); grad_scales: n_heads HOST floats; scratch: 32 x n_heads bytes, zeroed by this call.  Per head identical to osvos_cbce_step. */
 int osvos_cbce_step_multi(const float* const* outs, const float* label, float* const* losses, float* const* grads, void* scratch,
                           long count, int N, int mode, int n_heads, const float* grad_scales, float* const* running, void* stream);
+/* General form (the three calls above forward to it with flags = 0, counts = NULL).
+ *   flags & OSVOS_CBCE_PER_IMAGE: each of the N images is its own reference batch of ONE -- class weights from its own label, size_average
+ *     divides by the elements of one image, batch_average by 1 -- and `loss` receives the SUM of the N losses: the nAveGrad micro-batches of
+ *     an accumulation window (train_online.py:116-149: cbce(..., batch of 1); loss /= nAveGrad; backward(); running_loss += loss) in ONE call
+ *     on a batch-N forward, with grad_scale = 1 / nAveGrad.
+ *   counts != NULL: device fp32[3] = {n_pos, n_total, n_images} of the GLOBAL batch these tensors are a shard of (the count exchange of a
+ *     batch sharded over ranks; layers/osvos_layers.py:28-34,43-46 count over the whole input tensor): weights and divisors come
+ *     from them, no count sweep runs.  Summed over the shards the losses / gradients are those of the whole batch.  Not with PER_IMAGE.
+ *   scratch: osvos_cbce_scratch_bytes(n_heads, N, flags) bytes, zeroed by the call. */
+#define OSVOS_CBCE_PER_IMAGE 1
+size_t osvos_cbce_scratch_bytes(int n_heads, int N, int flags);
+int osvos_cbce_step_ex(const float* const* outs, const float* label, float* const* losses, float* const* grads, void* scratch, long count,
+                       int N, int mode, int flags, const float* counts, int n_heads, const float* grad_scales, float* const* running,
+                       void* stream);
 /* y[i] = x[i] * (*scalar)   (loss.backward() chain rule with a device-resident upstream grad) */
 int osvos_scale(const float* x, const float* scalar, float* y, long count, void* stream);
 
@@ -259,6 +273,7 @@ int osvos_net_arm_grad_events(void* const* events, int n);
 int osvos_comm_unique_id(void* id128);
 int osvos_comm_init(void** comm, int rank, int world, const void* id128);
 int osvos_comm_allreduce_f32(void* comm, float* buf, size_t count, void* stream);
+int osvos_comm_allreduce_f64(void* comm, double* buf, size_t count, void* stream);   /* sum of doubles: class counts, loss statistics (exact) */
 int osvos_comm_allreduce_chunks_f32(void* comm, float* buf, const size_t* first, const size_t* count, void* const* ready_events, int n,
                                     void* comm_stream);
 int osvos_comm_destroy(void* comm);

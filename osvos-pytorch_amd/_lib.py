@@ -69,6 +69,8 @@ PROTOTYPES = {
     "osvos_cbce": (_i, [_vp, _vp, _vp, _vp, _vp, _l, _i, _i, _vp]),
     "osvos_cbce_step": (_i, [_vp, _vp, _vp, _vp, _vp, _l, _i, _i, _f, _vp, _vp]),
     "osvos_cbce_step_multi": (_i, [_vp, _vp, _vp, _vp, _vp, _l, _i, _i, _i, _vp, _vp, _vp]),
+    "osvos_cbce_scratch_bytes": (_sz, [_i, _i, _i]),
+    "osvos_cbce_step_ex": (_i, [_vp, _vp, _vp, _vp, _vp, _l, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "osvos_scale": (_i, [_vp, _vp, _vp, _l, _vp]),
     "osvos_net_wbuf_bytes": (_sz, [_i]),
     "osvos_net_ws_bytes": (_sz, [_i, _i, _i, _i]),
@@ -81,6 +83,7 @@ PROTOTYPES = {
     "osvos_comm_unique_id": (_i, [_vp]),
     "osvos_comm_init": (_i, [_vp, _i, _i, _vp]),
     "osvos_comm_allreduce_f32": (_i, [_vp, _vp, _sz, _vp]),
+    "osvos_comm_allreduce_f64": (_i, [_vp, _vp, _sz, _vp]),
     "osvos_comm_allreduce_chunks_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "osvos_comm_destroy": (_i, [_vp]),
     "osvos_net_ws_query": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),

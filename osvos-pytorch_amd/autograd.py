@@ -280,31 +280,59 @@ class CBCELossFunction(torch.autograd.Function):
         return gx, None, None
 
 
-def cbce_step(output, label, mode, grad_scale=1.0, running=None):
+class CBCECountsFunction(torch.autograd.Function):
+    """class-balanced BCE of a SHARD of a batch with the global batch's (n_pos, n_total, n_images) as arguments (parallel.cbce_with_counts):
+    the HIP loss kernel of ``CBCELossFunction`` with external counts."""
+
+    @staticmethod
+    def forward(ctx, output, label, counts, mode):
+        loss, grad = cbce_step(output, label, mode, 1.0, None, counts=counts)
+        ctx.grad = grad if ctx.needs_input_grad[0] else None
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        grad = ctx.grad
+        if grad is None:
+            return None, None, None, None
+        g = g.detach().to(torch.float32).contiguous()
+        gx = torch.empty_like(grad)
+        check(lib().osvos_scale(C.c_void_p(grad.data_ptr()), C.c_void_p(g.data_ptr()), C.c_void_p(gx.data_ptr()), grad.numel(), _stream()), "scale")
+        return gx, None, None, None
+
+
+CBCE_PER_IMAGE = 1      # include/osvos_hip.h OSVOS_CBCE_PER_IMAGE
+
+
+def _counts_tensor(counts, dev):
+    """(n_pos, n_total, n_images) of a global batch -> device fp32[3] (the class weights are float32 quotients in the reference too)"""
+    if counts is None:
+        return None
+    if torch.is_tensor(counts):
+        t = counts.detach().to(device=dev, dtype=torch.float32).contiguous()
+    else:
+        t = torch.stack([c.detach().to(device=dev, dtype=torch.float32).reshape(()) if torch.is_tensor(c) else torch.tensor(float(c), device=dev)
+                         for c in counts])
+    if t.numel() != 3:
+        raise RuntimeError("counts must hold (n_pos, n_total, n_images)")
+    return t
+
+
+def cbce_step(output, label, mode, grad_scale=1.0, running=None, per_image=False, counts=None):
     """One training-loop use of the class-balanced BCE without the autograd scalar chain behind it: returns ``(loss, grad)`` where ``loss``
     is the plain 0-dim loss (detached; what the reference adds to ``running_loss``, train_online.py:128) and ``grad`` =
     ``grad_scale * dLoss/dOutput`` -- ready for ``torch.autograd.backward([output], [grad])``.  ``grad_scale`` is the upstream gradient the
     reference's ``loss /= nAveGrad; loss.backward()`` hands this loss (train_online.py:140-141); ``running`` (0-dim fp32 CUDA tensor) gets
     ``+= loss`` inside the kernel.  Same roundings as ``class_balanced_cross_entropy_loss(...)``, ``/=``, ``.backward()``; five small
-    ATen launches (ones, div, its backward, add, scale) per micro-batch fewer between the loss and the head's backward."""
-    if not output.is_cuda:
-        raise RuntimeError("class_balanced_cross_entropy_loss (osvos_pytorch_amd) needs CUDA tensors; no CPU fallback")
-    out = output.detach().contiguous().float()
-    lab = label.detach().to(device=out.device, dtype=torch.float32).contiguous()
-    if lab.numel() != out.numel():
-        raise RuntimeError("output and label must have the same number of elements")
-    if running is not None and not (running.is_cuda and running.dtype == torch.float32 and running.numel() == 1):
-        raise RuntimeError("running must be a one-element float32 CUDA tensor")
-    loss = torch.empty((), device=out.device, dtype=torch.float32)
-    grad = torch.empty_like(out)
-    scratch = torch.empty(4, device=out.device, dtype=torch.float64)
-    check(lib().osvos_cbce_step(C.c_void_p(out.data_ptr()), C.c_void_p(lab.data_ptr()), C.c_void_p(loss.data_ptr()), C.c_void_p(grad.data_ptr()),
-                                C.c_void_p(scratch.data_ptr()), out.numel(), out.shape[0], int(mode), float(grad_scale),
-                                C.c_void_p(running.data_ptr()) if running is not None else None, _stream()), "cbce_step")
-    return loss, grad.view_as(output)
+    ATen launches (ones, div, its backward, add, scale) per micro-batch fewer between the loss and the head's backward.
+    ``per_image``: every image of the batch is its own reference batch of one (own class weights; the losses are summed) -- the micro-batches
+    of an accumulation window in one call.  ``counts``: ``(n_pos, n_total, n_images)`` of the GLOBAL batch this tensor is a shard of
+    (``parallel.global_class_counts``): weights and divisors come from them."""
+    losses, grads = cbce_step_multi([output], label, mode, [grad_scale], [running], per_image=per_image, counts=counts)
+    return losses[0], grads[0]
 
 
-def cbce_step_multi(outputs, label, mode, grad_scales, runnings=None):
+def cbce_step_multi(outputs, label, mode, grad_scales, runnings=None, per_image=False, counts=None):
     """``cbce_step`` for several heads against one label (the parent loop's five losses, train_parent.py:143-147) in ONE library call: the
     label's class counts are formed once and the loss / gradient sweep of all heads is one launch.  Returns ``(losses, grads)``: ``losses`` a
     float32 CUDA tensor of ``len(outputs)`` plain losses (detached), ``grads[k] = grad_scales[k] * dLoss_k/dOutput_k``; ``runnings`` (list of
@@ -314,6 +342,8 @@ def cbce_step_multi(outputs, label, mode, grad_scales, runnings=None):
         raise RuntimeError("cbce_step_multi: 1..8 heads with one grad_scale (and one running entry) each")
     if not all(o.is_cuda for o in outputs):
         raise RuntimeError("class_balanced_cross_entropy_loss (osvos_pytorch_amd) needs CUDA tensors; no CPU fallback")
+    if per_image and counts is not None:
+        raise RuntimeError("per_image and counts exclude each other")
     outs = [o.detach().contiguous().float() for o in outputs]
     dev = outs[0].device
     lab = label.detach().to(device=dev, dtype=torch.float32).contiguous()
@@ -322,15 +352,18 @@ def cbce_step_multi(outputs, label, mode, grad_scales, runnings=None):
     for r in (runnings or []):
         if r is not None and not (r.is_cuda and r.dtype == torch.float32 and r.numel() == 1):
             raise RuntimeError("running entries must be one-element float32 CUDA tensors")
+    n_img = int(outs[0].shape[0])
+    flags = CBCE_PER_IMAGE if per_image else 0
+    cnt = _counts_tensor(counts, dev)
     losses = torch.empty(n, device=dev, dtype=torch.float32)
     grads = [torch.empty_like(o) for o in outs]
-    scratch = torch.empty(4 * n, device=dev, dtype=torch.float64)
+    scratch = torch.empty(int(lib().osvos_cbce_scratch_bytes(n, n_img, flags)), device=dev, dtype=torch.uint8)
     vp = C.c_void_p
     a_out = (vp * n)(*[vp(o.data_ptr()) for o in outs])
     a_loss = (vp * n)(*[vp(losses.data_ptr() + 4 * k) for k in range(n)])
     a_grad = (vp * n)(*[vp(g.data_ptr()) for g in grads])
     a_run = (vp * n)(*[vp(r.data_ptr()) if r is not None else None for r in (runnings or [None] * n)])
     a_scale = (C.c_float * n)(*[float(s) for s in grad_scales])
-    check(lib().osvos_cbce_step_multi(a_out, vp(lab.data_ptr()), a_loss, a_grad, vp(scratch.data_ptr()), lab.numel(), outs[0].shape[0], int(mode), n,
-                                      a_scale, a_run, _stream()), "cbce_step_multi")
+    check(lib().osvos_cbce_step_ex(a_out, vp(lab.data_ptr()), a_loss, a_grad, vp(scratch.data_ptr()), lab.numel(), n_img, int(mode), flags,
+                                   vp(cnt.data_ptr()) if cnt is not None else None, n, a_scale, a_run, _stream()), "cbce_step")
     return losses, [g.view_as(o) for g, o in zip(grads, outputs)]

@@ -16,7 +16,7 @@ namespace {
 typedef int ncclResult_t;                    // ncclSuccess = 0
 typedef struct ncclComm* ncclComm_t;
 struct UniqueId { char internal[128]; };     // ncclUniqueId (NCCL_UNIQUE_ID_BYTES = 128)
-constexpr int kNcclFloat32 = 7, kNcclSum = 0;    // rccl.h: ncclFloat32 = 7, ncclSum = 0
+constexpr int kNcclFloat32 = 7, kNcclFloat64 = 8, kNcclSum = 0;    // rccl.h: ncclFloat32 = 7, ncclFloat64 = 8, ncclSum = 0
 
 struct Rccl {
   void* lib = nullptr;
@@ -105,6 +105,15 @@ int osvos_comm_allreduce_f32(void* comm, float* buf, size_t count, void* stream)
   OSVOS_ARG_CHECK(comm && buf && count > 0, "comm_allreduce: bad arguments");
   if (int rc = need_rccl()) return rc;
   OSVOS_NCCL_CHECK(rccl().AllReduce(buf, buf, count, kNcclFloat32, kNcclSum, (ncclComm_t)comm, (hipStream_t)stream));
+  return 0;
+}
+
+// float64 sum: class counts and loss statistics (exact for integers below 2^53; the fp32 form rounds counts above 2^24 -- about batch 41 at
+// 854x480 -- and epoch loss sums near 1e7)
+int osvos_comm_allreduce_f64(void* comm, double* buf, size_t count, void* stream) {
+  OSVOS_ARG_CHECK(comm && buf && count > 0, "comm_allreduce_f64: bad arguments");
+  if (int rc = need_rccl()) return rc;
+  OSVOS_NCCL_CHECK(rccl().AllReduce(buf, buf, count, kNcclFloat64, kNcclSum, (ncclComm_t)comm, (hipStream_t)stream));
   return 0;
 }
 

@@ -362,30 +362,37 @@ __global__ __launch_bounds__(C::NT, C::OCC) void conv3x3_f32x3_kernel(ConvArgsX 
       const unsigned vf = ((tile_id * nch + 1u) * G - 1u) / sk_U;        // owner of the tile's first unit ...
       const unsigned vl = ((tile_id + 1u) * nch * G - 1u) / sk_U;        // ... and of its last one: contributors vf .. vl, in K order
       const unsigned nparts = vl - vf + 1u, cme = vme - vf;
-      f32x4* const slots = reinterpret_cast<f32x4*>(a.sk_part);
-      f32x4* const mine = slots + (size_t)(2u * vme + (tile_id == my_first_tile ? 0u : 1u)) * C::SK_SLOT_F4;
-#pragma unroll
-      for (int mi = 0; mi < C::WM; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < C::WN; ++ni)
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            mine[((mi * C::WN + ni) * 4 + q) * C::NT + tid] = f32x4{acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]};
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's part has left the CU
-      __syncthreads();
+      // Partial slots are written with sc1 (write-through) stores and read with sc1 loads: agent-scope coherent without the L2-wide
+      // write-back / invalidate of a release / acquire fence pair (MI355X_MICROARCH.md: "16-B sc1 stores + drained flag", publish-large:
+      // 3.0 vs 8.2 us per 64 KB -- and the first form of this kernel, with plain stores + fences, LOST 11 % to the plain grid on conv3_2:
+      // every fence flushed an L2 full of other workgroups' freshly written output tiles).
+      constexpr int SC1 = 16;
+      const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(a.sk_part, 0, (int)((size_t)G * 2 * C::SK_SLOT_F4 * 16), 0x00020000);
       unsigned* const flag = reinterpret_cast<unsigned*>(As + C::BUF_U4 + 1);
-      if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (the compiler may drop its own wait after buffer_wbl2: MI355X_MICROARCH.md, compiler hazard)
-        *flag = __hip_atomic_fetch_add(a.sk_tickets + tile_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
+      // If every other contributor has already arrived, this workgroup is the last one whatever it does: it keeps its part in registers and
+      // skips the publish (the usual case for the workgroup that holds a tile's LAST K range as the first segment of its share).
+      if (tid == 0) *flag = __hip_atomic_load(a.sk_tickets + tile_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __syncthreads();
-      if (*flag != nparts - 1u) continue;                   // not the last arriver: on to the next segment (uniform)
-      if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        a.sk_tickets[tile_id] = 0u;                          // ready for the next launch that uses the workspace
+      bool last = *flag == nparts - 1u;
+      if (!last) {
+        const unsigned mine = (2u * vme + (tile_id == my_first_tile ? 0u : 1u)) * (unsigned)(C::SK_SLOT_F4 * 16);
+#pragma unroll
+        for (int mi = 0; mi < C::WM; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < C::WN; ++ni)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const f32x4 v = {acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]};
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), prs, mine + (unsigned)((((mi * C::WN + ni) * 4 + q) * C::NT + tid) * 16), 0, SC1);
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's part has been written through
+        __syncthreads();
+        if (tid == 0) *flag = __hip_atomic_fetch_add(a.sk_tickets + tile_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        last = *flag == nparts - 1u;
+        if (!last) continue;                                  // on to the next segment (uniform)
       }
-      __syncthreads();
+      if (tid == 0) a.sk_tickets[tile_id] = 0u;               // ready for the next launch that uses the workspace
       // sum of the parts in contributor (= K) order, this workgroup's own part taken from its registers: the same bits whoever arrives last
       f32x16 own[C::WM][C::WN];
 #pragma unroll
@@ -396,7 +403,7 @@ __global__ __launch_bounds__(C::NT, C::OCC) void conv3x3_f32x3_kernel(ConvArgsX 
         const bool is_me = j == cme;
         const unsigned vo = vf + j;
         const unsigned first_tile_o = (unsigned)(((unsigned long long)vo * sk_U) / G) / nch;
-        const f32x4* const src = slots + (size_t)(2u * vo + (tile_id == first_tile_o ? 0u : 1u)) * C::SK_SLOT_F4;
+        const unsigned src = (2u * vo + (tile_id == first_tile_o ? 0u : 1u)) * (unsigned)(C::SK_SLOT_F4 * 16);
         f32x4 part[C::WM][C::WN][4];
 #pragma unroll
         for (int mi = 0; mi < C::WM; ++mi)
@@ -405,7 +412,7 @@ __global__ __launch_bounds__(C::NT, C::OCC) void conv3x3_f32x3_kernel(ConvArgsX 
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               if (is_me) part[mi][ni][q] = f32x4{own[mi][ni][4 * q], own[mi][ni][4 * q + 1], own[mi][ni][4 * q + 2], own[mi][ni][4 * q + 3]};
-              else part[mi][ni][q] = src[((mi * C::WN + ni) * 4 + q) * C::NT + tid];
+              else part[mi][ni][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(prs, src + (unsigned)((((mi * C::WN + ni) * 4 + q) * C::NT + tid) * 16), 0, SC1));
             }
 #pragma unroll
         for (int mi = 0; mi < C::WM; ++mi)
@@ -796,11 +803,17 @@ int osvos_conv3x3_f32x3_epi(const float* x, const float* wpk, const void* wpk3, 
     int g = epi->sk_grid > 0 ? epi->sk_grid : (env_grid > 0 ? env_grid : osvos_cu_count());
     if (g > kSkMaxGrid) g = kSkMaxGrid;
     const long rounds = (ntiles * a.ksplit + g - 1) / g;
-    const bool lossy = a.ksplit > 1 || (rounds * g - ntiles) * 100 >= (long)env_loss * rounds * g;
+    // Measured per layer at 854x480 batch 1 (profiles/r04_tune_streamk.txt, three boxes): the 64-cout tiles (12, 14: 64 KB partial slots) WIN --
+    // conv1_2 -6 %, conv4_1 -4 %, conv4_2 / 4_3 -5...-7 %, conv5_x level with partial-sum launches + finalize and one launch fewer -- while the
+    // 128-cout tile (10: conv2_x / conv3_x, 128 KB slots, short K ranges on conv2_x / conv3_1) LOSES 1-12 % although every workgroup issues a
+    // fifth fewer MFMAs.  The automatic choice therefore covers tiles 12 and 14 only; tile 10 runs stream-K when forced (tests, tuning).
+    const bool lossy = (tile == 12 || tile == 14) && (a.ksplit > 1 || (rounds * g - ntiles) * 100 >= (long)env_loss * rounds * g);
     if (ntiles <= kSkMaxTiles && units >= g && (epi->sk_grid > 0 || lossy)) {
       sk_grid = g;
       a.ksplit = 1;
       a.sk_order = a.map ? 0 : 1;      // activations > weights: Cout tiles of one halo back to back; else one weight slice per XCD
+      OSVOS_ENV_INT(env_order, "OSVOS_X3_STREAMK_ORDER", -1);
+      if (env_order == 0 || env_order == 1) a.sk_order = env_order;
       a.sk_tickets = reinterpret_cast<unsigned*>(epi->sk_ws);
       a.sk_part = reinterpret_cast<float*>(reinterpret_cast<char*>(epi->sk_ws) + kSkTicketBytes);
     }

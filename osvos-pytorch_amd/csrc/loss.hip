@@ -11,22 +11,36 @@
 
 namespace {
 
-struct Scratch {            // 32 bytes, zeroed per call
-  unsigned long long npos;
-  double lpos, lneg;
-  double spare;
+// Scratch of one call, zeroed by it: npos[G] (unsigned long long), then lpos[H][G], lneg[H][G] (doubles) -- G = count groups (1, or the N
+// images in the per-image mode), H = heads.  8 G + 16 H G bytes (osvos_cbce_scratch_bytes); with G = 1 that fits the 32 bytes per head
+// the first form of the interface asked for.
+struct ScratchView {
+  unsigned long long* npos;
+  double* lpos;
+  double* lneg;
 };
+__device__ __host__ inline ScratchView scratch_view(void* p, int G, int H) {
+  ScratchView v;
+  v.npos = reinterpret_cast<unsigned long long*>(p);
+  v.lpos = reinterpret_cast<double*>(v.npos + G);
+  v.lneg = v.lpos + (size_t)H * G;
+  return v;
+}
 
-// (both sweeps read 16 bytes per lane and load: `n4` float4 groups, then the <= 3 leftover elements by the first lanes of workgroup 0)
-__global__ void cbce_count_kernel(const float* __restrict__ label, long count, Scratch* sc) {
+// (both sweeps read 16 bytes per lane and load over the first 4 * n4 elements of a group, element-wise over the rest: n4 = elements / 4 for
+//  16-byte aligned tensors -- the rest is then at most 3 elements -- and 0 for tensors that are not: a contiguous but offset view such as
+//  outputs[-1][1:2] with H * W % 4 != 0 takes the scalar sweep instead of being refused)
+__global__ void cbce_count_kernel(const float* __restrict__ label, long per_group, long n4, unsigned long long* npos) {
+  const int grp = blockIdx.y;
+  const float* lab = label + (size_t)grp * per_group;
   unsigned int c = 0;
-  const long n4 = count >> 2;
-  const f32x4* l4 = reinterpret_cast<const f32x4*>(label);
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+  const f32x4* l4 = reinterpret_cast<const f32x4*>(lab);
+  const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x, nth = (long)gridDim.x * blockDim.x;
+  for (long i = tid; i < n4; i += nth) {
     const f32x4 v = l4[i];
     c += (v[0] >= 0.5f ? 1u : 0u) + (v[1] >= 0.5f ? 1u : 0u) + (v[2] >= 0.5f ? 1u : 0u) + (v[3] >= 0.5f ? 1u : 0u);
   }
-  if (blockIdx.x == 0 && (long)threadIdx.x < count - 4 * n4) c += label[4 * n4 + threadIdx.x] >= 0.5f ? 1u : 0u;
+  for (long i = 4 * n4 + tid; i < per_group; i += nth) c += lab[i] >= 0.5f ? 1u : 0u;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
   __shared__ unsigned int red[4];
@@ -34,7 +48,7 @@ __global__ void cbce_count_kernel(const float* __restrict__ label, long count, S
   __syncthreads();
   if (threadIdx.x == 0) {
     c = red[0] + red[1] + red[2] + red[3];
-    if (c) atomicAdd(&sc->npos, (unsigned long long)c);     // one atomic per workgroup (<= 128)
+    if (c) atomicAdd(&npos[grp], (unsigned long long)c);     // one atomic per workgroup
   }
 }
 
@@ -56,51 +70,6 @@ __device__ __forceinline__ float cbce_elem(float x, float lab, float wpos, float
   return gi * gscale;
 }
 
-__global__ void cbce_main_kernel(const float* __restrict__ out, const float* __restrict__ label,
-                                 float* __restrict__ grad, long count, float inv_div, float gscale, Scratch* sc) {
-  const float ntot = (float)count;
-  const float npos = (float)sc->npos;
-  const float wpos = (ntot - npos) / ntot, wneg = npos / ntot;
-  const bool want = grad != nullptr;
-  double lpos = 0.0, lneg = 0.0;
-  const long n4 = count >> 2;
-  const f32x4* o4 = reinterpret_cast<const f32x4*>(out);
-  const f32x4* l4 = reinterpret_cast<const f32x4*>(label);
-  f32x4* g4 = reinterpret_cast<f32x4*>(grad);
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
-    const f32x4 x = o4[i], lab = l4[i];
-    f32x4 g;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) g[e] = cbce_elem(x[e], lab[e], wpos, wneg, inv_div, gscale, want, lpos, lneg);
-    if (want) g4[i] = g;
-  }
-  if (blockIdx.x == 0 && (long)threadIdx.x < count - 4 * n4) {
-    const long i = 4 * n4 + threadIdx.x;
-    const float g = cbce_elem(out[i], label[i], wpos, wneg, inv_div, gscale, want, lpos, lneg);
-    if (want) grad[i] = g;
-  }
-  lpos = wave_sum(lpos);
-  lneg = wave_sum(lneg);
-  __shared__ double red[4][2];
-  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = lpos; red[threadIdx.x >> 6][1] = lneg; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    atomicAdd(&sc->lpos, red[0][0] + red[1][0] + red[2][0] + red[3][0]);
-    atomicAdd(&sc->lneg, red[0][1] + red[1][1] + red[2][1] + red[3][1]);
-  }
-}
-
-__global__ void cbce_final_kernel(const Scratch* sc, long count, float inv_div, float* loss, float* running) {
-  const float ntot = (float)count;
-  const float npos = (float)sc->npos;
-  const float wpos = (ntot - npos) / ntot, wneg = npos / ntot;
-  const float l = (float)(((double)wpos * sc->lpos + (double)wneg * sc->lneg) * (double)inv_div);
-  loss[0] = l;
-  if (running != nullptr) running[0] += l;      // running_loss += loss (train_online.py:128) without a host round trip or an extra launch
-}
-
-// ---- several heads against ONE label in three launches (train_parent.py:145: five losses per micro-batch): the label's class counts are
-// formed once, the loss / gradient sweep runs with blockIdx.y = head, one thread per head finalises.  Same arithmetic per head as above.
 constexpr int kMaxHeads = 8;
 struct CbceHeads {
   const float* out[kMaxHeads];
@@ -111,30 +80,51 @@ struct CbceHeads {
   int n;
 };
 
-__global__ void cbce_main_multi_kernel(CbceHeads hd, const float* __restrict__ label, long count, float inv_div, Scratch* sc) {
-  const int head = blockIdx.y;
-  const float ntot = (float)count;
-  const float npos = (float)sc[0].npos;
-  const float wpos = (ntot - npos) / ntot, wneg = npos / ntot;
-  const float* __restrict__ out = hd.out[head];
-  float* __restrict__ grad = hd.grad[head];
+// What a call weights and divides with (osvos_layers.py:28-34,43-46), per count group `grp`:
+//   default          counts of the whole input tensor, size_average / count, batch_average / N
+//   per image        counts of image `grp` alone, size_average / (elements of one image), batch_average / 1: every image is its own
+//                    reference batch of one (the micro-batches of an accumulation window, train_online.py:116-149, in one call)
+//   external counts  {n_pos, n_total, n_images} of the GLOBAL batch this call holds a shard of (device floats from the count exchange of a
+//                    sharded batch): weights and divisors from them
+struct CbceNorm {
+  const float* counts;      // external counts or NULL
+  int mode;                 // 0 size_average, 1 batch_average, 2 neither
+  int N;                    // images of this call
+  int per_image;
+};
+__device__ __forceinline__ void cbce_weights(const CbceNorm& nm, const unsigned long long* npos_grp, int grp, long per_group, float& wpos, float& wneg, float& inv_div) {
+  float ntot, npos, nimg;
+  if (nm.counts != nullptr) { npos = nm.counts[0]; ntot = nm.counts[1]; nimg = nm.counts[2]; }
+  else { npos = (float)npos_grp[grp]; ntot = (float)per_group; nimg = nm.per_image ? 1.f : (float)nm.N; }
+  wpos = (ntot - npos) / ntot;
+  wneg = npos / ntot;
+  inv_div = nm.mode == 0 ? 1.f / ntot : (nm.mode == 1 ? 1.f / nimg : 1.f);
+}
+
+// grid (workgroups, count groups, heads)
+__global__ void cbce_main_kernel(CbceHeads hd, const float* __restrict__ label, long per_group, long n4, CbceNorm nm, ScratchView sc, int G) {
+  const int grp = blockIdx.y, head = blockIdx.z;
+  float wpos, wneg, inv_div;
+  cbce_weights(nm, sc.npos, grp, per_group, wpos, wneg, inv_div);
+  const float* __restrict__ out = hd.out[head] + (size_t)grp * per_group;
+  const float* __restrict__ lab = label + (size_t)grp * per_group;
+  float* __restrict__ grad = hd.grad[head] != nullptr ? hd.grad[head] + (size_t)grp * per_group : nullptr;
   const float gscale = hd.gscale[head];
   const bool want = grad != nullptr;
   double lpos = 0.0, lneg = 0.0;
-  const long n4 = count >> 2;
   const f32x4* o4 = reinterpret_cast<const f32x4*>(out);
-  const f32x4* l4 = reinterpret_cast<const f32x4*>(label);
+  const f32x4* l4 = reinterpret_cast<const f32x4*>(lab);
   f32x4* g4 = reinterpret_cast<f32x4*>(grad);
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
-    const f32x4 x = o4[i], lab = l4[i];
+  const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x, nth = (long)gridDim.x * blockDim.x;
+  for (long i = tid; i < n4; i += nth) {
+    const f32x4 x = o4[i], lb = l4[i];
     f32x4 g;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) g[e] = cbce_elem(x[e], lab[e], wpos, wneg, inv_div, gscale, want, lpos, lneg);
+    for (int e = 0; e < 4; ++e) g[e] = cbce_elem(x[e], lb[e], wpos, wneg, inv_div, gscale, want, lpos, lneg);
     if (want) g4[i] = g;
   }
-  if (blockIdx.x == 0 && (long)threadIdx.x < count - 4 * n4) {
-    const long i = 4 * n4 + threadIdx.x;
-    const float g = cbce_elem(out[i], label[i], wpos, wneg, inv_div, gscale, want, lpos, lneg);
+  for (long i = 4 * n4 + tid; i < per_group; i += nth) {
+    const float g = cbce_elem(out[i], lab[i], wpos, wneg, inv_div, gscale, want, lpos, lneg);
     if (want) grad[i] = g;
   }
   lpos = wave_sum(lpos);
@@ -143,20 +133,25 @@ __global__ void cbce_main_multi_kernel(CbceHeads hd, const float* __restrict__ l
   if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = lpos; red[threadIdx.x >> 6][1] = lneg; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    atomicAdd(&sc[head].lpos, red[0][0] + red[1][0] + red[2][0] + red[3][0]);
-    atomicAdd(&sc[head].lneg, red[0][1] + red[1][1] + red[2][1] + red[3][1]);
+    atomicAdd(&sc.lpos[(size_t)head * G + grp], red[0][0] + red[1][0] + red[2][0] + red[3][0]);
+    atomicAdd(&sc.lneg[(size_t)head * G + grp], red[0][1] + red[1][1] + red[2][1] + red[3][1]);
   }
 }
 
-__global__ void cbce_final_multi_kernel(CbceHeads hd, const Scratch* sc, long count, float inv_div) {
+// one thread per head: loss = sum over the count groups of (w_pos * lpos + w_neg * lneg) / div  (one group unless per image: there the
+// sum of the images' losses = what the reference's loop adds to running_loss over the window)
+__global__ void cbce_final_kernel(CbceHeads hd, long per_group, CbceNorm nm, ScratchView sc, int G) {
   const int head = threadIdx.x;
   if (head >= hd.n) return;
-  const float ntot = (float)count;
-  const float npos = (float)sc[0].npos;
-  const float wpos = (ntot - npos) / ntot, wneg = npos / ntot;
-  const float l = (float)(((double)wpos * sc[head].lpos + (double)wneg * sc[head].lneg) * (double)inv_div);
-  hd.loss[head][0] = l;
-  if (hd.running[head] != nullptr) hd.running[head][0] += l;
+  float total = 0.f;
+  for (int grp = 0; grp < G; ++grp) {
+    float wpos, wneg, inv_div;
+    cbce_weights(nm, sc.npos, grp, per_group, wpos, wneg, inv_div);
+    const float l = (float)(((double)wpos * sc.lpos[(size_t)head * G + grp] + (double)wneg * sc.lneg[(size_t)head * G + grp]) * (double)inv_div);
+    total = grp == 0 ? l : total + l;      // (fp32 adds in image order: what `running_loss += loss.item()` does on the host in double is within 1 ulp of this)
+  }
+  hd.loss[head][0] = total;
+  if (hd.running[head] != nullptr) hd.running[head][0] += total;      // running_loss += loss (train_online.py:128) without a host round trip or an extra launch
 }
 
 __global__ void scale_kernel(const float* __restrict__ x, const float* __restrict__ scalar, float* __restrict__ y, long count) {
@@ -186,41 +181,29 @@ inline int grid_for(long total, int cap) {
 
 }  // namespace
 
-extern "C" int osvos_cbce(const float* out, const float* label, float* loss, float* grad, void* scratch,
-                          long count, int N, int mode, void* stream_) {
-  return osvos_cbce_step(out, label, loss, grad, scratch, count, N, mode, 1.f, nullptr, stream_);
+extern "C" size_t osvos_cbce_scratch_bytes(int n_heads, int N, int flags) {
+  const size_t G = (flags & OSVOS_CBCE_PER_IMAGE) ? (size_t)(N > 0 ? N : 1) : 1, H = (size_t)(n_heads > 0 ? n_heads : 1);
+  return 8 * G + 16 * H * G;
 }
 
-extern "C" int osvos_cbce_step(const float* out, const float* label, float* loss, float* grad, void* scratch,
-                               long count, int N, int mode, float grad_scale, float* running, void* stream_) {
+extern "C" int osvos_cbce_step_ex(const float* const* outs, const float* label, float* const* losses, float* const* grads, void* scratch, long count,
+                                  int N, int mode, int flags, const float* counts, int n_heads, const float* grad_scales, float* const* running,
+                                  void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  OSVOS_ARG_CHECK(out && label && loss && scratch && count > 0 && N > 0, "cbce: bad arguments");
+  OSVOS_ARG_CHECK(outs && label && losses && scratch && grad_scales && count > 0 && N > 0, "cbce: bad arguments");
+  OSVOS_ARG_CHECK(n_heads >= 1 && n_heads <= kMaxHeads, "cbce: %d heads (1..%d)", n_heads, kMaxHeads);
   OSVOS_ARG_CHECK(mode >= 0 && mode <= 2, "cbce: mode %d", mode);
-  OSVOS_ARG_CHECK(((uintptr_t)out | (uintptr_t)label | (uintptr_t)grad) % 16 == 0, "cbce: out / label / grad must be 16-byte aligned (whole tensors are)");
-  const float inv_div = mode == 0 ? 1.f / (float)count : (mode == 1 ? 1.f / (float)N : 1.f);
-  Scratch* sc = reinterpret_cast<Scratch*>(scratch);
-  OSVOS_HIP_CHECK(hipMemsetAsync(sc, 0, sizeof(Scratch), stream));
-  // one double atomic pair per workgroup: few workgroups for a single frame (11 us), more for batches (94 -> ~25 us at batch 12)
-  const int g = grid_for(count >> 2, count > (1L << 21) ? 512 : 128);
-  hipLaunchKernelGGL(cbce_count_kernel, dim3(g), dim3(256), 0, stream, label, count, sc);
-  hipLaunchKernelGGL(cbce_main_kernel, dim3(g), dim3(256), 0, stream, out, label, grad, count, inv_div, grad_scale, sc);
-  hipLaunchKernelGGL(cbce_final_kernel, dim3(1), dim3(1), 0, stream, sc, count, inv_div, loss, running);
-  OSVOS_LAUNCH_CHECK();
-  return 0;
-}
-
-extern "C" int osvos_cbce_step_multi(const float* const* outs, const float* label, float* const* losses, float* const* grads, void* scratch,
-                                     long count, int N, int mode, int n_heads, const float* grad_scales, float* const* running, void* stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  OSVOS_ARG_CHECK(outs && label && losses && scratch && grad_scales && count > 0 && N > 0, "cbce_multi: bad arguments");
-  OSVOS_ARG_CHECK(n_heads >= 1 && n_heads <= kMaxHeads, "cbce_multi: %d heads (1..%d)", n_heads, kMaxHeads);
-  OSVOS_ARG_CHECK(mode >= 0 && mode <= 2, "cbce_multi: mode %d", mode);
+  const bool per_image = (flags & OSVOS_CBCE_PER_IMAGE) != 0;
+  OSVOS_ARG_CHECK((flags & ~OSVOS_CBCE_PER_IMAGE) == 0 && !(per_image && counts != nullptr), "cbce: flags 0x%x (per-image counts and external counts exclude each other)", flags);
+  OSVOS_ARG_CHECK(!per_image || (count % N == 0 && N <= 65535), "cbce: per-image mode needs count %% N == 0 (%ld, %d)", count, N);
+  const int G = per_image ? N : 1;
+  const long per_group = count / G;
   CbceHeads hd;
   hd.n = n_heads;
   uintptr_t align = (uintptr_t)label;
   for (int h = 0; h < kMaxHeads; ++h) {
     const bool live = h < n_heads;
-    OSVOS_ARG_CHECK(!live || (outs[h] && losses[h]), "cbce_multi: head %d: null pointer", h);
+    OSVOS_ARG_CHECK(!live || (outs[h] && losses[h]), "cbce: head %d: null pointer", h);
     hd.out[h] = live ? outs[h] : nullptr;
     hd.grad[h] = live && grads ? grads[h] : nullptr;
     hd.loss[h] = live ? losses[h] : nullptr;
@@ -228,16 +211,43 @@ extern "C" int osvos_cbce_step_multi(const float* const* outs, const float* labe
     hd.gscale[h] = live ? grad_scales[h] : 0.f;
     if (live) align |= (uintptr_t)hd.out[h] | (uintptr_t)hd.grad[h];
   }
-  OSVOS_ARG_CHECK(align % 16 == 0, "cbce_multi: out / label / grad must be 16-byte aligned (whole tensors are)");
-  const float inv_div = mode == 0 ? 1.f / (float)count : (mode == 1 ? 1.f / (float)N : 1.f);
-  Scratch* sc = reinterpret_cast<Scratch*>(scratch);      // n_heads x 32 bytes
-  OSVOS_HIP_CHECK(hipMemsetAsync(sc, 0, sizeof(Scratch) * n_heads, stream));
-  const int g = grid_for(count >> 2, count > (1L << 21) ? 512 : 128);
-  hipLaunchKernelGGL(cbce_count_kernel, dim3(g), dim3(256), 0, stream, label, count, sc);
-  hipLaunchKernelGGL(cbce_main_multi_kernel, dim3(g, n_heads), dim3(256), 0, stream, hd, label, count, inv_div, sc);
-  hipLaunchKernelGGL(cbce_final_multi_kernel, dim3(1), dim3(64), 0, stream, hd, sc, count, inv_div);
+  // 16-byte sweeps need every group of every tensor aligned; anything else (an offset view, odd image sizes in the per-image mode) takes the
+  // element-wise sweep -- slower, same numbers, not an error
+  const bool vec = align % 16 == 0 && (G == 1 || per_group % 4 == 0);
+  const long n4 = vec ? per_group >> 2 : 0;
+  CbceNorm nm;
+  nm.counts = counts; nm.mode = mode; nm.N = N; nm.per_image = per_image ? 1 : 0;
+  const ScratchView sc = scratch_view(scratch, G, n_heads);
+  OSVOS_HIP_CHECK(hipMemsetAsync(scratch, 0, osvos_cbce_scratch_bytes(n_heads, N, flags), stream));
+  // one double atomic pair per workgroup: few workgroups for a single frame (11 us), more for batches (94 -> ~25 us at batch 12)
+  const long work = vec ? n4 : per_group;
+  int g = grid_for(work, count > (1L << 21) ? 512 : 128);
+  if (G > 1) { g = (g + G - 1) / G; if (g < 16) g = 16; }
+  if (counts == nullptr) hipLaunchKernelGGL(cbce_count_kernel, dim3(g, G), dim3(256), 0, stream, label, per_group, n4, sc.npos);
+  hipLaunchKernelGGL(cbce_main_kernel, dim3(g, G, n_heads), dim3(256), 0, stream, hd, label, per_group, n4, nm, sc, G);
+  hipLaunchKernelGGL(cbce_final_kernel, dim3(1), dim3(64), 0, stream, hd, per_group, nm, sc, G);
   OSVOS_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int osvos_cbce_step(const float* out, const float* label, float* loss, float* grad, void* scratch,
+                               long count, int N, int mode, float grad_scale, float* running, void* stream_) {
+  OSVOS_ARG_CHECK(out && label && loss && scratch, "cbce: bad arguments");
+  const float* outs[1] = {out};
+  float* losses[1] = {loss};
+  float* grads[1] = {grad};
+  float* runs[1] = {running};
+  return osvos_cbce_step_ex(outs, label, losses, grads, scratch, count, N, mode, 0, nullptr, 1, &grad_scale, runs, stream_);
+}
+
+extern "C" int osvos_cbce(const float* out, const float* label, float* loss, float* grad, void* scratch,
+                          long count, int N, int mode, void* stream_) {
+  return osvos_cbce_step(out, label, loss, grad, scratch, count, N, mode, 1.f, nullptr, stream_);
+}
+
+extern "C" int osvos_cbce_step_multi(const float* const* outs, const float* label, float* const* losses, float* const* grads, void* scratch,
+                                     long count, int N, int mode, int n_heads, const float* grad_scales, float* const* running, void* stream_) {
+  return osvos_cbce_step_ex(outs, label, losses, grads, scratch, count, N, mode, 0, nullptr, n_heads, grad_scales, running, stream_);
 }
 
 extern "C" int osvos_scale(const float* x, const float* scalar, float* y, long count, void* stream) {

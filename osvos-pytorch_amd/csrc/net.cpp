@@ -266,11 +266,14 @@ inline bool fuse_pool(int dtype) {
   return on && (dtype == OSVOS_F32_X3 || use_store(dtype));
 }
 
-// f32x3 stream-K (conv3x3_f32x3.hip): OSVOS_X3_STREAMK = 0 off, 1 (default) the forward's main-stream convolutions -- nothing runs beside them at
-// batch 1, the CUs a plain grid leaves without a tile just idle --, 2 also the data-gradient chain (whose idle CUs the weight-gradient stream
-// already fills)
+// f32x3 stream-K (conv3x3_f32x3.hip): OSVOS_X3_STREAMK = 0 (default) off, 1 the forward's main-stream convolutions, 2 also the data-gradient
+// chain.  Built and measured in round 4 (profiles/r04_tune_streamk.txt): op level the 64-cout tiles gain 4-7 % (conv1_2, conv4_x)
+// and the 128-cout tile loses 1-12 % (conv2_x, conv3_x); in the network, with the automatic choice restricted to the winners, the headline
+// loop reads 234.8-235.9 frames/s against 235.2-236.2 without it (three alternating runs on one box) and configs[4] 157.2-157.3 against
+// 157.3-157.5 -- the CUs a plain grid leaves without a tile are not idle in the step: the side-branch convolutions of the second stream run
+// there.  Mode 2 costs 3.6 % (the weight-gradient stream already fills the data-gradient chain's idle CUs).  Hence opt-in.
 inline int streamk_mode() {
-  static const int v = [] { const char* e = getenv("OSVOS_X3_STREAMK"); return e ? atoi(e) : 1; }();
+  static const int v = [] { const char* e = getenv("OSVOS_X3_STREAMK"); return e ? atoi(e) : 0; }();
   return v;
 }
 
@@ -747,7 +750,7 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
       } else if (dx_nchw != nullptr && (dtype == OSVOS_F32 || dtype == OSVOS_F32_X3)) {
         rc = osvos_conv3x3_dgrad_c3_f32(reinterpret_cast<const float*>(g), reinterpret_cast<const float*>(at(wbuf, P.dgrad[0])), dx_nchw, N, h, w, d[0].cout, stream);
         if (rc) return rc;
-      } else if (dx_nchw != nullptr && store && P.dgrad0_f32 != (size_t)-1) {      // bf16 trunk tensors: the same bandwidth kernel, bf16 dy in
+      } else if (dx_nchw != nullptr && store && P.dgrad0_f32 != (size_t)-1 && getenv("OSVOS_TMP_NO_C3B") == nullptr) {      // bf16 trunk tensors: the same bandwidth kernel, bf16 dy in
         rc = osvos_conv3x3_dgrad_c3_bf16in(g, reinterpret_cast<const float*>(at(wbuf, P.dgrad0_f32)), dx_nchw, N, h, w, d[0].cout, stream);
         if (rc) return rc;
       } else if (dx_nchw != nullptr) {

@@ -28,19 +28,25 @@ def class_balanced_cross_entropy_loss(output, label, size_average=True, batch_av
     return CBCELossFunction.apply(output, label, mode)
 
 
-def class_balanced_cross_entropy_loss_step(output, label, size_average=True, batch_average=True, grad_scale=1.0, running=None):
+def class_balanced_cross_entropy_loss_step(output, label, size_average=True, batch_average=True, grad_scale=1.0, running=None, per_image=False,
+                                           counts=None):
     """The loss as ONE micro-batch of the training loops uses it (train_online.py:127-141): ``(loss, grad)`` with ``grad`` already
     multiplied by the upstream gradient ``grad_scale`` (1 / nAveGrad ...) and ``running += loss`` done on the device; hand ``grad`` to
-    ``torch.autograd.backward([output], [grad])``.  An extension next to the reference's function above, not a replacement."""
+    ``torch.autograd.backward([output], [grad])``.  An extension next to the reference's function above, not a replacement.
+    ``per_image=True``: the N images of ``output`` are N reference micro-batches of one image each (own class weights per image, the N losses
+    summed) -- a whole accumulation window in one call.  ``counts=(n_pos, n_total, n_images)``: the tensors are a shard of a global batch with
+    these counts (``parallel.global_class_counts``)."""
     mode = 0 if size_average else (1 if batch_average else 2)
-    return cbce_step(output, label, mode, grad_scale, running)
+    return cbce_step(output, label, mode, grad_scale, running, per_image=per_image, counts=counts)
 
 
-def class_balanced_cross_entropy_loss_step_multi(outputs, label, size_average=True, batch_average=True, grad_scales=None, running=None):
+def class_balanced_cross_entropy_loss_step_multi(outputs, label, size_average=True, batch_average=True, grad_scales=None, running=None, per_image=False,
+                                                 counts=None):
     """``class_balanced_cross_entropy_loss_step`` for all heads of a micro-batch in one call (the parent loop: train_parent.py:143-147):
     ``(losses, grads)`` with ``losses`` a float32 tensor of the plain per-head losses."""
     mode = 0 if size_average else (1 if batch_average else 2)
-    return cbce_step_multi(list(outputs), label, mode, list(grad_scales) if grad_scales is not None else [1.0] * len(outputs), running)
+    return cbce_step_multi(list(outputs), label, mode, list(grad_scales) if grad_scales is not None else [1.0] * len(outputs), running,
+                           per_image=per_image, counts=counts)
 
 
 def center_crop(x, height, width):

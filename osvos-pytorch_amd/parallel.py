@@ -35,11 +35,29 @@ def _grad_group(name):
     return 0
 
 
+def comm_port():
+    """TCP port of the id store of the C-ABI communicator: OSVOS_COMM_PORT, else MASTER_PORT + 1"""
+    p = os.environ.get("OSVOS_COMM_PORT")
+    if p:
+        port = int(p)
+        if not (1024 <= port <= 65535):
+            raise ValueError("OSVOS_COMM_PORT = %s: need a port in 1024..65535" % p)
+        return port
+    return int(os.environ.get("MASTER_PORT", "29500")) + 1
+
+
+def _store_timeout():
+    import datetime
+    return datetime.timedelta(seconds=float(os.environ.get("OSVOS_COMM_TIMEOUT", "120")))
+
+
 class AbiCommunicator:
     """RCCL communicator held through the C ABI (``osvos_comm_*``, csrc/comm.cpp) instead of torch.distributed: the gradient sum is
     then a plain ``ncclAllReduce`` enqueued by the library -- and, chunked behind the backward's gradient-ready events, costs the host
     seven stream-wait + enqueue pairs instead of seven torch.distributed work objects.  The 128-byte RCCL id travels from rank 0 to
-    the others through a ``torch.distributed.TCPStore`` at MASTER_ADDR : MASTER_PORT + 1 (no process group needed)."""
+    the others through a ``torch.distributed.TCPStore`` (no process group needed) at MASTER_ADDR : OSVOS_COMM_PORT -- an explicit port of
+    the job's own; without the variable MASTER_PORT + 1 is used, and a port that is already taken (a second job on the node) is reported as
+    such instead of hanging the rendezvous."""
 
     def __init__(self, rank, world, device):
         import ctypes as C
@@ -50,8 +68,13 @@ class AbiCommunicator:
         if rank == 0:
             check(self._lib.osvos_comm_unique_id(ident), "comm_unique_id")
         if world > 1:
-            port = int(os.environ.get("MASTER_PORT", "29500")) + 1
-            store = dist.TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), port, world, rank == 0)
+            port = comm_port()
+            try:
+                store = dist.TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), port, world, rank == 0, timeout=_store_timeout())
+            except Exception as e:      # (rank 0: EADDRINUSE; others: nobody listening within the timeout)
+                raise RuntimeError("osvos communicator: cannot %s the id store at %s:%d (%s).  Another job on this node probably uses the port: "
+                                   "give every job its own OSVOS_COMM_PORT (default MASTER_PORT + 1)."
+                                   % ("open" if rank == 0 else "reach", os.environ.get("MASTER_ADDR", "127.0.0.1"), port, e)) from e
             if rank == 0:
                 store.set("osvos_comm_id", bytes(ident.raw))
             else:
@@ -62,9 +85,13 @@ class AbiCommunicator:
             check(self._lib.osvos_comm_init(C.byref(self.handle), rank, world, ident), "comm_init")
 
     def all_reduce(self, flat):
+        """in-place sum over the ranks of a contiguous float32 (gradients) or float64 (class counts, loss statistics: exact) CUDA tensor"""
         C = self._C
-        self._check(self._lib.osvos_comm_allreduce_f32(self.handle, C.c_void_p(flat.data_ptr()), flat.numel(),
-                                                       C.c_void_p(torch.cuda.current_stream(flat.device).cuda_stream)), "comm_allreduce")
+        if flat.dtype not in (torch.float32, torch.float64) or not flat.is_contiguous():
+            raise RuntimeError("AbiCommunicator.all_reduce: contiguous float32 / float64 tensors only (got %s)" % flat.dtype)
+        fn = self._lib.osvos_comm_allreduce_f32 if flat.dtype == torch.float32 else self._lib.osvos_comm_allreduce_f64
+        self._check(fn(self.handle, C.c_void_p(flat.data_ptr()), flat.numel(), C.c_void_p(torch.cuda.current_stream(flat.device).cuda_stream)),
+                    "comm_allreduce")
 
     def all_reduce_chunks(self, flat, slices, events, comm_stream):
         C = self._C
@@ -267,9 +294,7 @@ def global_class_counts(label, group=None, comm=None):
     t = torch.stack([lab.sum().double(), torch.tensor(float(label.numel()), device=label.device, dtype=torch.float64),
                      torch.tensor(float(label.shape[0]), device=label.device, dtype=torch.float64)])
     if comm is not None and comm.world > 1:
-        f = t.float()
-        comm.all_reduce(f)                       # (the ABI communicator sums fp32: exact for counts below 2^24 per image batch)
-        t = f.double()
+        comm.all_reduce(t)                       # float64 sum (osvos_comm_allreduce_f64): exact for any count
     elif comm is None and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(t, group=group)
     return t[0], t[1], t[2]
@@ -278,8 +303,14 @@ def global_class_counts(label, group=None, comm=None):
 def cbce_with_counts(output, label, n_pos, n_total, n_images, size_average=False, batch_average=True):
     """class_balanced_cross_entropy_loss (osvos_layers.py:19-48) of this rank's SHARD of a batch, weighted and normalised with the GLOBAL counts
     of ``global_class_counts``: summed over the ranks it is the reference loss of the whole batch (same operation order per element; the class
-    weights stay float32 quotients like the reference's).  Plain torch ops (autograd-differentiable, any device): the exchange is a host-side
-    extension next to the reference API, not a hot-path kernel."""
+    weights stay float32 quotients like the reference's).  CUDA tensors take the HIP loss kernel with the counts as arguments
+    (``osvos_cbce_step_ex``: no count sweep, weights and divisors from the global numbers; differentiable through ``CBCECountsFunction``); CPU
+    tensors (the gloo tests) the plain torch expression below."""
+    if output.is_cuda:
+        from .autograd import CBCECountsFunction
+        mode = 0 if size_average else (1 if batch_average else 2)
+        cnt = torch.stack([n_pos.reshape(()).float(), n_total.reshape(()).float(), n_images.reshape(()).float()]).to(output.device)
+        return CBCECountsFunction.apply(output, label, cnt, mode)
     labels = (label >= 0.5).float()
     n_pos32, n_tot32 = n_pos.float(), n_total.float()
     w_pos, w_neg = (n_tot32 - n_pos32) / n_tot32, n_pos32 / n_tot32

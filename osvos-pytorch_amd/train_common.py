@@ -91,6 +91,9 @@ class TrainLoop(object):
         return r
 
     def micro_batch(self, inputs, gts, epoch=0):
+        """One micro-batch.  Returns ``(loss, stepped)``: ``loss`` is the PLAIN loss of the fused head (detached 0-dim tensor; not divided by
+        nAveGrad, side heads not mixed in) on every code path -- what the reference prints per iteration; sums over an epoch come from
+        ``pop_running``.  ``stepped``: this micro-batch closed an optimizer-step window."""
         outputs = self.net.forward(inputs)
         running = self._acc(epoch)
         self.counts[epoch] += 1
@@ -99,17 +102,49 @@ class TrainLoop(object):
         if self.mode == 'online':
             loss = self.loss_fn(outputs[-1], gts, size_average=False)
             running[0] += loss.detach()
+            plain = loss.detach().clone()
         else:
             losses = [self.loss_fn(o, gts, size_average=False) for o in outputs]
             for r, l in zip(running, losses):
                 r += l.detach()
+            plain = losses[-1].detach().clone()
             loss = (1 - epoch / self.n_epochs) * sum(losses[:-1]) + losses[-1]
         loss /= self.n_ave_grad
         will_step = (self.ave + 1) % self.local_ave == 0 and (self.max_steps is None or self.steps < self.max_steps)
         if self.reducer is not None and will_step:
             self.reducer.arm()          # last micro-batch of the step: reduce each gradient group as soon as its backward is done
         loss.backward()
-        return loss, self._after_backward(will_step)
+        return plain, self._after_backward(will_step)
+
+    def window_batch(self, inputs, gts, epoch=0):
+        """A whole accumulation window in ONE forward / backward (round 4): ``inputs`` holds the ``local_ave`` frames this rank contributes to
+        the optimizer step as a batch; each image is its own reference micro-batch -- class weights from its own label, loss divided by
+        nAveGrad (``per_image`` mode of the loss kernel) -- so the accumulated gradient is the one ``local_ave`` ``micro_batch`` calls leave,
+        up to fp32 summation order (train_online.py:116-149 / train_parent.py:132-172; the micro-batches of a window share the weights, nothing
+        couples the images of a batch in this network).  conv5_x sees M = 5 x 1620 pixels instead of 1620, every launch of the step is issued
+        once instead of nAveGrad times.  Returns ``(sum of the window's plain fused losses, stepped)``."""
+        n = int(inputs.shape[0])
+        if n != self.local_ave or self.ave != 0:
+            raise RuntimeError("window_batch: needs exactly local_ave = %d frames at the start of a window (got %d, %d accumulated)" % (self.local_ave, n, self.ave))
+        if not inputs.is_cuda:
+            raise RuntimeError("window_batch: CUDA tensors only (the per-image loss mode lives in the HIP kernel)")
+        outputs = self.net.forward(inputs)
+        running = self._acc(epoch)
+        self.counts[epoch] += n
+        inv = np.float32(1.0) / np.float32(self.n_ave_grad)
+        if self.mode == 'online':
+            heads, scales = [outputs[-1]], [inv]
+        else:
+            side = np.float32(inv * np.float32(1 - epoch / self.n_epochs))
+            heads, scales = list(outputs), [side] * (len(outputs) - 1) + [inv]
+        losses, grads = class_balanced_cross_entropy_loss_step_multi(heads, gts, size_average=False, grad_scales=[float(s) for s in scales],
+                                                                     running=list(running), per_image=True)
+        will_step = self.max_steps is None or self.steps < self.max_steps
+        if self.reducer is not None and will_step:
+            self.reducer.arm()
+        torch.autograd.backward(heads, grads)
+        self.ave = self.local_ave - 1
+        return losses[-1], self._after_backward(will_step)
 
     def _micro_batch_fused(self, outputs, gts, running, epoch):
         """The same micro-batch with the upstream gradients of ``loss /= nAveGrad; loss.backward()`` (train_online.py:140-141;
@@ -134,7 +169,7 @@ class TrainLoop(object):
         if self.reducer is not None and will_step:
             self.reducer.arm()
         torch.autograd.backward(heads, grads)
-        return loss, self._after_backward(will_step)       # (loss: the fused head's plain loss, not divided by nAveGrad)
+        return loss.detach(), self._after_backward(will_step)       # (the fused head's plain loss, like the other path)
 
     def _after_backward(self, will_step):
         self.ave += 1
@@ -171,6 +206,36 @@ class TrainLoop(object):
     def pop_count(self, epoch):
         return self.counts.pop(epoch, 0)
 
+    # ---- exact resume (round 4).  The reference saves the network only (train_parent.py:175-176): a resumed run starts with
+    # zero momentum and drops the micro-batches accumulated in the open window.  With these two an interrupted run continues BIT FOR BIT.
+    def state_dict(self):
+        """Everything of the loop that is not in the network or the optimizer: the position inside the open accumulation window (``ave``),
+        the gradients accumulated in it so far (THIS rank's share), the running loss sums / counts of epochs whose statistics have not been
+        exchanged yet, and the step counter (informational)."""
+        self.finish()
+        grads = {}
+        if self.ave > 0:
+            for name, p in self.net.named_parameters():
+                if p.grad is not None:
+                    grads[name] = p.grad.detach().cpu().clone()
+        running = {int(e): [float(r.item()) for r in rs] for e, rs in self._running.items()}
+        return {'ave': int(self.ave), 'steps': int(self.steps), 'local_ave': int(self.local_ave), 'n_ave_grad': int(self.n_ave_grad),
+                'grads': grads, 'running': running, 'counts': {int(e): int(c) for e, c in self.counts.items()}}
+
+    def load_state_dict(self, sd):
+        if int(sd['local_ave']) != self.local_ave or int(sd['n_ave_grad']) != self.n_ave_grad:
+            raise RuntimeError("TrainLoop.load_state_dict: the checkpoint was written with nAveGrad %d / %d micro-batches per rank and step, this "
+                               "run has %d / %d (an open accumulation window cannot be re-partitioned)"
+                               % (sd['n_ave_grad'], sd['local_ave'], self.n_ave_grad, self.local_ave))
+        self.ave = int(sd['ave'])
+        params = dict(self.net.named_parameters())
+        with torch.no_grad():
+            for name, g in sd['grads'].items():
+                p = params[name]
+                p.grad = g.to(device=p.device, dtype=p.dtype).contiguous()
+        self._running = {int(e): [torch.tensor(v, device=self._dev, dtype=torch.float32) for v in vals] for e, vals in sd['running'].items()}
+        self.counts = {int(e): int(c) for e, c in sd['counts'].items()}
+
 
 class StepSchedule(object):
     """Where the optimizer steps of a run fall in the global micro-batch stream, and with them the only places at which every rank
@@ -183,16 +248,19 @@ class StepSchedule(object):
     gradient collective of the window that holds the epoch's LAST iteration (``closing_step``) -- every rank has finished its share
     of the epoch by then -- and epochs that end in the trailing partial window are exchanged after the last epoch."""
 
-    def __init__(self, n_items, n_ave_grad, first_epoch, n_epochs):
+    def __init__(self, n_items, n_ave_grad, first_epoch, n_epochs, carry=0):
+        """``carry``: iterations (summed over all ranks) already accumulated in the open window when the run starts -- 0 for a fresh run and for
+        a reference-style resume (which drops them), ``(first_epoch * n_items) % n_ave_grad`` for an exact resume (TrainLoop.load_state_dict)."""
         self.n_items, self.n_ave_grad = int(n_items), int(n_ave_grad)
         self.first_epoch, self.n_epochs = int(first_epoch), int(n_epochs)
+        self.carry = int(carry)
         self.total_iterations = max(0, self.n_epochs - self.first_epoch) * self.n_items
-        self.total_steps = self.total_iterations // self.n_ave_grad          # complete windows: what EVERY rank steps, no more
+        self.total_steps = (self.carry + self.total_iterations) // self.n_ave_grad          # complete windows: what EVERY rank steps, no more
 
     def closing_step(self, epoch):
         """Index of the optimizer step whose window holds the last iteration of `epoch`; None when that is the trailing partial
         window (no step, no gradient collective: such epochs are closed after the training loop)."""
-        last = (epoch + 1 - self.first_epoch) * self.n_items - 1
+        last = self.carry + (epoch + 1 - self.first_epoch) * self.n_items - 1
         k = last // self.n_ave_grad
         return k if k < self.total_steps else None
 

@@ -915,3 +915,63 @@ def test_conv3x3_f32x3_streamk(case):
     # the tickets are back at zero: the workspace is ready for the next launch
     ws = ops.streamk_workspace(xg.device)
     assert int(ws[:ops.lib().osvos_conv3x3_x3_streamk_ticket_bytes()].view(torch.int32).abs().max()) == 0
+
+
+def test_cbce_per_image_counts_external_counts_and_offset_views():
+    """osvos_cbce_step_ex: (1) per-image mode == the sequential single-image calls of an accumulation window (gradients bit-identical, the
+    summed loss to fp32 round-off), incl. image sizes that are not multiples of four (element-wise sweep); (2) external counts: two shards
+    with the GLOBAL counts give the whole batch's loss (sum) and gradients (concatenation), and equal the torch expression of
+    parallel.cbce_with_counts on the CPU; (3) contiguous but 4-byte-offset views (used to be refused) give the numbers of their
+    aligned copies."""
+    from osvos_pytorch_amd.layers.osvos_layers import class_balanced_cross_entropy_loss_step as one
+    from osvos_pytorch_amd.layers.osvos_layers import class_balanced_cross_entropy_loss_step_multi as multi
+    from osvos_pytorch_amd.layers.osvos_layers import class_balanced_cross_entropy_loss as cbce
+    from osvos_pytorch_amd import parallel
+    g = torch.Generator(device="cuda").manual_seed(23)
+    for (n, h, w) in [(5, 37, 53), (4, 32, 48), (3, 7, 9)]:
+        out = torch.randn(n, 1, h, w, device="cuda", generator=g) * 3 - 1
+        lab = (torch.rand(n, 1, h, w, device="cuda", generator=g) > torch.linspace(0.5, 0.95, n, device="cuda").view(n, 1, 1, 1)).float()
+        # (1) the window in one call vs image by image
+        run_a, run_b = torch.zeros((), device="cuda"), torch.zeros((), device="cuda")
+        seq = [one(out[j:j + 1].clone(), lab[j:j + 1].clone(), size_average=False, grad_scale=1.0 / n, running=run_a) for j in range(n)]
+        loss, grad = one(out, lab, size_average=False, grad_scale=1.0 / n, running=run_b, per_image=True)
+        torch.cuda.synchronize()
+        for j in range(n):
+            assert torch.equal(grad[j:j + 1], seq[j][1]), (n, h, w, j)
+        tot = sum(float(s[0]) for s in seq)
+        assert abs(float(loss) - tot) <= 3e-7 * abs(tot) and abs(float(run_b) - float(run_a)) <= 3e-7 * abs(tot), (float(loss), tot)
+        # all five heads at once
+        outs5 = [torch.randn(n, 1, h, w, device="cuda", generator=g) for _ in range(5)]
+        l5, g5 = multi(outs5, lab, size_average=False, grad_scales=[0.1] * 5, per_image=True)
+        for k in range(5):
+            lk, gk = one(outs5[k], lab, size_average=False, grad_scale=0.1, per_image=True)
+            assert torch.equal(g5[k], gk) and abs(float(l5[k]) - float(lk)) <= 3e-7 * abs(float(lk))
+        # (2) two shards + global counts == the whole batch
+        if n >= 2:
+            whole_l, whole_g = one(out, lab, size_average=False, grad_scale=1.0)
+            cnts = parallel.global_class_counts(lab)
+            k = n // 2
+            la, ga = one(out[:k].contiguous(), lab[:k].contiguous(), size_average=False, counts=cnts)
+            lb, gb = one(out[k:].contiguous(), lab[k:].contiguous(), size_average=False, counts=cnts)
+            assert torch.equal(torch.cat([ga, gb]), whole_g)
+            assert abs(float(la) + float(lb) - float(whole_l)) <= 3e-7 * abs(float(whole_l))
+            o2 = out[:k].clone().requires_grad_()
+            lc = parallel.cbce_with_counts(o2, lab[:k], *cnts)            # HIP path, differentiable
+            (lc * 0.5).backward()
+            oc = out[:k].cpu().clone().requires_grad_()
+            lcpu = parallel.cbce_with_counts(oc, lab[:k].cpu(), *[c.cpu() for c in cnts])      # torch expression
+            (lcpu * 0.5).backward()
+            assert abs(float(lc) - float(lcpu)) <= 1e-5 * abs(float(lcpu))
+            assert float((o2.grad.cpu() - oc.grad).abs().max()) <= 1e-5 * float(oc.grad.abs().max())
+        # (3) offset views
+        if (h * w) % 4 != 0:
+            base_o, base_l = out.reshape(-1), lab.reshape(-1)
+            vo, vl = base_o[1:1 + h * w].view(1, 1, h, w), base_l[1:1 + h * w].view(1, 1, h, w)
+            assert vo.data_ptr() % 16 != 0
+            xa = vo.clone().requires_grad_()
+            cbce(xa, vl.clone(), size_average=False).backward()
+            xv = vo.detach().requires_grad_()
+            lv = cbce(xv, vl, size_average=False)
+            lv.backward()
+            l2, g2 = one(vo, vl, size_average=False)
+            assert torch.equal(xv.grad, xa.grad) and torch.equal(g2, xa.grad)

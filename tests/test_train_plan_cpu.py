@@ -214,3 +214,34 @@ def test_train_parent_main_two_ranks_over_epoch_boundaries(tmp_path):
         torch.testing.assert_close(r0["sd"][k], single["sd"][k], rtol=2e-5, atol=1e-7, msg=k)
     init = _cpu_net(seed=1).state_dict()
     assert any(not torch.equal(single["sd"][k], init[k]) for k in single["sd"] if k.startswith("stages."))
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_exact_resume_with_optimizer_state_continues_bit_for_bit(tmp_path, world):
+    """--save-optimizer (round 4): train_parent.main() over 4 epochs of 7 frames with nAveGrad 4 writes, at the end of epoch 1
+    -- 14 iterations in, i.e. in the MIDDLE of an accumulation window, with the statistics of epoch 1 still pending -- the SGD momentum
+    buffers, the open window's counters and gradients (one share per rank) and the pending sums.  A second run resumed from that snapshot
+    (--resume-epoch 2) must end on the SAME BITS as the uninterrupted one, single process and two gloo ranks alike; a reference-style resume
+    (network only: momentum and the open window lost) must not."""
+    sys.path.insert(0, REPO)
+    base = ["--synthetic", "7", "--epochs", "4", "--n-ave-grad", "4", "--height", "24", "--width", "32", "--seed", "7", "--lr", "1e-6", "--snapshot", "1"]
+    port = 33100 + (os.getpid() % 1500) + 10 * world
+    full = str(tmp_path / "full")
+    mp.spawn(_main_worker, args=(world, port, full, base + ["--save-optimizer"]), nprocs=world, join=True)
+    a = [torch.load(full + ".%d" % r) for r in range(world)]
+    for r in range(world):
+        assert os.path.exists(str(tmp_path / ("parent_epoch-1.optim.pth" if r == 0 else "parent_epoch-1.optim.rank%d.pth" % r)))
+    ck = torch.load(str(tmp_path / "parent_epoch-1.optim.pth"), weights_only=False)
+    assert ck["carry"] == 2 and ck["loop"]["ave"] == 2 // world and len(ck["loop"]["grads"]) > 30 and ck["optimizer"]["state"]
+    res = str(tmp_path / "resumed")
+    mp.spawn(_main_worker, args=(world, port + 1, res, base + ["--save-optimizer", "--resume-epoch", "2"]), nprocs=world, join=True)
+    b = [torch.load(res + ".%d" % r) for r in range(world)]
+    assert a[0]["steps"] == 7 and b[0]["steps"] == 7 - 3          # 28 iterations = 7 windows; 3 of them closed before the snapshot
+    for r in range(world):
+        for k in a[0]["sd"]:
+            assert torch.equal(a[r]["sd"][k], b[r]["sd"][k]), (world, r, k)
+    # the reference's resume (no optimizer file read): a different trajectory
+    ref = str(tmp_path / "refstyle")
+    mp.spawn(_main_worker, args=(world, port + 2, ref, base + ["--resume-epoch", "2"]), nprocs=world, join=True)
+    c = torch.load(ref + ".0")
+    assert any(not torch.equal(a[0]["sd"][k], c["sd"][k]) for k in a[0]["sd"] if k.startswith("stages."))

@@ -107,18 +107,26 @@ def main(argv=None, build_net=None, loss_fn=None):
     ap.add_argument('--prefetch', type=int, default=3, help='--device-augment: frames decoded / copied ahead of the training step')
     ap.add_argument('--precision', default=os.environ.get('OSVOS_PRECISION', 'fp32x3'), choices=['fp32', 'fp32x3', 'bf16'])
     ap.add_argument('--lr', type=float, default=1e-8, help='base learning rate of the SGD groups (train_parent.py:83)')
+    ap.add_argument('--snapshot', type=int, default=40, help='store a model every this many epochs (train_parent.py:38)')
+    ap.add_argument('--save-optimizer', action='store_true',
+                    help='next to every parent_epoch-<e>.pth also write parent_epoch-<e>.optim.pth (SGD momentum buffers, the open accumulation '
+                         'window: counters + gradients, pending epoch statistics, augmentation RNG; one .optim.rank<r>.pth per further rank) and, '
+                         'with --resume-epoch, continue from it BIT FOR BIT.  The reference saves the network only and restarts momentum and '
+                         'the window on resume (train_parent.py:59-65,175-176): that remains the behaviour without this flag.')
     args = ap.parse_args(argv)
 
     rank, world, device = init_distributed()
     nEpochs, nAveGrad, resume_epoch = args.epochs, args.n_ave_grad, args.resume_epoch
     local_ave = check_world_divides(nAveGrad, world)      # raises when the world size does not divide nAveGrad
-    snapshot, nTestInterval = 40, 5
+    snapshot, nTestInterval = args.snapshot, 5
     save_dir = Path.save_root_dir()
     os.makedirs(save_dir, exist_ok=True)
     modelName = 'parent'
 
     if build_net is not None:
         net = build_net()
+        if resume_epoch > 0:
+            net.load_state_dict(torch.load(os.path.join(save_dir, modelName + '_epoch-' + str(resume_epoch - 1) + '.pth'), map_location='cpu'))
     elif resume_epoch == 0:
         have_caffe = os.path.exists(os.path.join(Path.models_dir(), 'vgg_caffe.mat'))
         have_pt = os.path.exists(os.path.join(Path.models_dir(), 'vgg_pytorch.pth'))
@@ -154,10 +162,32 @@ def main(argv=None, build_net=None, loss_fn=None):
     # Optimizer steps straddle epoch boundaries (2079 frames, nAveGrad 10), so "the end of an epoch" is NOT a point at which the ranks
     # stand at the same place of their collective sequence: the schedule says after which gradient all-reduce an epoch's statistics
     # may be exchanged, and how many complete step windows the run has (no rank steps on the trailing partial one).
-    sched = StepSchedule(len(trainset), nAveGrad, resume_epoch, nEpochs)
+    def optim_path(e, r):
+        return os.path.join(save_dir, modelName + '_epoch-' + str(e) + ('.optim.pth' if r == 0 else '.optim.rank%d.pth' % r))
+
+    carry, resume_state = 0, None
+    if args.save_optimizer and resume_epoch > 0 and os.path.exists(optim_path(resume_epoch - 1, 0)):
+        # exact resume: optimizer state (identical on every rank: rank 0's file) + this rank's share of the open window
+        common = torch.load(optim_path(resume_epoch - 1, 0), map_location='cpu', weights_only=False)
+        resume_state = common if rank == 0 else torch.load(optim_path(resume_epoch - 1, rank), map_location='cpu', weights_only=False)
+        if common['world'] != world:
+            raise SystemExit("exact resume: %s was written by %d ranks, this run has %d (the open accumulation window is sharded by rank)"
+                             % (optim_path(resume_epoch - 1, 0), common['world'], world))
+        optimizer.load_state_dict(common['optimizer'])
+        carry = int(common['carry'])
+        print("Exact resume from %s: %d iteration(s) of the open window restored" % (optim_path(resume_epoch - 1, 0), carry))
+    sched = StepSchedule(len(trainset), nAveGrad, resume_epoch, nEpochs, carry=carry)
     loop = TrainLoop(net, optimizer, mode='parent', n_ave_grad=nAveGrad, n_epochs=nEpochs, reducer=reducer, local_ave=local_ave,
                      loss_fn=loss_fn, max_steps=sched.total_steps)
     pending, started = [], {}          # epochs whose frames this rank has finished but whose statistics are not exchanged yet
+    if resume_state is not None:
+        loop.load_state_dict(resume_state['loop'])
+        pending = sorted(int(e) for e in resume_state['loop']['counts'])      # epochs finished before the snapshot, statistics still to exchange
+        for e in pending:
+            started[e] = timeit.default_timer()
+        if resume_state.get('py_random') is not None:
+            import random
+            random.setstate(resume_state['py_random'])
 
     def close_epochs(epochs):
         """Exchange + print the statistics of `epochs`: called by every rank right after the same gradient collective (or after the
@@ -165,8 +195,8 @@ def main(argv=None, build_net=None, loss_fn=None):
         for e in epochs:
             pending.remove(e)
             running, count = loop.pop_running(e), loop.pop_count(e)
-            if reducer is not None and reducer.comm is not None:      # OSVOS_DP_BACKEND=abi: the one collective of the C ABI, a float32 sum
-                t = torch.tensor(running + [float(count)], device=device, dtype=torch.float32)
+            if reducer is not None and reducer.comm is not None:      # OSVOS_DP_BACKEND=abi: the C ABI's float64 sum
+                t = torch.tensor(running + [float(count)], device=device, dtype=torch.float64)
                 reducer.comm.all_reduce(t)
             elif reducer is not None:
                 import torch.distributed as dist
@@ -193,8 +223,16 @@ def main(argv=None, build_net=None, loss_fn=None):
             _, stepped = loop.micro_batch(inputs, gts, epoch=epoch)      # forward, 5 losses, /= nAveGrad, backward, step every local_ave
             if stepped:
                 close_epochs(sched.closed_by(loop.steps, pending))      # right after the SAME gradient collective on every rank
-        if (epoch % snapshot) == snapshot - 1 and epoch != 0 and rank == 0:
-            torch.save(net.state_dict(), os.path.join(save_dir, modelName + '_epoch-' + str(epoch) + '.pth'))
+        if (epoch % snapshot) == snapshot - 1 and epoch != 0:
+            if rank == 0:
+                torch.save(net.state_dict(), os.path.join(save_dir, modelName + '_epoch-' + str(epoch) + '.pth'))
+            if args.save_optimizer:
+                import random
+                st = {'loop': loop.state_dict(), 'world': world, 'py_random': random.getstate() if augment is not None else None,
+                      'carry': (sched.carry + (epoch + 1 - resume_epoch) * len(trainset)) % nAveGrad}
+                if rank == 0:
+                    st['optimizer'] = optimizer.state_dict()
+                torch.save(st, optim_path(epoch, rank))
         if testset is not None and epoch % nTestInterval == (nTestInterval - 1):
             from layers.osvos_layers import class_balanced_cross_entropy_loss as cbce
             with torch.no_grad():
