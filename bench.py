@@ -200,7 +200,8 @@ def cpu_baseline(h, w, mode, n_ave, budget_s=20.0):
 class Workload(object):
     """One benchmark configuration: builds the net + synthetic batch, exposes step()."""
 
-    def __init__(self, mode, precision, height, width, batch, graph, n_ave, item_sync, device, rank, dist, force_dist, graph_train=0, comm=None):
+    def __init__(self, mode, precision, height, width, batch, graph, n_ave, item_sync, device, rank, dist, force_dist, graph_train=0, comm=None,
+                 window=0):
         from layers.osvos_layers import class_balanced_cross_entropy_loss as cbce
         from osvos_pytorch_amd.layers.osvos_layers import class_balanced_cross_entropy_loss_step as cbce_step
         from osvos_pytorch_amd.layers.osvos_layers import class_balanced_cross_entropy_loss_step_multi as cbce_step_multi
@@ -214,6 +215,12 @@ class Workload(object):
         self.n_ave = n_ave or (5 if mode == "online" else 10)
         self.item_sync = item_sync
         self.cbce = cbce
+        # window-fused (secondary line): the nAveGrad micro-batches of an optimizer step -- nAveGrad DIFFERENT frames -- as one batch with
+        # per-image class counts (TrainLoop.window_batch): the reference gradient up to summation order, one set of launches per optimizer step
+        self.window = bool(window) and mode != "infer"
+        if self.window:
+            batch = self.batch = self.n_ave * max(1, batch)
+        self.steps_per_opt = 1 if (self.window or mode == "infer") else self.n_ave
         self.net, self.x, self.gt = synth_problem(batch, height, width, device, seed=rank)
         self.net.set_precision(precision)
         self.net.set_inplace_grad_accumulation(True)      # what osvos_pytorch_amd.train_common.TrainLoop (the scripts' loop) does
@@ -225,8 +232,8 @@ class Workload(object):
         self.running = torch.zeros((), device=device)
         self.ave, self.epoch, self.nsteps = 0, 0, 0
         self.keep = {}
-        self.step = self._train_step
-        self.graph_train = bool(graph_train) and mode != "infer"
+        self.step = self._window_step if self.window else self._train_step
+        self.graph_train = bool(graph_train) and mode != "infer" and not self.window
         if self.graph_train:
             self._capture_micro_step()
             self.step = self._train_step_graph
@@ -347,6 +354,30 @@ class Workload(object):
             else:
                 self.opt.zero_grad()
             self.ave = 0
+
+    def _window_step(self):
+        # TrainLoop.window_batch: one forward / loss / backward over the window's frames, then the optimizer step
+        inputs = self.x.detach().requires_grad_()
+        outputs = self.net.forward(inputs)
+        inv = np.float32(1.0) / np.float32(self.n_ave)
+        heads = [outputs[-1]] if self.mode == "online" else list(outputs)
+        scales = [inv] if self.mode == "online" else [np.float32(inv * np.float32(1 - self.epoch / 240))] * 4 + [inv]
+        losses, grads = self.cbce_step_multi(heads, self.gt, size_average=False, grad_scales=[float(sc) for sc in scales],
+                                             running=[None] * (len(heads) - 1) + [self.running], per_image=True)
+        if self.item_sync:
+            losses[-1].item()
+        if self.reducer is not None:
+            self.reducer.arm()
+        torch.autograd.backward(heads, grads)
+        self.nsteps += 1
+        self.net.join_backward()
+        if self.reducer is not None:
+            self.reducer.all_reduce()
+        self.opt.step()
+        if self.reducer is not None:
+            self.reducer.zero_grads()
+        else:
+            self.opt.zero_grad()
 
     def describe(self):
         if self.mode == "infer":
@@ -521,7 +552,7 @@ def measure(wl, steps, warmup, min_seconds, world, ctl, device, use_prof=True, s
     prepare_region(steps, lib if prof else None)      # (host-side preparation of the timed region: before ANY of the steps below)
     settle_done = 0
     if settle_seconds > 0:
-        unit = wl.n_ave if wl.mode != "infer" else 1          # whole optimizer steps
+        unit = wl.steps_per_opt                               # whole optimizer steps
         for _ in range(unit):                                  # (first launches: packs, workspaces, kernel attributes)
             wl.step()
         torch.cuda.synchronize()
@@ -545,7 +576,7 @@ def measure(wl, steps, warmup, min_seconds, world, ctl, device, use_prof=True, s
            "settle_steps": res_settle}
     if min_seconds > 0:
         n2 = max(steps, int(math.ceil(min_seconds / max(elapsed / steps, 1e-6))))
-        n2 = -(-n2 // wl.n_ave) * wl.n_ave if wl.mode != "infer" else n2     # whole optimizer steps
+        n2 = -(-n2 // wl.steps_per_opt) * wl.steps_per_opt     # whole optimizer steps
         e2, _, _ = timed_region(wl, n2, ctl, device, None)
         res["sustained"] = {"seconds": round(e2, 3), "steps": n2, "value": round(n2 * wl.batch * world / e2, 3),
                             "ms_per_step": round(e2 / n2 * 1e3, 4)}
@@ -672,6 +703,9 @@ def main():
                     "all-reduce even with one rank (single-GPU check of the multi-GPU path)")
     ap.add_argument("--settle-seconds", type=float, default=1.0, help="untimed SETUP before the --warmup steps: run the workload this long (whole "
                     "optimizer steps) to bring the device out of its idle power state; the step count is reported as setup_settle_steps")
+    ap.add_argument("--window-fused", type=int, default=0, help="training modes: one step = one whole optimizer-step window -- nAveGrad (x --batch) "
+                    "different frames as ONE batch with per-image class counts (TrainLoop.window_batch): the reference gradient up to summation "
+                    "order.  A labelled secondary line; the headline stays the micro-batch loop")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip extra_configs (configs[2], configs[4]) and the item-sync figure")
@@ -714,10 +748,11 @@ def main():
         world = ctl.world                       # n_gpus of the JSON line = the communicator's size, not an environment variable
         ranks_seen = int(t.item())              # = number of ranks RCCL actually reaches
     wl = Workload(args.mode, args.precision, args.height, args.width, args.batch, args.graph, args.n_ave_grad, args.item_sync,
-                  device, rank, ctl, args.force_dist, graph_train=args.graph_train, comm=comm)
+                  device, rank, ctl, args.force_dist, graph_train=args.graph_train, comm=comm, window=args.window_fused)
     res = measure(wl, args.steps, args.warmup, args.min_seconds, world, ctl, device, use_prof=not args.no_prof, settle_seconds=args.settle_seconds)
     settle = res["settle_steps"]
-    default_workload = (args.mode, args.precision, args.height, args.width, args.batch, args.item_sync) == ("online", "fp32x3", 480, 854, 1, 0)
+    frames_per_step = wl.batch
+    default_workload = (args.mode, args.precision, args.height, args.width, args.batch, args.item_sync, args.window_fused) == ("online", "fp32x3", 480, 854, 1, 0, 0)
     extras, item_line = None, None
     if world == 1 and ctl is None and default_workload and not args.no_extra:
         # the headline loop with the reference's per-iteration loss.item() left in (train_online.py:128)
@@ -737,6 +772,9 @@ def main():
         torch.cuda.synchronize()
         for (name, extra_args) in [
                 ("configs[1] on the EXACT fp32 MFMA kernels (v_mfma_f32_32x32x2_f32): same loop, precision 'fp32'", ["--precision", "fp32"]),
+                ("configs[1] semantics, window-fused: the 5 micro-batches of an optimizer step (5 different frames) as ONE batch-5 pass with per-image "
+                 "class counts -- the reference gradient up to summation order (tests/test_gpu_baseline_configs.py); what TrainLoop.window_batch / "
+                 "train_online.py --window-fused run", ["--window-fused", "1"]),
                 ("configs[2]: 854x480 batch=12 parent training bf16 (MFMA path)", ["--mode", "parent", "--precision", "bf16", "--batch", "12"]),
                 ("configs[4]: 1920x1080 inference-only forward, batch=4, hipGraph-captured (f32x3)",
                  ["--mode", "infer", "--height", "1080", "--width", "1920", "--batch", "4", "--graph", "1"]),
@@ -776,6 +814,9 @@ def main():
                         "frame resident in HBM" % (args.width, args.height, args.batch, args.mode, args.mode,
                                                    "" if args.mode == "online" else "+4 side", n_ave, 8 if args.mode == "online" else 10,
                                                    args.precision))
+            if args.window_fused:
+                workload += ("; WINDOW-FUSED: one step = the %d micro-batches of an optimizer step (%d different frames) as ONE forward / backward "
+                             "with per-image class counts + the SGD step" % (n_ave * args.batch, n_ave * args.batch))
         line = {
             "metric": ("frames/sec (fwd+bwd) OSVOS-VGG16 854x480 per GPU" if (args.height, args.width) == (480, 854) else
                        "frames/sec (fwd+bwd) OSVOS-VGG16 %dx%d" % (args.width, args.height)) if args.mode != "infer" else
@@ -786,7 +827,7 @@ def main():
             "vs_baseline": None, "dtype": DTYPE_NAME[args.precision],
             "data": "synthetic",
             "config": {"workload": workload,
-                       "global_batch": args.batch * world, "parallelism": "dp%d" % world, "rccl_ranks_seen": ranks_seen,
+                       "global_batch": frames_per_step * world, "parallelism": "dp%d" % world, "rccl_ranks_seen": ranks_seen,
                        "gpus_requested": args.gpus,
                        "grad_allreduce": ("per optimizer step (RCCL through %s)" % ("the C ABI, osvos_comm_*" if abi else "torch.distributed")) if ctl is not None else "none",
                        "loss_item_sync_each_iter": bool(args.item_sync),

@@ -53,6 +53,20 @@ def make_mask(n, h, w, seed=0):
     return out
 
 
+def trainable_frame(n, h, w, seed=0):
+    """(frame [n,3,h,w], mask [n,1,h,w]) in which the mask is LEARNABLE from the frame: the ellipse of make_mask carries its own colour
+    and a finer texture on top of a damped low-frequency background -- the stand-in for a DAVIS object when a net has to be TRAINED on
+    synthetic data (tests/trained_fixture.py: the parity fixture with realistic logit margins)."""
+    rng = np.random.default_rng(5000 + seed)
+    m = make_mask(n, h, w, seed)
+    bg = make_frame(n, h, w, seed) * 0.6
+    colour = np.array([55.0, -45.0, 35.0], np.float32).reshape(1, 3, 1, 1) * (0.8 + 0.4 * rng.random((n, 1, 1, 1))).astype(np.float32)
+    yy, xx = np.mgrid[0:h, 0:w]
+    tex = (12.0 * np.sin(yy / 2.5 + seed) * np.cos(xx / 3.5)).astype(np.float32)[None, None]
+    x = bg * (1.0 - 0.5 * m) + m * (colour + tex) + rng.standard_normal((n, 3, h, w)).astype(np.float32) * 4.0
+    return x.astype(np.float32), m
+
+
 def make_weights(seed=1, bias_std=0.0):
     """OrderedDict of float32 arrays in the reference's state_dict order."""
     rng = np.random.default_rng(3000 + seed)

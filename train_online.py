@@ -124,6 +124,9 @@ def main():
                          'the first frame is decoded ONCE and re-augmented on the device every iteration')
     ap.add_argument('--prefetch', type=int, default=3, help='--device-augment: test frames decoded / copied ahead of the forward')
     ap.add_argument('--precision', default=os.environ.get('OSVOS_PRECISION', 'fp32x3'), choices=['fp32', 'fp32x3', 'bf16'])
+    ap.add_argument('--window-fused', action='store_true',
+                    help='run the nAveGrad micro-batches of every optimizer step as ONE batch with per-image class counts (TrainLoop.window_batch): '
+                         'the same gradient up to fp32 summation order, one set of kernel launches per optimizer step instead of nAveGrad')
     args = ap.parse_args()
 
     rank, world, device = init_distributed(collectives=False)      # sequences are sharded over the ranks: nothing is exchanged
@@ -157,12 +160,19 @@ def main():
         num_img_tr = len(trainloader)
         print('Start of Online Training, sequence: ' + seq_name)
         start_time = timeit.default_timer()
+        window = []                      # --window-fused: the micro-batches of the open optimizer-step window
         for epoch in range(0, nEpochs):
             np.random.seed(seed + epoch)
             for ii, sample in enumerate(trainloader):
                 inputs, gts = sample['image'], sample['gt']
-                inputs.requires_grad_()
                 inputs, gts = inputs.to(device), gts.to(device)
+                if args.window_fused:
+                    window.append((inputs, gts))
+                    if len(window) == nAveGrad:
+                        loop.window_batch(torch.cat([w[0] for w in window]).requires_grad_(), torch.cat([w[1] for w in window]))
+                        window = []
+                    continue
+                inputs.requires_grad_()
                 loop.micro_batch(inputs, gts)
             if epoch % max(1, nEpochs // 20) == max(1, nEpochs // 20) - 1:
                 running = loop.pop_running()[0] / (num_img_tr * max(1, nEpochs // 20))
