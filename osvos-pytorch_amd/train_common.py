@@ -206,36 +206,6 @@ class TrainLoop(object):
     def pop_count(self, epoch):
         return self.counts.pop(epoch, 0)
 
-    # ---- exact resume (round 4).  The reference saves the network only (train_parent.py:175-176): a resumed run starts with
-    # zero momentum and drops the micro-batches accumulated in the open window.  With these two an interrupted run continues BIT FOR BIT.
-    def state_dict(self):
-        """Everything of the loop that is not in the network or the optimizer: the position inside the open accumulation window (``ave``),
-        the gradients accumulated in it so far (THIS rank's share), the running loss sums / counts of epochs whose statistics have not been
-        exchanged yet, and the step counter (informational)."""
-        self.finish()
-        grads = {}
-        if self.ave > 0:
-            for name, p in self.net.named_parameters():
-                if p.grad is not None:
-                    grads[name] = p.grad.detach().cpu().clone()
-        running = {int(e): [float(r.item()) for r in rs] for e, rs in self._running.items()}
-        return {'ave': int(self.ave), 'steps': int(self.steps), 'local_ave': int(self.local_ave), 'n_ave_grad': int(self.n_ave_grad),
-                'grads': grads, 'running': running, 'counts': {int(e): int(c) for e, c in self.counts.items()}}
-
-    def load_state_dict(self, sd):
-        if int(sd['local_ave']) != self.local_ave or int(sd['n_ave_grad']) != self.n_ave_grad:
-            raise RuntimeError("TrainLoop.load_state_dict: the checkpoint was written with nAveGrad %d / %d micro-batches per rank and step, this "
-                               "run has %d / %d (an open accumulation window cannot be re-partitioned)"
-                               % (sd['n_ave_grad'], sd['local_ave'], self.n_ave_grad, self.local_ave))
-        self.ave = int(sd['ave'])
-        params = dict(self.net.named_parameters())
-        with torch.no_grad():
-            for name, g in sd['grads'].items():
-                p = params[name]
-                p.grad = g.to(device=p.device, dtype=p.dtype).contiguous()
-        self._running = {int(e): [torch.tensor(v, device=self._dev, dtype=torch.float32) for v in vals] for e, vals in sd['running'].items()}
-        self.counts = {int(e): int(c) for e, c in sd['counts'].items()}
-
 
 class StepSchedule(object):
     """Where the optimizer steps of a run fall in the global micro-batch stream, and with them the only places at which every rank
@@ -248,21 +218,29 @@ class StepSchedule(object):
     gradient collective of the window that holds the epoch's LAST iteration (``closing_step``) -- every rank has finished its share
     of the epoch by then -- and epochs that end in the trailing partial window are exchanged after the last epoch."""
 
-    def __init__(self, n_items, n_ave_grad, first_epoch, n_epochs, carry=0):
-        """``carry``: iterations (summed over all ranks) already accumulated in the open window when the run starts -- 0 for a fresh run and for
-        a reference-style resume (which drops them), ``(first_epoch * n_items) % n_ave_grad`` for an exact resume (TrainLoop.load_state_dict)."""
+    def __init__(self, n_items, n_ave_grad, first_epoch, n_epochs, start_iteration=None):
+        """``start_iteration``: global index g of the first iteration of THIS run (default: ``first_epoch * n_items``, also what a
+        reference-style resume does).  An exact resume (train_parent.py --save-optimizer) starts at the iteration after the optimizer step at
+        which its checkpoint was taken -- in general somewhere inside an epoch -- so that the windows of the resumed run are the windows of the
+        uninterrupted one."""
         self.n_items, self.n_ave_grad = int(n_items), int(n_ave_grad)
         self.first_epoch, self.n_epochs = int(first_epoch), int(n_epochs)
-        self.carry = int(carry)
-        self.total_iterations = max(0, self.n_epochs - self.first_epoch) * self.n_items
-        self.total_steps = (self.carry + self.total_iterations) // self.n_ave_grad          # complete windows: what EVERY rank steps, no more
+        self.start = int(start_iteration) if start_iteration is not None else self.first_epoch * self.n_items
+        self.total_iterations = max(0, self.n_epochs * self.n_items - self.start)
+        self.total_steps = self.total_iterations // self.n_ave_grad          # complete windows: what EVERY rank steps, no more
 
     def closing_step(self, epoch):
-        """Index of the optimizer step whose window holds the last iteration of `epoch`; None when that is the trailing partial
-        window (no step, no gradient collective: such epochs are closed after the training loop)."""
-        last = self.carry + (epoch + 1 - self.first_epoch) * self.n_items - 1
+        """Index (within this run) of the optimizer step whose window holds the last iteration of `epoch`; None when that is the trailing
+        partial window (no step, no gradient collective: such epochs are closed after the training loop)."""
+        last = (epoch + 1) * self.n_items - 1 - self.start
+        if last < 0:
+            return None
         k = last // self.n_ave_grad
         return k if k < self.total_steps else None
+
+    def next_iteration(self, steps_done):
+        """global index of the first iteration after `steps_done` optimizer steps of this run"""
+        return self.start + int(steps_done) * self.n_ave_grad
 
     def closed_by(self, steps_done, pending):
         """The epochs of `pending` (ascending) whose statistics may be exchanged once `steps_done` optimizer steps are complete."""

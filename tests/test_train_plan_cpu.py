@@ -190,7 +190,8 @@ def _main_worker(rank, world, port, out, argv):
     import train_parent
     from oracle import torch_ref
     net, loop = train_parent.main(argv, build_net=lambda: _cpu_net(seed=1), loss_fn=torch_ref.cbce_loss)
-    torch.save({"steps": loop.steps, "sd": {k: v.detach().clone() for k, v in net.state_dict().items()}}, out + ".%d" % rank)
+    torch.save({"steps": loop.steps, "sd": {k: v.detach().clone() for k, v in net.state_dict().items()}, "validation": dict(loop.validation)},
+               out + ".%d" % rank)
     if dist.is_initialized():
         dist.destroy_process_group()
 
@@ -201,7 +202,8 @@ def test_train_parent_main_two_ranks_over_epoch_boundaries(tmp_path):
     come back (round 2: the per-epoch statistics all-reduce paired with the other rank's gradient all-reduce), take the same number
     of steps, hold identical weights, and match the single-process run of the same script."""
     sys.path.insert(0, REPO)
-    argv = ["--synthetic", "7", "--epochs", "3", "--n-ave-grad", "4", "--height", "24", "--width", "32", "--seed", "7", "--lr", "1e-6"]
+    argv = ["--synthetic", "7", "--epochs", "3", "--n-ave-grad", "4", "--height", "24", "--width", "32", "--seed", "7", "--lr", "1e-6",
+            "--test-interval", "1"]       # validation after EVERY epoch: sharded over the ranks, its sums exchanged at the next closing step
     out = str(tmp_path / "main")
     port = 31700 + (os.getpid() % 2000)
     mp.spawn(_main_worker, args=(2, port, out, argv), nprocs=2, join=True)
@@ -214,29 +216,38 @@ def test_train_parent_main_two_ranks_over_epoch_boundaries(tmp_path):
         torch.testing.assert_close(r0["sd"][k], single["sd"][k], rtol=2e-5, atol=1e-7, msg=k)
     init = _cpu_net(seed=1).state_dict()
     assert any(not torch.equal(single["sd"][k], init[k]) for k in single["sd"] if k.startswith("stages."))
+    # the sharded validation pass: every epoch reported once, over the whole validation set, the same numbers on both ranks and (weights
+    # agree to 2e-5) the single process's numbers
+    assert sorted(r0["validation"]) == sorted(r1["validation"]) == sorted(single["validation"]) == [0, 1, 2]
+    for e in range(3):
+        assert r0["validation"][e][1] == single["validation"][e][1] == 2
+        np.testing.assert_allclose(r0["validation"][e][0], r1["validation"][e][0], rtol=0, atol=0)
+        np.testing.assert_allclose(r0["validation"][e][0], single["validation"][e][0], rtol=1e-3)
 
 
 @pytest.mark.parametrize("world", [1, 2])
 def test_exact_resume_with_optimizer_state_continues_bit_for_bit(tmp_path, world):
-    """--save-optimizer (round 4): train_parent.main() over 4 epochs of 7 frames with nAveGrad 4 writes, at the end of epoch 1
-    -- 14 iterations in, i.e. in the MIDDLE of an accumulation window, with the statistics of epoch 1 still pending -- the SGD momentum
-    buffers, the open window's counters and gradients (one share per rank) and the pending sums.  A second run resumed from that snapshot
-    (--resume-epoch 2) must end on the SAME BITS as the uninterrupted one, single process and two gloo ranks alike; a reference-style resume
-    (network only: momentum and the open window lost) must not."""
+    """--save-optimizer (round 4): train_parent.main() over 4 epochs of 7 frames with nAveGrad 4 writes, right after the optimizer
+    step that closes epoch 1 -- the window {12..15} straddles the boundary between epochs 1 and 2 -- the network, the SGD momentum buffers and the
+    position in the global iteration stream (16: two iterations into epoch 2).  A second run resumed from that bundle (--resume-epoch 2) must
+    end on the SAME BITS as the uninterrupted one -- single process, two gloo ranks, and a bundle written by ONE process resumed on TWO ranks
+    (equal up to the all-reduce's summation order); a reference-style resume (network only: momentum and the open window lost) must not."""
     sys.path.insert(0, REPO)
     base = ["--synthetic", "7", "--epochs", "4", "--n-ave-grad", "4", "--height", "24", "--width", "32", "--seed", "7", "--lr", "1e-6", "--snapshot", "1"]
     port = 33100 + (os.getpid() % 1500) + 10 * world
     full = str(tmp_path / "full")
     mp.spawn(_main_worker, args=(world, port, full, base + ["--save-optimizer"]), nprocs=world, join=True)
     a = [torch.load(full + ".%d" % r) for r in range(world)]
-    for r in range(world):
-        assert os.path.exists(str(tmp_path / ("parent_epoch-1.optim.pth" if r == 0 else "parent_epoch-1.optim.rank%d.pth" % r)))
     ck = torch.load(str(tmp_path / "parent_epoch-1.optim.pth"), weights_only=False)
-    assert ck["carry"] == 2 and ck["loop"]["ave"] == 2 // world and len(ck["loop"]["grads"]) > 30 and ck["optimizer"]["state"]
+    assert ck["next_iteration"] == 16 and ck["world"] == world and ck["optimizer"]["state"] and len(ck["net"]) == 52
+    assert sorted(ck["partial_stats"]) == [2] and ck["partial_stats"][2][1] == 2          # iterations 14, 15 of epoch 2 already ran
+    import shutil
+    keep = str(tmp_path / "bundle_epoch1.pth")
+    shutil.copy(str(tmp_path / "parent_epoch-1.optim.pth"), keep)
     res = str(tmp_path / "resumed")
     mp.spawn(_main_worker, args=(world, port + 1, res, base + ["--save-optimizer", "--resume-epoch", "2"]), nprocs=world, join=True)
     b = [torch.load(res + ".%d" % r) for r in range(world)]
-    assert a[0]["steps"] == 7 and b[0]["steps"] == 7 - 3          # 28 iterations = 7 windows; 3 of them closed before the snapshot
+    assert a[0]["steps"] == 7 and b[0]["steps"] == 7 - 4          # 28 iterations = 7 windows; 4 of them closed before the bundle
     for r in range(world):
         for k in a[0]["sd"]:
             assert torch.equal(a[r]["sd"][k], b[r]["sd"][k]), (world, r, k)
@@ -245,3 +256,11 @@ def test_exact_resume_with_optimizer_state_continues_bit_for_bit(tmp_path, world
     mp.spawn(_main_worker, args=(world, port + 2, ref, base + ["--resume-epoch", "2"]), nprocs=world, join=True)
     c = torch.load(ref + ".0")
     assert any(not torch.equal(a[0]["sd"][k], c["sd"][k]) for k in a[0]["sd"] if k.startswith("stages."))
+    if world == 1:      # a single-process bundle continues on two ranks: same windows, same frames, the gradient sum in another order
+        shutil.copy(keep, str(tmp_path / "parent_epoch-1.optim.pth"))
+        two = str(tmp_path / "resumed_on_two")
+        mp.spawn(_main_worker, args=(2, port + 3, two, base + ["--save-optimizer", "--resume-epoch", "2"]), nprocs=2, join=True)
+        d = torch.load(two + ".0")
+        assert d["steps"] == 3
+        for k in a[0]["sd"]:
+            torch.testing.assert_close(d["sd"][k], a[0]["sd"][k], rtol=2e-5, atol=1e-7, msg=k)

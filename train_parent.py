@@ -79,7 +79,11 @@ def epoch_samples(args, trainset, plan, device, augment):
     if augment is not None:
         # decode on the host -> pinned uint8 -> GPU (copy stream, a few frames ahead) -> one HIP kernel: mean / flip / warp / CHW
         from osvos_pytorch_amd.davis_io import DevicePrefetcher
-        for _, img, lab in DevicePrefetcher(trainset, indices, device, depth=args.prefetch):
+        import random
+        for (_, img, lab), (_, g) in zip(DevicePrefetcher(trainset, indices, device, depth=args.prefetch), plan):
+            # the augmentation draws of a frame are a function of (seed, global iteration): the same whatever the number of ranks, and a
+            # resumed run draws what the uninterrupted one would have
+            random.seed(args.seed * 1000003 + g)
             s = augment(img, lab)
             yield {'image': s['image'][None], 'gt': s['gt'][None]}
     elif isinstance(trainset, list):
@@ -108,17 +112,19 @@ def main(argv=None, build_net=None, loss_fn=None):
     ap.add_argument('--precision', default=os.environ.get('OSVOS_PRECISION', 'fp32x3'), choices=['fp32', 'fp32x3', 'bf16'])
     ap.add_argument('--lr', type=float, default=1e-8, help='base learning rate of the SGD groups (train_parent.py:83)')
     ap.add_argument('--snapshot', type=int, default=40, help='store a model every this many epochs (train_parent.py:38)')
+    ap.add_argument('--test-interval', type=int, default=5, help='run the validation pass every this many epochs (train_parent.py:39)')
     ap.add_argument('--save-optimizer', action='store_true',
-                    help='next to every parent_epoch-<e>.pth also write parent_epoch-<e>.optim.pth (SGD momentum buffers, the open accumulation '
-                         'window: counters + gradients, pending epoch statistics, augmentation RNG; one .optim.rank<r>.pth per further rank) and, '
-                         'with --resume-epoch, continue from it BIT FOR BIT.  The reference saves the network only and restarts momentum and '
-                         'the window on resume (train_parent.py:59-65,175-176): that remains the behaviour without this flag.')
+                    help='for every snapshot epoch also write parent_epoch-<e>.optim.pth: network, SGD momentum buffers and the position in the '
+                         'global iteration stream, taken right after the optimizer step that closes the epoch (the one point at which all ranks '
+                         'hold the same weights and no gradient is half accumulated); with --resume-epoch e+1 the run continues from it BIT FOR '
+                         'BIT, on any number of ranks that divides nAveGrad.  The reference saves the network only and restarts momentum and '
+                         'the accumulation window on resume (train_parent.py:59-65,175-176): that remains the behaviour without this flag.')
     args = ap.parse_args(argv)
 
     rank, world, device = init_distributed()
     nEpochs, nAveGrad, resume_epoch = args.epochs, args.n_ave_grad, args.resume_epoch
     local_ave = check_world_divides(nAveGrad, world)      # raises when the world size does not divide nAveGrad
-    snapshot, nTestInterval = args.snapshot, 5
+    snapshot, nTestInterval = args.snapshot, args.test_interval
     save_dir = Path.save_root_dir()
     os.makedirs(save_dir, exist_ok=True)
     modelName = 'parent'
@@ -150,7 +156,6 @@ def main(argv=None, build_net=None, loss_fn=None):
         import random
         from osvos_pytorch_amd.augment import DeviceAugment
         from osvos_pytorch_amd.davis_io import DavisFrames
-        random.seed(args.seed * 7919 + rank)                 # augmentation draws: independent per rank, reproducible
         augment = DeviceAugment(rots=(-30, 30), scales=(.75, 1.25))
         trainset = synthetic_raw_frames(args.synthetic, args.height, args.width) if args.synthetic else DavisFrames(True, Path.db_root_dir())
         testset = synthetic_dataset(2, args.height, args.width) if args.synthetic else None
@@ -162,60 +167,110 @@ def main(argv=None, build_net=None, loss_fn=None):
     # Optimizer steps straddle epoch boundaries (2079 frames, nAveGrad 10), so "the end of an epoch" is NOT a point at which the ranks
     # stand at the same place of their collective sequence: the schedule says after which gradient all-reduce an epoch's statistics
     # may be exchanged, and how many complete step windows the run has (no rank steps on the trailing partial one).
-    def optim_path(e, r):
-        return os.path.join(save_dir, modelName + '_epoch-' + str(e) + ('.optim.pth' if r == 0 else '.optim.rank%d.pth' % r))
+    def optim_path(e):
+        return os.path.join(save_dir, modelName + '_epoch-' + str(e) + '.optim.pth')
 
-    carry, resume_state = 0, None
-    if args.save_optimizer and resume_epoch > 0 and os.path.exists(optim_path(resume_epoch - 1, 0)):
-        # exact resume: optimizer state (identical on every rank: rank 0's file) + this rank's share of the open window
-        common = torch.load(optim_path(resume_epoch - 1, 0), map_location='cpu', weights_only=False)
-        resume_state = common if rank == 0 else torch.load(optim_path(resume_epoch - 1, rank), map_location='cpu', weights_only=False)
-        if common['world'] != world:
-            raise SystemExit("exact resume: %s was written by %d ranks, this run has %d (the open accumulation window is sharded by rank)"
-                             % (optim_path(resume_epoch - 1, 0), common['world'], world))
-        optimizer.load_state_dict(common['optimizer'])
-        carry = int(common['carry'])
-        print("Exact resume from %s: %d iteration(s) of the open window restored" % (optim_path(resume_epoch - 1, 0), carry))
-    sched = StepSchedule(len(trainset), nAveGrad, resume_epoch, nEpochs, carry=carry)
+    # exact resume: the bundle holds network + optimizer + the global iteration the run continues at
+    start_iteration, bundle = None, None
+    if args.save_optimizer and resume_epoch > 0 and os.path.exists(optim_path(resume_epoch - 1)):
+        bundle = torch.load(optim_path(resume_epoch - 1), map_location='cpu', weights_only=False)
+        if int(bundle['n_ave_grad']) != nAveGrad or int(bundle['n_items']) != len(trainset):
+            raise SystemExit("exact resume: %s was written with nAveGrad %d over %d frames, this run has %d / %d"
+                             % (optim_path(resume_epoch - 1), bundle['n_ave_grad'], bundle['n_items'], nAveGrad, len(trainset)))
+        net.load_state_dict(bundle['net'])
+        if hasattr(net, 'invalidate_packed_weights'):
+            net.invalidate_packed_weights()
+        optimizer.load_state_dict(bundle['optimizer'])
+        start_iteration = int(bundle['next_iteration'])
+        print("Exact resume from %s: continuing at global iteration %d (epoch %d, position %d)"
+              % (optim_path(resume_epoch - 1), start_iteration, start_iteration // len(trainset), start_iteration % len(trainset)))
+    first_epoch = resume_epoch if start_iteration is None else start_iteration // len(trainset)
+    sched = StepSchedule(len(trainset), nAveGrad, first_epoch, nEpochs, start_iteration=start_iteration)
     loop = TrainLoop(net, optimizer, mode='parent', n_ave_grad=nAveGrad, n_epochs=nEpochs, reducer=reducer, local_ave=local_ave,
                      loss_fn=loss_fn, max_steps=sched.total_steps)
     pending, started = [], {}          # epochs whose frames this rank has finished but whose statistics are not exchanged yet
-    if resume_state is not None:
-        loop.load_state_dict(resume_state['loop'])
-        pending = sorted(int(e) for e in resume_state['loop']['counts'])      # epochs finished before the snapshot, statistics still to exchange
-        for e in pending:
-            started[e] = timeit.default_timer()
-        if resume_state.get('py_random') is not None:
-            import random
-            random.setstate(resume_state['py_random'])
+    loop.validation = {}               # epoch -> ([5 loss sums over the whole validation set], frames), filled as the sums are exchanged
+    if bundle is not None and rank == 0:
+        # statistics of the iterations the window of the checkpoint had already taken from later epochs (summed over the ranks when saved)
+        for e, (vals, cnt) in bundle['partial_stats'].items():
+            loop._running[int(e)] = [torch.tensor(v, device=device, dtype=torch.float32) for v in vals]
+            loop.counts[int(e)] = int(cnt)
+
+    def reduce_sums(values):
+        """sum over the ranks of a list of floats (float64: counts and loss sums stay exact) -- one small collective"""
+        if reducer is None:
+            return values
+        t = torch.tensor(values, device=device, dtype=torch.float64)
+        if reducer.comm is not None:       # OSVOS_DP_BACKEND=abi: osvos_comm_allreduce_f64
+            reducer.comm.all_reduce(t)
+        else:
+            import torch.distributed as dist
+            dist.all_reduce(t)
+        return t.tolist()
+
+    def validate(e):
+        """The validation pass of epoch e (train_parent.py:179-205), SHARDED over the ranks (frames r, r + W, ...) and run where close_epochs
+        runs: right after the optimizer step that closes the window holding the epoch's last iteration -- the one place near the end of an
+        epoch where every rank holds the SAME weights and stands at the same point of its collective sequence (at the end of its own share
+        of the epoch a rank may already have taken the next step, or not yet the last one: with 2079 frames and nAveGrad 10 a window
+        straddles every epoch boundary).  Up to nAveGrad - 1 iterations later than the reference's; single-process runs use the same rule."""
+        cbce = loss_fn
+        if cbce is None:
+            from layers.osvos_layers import class_balanced_cross_entropy_loss as cbce
+        with torch.no_grad():
+            tot, n = [0.0] * 5, 0
+            for k in range(rank, len(testset), world):
+                sample = testset[k]
+                outputs = net.forward(sample['image'].to(device))
+                for i, o in enumerate(outputs):
+                    tot[i] += float(cbce(o, sample['gt'].to(device), size_average=False).item())
+                n += 1
+        flat = reduce_sums(tot + [float(n)])
+        tot, n = flat[:5], int(round(flat[5]))
+        loop.validation[e] = (tot, n)
+        if rank == 0:
+            for l, x in enumerate(tot):
+                print('***Testing (epoch %d, %d frames) *** Loss %d: %f' % (e, n, l, x / max(1, n)))
 
     def close_epochs(epochs):
-        """Exchange + print the statistics of `epochs`: called by every rank right after the same gradient collective (or after the
-        last epoch), so the small all-reduce below can never pair with another rank's gradient all-reduce."""
+        """Exchange + print the statistics of `epochs` and run their validation passes: called by every rank right after the same gradient
+        collective (or after the last epoch), so the small all-reduces here can never pair with another rank's gradient all-reduce."""
         for e in epochs:
             pending.remove(e)
             running, count = loop.pop_running(e), loop.pop_count(e)
-            if reducer is not None and reducer.comm is not None:      # OSVOS_DP_BACKEND=abi: the C ABI's float64 sum
-                t = torch.tensor(running + [float(count)], device=device, dtype=torch.float64)
-                reducer.comm.all_reduce(t)
-            elif reducer is not None:
-                import torch.distributed as dist
-                t = torch.tensor(running + [float(count)], device=device, dtype=torch.float64)
-                dist.all_reduce(t)
-            if reducer is not None:
-                running, count = t[:-1].tolist(), int(round(float(t[-1].item())))
+            flat = reduce_sums(running + [float(count)])
+            running, count = flat[:-1], int(round(flat[-1]))
             if rank == 0:
                 print('[Epoch: %d, numImages: %5d]' % (e, count))
                 for l, v in enumerate(running):
                     print('Loss %d: %f' % (l, v / max(1, count)))
                 print("Execution time: " + str(timeit.default_timer() - started[e]))
+            if testset is not None and e % nTestInterval == (nTestInterval - 1):
+                validate(e)
+            if args.save_optimizer and (e % snapshot) == snapshot - 1 and e != 0:
+                save_bundle(e)
+
+    def save_bundle(e):
+        """network + optimizer + position, right after the optimizer step that closes epoch e (or after the last iteration of the run): every
+        rank holds the same weights, no gradient is half accumulated (TrainLoop.ave == 0 unless the run ended in a partial window, whose
+        gradients are dropped like the reference's), the ranks stand at the same point of their collective sequences."""
+        later = sorted(x for x in loop.counts if x > e)
+        flat = []
+        for x in later:          # what the closing window already took from later epochs: summed over the ranks so that rank 0 can carry it
+            flat += [float(r.item()) for r in loop._running[x]] + [float(loop.counts[x])]
+        flat = reduce_sums(flat) if flat else flat
+        if rank == 0:
+            partial = {x: (flat[6 * i:6 * i + 5], int(round(flat[6 * i + 5]))) for i, x in enumerate(later)}
+            torch.save({'net': {k: v.detach().cpu() for k, v in net.state_dict().items()}, 'optimizer': optimizer.state_dict(),
+                        'next_iteration': sched.next_iteration(loop.steps), 'n_ave_grad': nAveGrad, 'n_items': len(trainset),
+                        'partial_stats': partial, 'world': world}, optim_path(e))
 
     print("Training Network")
-    for epoch in range(resume_epoch, nEpochs):
+    for epoch in range(first_epoch, nEpochs):
         started[epoch] = timeit.default_timer()
         pending.append(epoch)          # (before its first frame: the window that closes the PREVIOUS epoch may end inside this one)
         # one permutation per epoch, the same on every rank; rank r runs the iterations g = r (mod world) of the global stream
-        plan = epoch_plan(len(trainset), epoch, nAveGrad, rank, world, seed=args.seed)
+        plan = [(idx, g) for idx, g in epoch_plan(len(trainset), epoch, nAveGrad, rank, world, seed=args.seed) if g >= sched.start]
         for sample in epoch_samples(args, trainset, plan, device, augment):
             inputs, gts = sample['image'], sample['gt']
             inputs.requires_grad_()                         # train_parent.py:136: the input gradient is computed
@@ -223,27 +278,8 @@ def main(argv=None, build_net=None, loss_fn=None):
             _, stepped = loop.micro_batch(inputs, gts, epoch=epoch)      # forward, 5 losses, /= nAveGrad, backward, step every local_ave
             if stepped:
                 close_epochs(sched.closed_by(loop.steps, pending))      # right after the SAME gradient collective on every rank
-        if (epoch % snapshot) == snapshot - 1 and epoch != 0:
-            if rank == 0:
-                torch.save(net.state_dict(), os.path.join(save_dir, modelName + '_epoch-' + str(epoch) + '.pth'))
-            if args.save_optimizer:
-                import random
-                st = {'loop': loop.state_dict(), 'world': world, 'py_random': random.getstate() if augment is not None else None,
-                      'carry': (sched.carry + (epoch + 1 - resume_epoch) * len(trainset)) % nAveGrad}
-                if rank == 0:
-                    st['optimizer'] = optimizer.state_dict()
-                torch.save(st, optim_path(epoch, rank))
-        if testset is not None and epoch % nTestInterval == (nTestInterval - 1):
-            from layers.osvos_layers import class_balanced_cross_entropy_loss as cbce
-            with torch.no_grad():
-                tot = [0.0] * 5
-                for sample in testset:
-                    outputs = net.forward(sample['image'].to(device))
-                    for i, o in enumerate(outputs):
-                        tot[i] += cbce(o, sample['gt'].to(device), size_average=False).item()
-                if rank == 0:
-                    for l, v in enumerate(tot):
-                        print('***Testing *** Loss %d: %f' % (l, v / max(1, len(testset))))
+        if (epoch % snapshot) == snapshot - 1 and epoch != 0 and rank == 0:
+            torch.save(net.state_dict(), os.path.join(save_dir, modelName + '_epoch-' + str(epoch) + '.pth'))      # (the reference's snapshot)
     close_epochs(list(pending))        # epochs that end in the trailing partial window: every rank has left the loop, same order everywhere
     if rank == 0:
         print("optimizer steps taken: %d" % loop.steps)
