@@ -418,17 +418,25 @@ def pipe_sustained_tflops(device):
     return out
 
 
-def load_traffic():
-    """HBM-side bytes per launch of the dominant kernel from the rocprofv3 --pmc passes (FETCH_SIZE x 2 on gfx950 +
-    WRITE_SIZE, MI355X_MICROARCH.md section HBM), as written by tools/pmc_traffic.py into profiles/ together with the
-    commit it was measured at.  None when that file is absent -- bench.py itself cannot read PMC counters."""
-    name = next((n for n in ("r03_pmc_traffic.json", "r02_pmc_traffic.json") if os.path.exists(os.path.join(REPO, "profiles", n))), "r03_pmc_traffic.json")
+def load_traffic(wl):
+    """HBM-side bytes per STEP of the step's kernels from rocprofv3 --pmc passes over bench.py itself (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE,
+    MI355X_MICROARCH.md section HBM), as written by tools/pmc_step_traffic.py (tools/gpu_pmc_step.sh) into profiles/ together with the commit it
+    was measured at: one file per workload of BASELINE.json.  None when the workload has no file -- bench.py itself cannot read PMC counters."""
+    key = None
+    if (wl.mode, wl.precision, wl.h, wl.w, wl.batch, wl.window) == ("online", "fp32x3", 480, 854, 1, False):
+        key = "configs1"
+    elif (wl.mode, wl.precision, wl.h, wl.w, wl.batch, wl.window) == ("parent", "bf16", 480, 854, 12, False):
+        key = "configs2"
+    if key is None:
+        return None
+    name = "r04_pmc_traffic_%s.json" % key
     path = os.path.join(REPO, "profiles", name)
     try:
         with open(path) as f:
             t = json.load(f)
         t["source"] = "profiles/" + name
-        t["static"] = True      # rocprofv3 PMC passes cannot run inside this process: measured by tools/pmc_traffic.py at the commit named in the file
+        t["static"] = True      # rocprofv3 PMC passes cannot run inside this process: measured by tools/gpu_pmc_step.sh at the commit named in the file
+        t["per_kernel"] = dict(list(t.get("per_kernel", {}).items())[:8])      # (the line carries the eight largest; the file has them all)
         return t
     except Exception:
         return None
@@ -639,7 +647,7 @@ def measure(wl, steps, warmup, min_seconds, world, ctl, device, use_prof=True, s
                 "families": {"conv_fwd": {"ms_per_step": round(ms[0] / n_prof, 3), "tflops": round(mult_f * fl[0] / (ms[0] * 1e-3) / 1e12, 2) if ms[0] else None},
                              "conv_bwd_dgrad+wgrad": {"ms_per_step": round(ms[1] / n_prof, 3), "tflops": round(mult_b * fl[1] / (ms[1] * 1e-3) / 1e12, 2) if ms[1] else None}},
                 "step_conv_fraction_of_mfma_roofline": step_frac,
-                "traffic": load_traffic() if wl.precision == "fp32x3" else None}
+                "traffic": load_traffic(wl)}
         roof.update(x3_extra(ach / m_all, m_all))
     if roof is not None and wl.precision != "fp32" and torch.cuda.is_available():
         # next to the spec peak: the rate the pipe sustains on this chip, measured now (see pipe_sustained_tflops)
@@ -753,7 +761,7 @@ def main():
     settle = res["settle_steps"]
     frames_per_step = wl.batch
     default_workload = (args.mode, args.precision, args.height, args.width, args.batch, args.item_sync, args.window_fused) == ("online", "fp32x3", 480, 854, 1, 0, 0)
-    extras, item_line = None, None
+    extras, item_line, no_settle = None, None, None
     if world == 1 and ctl is None and default_workload and not args.no_extra:
         # the headline loop with the reference's per-iteration loss.item() left in (train_online.py:128)
         wl.item_sync = 1
@@ -794,6 +802,21 @@ def main():
                                "sustained": d.get("sustained"), "roofline": d.get("roofline")})
             except Exception as e:  # the headline must still be reported
                 extras.append({"config": name, "error": repr(e)})
+        # the headline command once more WITHOUT the settle phase, in its own process: what the ramp out of the idle power state costs a
+        # run that times its first steps (keep that cost visible)
+        no_settle = None
+        try:
+            cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup), "--min-seconds", "0",
+                   "--settle-seconds", "0", "--no-extra", "--no-cpu-baseline", "--no-prof"]
+            env = dict(os.environ)
+            for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+                env.pop(k, None)
+            out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+            d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+            no_settle = {"value": d["value"], "ms_per_step": d["ms_per_step"], "unit": d["unit"], "setup_settle_steps": d.get("setup_settle_steps"),
+                         "note": "same command with --settle-seconds 0 in a fresh process: warm-up and timed steps start on an idle device"}
+        except Exception as e:
+            no_settle = {"error": repr(e)}
         wl = None
     else:
         running_loss = float(wl.running.item()) / max(1, wl.nsteps) if wl.nsteps else 0.0
@@ -823,6 +846,7 @@ def main():
                       "frames/sec (forward only) OSVOS-VGG16 %dx%d" % (args.width, args.height),
             "value": round(res["value"], 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "setup_settle_steps": settle,      # untimed SETUP steps before the warm-up (device out of its idle power state; --settle-seconds)
+            "value_without_settle": no_settle,
             "ms_per_step": round(res["ms_per_step"], 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": DTYPE_NAME[args.precision],
             "data": "synthetic",

@@ -65,9 +65,8 @@ class AbiCommunicator:
         self._C, self._check, self._lib = C, check, lib()
         self.rank, self.world, self.device = rank, world, torch.device(device)
         ident = (C.c_char * 128)()
-        if rank == 0:
-            check(self._lib.osvos_comm_unique_id(ident), "comm_unique_id")
-        if world > 1:
+        store = None
+        if world > 1:      # the rendezvous first: a taken port is reported before RCCL or the device are touched
             port = comm_port()
             try:
                 store = dist.TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), port, world, rank == 0, timeout=_store_timeout())
@@ -75,6 +74,9 @@ class AbiCommunicator:
                 raise RuntimeError("osvos communicator: cannot %s the id store at %s:%d (%s).  Another job on this node probably uses the port: "
                                    "give every job its own OSVOS_COMM_PORT (default MASTER_PORT + 1)."
                                    % ("open" if rank == 0 else "reach", os.environ.get("MASTER_ADDR", "127.0.0.1"), port, e)) from e
+        if rank == 0:
+            check(self._lib.osvos_comm_unique_id(ident), "comm_unique_id")
+        if store is not None:
             if rank == 0:
                 store.set("osvos_comm_id", bytes(ident.raw))
             else:

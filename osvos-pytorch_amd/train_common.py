@@ -308,8 +308,11 @@ def init_distributed(collectives=True):
         device = torch.device('cuda', local)
     else:
         device = torch.device('cpu')
-    if world > 1 and collectives:
+    force = os.environ.get('OSVOS_DP_FORCE', '0') == '1'      # one rank, communicator and gradient all-reduce anyway: single-GPU run of the DP path
+    if (world > 1 or (force and device.type == 'cuda')) and collectives:
         import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         if device.type != 'cuda':
             dist.init_process_group('gloo')
@@ -317,7 +320,7 @@ def init_distributed(collectives=True):
             from .parallel import AbiCommunicator
             _ABI_COMM = AbiCommunicator(rank, world, device)
         else:
-            dist.init_process_group('nccl', device_id=device)
+            dist.init_process_group('nccl', device_id=device, rank=rank, world_size=world)
             dist.barrier()          # (first collective: RCCL's own lazy initialisation happens now, not inside the first optimizer step)
     return rank, world, device
 
@@ -326,7 +329,8 @@ def make_reducer(net, world, average=False):
     """The gradient exchange of the data-parallel loop: torch.distributed ('nccl' = RCCL) by default, RCCL through the library's own C ABI
     with OSVOS_DP_BACKEND=abi (osvos_comm_*: no process group at all; the chunked overlap is cheap there).  Either communicator was brought up by
     init_distributed, before the network existed."""
-    if world <= 1:
+    force = os.environ.get('OSVOS_DP_FORCE', '0') == '1' and next(net.parameters()).is_cuda
+    if world <= 1 and not force:
         return None
     comm = _ABI_COMM          # OSVOS_DP_BACKEND=abi: created by init_distributed before anything touched the device
-    return GradientAllReducer(net, average=average, comm=comm)
+    return GradientAllReducer(net, average=average, comm=comm, always=force)

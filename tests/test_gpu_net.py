@@ -100,17 +100,8 @@ def test_sgd_trajectory_matches_reference_golden():
     from layers.osvos_layers import class_balanced_cross_entropy_loss as cbce
     g, wts, x, m = load_case("c48x64")
     net = build_net(wts)
-    lr, wd = 1e-8, 0.0002
-    opt = torch.optim.SGD([
-        {'params': [pr[1] for pr in net.stages.named_parameters() if 'weight' in pr[0]], 'weight_decay': wd},
-        {'params': [pr[1] for pr in net.stages.named_parameters() if 'bias' in pr[0]], 'lr': lr * 2},
-        {'params': [pr[1] for pr in net.side_prep.named_parameters() if 'weight' in pr[0]], 'weight_decay': wd},
-        {'params': [pr[1] for pr in net.side_prep.named_parameters() if 'bias' in pr[0]], 'lr': lr * 2},
-        {'params': [pr[1] for pr in net.upscale.named_parameters() if 'weight' in pr[0]], 'lr': 0},
-        {'params': [pr[1] for pr in net.upscale_.named_parameters() if 'weight' in pr[0]], 'lr': 0},
-        {'params': net.fuse.weight, 'lr': lr / 100, 'weight_decay': wd},
-        {'params': net.fuse.bias, 'lr': 2 * lr / 100},
-    ], lr=lr, momentum=0.9)
+    from osvos_pytorch_amd.train_common import make_sgd
+    opt = make_sgd(net, "online", lr=1e-8, fused=False)      # the scripts' own parameter-group table on torch.optim.SGD (FusedSGD: test_gpu_ops)
     w0 = {k: v.detach().clone() for k, v in net.state_dict().items()}
     losses = []
     xd, gt = torch.from_numpy(x).cuda(), torch.from_numpy(m).cuda()

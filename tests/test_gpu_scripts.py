@@ -28,7 +28,7 @@ def test_train_online_synthetic(tmp_path):
 
 def test_train_parent_synthetic(tmp_path):
     out = _run(["train_parent.py", "--synthetic", "4", "--epochs", "5", "--n-ave-grad", "2", "--height", "40", "--width", "56"], tmp_path)
-    assert "Loss 4:" in out and "***Testing *** Loss 4" in out
+    assert "Loss 4:" in out and "***Testing (epoch 4, 2 frames) *** Loss 4" in out
 
 
 def test_data_parallel_path_on_rccl_single_rank(tmp_path):
@@ -49,3 +49,26 @@ def test_train_online_device_augment_synthetic(tmp_path):
     out = _run(["train_online.py", "--synthetic", "--epochs", "10", "--height", "48", "--width", "64", "--device-augment"], tmp_path,
                {"SEQ_NAME": "blackswan"})
     assert "Online training time" in out and os.path.exists(os.path.join(str(tmp_path), "Results", "blackswan", "00000.png"))
+
+
+def test_train_parent_through_both_rccl_backends_on_one_rank_is_bit_identical(tmp_path):
+    """The SCRIPT's data-parallel path on the real backend with one rank (OSVOS_DP_FORCE=1: communicator first, flat gradient arena, one
+    all-reduce per optimizer step, epoch statistics + sharded validation through the same communicator): torch.distributed's nccl (= RCCL)
+    group, and RCCL through the library's own C ABI with the chunked overlap behind the gradient-ready events (OSVOS_DP_BACKEND=abi,
+    OSVOS_DP_OVERLAP=1, its id store on an explicit OSVOS_COMM_PORT).  A one-rank sum is the identity: the weights after 8 optimizer steps
+    must equal the run without any communicator BIT FOR BIT, and the printed statistics must be the same lines."""
+    import torch
+    argv = ["train_parent.py", "--synthetic", "4", "--epochs", "4", "--n-ave-grad", "2", "--height", "40", "--width", "56", "--snapshot", "2",
+            "--test-interval", "2"]
+    runs = {}
+    for tag, env in {"plain": {}, "torch": {"OSVOS_DP_FORCE": "1", "MASTER_PORT": "29641"},
+                     "abi": {"OSVOS_DP_FORCE": "1", "OSVOS_DP_BACKEND": "abi", "OSVOS_DP_OVERLAP": "1", "OSVOS_COMM_PORT": "29655", "MASTER_PORT": "29643"}}.items():
+        d = tmp_path / tag
+        d.mkdir()
+        out = _run(argv, d, env)
+        assert "optimizer steps taken: 8" in out and "***Testing (epoch 3, 2 frames) *** Loss 4" in out, out[-1500:]
+        runs[tag] = (torch.load(str(d / "parent_epoch-3.pth")), [l for l in out.splitlines() if l.startswith("Loss ") or l.startswith("***Testing")])
+    for tag in ("torch", "abi"):
+        for k, v in runs["plain"][0].items():
+            assert torch.equal(v, runs[tag][0][k]), (tag, k)
+        assert runs[tag][1] == runs["plain"][1], tag

@@ -99,3 +99,26 @@ def test_bytescale_matches_the_scipy_golden():
         pred = np.squeeze(1 / (1 + np.exp(-g["logits"][n].transpose(1, 2, 0))))
         assert np.array_equal(bytescale_scipy11(pred), g["bytescale%d" % n]), n
         assert np.array_equal(g["imsave%d" % n], g["bytescale%d" % n]), n          # imsave writes exactly those bytes
+
+
+def test_the_scripts_sgd_group_table_is_the_oracles():
+    """ONE parameter-group table: the product's ``train_common.make_sgd`` (what train_online.py / train_parent.py / bench.py build their
+    optimizer from) against the oracle's independent restatement of train_online.py:79-88 / train_parent.py:87-103 (``torch_ref.sgd_groups``,
+    itself pinned to the real reference's SGD trajectory by tests/test_oracle_golden.py): same groups in the same order, same tensors by
+    name, same lr / weight_decay / momentum -- for both loops."""
+    import io
+    import contextlib
+    import networks.vgg_osvos as vo
+    from oracle import torch_ref
+    from osvos_pytorch_amd.train_common import make_sgd
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = vo.OSVOS(pretrained=0)
+    names = {id(p): k for k, p in net.named_parameters()}
+    p = dict(net.named_parameters())
+    for mode in ("online", "parent"):
+        ours = make_sgd(net, mode, lr=3e-8, fused=False)
+        ref = torch.optim.SGD(torch_ref.sgd_groups(p, lr=3e-8, mode=mode), lr=3e-8, momentum=0.9)
+        assert len(ours.param_groups) == len(ref.param_groups) == (8 if mode == "online" else 10)
+        for a, b in zip(ours.param_groups, ref.param_groups):
+            assert [names[id(t)] for t in a["params"]] == [names[id(t)] for t in b["params"]]
+            assert a["lr"] == b["lr"] and a["weight_decay"] == b["weight_decay"] and a["momentum"] == b["momentum"] == 0.9

@@ -140,3 +140,29 @@ def test_count_exchange_makes_a_sharded_batch_equal_the_single_process_batch_los
     torch.manual_seed(100)
     model = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3), torch.nn.Conv2d(4, 2, 1))
     assert torch.equal(r0["w"], torch.cat([p.data.flatten() for p in model.parameters()]))
+
+
+def test_abi_communicator_reports_a_taken_port_instead_of_hanging(monkeypatch):
+    """the C-ABI communicator's id store used MASTER_PORT + 1 silently -- a second job on the node collided.  The port is
+    OSVOS_COMM_PORT now, the rendezvous is opened before RCCL or the device are touched, and a taken port raises with the variable's name."""
+    import socket
+    from osvos_pytorch_amd import parallel
+    s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+    s.bind(("127.0.0.1", 0))
+    s.listen(1)
+    port = s.getsockname()[1]
+    monkeypatch.setenv("OSVOS_COMM_PORT", str(port))
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("OSVOS_COMM_TIMEOUT", "5")
+    assert parallel.comm_port() == port
+    try:
+        with pytest.raises(RuntimeError, match="OSVOS_COMM_PORT"):
+            parallel.AbiCommunicator(0, 2, "cpu")
+    finally:
+        s.close()
+    monkeypatch.delenv("OSVOS_COMM_PORT")
+    monkeypatch.setenv("MASTER_PORT", "29500")
+    assert parallel.comm_port() == 29501
+    monkeypatch.setenv("OSVOS_COMM_PORT", "80")
+    with pytest.raises(ValueError):
+        parallel.comm_port()
