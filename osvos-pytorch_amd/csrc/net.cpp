@@ -39,7 +39,6 @@ int last_of_stage(int si) {
 
 struct WbufLayout {
   size_t fwd[kNumConv], dgrad[kNumConv], bias[kNumConv];
-  size_t dgrad0_f32;         // bf16 mode: fp32 data-gradient pack of conv1_1 for the input-gradient kernel (dgrad_c3.hip, bf16 dy in); (size_t)-1 = none
   size_t fwd3[kNumConv], dgrad3[kNumConv];      // OSVOS_F32_X3: pre-split bf16x3 packs of the layers the f32x3 kernels take ((size_t)-1: none)
   size_t wd[4], bd[4], wf, bf, f1[4], f16[4];
   size_t weff[4];            // generic head only: Weff_i[16][k*k] (head_generic.hip)
@@ -63,7 +62,6 @@ WbufLayout wbuf_layout(int dtype) {
       if (d[l].cout % 16 == 0) L.dgrad3[l] = take(osvos_wpack_x3_bytes(d[l].cin, d[l].cout));
     }
   }
-  L.dgrad0_f32 = dtype == OSVOS_F32_BF16MFMA ? take(osvos_wpack_dgrad_bytes(d[0].cout, d[0].cin, OSVOS_F32)) : (size_t)-1;
   for (int i = 0; i < 4; ++i) { L.wd[i] = take(16 * sizeof(float)); L.bd[i] = take(sizeof(float)); }
   L.wf = take(64 * sizeof(float));
   L.bf = take(sizeof(float));
@@ -368,10 +366,7 @@ int osvos_net_pack(const float* const* params, void* wbuf, int dtype_, int with_
     const int rc = osvos_pack_x3_multi(xw, xd, xco, xci, xdg, nx, stream);
     if (rc) return rc;
   }
-  if (with_dgrad && L.dgrad0_f32 != (size_t)-1) {
-    const int rc = osvos_pack_conv3x3_dgrad(params[d[0].w_param], at(wbuf, L.dgrad0_f32), d[0].cout, d[0].cin, OSVOS_F32, stream);
-    if (rc) return rc;
-  }
+
   for (int i = 0; i < 4; ++i) {
     const int k = 4 << i;
     srcs[ns] = params[42 + 2 * i]; dsts[ns] = L.wd[i]; counts[ns] = 16; ++ns;
@@ -750,9 +745,9 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
       } else if (dx_nchw != nullptr && (dtype == OSVOS_F32 || dtype == OSVOS_F32_X3)) {
         rc = osvos_conv3x3_dgrad_c3_f32(reinterpret_cast<const float*>(g), reinterpret_cast<const float*>(at(wbuf, P.dgrad[0])), dx_nchw, N, h, w, d[0].cout, stream);
         if (rc) return rc;
-      } else if (dx_nchw != nullptr && store && P.dgrad0_f32 != (size_t)-1 && getenv("OSVOS_TMP_NO_C3B") == nullptr) {      // bf16 trunk tensors: the same bandwidth kernel, bf16 dy in
-        rc = osvos_conv3x3_dgrad_c3_bf16in(g, reinterpret_cast<const float*>(at(wbuf, P.dgrad0_f32)), dx_nchw, N, h, w, d[0].cout, stream);
-        if (rc) return rc;
+      // (bf16 trunk tensors: the bf16-input form of that kernel, osvos_conv3x3_dgrad_c3_bf16act, was measured at batch 12 in round 4 -- the fp32
+      //  FMA kernel is FMA / LDS bound, 12 x its 82 us, and the whole step read 1073-1081 frames/s with it against 1100 with the 32-cout bf16
+      //  MFMA tile below: not wired in)
       } else if (dx_nchw != nullptr) {
         rc = conv_main(g, g_b, at(wbuf, P.dgrad[0]), nullptr, nullptr, nullptr, at(ws, L.dxin), nullptr, N, h, w, d[0].cout, 3, 4, 0, dtype,
                        nullptr, stream, P.dgrad3[0] != (size_t)-1 ? at(wbuf, P.dgrad3[0]) : nullptr);

@@ -78,64 +78,95 @@ class ArrayFrames(object):
         return self.frames[idx]
 
 
+_COPY_STREAMS = {}
+
+
+def _copy_stream(device):
+    key = str(device)
+    if key not in _COPY_STREAMS:
+        _COPY_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _COPY_STREAMS[key]
+
+
+_PINNED = {}      # (slot, shapes) -> pinned staging buffers, kept for the life of the process: pinning host memory costs milliseconds per buffer,
+                  # and train_parent.py builds one prefetcher per epoch (profiles/r04_scripts_e2e.txt: the feeder stall of round 4)
+
+
 class DevicePrefetcher(object):
     """Iterate ``(index, uint8 CUDA frame [H,W,3], uint8 CUDA label [H,W] | None)`` over ``indices`` of ``frames``.
 
-    A host thread decodes ``depth`` frames ahead into a ring of pinned staging buffers; the H2D copies run on their own stream
-    and the consumer's stream waits on the copy event only -- decode, PCIe and the training step overlap.  A staging slot is
-    re-used only after the copy that read it has completed (event), so the ring needs no extra synchronisation."""
+    A host thread decodes ``depth`` frames ahead into a ring of pinned staging buffers -- CPU work only; the CONSUMER (the thread that also
+    launches the training step) enqueues the H2D copies on a copy stream of their own and makes its stream wait on the copy event only, so
+    decode, PCIe and the training step overlap.  A staging slot is handed back to the producer only after the copy that read it has completed
+    (event), so the ring needs no extra synchronisation.  (Round 4: the first form issued the copies, their events and the event waits from
+    the PRODUCER thread; with the autograd engine's thread launching ~100 kernels per backward through ctypes at the same time, the backward
+    call took 8-12 ms of host time instead of 1.4 -- train_parent.py --device-augment ran at 80 frames/s beside a 560 frames/s kernel loop.
+    No HIP call is made from the producer thread now; profiles/r04_scripts_e2e.txt.)"""
 
     def __init__(self, frames, indices, device, depth=3):
         self.frames, self.indices, self.device, self.depth = frames, list(indices), torch.device(device), max(1, int(depth))
         if self.device.type != 'cuda':
             raise RuntimeError("DevicePrefetcher feeds the GPU input pipeline; it needs a CUDA (ROCm) device")
-        self.copy_stream = torch.cuda.Stream(device=self.device)
+        self.copy_stream = _copy_stream(self.device)
         self.q = queue.Queue(maxsize=self.depth)
-        self.slots = [None] * (self.depth + 1)           # pinned (img, lab) buffers, allocated at the first frame's size
-        self.slot_free = [None] * (self.depth + 1)       # event: the H2D copy out of this slot is done
+        self.free = queue.Queue()                        # slots the consumer has finished copying out of
+        for k in range(self.depth + 2):
+            self.free.put(k)
+        self.slots = [None] * (self.depth + 2)           # pinned (img, lab) buffers, allocated at the first frame's size
         self.thread = threading.Thread(target=self._produce, daemon=True)
         self.thread.start()
 
     def _pinned(self, k, img, lab):
         cur = self.slots[k]
         if cur is None or cur[0].shape != img.shape or (lab is not None and (cur[1] is None or cur[1].shape != lab.shape)):
-            cur = (torch.empty(img.shape, dtype=torch.uint8).pin_memory(),
-                   torch.empty(lab.shape, dtype=torch.uint8).pin_memory() if lab is not None else None)
+            key = (k, tuple(img.shape), tuple(lab.shape) if lab is not None else None)
+            cur = _PINNED.get(key)
+            if cur is None:
+                cur = _PINNED[key] = (torch.empty(img.shape, dtype=torch.uint8).pin_memory(),
+                                      torch.empty(lab.shape, dtype=torch.uint8).pin_memory() if lab is not None else None)
             self.slots[k] = cur
         return cur
 
     def _produce(self):
         try:
-            for n, idx in enumerate(self.indices):
+            for idx in self.indices:
                 img, lab = self.frames[idx]
-                k = n % (self.depth + 1)
-                if self.slot_free[k] is not None:
-                    self.slot_free[k].synchronize()
+                k = self.free.get()                      # a slot whose previous copy has completed
                 pi, pl = self._pinned(k, img, lab)
-                pi.copy_(torch.from_numpy(img))
+                np.copyto(pi.numpy(), img)               # (numpy releases the GIL for the copy; also for the strided views synthetic frames are)
                 if lab is not None:
-                    pl.copy_(torch.from_numpy(lab))
-                with torch.cuda.stream(self.copy_stream):
-                    di = pi.to(self.device, non_blocking=True)
-                    dl = pl.to(self.device, non_blocking=True) if lab is not None else None
-                    ev = torch.cuda.Event()
-                    ev.record(self.copy_stream)
-                self.slot_free[k] = ev
-                self.q.put((idx, di, dl, ev))
+                    np.copyto(pl.numpy(), lab)
+                self.q.put((idx, k, lab is not None))
             self.q.put(None)
         except BaseException as e:          # surface decode errors in the consumer instead of hanging it
             self.q.put(e)
 
     def __iter__(self):
+        inflight = []                        # (slot, event) of copies not known to be complete yet
+        main = torch.cuda.current_stream(self.device)
         while True:
             item = self.q.get()
             if item is None:
+                for _, e0 in inflight:       # the pinned buffers outlive this object (pool): no copy may still be reading them
+                    e0.synchronize()
                 return
             if isinstance(item, BaseException):
                 raise item
-            idx, di, dl, ev = item
-            torch.cuda.current_stream(self.device).wait_event(ev)
-            di.record_stream(torch.cuda.current_stream(self.device))
+            idx, k, has_lab = item
+            pi, pl = self.slots[k]
+            with torch.cuda.stream(self.copy_stream):
+                di = pi.to(self.device, non_blocking=True)
+                dl = pl.to(self.device, non_blocking=True) if has_lab else None
+                ev = torch.cuda.Event()
+                ev.record(self.copy_stream)
+            inflight.append((k, ev))
+            while inflight and (inflight[0][1].query() or len(inflight) > self.depth):
+                k0, e0 = inflight.pop(0)
+                if not e0.query():
+                    e0.synchronize()
+                self.free.put(k0)
+            main.wait_event(ev)
+            di.record_stream(main)
             if dl is not None:
-                dl.record_stream(torch.cuda.current_stream(self.device))
+                dl.record_stream(main)
             yield idx, di, dl

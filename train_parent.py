@@ -106,6 +106,8 @@ def main(argv=None, build_net=None, loss_fn=None):
     ap.add_argument('--height', type=int, default=480)
     ap.add_argument('--width', type=int, default=854)
     ap.add_argument('--seed', type=int, default=0, help='seed of the per-epoch frame permutation (identical on every rank)')
+    ap.add_argument('--init-seed', type=int, default=None,
+                    help='torch.manual_seed before the network is constructed (the reference leaves its N(0, 0.001) initialisation unseeded: default)')
     ap.add_argument('--device-augment', action='store_true',
                     help='input pipeline on the GPU: Pillow decode -> pinned uint8 -> osvos_augment_frame (flip, scale+rotate, mean, CHW)')
     ap.add_argument('--prefetch', type=int, default=3, help='--device-augment: frames decoded / copied ahead of the training step')
@@ -129,6 +131,8 @@ def main(argv=None, build_net=None, loss_fn=None):
     os.makedirs(save_dir, exist_ok=True)
     modelName = 'parent'
 
+    if args.init_seed is not None:
+        torch.manual_seed(args.init_seed)
     if build_net is not None:
         net = build_net()
         if resume_epoch > 0:
