@@ -8,9 +8,8 @@ import shutil
 import subprocess
 import threading
 
-# see bench.py: three backward streams + RCCL's need more than ROCm's default 4 hardware queues (effective only if this module is
-# imported before the process touches the GPU)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# (GPU_MAX_HW_QUEUES -- how many hardware queues ROCm maps the process's HIP streams onto -- is the CALLER's choice and must be made before
+# the first GPU call: the scripts ask for 4, bench.py for 8; see the note at the top of train_parent.py.)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "libosvos_hip.so")

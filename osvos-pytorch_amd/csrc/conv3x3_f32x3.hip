@@ -629,63 +629,66 @@ int pick_ksplit_x(const TileInfoX& t, int N, int H, int W, int Cin, int Cout, in
 }
 
 // pre-split pack: wpk3[((piece * 9 + tap) * CG + cg) * CoutP + co][e] = piece(W[co][8 cg + e][tap])  (dgrad = 0), or the rotated /
-// transposed filter of the data gradient (dgrad = 1: roles of Cin and Cout swapped, tap -> 8 - tap); zero padded
-__global__ void pack_x3_kernel(const float* __restrict__ w, unsigned short* __restrict__ wpk3, int Cout, int Cin, int K, int M, int MP, int dgrad) {
-  // K = reduction channels (Cin of the conv this pack feeds), M = its output channels, MP = M rounded up to 32
-  const int CG = K / 8;
-  const long plane = 9L * CG * MP * 8;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < plane; i += (long)gridDim.x * blockDim.x) {
-    const int e = (int)(i & 7);
-    long t = i >> 3;
-    const int m = (int)(t % MP);
-    t /= MP;
-    const int cg = (int)(t % CG);
-    const int tap = (int)(t / CG);
-    const int k = cg * 8 + e;
-    float v = 0.f;
-    if (m < M) v = dgrad ? w[((long)k * Cin + m) * 9 + (8 - tap)] : w[((long)m * Cin + k) * 9 + tap];      // dgrad: k runs over Cout, m over Cin
-    unsigned p0, p1, p2;
-    split2(v, 0.f, p0, p1, p2);
-    wpk3[i] = (unsigned short)(p0 & 0xffffu);
-    wpk3[plane + i] = (unsigned short)(p1 & 0xffffu);
-    wpk3[2 * plane + i] = (unsigned short)(p2 & 0xffffu);
-  }
-}
-
-// every layer's pre-split packs in ONE launch (the table rides in the kernel arguments): osvos_net_pack re-packs all 17 filters, forward and
-// data-gradient form, after every optimizer step -- 34 launches of ~5 us each back to back on the stream the next forward waits on
+// transposed filter of the data gradient (dgrad = 1: roles of Cin and Cout swapped, tap -> 8 - tap); zero padded.
+// Every layer's packs in ONE launch (the table rides in the kernel arguments): osvos_net_pack re-packs all 17 filters, forward and
+// data-gradient form, after every optimizer step, on the stream the next forward waits on.
+// A unit of work = one (channel group cg, 32 output channels m0..m0+31) block of a pack: its 32 x 8 x 9 source values are whole contiguous
+// runs of the OIHW filter (forward form: 72 floats per output channel; data-gradient form: 288 floats per reduction channel), read as
+// such, turned through LDS, and written as nine 512-byte runs per piece plane.  (Rounds 2-3 gathered one float per thread at a 36-byte
+// stride: 15x the filter bytes fetched per launch, 163 us per optimizer step -- profiles/r04_pmc_traffic_configs1.json.)
 struct PackX3Table {
   const float* w[OSVOS_PACK_MAX];
   unsigned short* dst[OSVOS_PACK_MAX];
   int Cout[OSVOS_PACK_MAX], Cin[OSVOS_PACK_MAX], dgrad[OSVOS_PACK_MAX];
-  long start[OSVOS_PACK_MAX + 1];      // in 256-element blocks of the (piece-plane) index space
+  long start[OSVOS_PACK_MAX + 1];      // in (cg, 32-channel) units
   int n;
 };
 
 __global__ __launch_bounds__(256) void pack_x3_multi_kernel(PackX3Table t) {
+  constexpr int ROW = 8 * 9 + 1;                      // one output channel's 8 x 9 values, padded
+  __shared__ float tile[32 * ROW];
   for (long blk = blockIdx.x; blk < t.start[t.n]; blk += gridDim.x) {
     int k = 0;
     while (blk >= t.start[k + 1]) ++k;                       // uniform per workgroup: scalar loop
     const int dgrad = t.dgrad[k], Cout = t.Cout[k], Cin = t.Cin[k];
     const int K = dgrad ? Cout : Cin, M = dgrad ? Cin : Cout, MP = (M + 31) / 32 * 32, CG = K / 8;
     const long plane = 9L * CG * MP * 8;
-    const long i = (blk - t.start[k]) * 256 + threadIdx.x;
-    if (i >= plane) continue;
-    const int e = (int)(i & 7);
-    long r = i >> 3;
-    const int m = (int)(r % MP);
-    r /= MP;
-    const int cg = (int)(r % CG);
-    const int tap = (int)(r / CG);
-    const int kk = cg * 8 + e;
-    float v = 0.f;
-    if (m < M) v = dgrad ? t.w[k][((long)kk * Cin + m) * 9 + (8 - tap)] : t.w[k][((long)m * Cin + kk) * 9 + tap];
-    unsigned p0, p1, p2;
-    split2(v, 0.f, p0, p1, p2);
+    const int u = (int)(blk - t.start[k]);
+    const int cg = u % CG, m0 = (u / CG) * 32;
+    const float* __restrict__ w = t.w[k];
+    __syncthreads();                                         // the previous unit's reads of `tile`
+#pragma unroll
+    for (int it = 0; it < 9; ++it) {
+      const int L = it * 256 + (int)threadIdx.x;             // 0 .. 2303
+      int ml, e, tap;
+      float v = 0.f;
+      if (dgrad) {                                           // row = reduction channel 8 cg + e (a Cout index): [m0 .. m0 + 31][9] contiguous
+        e = L / 288;
+        const int j = L % 288;
+        ml = j / 9;
+        tap = 8 - j % 9;
+        if (m0 + ml < M) v = w[((long)(cg * 8 + e) * Cin + m0) * 9 + j];
+      } else {                                               // row = output channel m0 + ml: [8 cg .. 8 cg + 7][9] contiguous
+        ml = L / 72;
+        const int j = L % 72;
+        e = j / 9;
+        tap = j % 9;
+        if (m0 + ml < M) v = w[((long)(m0 + ml) * Cin + cg * 8) * 9 + j];
+      }
+      tile[ml * ROW + e * 9 + tap] = v;
+    }
+    __syncthreads();
+    const int ml = (int)threadIdx.x >> 3, e = (int)threadIdx.x & 7;
     unsigned short* d = t.dst[k];
-    d[i] = (unsigned short)(p0 & 0xffffu);
-    d[plane + i] = (unsigned short)(p1 & 0xffffu);
-    d[2 * plane + i] = (unsigned short)(p2 & 0xffffu);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      unsigned p0, p1, p2;
+      split2(tile[ml * ROW + e * 9 + tap], 0.f, p0, p1, p2);
+      const long i = (((long)tap * CG + cg) * MP + m0 + ml) * 8 + e;
+      d[i] = (unsigned short)(p0 & 0xffffu);
+      d[plane + i] = (unsigned short)(p1 & 0xffffu);
+      d[2 * plane + i] = (unsigned short)(p2 & 0xffffu);
+    }
   }
 }
 
@@ -702,7 +705,7 @@ int osvos_pack_x3_multi(const float* const* ws, void* const* dsts, const int* Co
     const int K = dgrads[k] ? Couts[k] : Cins[k], M = dgrads[k] ? Cins[k] : Couts[k];
     OSVOS_ARG_CHECK(ws[k] && dsts[k] && K % 16 == 0 && M > 0, "pack_x3_multi: entry %d (K = %d, M = %d)", k, K, M);
     t.w[k] = ws[k]; t.dst[k] = reinterpret_cast<unsigned short*>(dsts[k]); t.Cout[k] = Couts[k]; t.Cin[k] = Cins[k]; t.dgrad[k] = dgrads[k] ? 1 : 0;
-    t.start[k + 1] = t.start[k] + (9L * K * osvos_cout_pad(M) + 255) / 256;
+    t.start[k + 1] = t.start[k] + (long)(K / 8) * (osvos_cout_pad(M) / 32);
   }
   const long blocks = t.start[n] < 8192 ? t.start[n] : 8192;
   hipLaunchKernelGGL(pack_x3_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, t);
@@ -718,13 +721,10 @@ int osvos_pack_x3(const float* w, void* wpk3, int Cout, int Cin, int dgrad, hipS
   OSVOS_ARG_CHECK(w && wpk3 && Cout > 0 && Cin > 0, "pack_x3: bad arguments");
   const int K = dgrad ? Cout : Cin, M = dgrad ? Cin : Cout;
   OSVOS_ARG_CHECK(K % 16 == 0, "pack_x3: %d reduction channels (must be a multiple of 16)", K);
-  const long plane = 9L * K * osvos_cout_pad(M);
-  long blocks = (plane + 255) / 256;
-  if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(pack_x3_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, w, reinterpret_cast<unsigned short*>(wpk3), Cout, Cin, K, M,
-                     osvos_cout_pad(M), dgrad);
-  OSVOS_LAUNCH_CHECK();
-  return 0;
+  const float* ws[1] = {w};
+  void* dsts[1] = {wpk3};
+  const int co[1] = {Cout}, ci[1] = {Cin}, dg[1] = {dgrad};
+  return osvos_pack_x3_multi(ws, dsts, co, ci, dg, 1, stream);
 }
 
 int osvos_conv3x3_f32x3_num_tiles(void) { return kNumTilesX; }

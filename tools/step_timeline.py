@@ -35,8 +35,9 @@ def analyze(si, verbose):
             ce = max(ce, e)
     busy += ce - cs
     tl = next(e[1] for e in ev if "cbce_count" in e[0])
-    print("step %d: span %.1f us, a kernel running %.1f us, %d idle gaps totalling %.1f us; forward (until the loss kernels) %.1f us, rest %.1f us"
-          % (si, (t1 - t0) / 1e3, busy / 1e3, len(gaps), sum(g[0] for g in gaps) / 1e3, (tl - t0) / 1e3, (t1 - tl) / 1e3))
+    period = (disp[starts[si + 1]][1] - t0) / 1e3
+    print("step %d: period (start to the next step's start) %.1f us, span %.1f us, a kernel running %.1f us, %d idle gaps totalling %.1f us; forward (until the loss kernels) %.1f us, rest %.1f us"
+          % (si, period, (t1 - t0) / 1e3, busy / 1e3, len(gaps), sum(g[0] for g in gaps) / 1e3, (tl - t0) / 1e3, (t1 - tl) / 1e3))
     print("   largest gaps (us @ offset us): %s" % [(round(g[0] / 1e3, 1), round(g[1] / 1e3)) for g in sorted(gaps, reverse=True)[:8]])
     if verbose:
         print("   %8s %8s  stream  kernel" % ("start", "us"))
@@ -46,6 +47,8 @@ def analyze(si, verbose):
                 print("   %8.1f %8.1f  s%-5d %s" % (off, (e[2] - e[1]) / 1e3, e[3], short(e[0])))
 
 
+per = sorted((disp[starts[i + 1]][1] - disp[starts[i]][1]) / 1e3 for i in range(max(0, step - 40), min(len(starts) - 1, step + 40)))
+print("step periods around step %d (%d steps): median %.1f us, min %.1f, p90 %.1f, max %.1f" % (step, len(per), per[len(per) // 2], per[0], per[int(len(per) * 0.9)], per[-1]))
 for si in (step - 2, step + 2):
     analyze(si, False)
 analyze(step, True)

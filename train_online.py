@@ -20,11 +20,14 @@ import os
 import sys
 import timeit
 
-# ROCm maps HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  The backward uses three streams (data gradients /
-# weight gradients / slab reduces); once torch.distributed's RCCL communicator adds its own streams two of ours end up on the same
-# hardware queue and serialise -- measured -7 % (128 -> 119 frames/s) from init_process_group alone.  Eight queues restore it.
+# ROCm maps HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  This process uses up to six streams: the network's four
+# (main, forward side stream, weight gradients, slab reduces), the input pipeline's copy stream (--device-augment) and RCCL's.  Measured on
+# MI355X (profiles/r04_scripts_e2e.txt): as soon as the copy stream gets a hardware queue of its own (5 or more queues) every step of
+# train_parent.py --device-augment stretches from 4.3 to 6.2 ms (231 -> 160 frames/s; bf16 514 -> 335), with or without a communicator;
+# with 4 queues the script runs at bench.py's rate.  Rounds 1-3 asked for 8 queues because a live RCCL communicator then costs the
+# resident-frame loop ~3 % less (bench.py --force-dist: 224 vs 217 frames/s); bench.py, which has no copy stream, still does.
 # Must be set before the HIP runtime initialises, i.e. before the first CUDA call of the process.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")
 
 import numpy as np
 import torch
@@ -172,7 +175,7 @@ def main():
                         loop.window_batch(torch.cat([w[0] for w in window]).requires_grad_(), torch.cat([w[1] for w in window]))
                         window = []
                     continue
-                inputs.requires_grad_()
+                inputs = inputs.detach().requires_grad_()      # (a fresh leaf: a frame the loader hands out again must not accumulate a .grad)
                 loop.micro_batch(inputs, gts)
             if epoch % max(1, nEpochs // 20) == max(1, nEpochs // 20) - 1:
                 running = loop.pop_running()[0] / (num_img_tr * max(1, nEpochs // 20))

@@ -22,11 +22,14 @@ import os
 import sys
 import timeit
 
-# ROCm maps HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  The backward uses three streams (data gradients /
-# weight gradients / slab reduces); once torch.distributed's RCCL communicator adds its own streams two of ours end up on the same
-# hardware queue and serialise -- measured -7 % (128 -> 119 frames/s) from init_process_group alone.  Eight queues restore it.
+# ROCm maps HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  This process uses up to six streams: the network's four
+# (main, forward side stream, weight gradients, slab reduces), the input pipeline's copy stream (--device-augment) and RCCL's.  Measured on
+# MI355X (profiles/r04_scripts_e2e.txt): as soon as the copy stream gets a hardware queue of its own (5 or more queues) every step of
+# train_parent.py --device-augment stretches from 4.3 to 6.2 ms (231 -> 160 frames/s; bf16 514 -> 335), with or without a communicator;
+# with 4 queues the script runs at bench.py's rate.  Rounds 1-3 asked for 8 queues because a live RCCL communicator then costs the
+# resident-frame loop ~3 % less (bench.py --force-dist: 224 vs 217 frames/s); bench.py, which has no copy stream, still does.
 # Must be set before the HIP runtime initialises, i.e. before the first CUDA call of the process.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")
 
 import torch
 
@@ -276,9 +279,11 @@ def main(argv=None, build_net=None, loss_fn=None):
         # one permutation per epoch, the same on every rank; rank r runs the iterations g = r (mod world) of the global stream
         plan = [(idx, g) for idx, g in epoch_plan(len(trainset), epoch, nAveGrad, rank, world, seed=args.seed) if g >= sched.start]
         for sample in epoch_samples(args, trainset, plan, device, augment):
-            inputs, gts = sample['image'], sample['gt']
-            inputs.requires_grad_()                         # train_parent.py:136: the input gradient is computed
-            inputs, gts = inputs.to(device), gts.to(device)
+            # train_parent.py:136-137 marks the HOST tensor as requiring grad and then moves it: the input gradient is computed and copied back
+            # to the host every iteration.  Here the device tensor is the leaf: the same gradient is computed, nothing is copied back (and a
+            # frame that is reused in the next epoch -- the --synthetic list -- does not grow a host-side .grad that is added to every epoch).
+            inputs, gts = sample['image'].to(device), sample['gt'].to(device)
+            inputs = inputs.detach().requires_grad_()
             _, stepped = loop.micro_batch(inputs, gts, epoch=epoch)      # forward, 5 losses, /= nAveGrad, backward, step every local_ave
             if stepped:
                 close_epochs(sched.closed_by(loop.steps, pending))      # right after the SAME gradient collective on every rank
