@@ -40,8 +40,8 @@ import time
 # ROCm maps HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  The backward uses three streams (data gradients /
 # weight gradients / slab reduces); once torch.distributed's RCCL communicator adds its own streams two of ours end up on the same
 # hardware queue and serialise -- measured -7 % (128 -> 119 frames/s) from init_process_group alone in round 1, 217 vs 224 frames/s with
-# --force-dist in round 4.  Eight queues restore it; without a communicator 4, 6 and 8 measure the same (232 frames/s).  (The scripts ask
-# for 4: their input pipeline's copy stream must NOT get a queue of its own -- see train_parent.py.)
+# --force-dist in round 4.  Eight queues restore it; without a communicator 4, 6 and 8 measure the same (232 frames/s).  (See the warning
+# at the top of train_parent.py about copy-only streams before adding a stream to a process that runs this network.)
 # Must be set before the HIP runtime initialises, i.e. before the first CUDA call of the process.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 

@@ -9,7 +9,7 @@ import subprocess
 import threading
 
 # (GPU_MAX_HW_QUEUES -- how many hardware queues ROCm maps the process's HIP streams onto -- is the CALLER's choice and must be made before
-# the first GPU call: the scripts ask for 4, bench.py for 8; see the note at the top of train_parent.py.)
+# the first GPU call: the scripts and bench.py ask for 8; see the note at the top of train_parent.py.)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "libosvos_hip.so")

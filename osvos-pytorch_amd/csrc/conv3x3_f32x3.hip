@@ -719,7 +719,7 @@ size_t osvos_wpack_x3_bytes(int M, int K) { return (size_t)3 * 9 * K * osvos_cou
 // w: OIHW fp32 [Cout][Cin][3][3].  dgrad = 0: pack for the forward conv (K = Cin, M = Cout); 1: for the data gradient (K = Cout, M = Cin)
 int osvos_pack_x3(const float* w, void* wpk3, int Cout, int Cin, int dgrad, hipStream_t stream) {
   OSVOS_ARG_CHECK(w && wpk3 && Cout > 0 && Cin > 0, "pack_x3: bad arguments");
-  const int K = dgrad ? Cout : Cin, M = dgrad ? Cin : Cout;
+  const int K = dgrad ? Cout : Cin;
   OSVOS_ARG_CHECK(K % 16 == 0, "pack_x3: %d reduction channels (must be a multiple of 16)", K);
   const float* ws[1] = {w};
   void* dsts[1] = {wpk3};

@@ -78,16 +78,6 @@ class ArrayFrames(object):
         return self.frames[idx]
 
 
-_COPY_STREAMS = {}
-
-
-def _copy_stream(device):
-    key = str(device)
-    if key not in _COPY_STREAMS:
-        _COPY_STREAMS[key] = torch.cuda.Stream(device=device)
-    return _COPY_STREAMS[key]
-
-
 _PINNED = {}      # (slot, shapes) -> pinned staging buffers, kept for the life of the process: pinning host memory costs milliseconds per buffer,
                   # and train_parent.py builds one prefetcher per epoch (profiles/r04_scripts_e2e.txt: the feeder stall of round 4)
 
@@ -95,19 +85,24 @@ _PINNED = {}      # (slot, shapes) -> pinned staging buffers, kept for the life 
 class DevicePrefetcher(object):
     """Iterate ``(index, uint8 CUDA frame [H,W,3], uint8 CUDA label [H,W] | None)`` over ``indices`` of ``frames``.
 
-    A host thread decodes ``depth`` frames ahead into a ring of pinned staging buffers -- CPU work only; the CONSUMER (the thread that also
-    launches the training step) enqueues the H2D copies on a copy stream of their own and makes its stream wait on the copy event only, so
-    decode, PCIe and the training step overlap.  A staging slot is handed back to the producer only after the copy that read it has completed
-    (event), so the ring needs no extra synchronisation.  (Round 4: the first form issued the copies, their events and the event waits from
-    the PRODUCER thread; with the autograd engine's thread launching ~100 kernels per backward through ctypes at the same time, the backward
-    call took 8-12 ms of host time instead of 1.4 -- train_parent.py --device-augment ran at 80 frames/s beside a 560 frames/s kernel loop.
-    No HIP call is made from the producer thread now; profiles/r04_scripts_e2e.txt.)"""
+    A host thread decodes ``depth`` frames ahead into a ring of pinned staging buffers -- CPU work only.  The CONSUMER (the thread that also
+    launches the training step) enqueues the two H2D copies of a frame on ITS OWN current stream, in line with the step that will read
+    them: 1.6 MB per 854x480 frame, ~40 us of a 4.2 ms step.  A staging slot goes back to the producer only after the copies that read it have
+    completed (an event on the same stream), which also keeps the host at most depth + 2 frames ahead of the GPU.
+
+    How it got here (round 4, profiles/r04_scripts_e2e.txt; train_parent.py --device-augment, frames/s, fp32x3 / bf16, next to bench.py's
+    239 / 555-594 for the same loop on a resident frame):
+      1. copies, events and event waits issued by the PRODUCER thread on a copy stream: the autograd engine's thread launches ~100 kernels
+         per backward through ctypes at the same time and the backward call took 8-12 ms of host time instead of 1.4 ............. - / 81
+      2. no HIP call from the producer; the consumer issues the copies on a separate copy stream, 8 hardware queues ................ 154 / 310
+      3. the same on 4 hardware queues (GPU_MAX_HW_QUEUES; with 5 or more the copy stream gets a queue of its own and every step
+         stretches from 4.3 to 6.2 ms) .......................................................................................... 216 / 492
+      4. no copy stream at all (this form) ........................................................................................ 232 / 555"""
 
     def __init__(self, frames, indices, device, depth=3):
         self.frames, self.indices, self.device, self.depth = frames, list(indices), torch.device(device), max(1, int(depth))
         if self.device.type != 'cuda':
             raise RuntimeError("DevicePrefetcher feeds the GPU input pipeline; it needs a CUDA (ROCm) device")
-        self.copy_stream = _copy_stream(self.device)
         self.q = queue.Queue(maxsize=self.depth)
         self.free = queue.Queue()                        # slots the consumer has finished copying out of
         for k in range(self.depth + 2):
@@ -143,7 +138,6 @@ class DevicePrefetcher(object):
 
     def __iter__(self):
         inflight = []                        # (slot, event) of copies not known to be complete yet
-        main = torch.cuda.current_stream(self.device)
         while True:
             item = self.q.get()
             if item is None:
@@ -154,19 +148,14 @@ class DevicePrefetcher(object):
                 raise item
             idx, k, has_lab = item
             pi, pl = self.slots[k]
-            with torch.cuda.stream(self.copy_stream):
-                di = pi.to(self.device, non_blocking=True)
-                dl = pl.to(self.device, non_blocking=True) if has_lab else None
-                ev = torch.cuda.Event()
-                ev.record(self.copy_stream)
+            di = pi.to(self.device, non_blocking=True)
+            dl = pl.to(self.device, non_blocking=True) if has_lab else None
+            ev = torch.cuda.Event()
+            ev.record()
             inflight.append((k, ev))
             while inflight and (inflight[0][1].query() or len(inflight) > self.depth):
                 k0, e0 = inflight.pop(0)
                 if not e0.query():
                     e0.synchronize()
                 self.free.put(k0)
-            main.wait_event(ev)
-            di.record_stream(main)
-            if dl is not None:
-                dl.record_stream(main)
             yield idx, di, dl

@@ -975,3 +975,29 @@ def test_cbce_per_image_counts_external_counts_and_offset_views():
             lv.backward()
             l2, g2 = one(vo, vl, size_average=False)
             assert torch.equal(xv.grad, xa.grad) and torch.equal(g2, xa.grad)
+
+
+@pytest.mark.parametrize("cout,cin", [(64, 64), (128, 64), (512, 512), (40, 32), (64, 3), (16, 48)])
+@pytest.mark.parametrize("dgrad", [False, True])
+def test_pack_x3_layout_and_pieces(cout, cin, dgrad):
+    """The pre-split pack (round 4: whole contiguous runs of the OIHW filter turned through LDS) against its definition:
+    pack[piece][tap][cg][m][e] with the three bf16 pieces of W[m][8 cg + e][tap] (forward) or W[8 cg + e][m][8 - tap] (data gradient),
+    output channels zero padded to a multiple of 32.  The pieces are checked through what they must satisfy: piece 0 is the value's bf16
+    truncation-or-rounding (within one bf16 ulp), the three pieces sum back to the fp32 value within 2^-22 relative, padding is zero."""
+    ops = _ops()
+    k, m = (cout, cin) if dgrad else (cin, cout)
+    if k % 16:
+        pytest.skip("reduction channels must be a multiple of 16")
+    g = torch.Generator().manual_seed(cout * 7 + cin + int(dgrad))
+    wt = torch.randn(cout, cin, 3, 3, generator=g)
+    buf = ops.pack_x3(wt.cuda(), dgrad=dgrad)
+    mp, cg = (m + 31) // 32 * 32, k // 8
+    pk = buf.view(torch.int16).view(3, 9, cg, mp, 8).cpu()
+    pieces = (pk.to(torch.int32) << 16).view(torch.float32).double()          # a bf16 is the upper half of its fp32
+    want = wt.flip(2, 3).permute(1, 0, 2, 3) if dgrad else wt                  # [m][k][3][3] with tap -> 8 - tap for the data gradient
+    want = want.reshape(m, cg, 8, 9).permute(3, 1, 0, 2).double()              # [tap][cg][m][e]
+    assert float(pieces[:, :, :, m:, :].abs().max()) == 0.0 if mp > m else True
+    got = pieces[:, :, :, :m, :]
+    scale = want.abs().clamp_min(1e-30)
+    assert float(((got[0] - want).abs() / scale).max()) <= 2.0 ** -7
+    assert float(((got.sum(0) - want).abs() / scale).max()) <= 2.0 ** -22

@@ -9,7 +9,7 @@ import torch
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")      # like train_parent.py
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # like train_parent.py
 import networks.vgg_osvos as vo  # noqa: E402
 import train_parent as tp  # noqa: E402
 from osvos_pytorch_amd.augment import DeviceAugment  # noqa: E402

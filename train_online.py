@@ -20,14 +20,14 @@ import os
 import sys
 import timeit
 
-# ROCm maps HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  This process uses up to six streams: the network's four
-# (main, forward side stream, weight gradients, slab reduces), the input pipeline's copy stream (--device-augment) and RCCL's.  Measured on
-# MI355X (profiles/r04_scripts_e2e.txt): as soon as the copy stream gets a hardware queue of its own (5 or more queues) every step of
-# train_parent.py --device-augment stretches from 4.3 to 6.2 ms (231 -> 160 frames/s; bf16 514 -> 335), with or without a communicator;
-# with 4 queues the script runs at bench.py's rate.  Rounds 1-3 asked for 8 queues because a live RCCL communicator then costs the
-# resident-frame loop ~3 % less (bench.py --force-dist: 224 vs 217 frames/s); bench.py, which has no copy stream, still does.
+# ROCm maps HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  The backward uses three streams (data gradients / weight
+# gradients / slab reduces); once a RCCL communicator adds its own, two of ours share a hardware queue and serialise (bench.py
+# --force-dist: 217 vs 224 frames/s; this script with OSVOS_DP_FORCE=1: 2.169 vs 2.143 s per 512-frame epoch).  Eight queues restore it;
+# without a communicator 4 and 8 measure the same.  A WARNING that cost this script 39 % for most of round 4: a stream that carries only
+# H2D copies must not get a hardware queue of its own next to these -- with the input pipeline's former copy stream on a 5th queue every
+# step stretched from 4.3 to 6.2 ms (profiles/r04_scripts_e2e.txt); the pipeline now copies on the consumer's stream (davis_io.py).
 # Must be set before the HIP runtime initialises, i.e. before the first CUDA call of the process.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np
 import torch
