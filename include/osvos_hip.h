@@ -113,8 +113,10 @@ int osvos_conv3x3_splitk(const void* x, const void* wpk, const float* bias, cons
  * (Cout % 16 == 0), wpk_dgrad = osvos_pack_conv3x3_dgrad(w, .., Cout, 3, OSVOS_F32) -> dx_nchw fp32 [N][3][H][W] directly.  A bandwidth
  * kernel (fp32 FMAs, filter through scalar loads) in place of a 32-cout MFMA tile that would waste 10x the matrix work. */
 int osvos_conv3x3_dgrad_c3(const float* dy, const float* wpk_dgrad, float* dx_nchw, int N, int H, int W, int Cout, void* stream);
-/* the same from a bf16 dy (NHWC bf16: the bf16-store mode); wpk_dgrad is still the OSVOS_F32 pack, arithmetic fp32 */
-int osvos_conv3x3_dgrad_c3_bf16act(const void* dy_bf16, const float* wpk_dgrad, float* dx_nchw, int N, int H, int W, int Cout, void* stream);
+/* the same from a bf16 dy (NHWC bf16: the bf16-store mode) on the matrix pipe, in the arithmetic of the bf16 mode (bf16 dy x bf16 filter, fp32
+ * accumulation; the whole 64-channel halo tile goes through LDS once, the filter is the MFMA's row operand): Cout = 64 only; wpk_bf16_dgrad =
+ * osvos_pack_conv3x3_dgrad(w, .., 64, 3, OSVOS_F32_BF16MFMA).  What the network's bf16-store mode runs for train_parent.py:136's input gradient. */
+int osvos_conv3x3_dgrad_c3_bf16mma(const void* dy_bf16, const void* wpk_bf16_dgrad, float* dx_nchw, int N, int H, int W, int Cout, void* stream);
 
 
 /* ---- bf16 operand storage for the bf16-MFMA path (dtype OSVOS_F32_BF16MFMA) ------------------------------------------

@@ -56,7 +56,7 @@ PROTOTYPES = {
     "osvos_maxpool2x2_bf16copy": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "osvos_maxpool2x2_bwd_bf16copy": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "osvos_conv3x3_dgrad_c3": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
-    "osvos_conv3x3_dgrad_c3_bf16act": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "osvos_conv3x3_dgrad_c3_bf16mma": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "osvos_wgrad_ws_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "osvos_conv3x3_wgrad": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "osvos_maxpool2x2": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),

@@ -161,8 +161,8 @@ int osvos_maxpool2x2_bwd_bf16copy(const float* x, const float* dy, const float* 
 int osvos_conv3x3_dgrad_c3(const float* dy, const float* wpk_dgrad, float* dx_nchw, int N, int H, int W, int Cout, void* stream) {
   return osvos_conv3x3_dgrad_c3_f32(dy, wpk_dgrad, dx_nchw, N, H, W, Cout, (hipStream_t)stream);
 }
-int osvos_conv3x3_dgrad_c3_bf16act(const void* dy_bf16, const float* wpk_dgrad, float* dx_nchw, int N, int H, int W, int Cout, void* stream) {
-  return osvos_conv3x3_dgrad_c3_bf16in(dy_bf16, wpk_dgrad, dx_nchw, N, H, W, Cout, (hipStream_t)stream);
+int osvos_conv3x3_dgrad_c3_bf16mma(const void* dy_bf16, const void* wpk_bf16_dgrad, float* dx_nchw, int N, int H, int W, int Cout, void* stream) {
+  return osvos_conv3x3_dgrad_c3_bf16mfma(dy_bf16, wpk_bf16_dgrad, dx_nchw, N, H, W, Cout, (hipStream_t)stream);
 }
 
 

@@ -11,9 +11,7 @@
 // read as wave-wide broadcasts: 2 + 3 LDS reads per 24 FMAs.  40 KB of LDS and <= 128 registers: four workgroups per CU cover each
 // other's load / barrier phases.  (A first form fed the filter through scalar loads: every (tap, quad) then waited out an s_load --
 // 202 us per launch.)  Result written straight into the caller's NCHW tensor (three planes, lanes = consecutive x).
-// BF16IN = 1 (round 4; the bf16-store mode of the network): dy arrives as bf16 NHWC -- half the bytes, one 16-byte load = 8 channels --
-// and is widened to fp32 on its way into LDS; filter and arithmetic stay fp32.  Replaces a 32-cout bf16 MFMA tile + layout kernel that
-// held the chip for 0.52 ms at batch 12 at the very end of the step (profiles/r03_step_timeline_bf16_b12.txt) for 0.63 GB of reads.
+// (The bf16-store mode of the network has its own kernel below: the whole halo tile once through LDS, MFMA.)
 #include "common.h"
 #include "kernels.h"
 
@@ -22,17 +20,15 @@ namespace {
 constexpr int TW = 32, TH = 16, HWD = TW + 2, HHT = TH + 2, PLANE = HHT * HWD;    // 512 pixels per workgroup, 612 halo pixels
 constexpr int CQ = 4;                                                             // channel quads per chunk (16 channels)
 constexpr int ITEMS = CQ * PLANE, NT = 256, NLD = (ITEMS + NT - 1) / NT;          // 16-byte items per chunk; loads per thread
-constexpr int ITEMS_B = 2 * PLANE, NLD_B = (ITEMS_B + NT - 1) / NT;               // bf16 input: an item = 8 channels = two quads
 constexpr int WITEMS = 9 * CQ * 3;                                                // 16-byte filter items per chunk: [tap][quad][ci] x 4 couts
 
 struct D3Args {
-  const void* dy;        // NHWC [N][H][W][Cout] fp32 (or bf16: BF16IN), Cout = 64
+  const float* dy;       // NHWC [N][H][W][Cout] fp32
   const float* wpk;      // data-gradient pack [9][Cout / 4][32][4]
   float* dx;             // NCHW [N][3][H][W]
   int N, H, W, Cout, tiles_x, tiles_y;
 };
 
-template <int BF16IN>
 __global__ __launch_bounds__(NT, 4) void dgrad_c3_kernel(D3Args a) {
   __shared__ f32x4 tile[ITEMS];
   __shared__ f32x4 wl[WITEMS];
@@ -44,7 +40,7 @@ __global__ __launch_bounds__(NT, 4) void dgrad_c3_kernel(D3Args a) {
   const int x0 = tx * TW, y0 = ty * TH;
   const int lx = tid % TW, ly = tid / TW;              // this thread's pixels: (ly, lx) and (ly + 8, lx)
   const int nchunks = a.Cout / 16;
-  constexpr int ES = BF16IN ? 2 : 4, NL = BF16IN ? NLD_B : NLD, NI = BF16IN ? ITEMS_B : ITEMS, CPI = BF16IN ? 8 : 4;      // element size, loads per thread, items, channels per item
+  constexpr int ES = 4, NL = NLD, NI = ITEMS, CPI = 4;      // element size, loads per thread, items, channels per item
   const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(a.dy)) + (size_t)n * a.H * a.W * a.Cout * ES, 0,
                                                                        (int)((size_t)a.H * a.W * a.Cout * ES), 0x00020000);
   constexpr unsigned OOB = 0x80000000u;
@@ -70,20 +66,7 @@ __global__ __launch_bounds__(NT, 4) void dgrad_c3_kernel(D3Args a) {
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
       const int e = tid + i * NT;
-      if constexpr (BF16IN != 0) {
-        if (NI % NT == 0 || e < NI) {      // item (g, pixel): channels 8 g .. 8 g + 7 -> quads 2 g, 2 g + 1 (a bf16 is the upper half of its fp32)
-          const int g = e / PLANE, pix = e % PLANE;
-          f32x4 lo, hi;
-          lo[0] = __uint_as_float(reg[i][0] << 16); lo[1] = __uint_as_float(reg[i][0] & 0xffff0000u);
-          lo[2] = __uint_as_float(reg[i][1] << 16); lo[3] = __uint_as_float(reg[i][1] & 0xffff0000u);
-          hi[0] = __uint_as_float(reg[i][2] << 16); hi[1] = __uint_as_float(reg[i][2] & 0xffff0000u);
-          hi[2] = __uint_as_float(reg[i][3] << 16); hi[3] = __uint_as_float(reg[i][3] & 0xffff0000u);
-          tile[(2 * g) * PLANE + pix] = lo;
-          tile[(2 * g + 1) * PLANE + pix] = hi;
-        }
-      } else {
-        if (NI % NT == 0 || e < NI) tile[e] = __builtin_bit_cast(f32x4, reg[i]);
-      }
+      if (NI % NT == 0 || e < NI) tile[e] = __builtin_bit_cast(f32x4, reg[i]);
     }
     if (tid < WITEMS) wl[tid] = wreg;
     __syncthreads();
@@ -117,6 +100,97 @@ __global__ __launch_bounds__(NT, 4) void dgrad_c3_kernel(D3Args a) {
   }
 }
 
+
+// ---- the same gradient from a bf16 dy on the matrix pipe (round 4; the bf16-store mode of the network, batch 12) ----------------------------
+// 630 MB of dy in, 59 MB out: a stream.  The 32-cout bf16 tile of the general convolution + a layout kernel took 0.52 ms at the very end of the
+// step (profiles/r03_step_timeline_bf16_b12.txt); the fp32-FMA kernel above fed with bf16 (a first attempt of this round) was FMA bound and
+// re-fetched every 128-byte pixel line once per 16-channel chunk (2.9 GB fetched for 0.63 GB).  Here a workgroup loads the WHOLE 64-channel halo tile once -- 34 x 18
+// pixels x 128 bytes, every pixel one full line, 78 KB of LDS as eight planes of 8-channel groups -- and its four waves run
+// v_mfma_f32_32x32x16_bf16 with the filter as the row operand (rows = the 3 input channels, zero padded to 32: the pack of the general bf16
+// data gradient, [tap][channel group][32] x 8 bf16, read by the three lanes that have a row) and 32 consecutive pixels of an image row as
+// columns: 36 MFMAs per row, the 36 filter fragments in registers, two rows in flight.  10x the useful matrix work and still ~70 us of MFMA
+// time at batch 12 against ~170 us of HBM time.  Lanes 0..31 hold (pixel, ci = 0..2) in accumulator registers 0..2: three 128-byte NCHW stores.
+constexpr int M_PIX = HHT * HWD, M_PLANE = M_PIX + 1;          // 612 halo pixels; planes one slot apart in bank phase
+constexpr int M_ITEMS = M_PIX * 8, M_NLD = (M_ITEMS + NT - 1) / NT;
+constexpr int M_LDS_BYTES = 8 * M_PLANE * 16;
+
+struct D3mArgs {
+  const void* dy;        // NHWC [N][H][W][64] bf16
+  const uint4* wpk;      // bf16 data-gradient pack [9][8][32] x (8 bf16)
+  float* dx;             // NCHW [N][3][H][W]
+  int N, H, W, tiles_x, tiles_y;
+};
+
+__global__ __launch_bounds__(NT, 2) void dgrad_c3_mfma_kernel(D3mArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_m[];
+  uint4* As = reinterpret_cast<uint4*>(smem_m);
+  typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+  typedef float f32x16 __attribute__((ext_vector_type(16)));
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+  int t = blockIdx.x;
+  const int tx = t % a.tiles_x;
+  t /= a.tiles_x;
+  const int ty = t % a.tiles_y, n = t / a.tiles_y;
+  const int x0 = tx * TW, y0 = ty * TH;
+  const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(a.dy)) + (size_t)n * a.H * a.W * 128, 0,
+                                                                       (int)((size_t)a.H * a.W * 128), 0x00020000);
+  constexpr unsigned OOB = 0x80000000u;
+  u32x4 reg[M_NLD];
+#pragma unroll
+  for (int i = 0; i < M_NLD; ++i) {      // item e = (halo pixel, 8-channel group): consecutive lanes walk a pixel's 128 bytes, then the next pixel of the row
+    const int e = tid + i * NT;
+    const int g = e & 7, pix = e >> 3;
+    const int gy = y0 + pix / HWD - 1, gx = x0 + pix % HWD - 1;
+    const unsigned off = (e < M_ITEMS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? (unsigned)((gy * a.W + gx) * 128 + g * 16) : OOB;
+    reg[i] = __builtin_amdgcn_raw_buffer_load_b128(drs, off, 0, 0);
+  }
+#pragma unroll
+  for (int i = 0; i < M_NLD; ++i) {
+    const int e = tid + i * NT;
+    if (e < M_ITEMS) As[(e & 7) * M_PLANE + (e >> 3)] = __builtin_bit_cast(uint4, reg[i]);
+  }
+  // the 36 filter fragments of this lane: row li of the (tap, channel group 2 ks + lh) block; rows 3..31 are zero without being read (a
+  // buffer load past num_records returns zeros: no branch, no second copy of the 144 registers).  Issued once the tile has left its 80
+  // staging registers -- the two sets together spill -- and in flight across the barrier.
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(a.wpk), 0, 9 * 8 * 32 * 16, 0x00020000);
+  const unsigned woff = li < 3 ? (unsigned)((lh * 32 + li) * 16) : OOB;
+  u32x4 wf[36];
+#pragma unroll
+  for (int st = 0; st < 36; ++st) wf[st] = __builtin_amdgcn_raw_buffer_load_b128(wrs, woff, ((st >> 2) * 8 + 2 * (st & 3)) * 32 * 16, 0);
+  __syncthreads();
+  // wave w: rows 4 w .. 4 w + 3 of the tile, two at a time (two independent accumulator chains)
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const int row = wave * 4 + half * 2;
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll
+    for (int st = 0; st < 36; ++st) {
+      const int tap = st >> 2, ks = st & 3;
+      const int r = tap / 3, s2 = tap % 3;
+      const uint4* base = As + (2 * ks + lh) * M_PLANE + (row + r) * HWD + li + s2;
+      const uint4 f0 = base[0], f1 = base[HWD];
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf[st]), __builtin_bit_cast(bf16x8_t, f0), acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf[st]), __builtin_bit_cast(bf16x8_t, f1), acc[1], 0, 0, 0);
+    }
+    if (lh == 0) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int oy = y0 + row + j, ox = x0 + li;
+        if (oy < a.H && ox < a.W) {
+          float* o = a.dx + ((size_t)n * 3 * a.H + oy) * a.W + ox;
+#pragma unroll
+          for (int ci = 0; ci < 3; ++ci) o[(size_t)ci * a.H * a.W] = acc[j][ci];
+        }
+      }
+    }
+  }
+}
+
 }  // namespace
 
 bool osvos_dgrad_c3_applicable(int Cin, int Cout) { return Cin == 3 && Cout % 16 == 0 && Cout >= 16; }
@@ -131,22 +205,29 @@ int osvos_conv3x3_dgrad_c3_f32(const float* dy, const float* wpk_dgrad, float* d
   a.tiles_x = ceil_div(W, TW); a.tiles_y = ceil_div(H, TH);
   const long blocks = (long)N * a.tiles_x * a.tiles_y;
   OSVOS_ARG_CHECK(blocks < (1L << 31), "dgrad c3: grid of %ld blocks", blocks);
-  hipLaunchKernelGGL(dgrad_c3_kernel<0>, dim3((unsigned)blocks), dim3(NT), 0, stream, a);
+  hipLaunchKernelGGL(dgrad_c3_kernel, dim3((unsigned)blocks), dim3(NT), 0, stream, a);
   OSVOS_LAUNCH_CHECK();
   return 0;
 }
 
-// the same from a bf16 dy (NHWC [N][H][W][Cout] bf16: the bf16-store mode of the network); the filter pack stays the fp32 one
-int osvos_conv3x3_dgrad_c3_bf16in(const void* dy_bf16, const float* wpk_dgrad, float* dx_nchw, int N, int H, int W, int Cout, hipStream_t stream) {
-  OSVOS_ARG_CHECK(dy_bf16 && wpk_dgrad && dx_nchw && N > 0 && H > 0 && W > 0, "dgrad c3 (bf16 in): bad arguments");
-  OSVOS_ARG_CHECK(osvos_dgrad_c3_applicable(3, Cout) && (long)H * W * Cout < (1L << 29), "dgrad c3: Cout %d (multiple of 16) / image too large", Cout);
-  D3Args a;
-  a.dy = dy_bf16; a.wpk = wpk_dgrad; a.dx = dx_nchw;
-  a.N = N; a.H = H; a.W = W; a.Cout = Cout;
+// dy: NHWC bf16 [N][H][W][64]; wpk_bf16_dgrad: the bf16 data-gradient pack of the [64][3][3][3] filter (osvos_pack_dgrad with the bf16 dtype:
+// [9][8][32] entries of 8 bf16); dx_nchw: [N][3][H][W] fp32.  bf16 operands, fp32 accumulation (the arithmetic of the general bf16 convolution).
+int osvos_conv3x3_dgrad_c3_bf16mfma(const void* dy_bf16, const void* wpk_bf16_dgrad, float* dx_nchw, int N, int H, int W, int Cout, hipStream_t stream) {
+  OSVOS_ARG_CHECK(dy_bf16 && wpk_bf16_dgrad && dx_nchw && N > 0 && H > 0 && W > 0, "dgrad c3 (bf16 mfma): bad arguments");
+  OSVOS_ARG_CHECK(Cout == 64 && (long)H * W * 128 < (1L << 31), "dgrad c3 (bf16 mfma): Cout %d (64 only) / image too large", Cout);
+  static bool attr_set_dev[OSVOS_MAX_DEVICES] = {};
+  bool& attr_set = attr_set_dev[osvos_current_device()];
+  if (!attr_set) {
+    OSVOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dgrad_c3_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, M_LDS_BYTES));
+    attr_set = true;
+  }
+  D3mArgs a;
+  a.dy = dy_bf16; a.wpk = reinterpret_cast<const uint4*>(wpk_bf16_dgrad); a.dx = dx_nchw;
+  a.N = N; a.H = H; a.W = W;
   a.tiles_x = ceil_div(W, TW); a.tiles_y = ceil_div(H, TH);
   const long blocks = (long)N * a.tiles_x * a.tiles_y;
-  OSVOS_ARG_CHECK(blocks < (1L << 31), "dgrad c3: grid of %ld blocks", blocks);
-  hipLaunchKernelGGL(dgrad_c3_kernel<1>, dim3((unsigned)blocks), dim3(NT), 0, stream, a);
+  OSVOS_ARG_CHECK(blocks < (1L << 31), "dgrad c3 (bf16 mfma): grid of %ld blocks", blocks);
+  hipLaunchKernelGGL(dgrad_c3_mfma_kernel, dim3((unsigned)blocks), dim3(NT), M_LDS_BYTES, stream, a);
   OSVOS_LAUNCH_CHECK();
   return 0;
 }

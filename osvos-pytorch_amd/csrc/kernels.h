@@ -36,7 +36,7 @@ int osvos_conv3x3_f32x3_epi(const float* x, const float* wpk, const void* wpk3, 
                             hipStream_t stream);
 bool osvos_dgrad_c3_applicable(int Cin, int Cout);
 int osvos_conv3x3_dgrad_c3_f32(const float* dy, const float* wpk_dgrad, float* dx_nchw, int N, int H, int W, int Cout, hipStream_t stream);
-int osvos_conv3x3_dgrad_c3_bf16in(const void* dy_bf16, const float* wpk_dgrad, float* dx_nchw, int N, int H, int W, int Cout, hipStream_t stream);
+int osvos_conv3x3_dgrad_c3_bf16mfma(const void* dy_bf16, const void* wpk_bf16_dgrad, float* dx_nchw, int N, int H, int W, int Cout, hipStream_t stream);
 size_t osvos_wgrad_ws_bytes_f32(int N, int H, int W, int Cin_s, int Cout);
 int osvos_conv3x3_wgrad_f32(const float* x, const float* dy, void* ws, float* dw, float* db,
                             int N, int H, int W, int Cin, int Cin_s, int Cout, int Cout_s,

@@ -745,9 +745,12 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
       } else if (dx_nchw != nullptr && (dtype == OSVOS_F32 || dtype == OSVOS_F32_X3)) {
         rc = osvos_conv3x3_dgrad_c3_f32(reinterpret_cast<const float*>(g), reinterpret_cast<const float*>(at(wbuf, P.dgrad[0])), dx_nchw, N, h, w, d[0].cout, stream);
         if (rc) return rc;
-      // (bf16 trunk tensors: the bf16-input form of that kernel, osvos_conv3x3_dgrad_c3_bf16act, was measured at batch 12 in round 4 -- the fp32
-      //  FMA kernel is FMA / LDS bound, 12 x its 82 us, and the whole step read 1073-1081 frames/s with it against 1100 with the 32-cout bf16
-      //  MFMA tile below: not wired in)
+      } else if (dx_nchw != nullptr && g_b != nullptr && d[0].cout == 64) {
+        // bf16 trunk tensors: the whole 64-channel halo tile once through LDS, filter rows on the matrix pipe, straight into NCHW (dgrad_c3.hip;
+        // same-box A/B at batch 12, two alternating rounds: 1118.7 / 1114.1 frames/s against 1099.1 / 1106.4 with the 32-cout tile + layout
+        // kernel below; the fp32-FMA kernel fed with bf16, a first attempt of the round, read 1073-1081 and is gone)
+        rc = osvos_conv3x3_dgrad_c3_bf16mfma(g_b, at(wbuf, P.dgrad[0]), dx_nchw, N, h, w, d[0].cout, stream);
+        if (rc) return rc;
       } else if (dx_nchw != nullptr) {
         rc = conv_main(g, g_b, at(wbuf, P.dgrad[0]), nullptr, nullptr, nullptr, at(ws, L.dxin), nullptr, N, h, w, d[0].cout, 3, 4, 0, dtype,
                        nullptr, stream, P.dgrad3[0] != (size_t)-1 ? at(wbuf, P.dgrad3[0]) : nullptr);

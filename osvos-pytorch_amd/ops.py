@@ -311,12 +311,14 @@ def conv3x3_x3_streamk(x, wpk3, bias, cout, relu=False, mask=None, tile=-1, grid
 
 
 def conv3x3_dgrad_c3(dy, w_oihw):
-    """input gradient of a 3-input-channel convolution: dy fp32 [N,H,W,Cout], filter [Cout,3,3,3] -> dx fp32 NCHW [N,3,H,W]"""
+    """input gradient of a 3-input-channel convolution: dy [N,H,W,Cout] fp32, or bf16 with Cout = 64 (the bf16 mode: bf16 filter, MFMA);
+    filter [Cout,3,3,3] -> dx fp32 NCHW [N,3,H,W]"""
     _need_cuda(dy, w_oihw)
     n, h, w, cout = dy.shape
     dx = torch.empty((n, 3, h, w), device=dy.device, dtype=torch.float32)
-    if dy.dtype == torch.bfloat16:      # bf16 dy (the bf16-store mode's trunk tensors); fp32 filter pack and arithmetic
-        check(lib().osvos_conv3x3_dgrad_c3_bf16act(_p(dy.contiguous()), _p(pack_dgrad(w_oihw)), _p(dx), n, h, w, cout, _stream()), "dgrad_c3 (bf16 in)")
+    if dy.dtype == torch.bfloat16:
+        check(lib().osvos_conv3x3_dgrad_c3_bf16mma(_p(dy.contiguous()), _p(pack_dgrad(w_oihw, F32_BF16MFMA)), _p(dx), n, h, w, cout, _stream()),
+              "dgrad_c3 (bf16 mfma)")
     else:
         check(lib().osvos_conv3x3_dgrad_c3(_p(dy.contiguous()), _p(pack_dgrad(w_oihw)), _p(dx), n, h, w, cout, _stream()), "dgrad_c3")
     return dx

@@ -805,12 +805,6 @@ def test_input_gradient_of_the_first_convolution(shape):
     assert dx.shape == (n, 3, h, w)
     emax, el2 = rel_err(dx.cpu(), ref)
     assert emax < 2e-5 and el2 < 1e-5, (shape, emax, el2)
-    # bf16 dy (the bf16-store mode): exact products of the bf16 values with the fp32 filter, fp32 accumulation
-    dyb = dy.bfloat16()
-    refb = F.conv_transpose2d(dyb.double(), wt.double(), padding=1)
-    dxb = ops.conv3x3_dgrad_c3(dyb.permute(0, 2, 3, 1).contiguous().cuda(), wt.cuda())
-    emax, el2 = rel_err(dxb.cpu(), refb)
-    assert emax < 2e-5 and el2 < 1e-5, (shape, "bf16 in", emax, el2)
 
 
 @pytest.mark.gpu
@@ -1001,3 +995,21 @@ def test_pack_x3_layout_and_pieces(cout, cin, dgrad):
     scale = want.abs().clamp_min(1e-30)
     assert float(((got[0] - want).abs() / scale).max()) <= 2.0 ** -7
     assert float(((got.sum(0) - want).abs() / scale).max()) <= 2.0 ** -22
+
+
+@pytest.mark.parametrize("shape", [(1, 9, 11), (2, 17, 35), (1, 16, 32), (3, 40, 70), (1, 33, 64)])
+def test_input_gradient_of_the_first_convolution_on_the_matrix_pipe(shape):
+    """dgrad_c3_mfma_kernel (the bf16-store mode's input gradient): bf16 dy x bf16 filter, fp32 accumulation.  Against float64 on the ROUNDED
+    operands the only error is the fp32 accumulation order (1e-5); against the unrounded filter it is the filter's bf16 rounding."""
+    ops = _ops()
+    n, h, w = shape
+    g = torch.Generator().manual_seed(17 + w)
+    dyb = torch.randn(n, 64, h, w, generator=g).bfloat16()
+    wt = torch.randn(64, 3, 3, 3, generator=g) / 5
+    dx = ops.conv3x3_dgrad_c3(dyb.permute(0, 2, 3, 1).contiguous().cuda(), wt.cuda())
+    assert dx.shape == (n, 3, h, w)
+    ref_r = F.conv_transpose2d(dyb.double(), wt.bfloat16().double(), padding=1)
+    emax, el2 = rel_err(dx.cpu(), ref_r)
+    assert emax < 2e-5 and el2 < 1e-5, (shape, emax, el2)
+    emax, el2 = rel_err(dx.cpu(), F.conv_transpose2d(dyb.double(), wt.double(), padding=1))
+    assert emax < 1e-2 and el2 < 4e-3, (shape, "vs the unrounded filter", emax, el2)
