@@ -18,7 +18,7 @@ for step in "$@"; do
     pytest) timeout 1200 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider --durations=25 ${arg:+-k "$arg"} > $O/pytest_gpu.log 2>&1; echo "exit $?" >> $O/pytest_gpu.log; grep -E "passed|failed|FAILED|Error" $O/pytest_gpu.log | tail -25 ;;
     smoke) timeout 300 python __graft_entry__.py smoke > $O/smoke.log 2>&1; tail -2 $O/smoke.log ;;
     bench) timeout 900 python bench.py $arg > $O/bench.log 2>$O/bench.err; tail -c 3000 $O/bench.log; tail -5 $O/bench.err ;;
-    prof) (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof -o bench -- python $R/bench.py $arg > $O/rocprof.log 2>&1); DB=$(find $O/prof -name "*.db" | head -1); python tools/prof_summary.py $DB ${PROF_STEPS:-25} $O/kernel_stats.txt "python bench.py $arg" > /dev/null 2>&1; head -40 $O/kernel_stats.txt ;;
+    prof) (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof -o bench -- python $R/bench.py $arg > $O/rocprof.log 2>&1); DB=$(find $O/prof -name "*.db" | head -1); python tools/prof_summary.py $DB ${PROF_STEPS:-0} $O/kernel_stats.txt "python bench.py $arg" > /dev/null 2>&1; head -40 $O/kernel_stats.txt ;;
     layers) # per-layer table (tools/layer_table.py): arg = "bf16 12" or "x3 1" (+ " --all")
        set -- $arg; M=$1; B=$2; X=${3:-}
        timeout 300 python tools/layer_table.py run --mode $M --batch $B $X | tail -1 > $O/layers_$M.json

@@ -1,14 +1,16 @@
 #!/usr/bin/env python3
 """Turn a rocprofv3 (ROCm 7.2, rocpd sqlite) kernel trace into the text summary kept under profiles/.
-usage: prof_summary.py <results.db> <steps> [out.txt] [command text]"""
+usage: prof_summary.py <results.db> <steps | 0 = count them: one cbce_count launch per step> [out.txt] [command text]"""
 import sqlite3
 import sys
 
 db = sqlite3.connect(sys.argv[1])
 steps = float(sys.argv[2])
 rows = list(db.execute("select name,total_calls,total_duration,average,percentage from top_kernels"))
+if steps <= 0:      # (round 4: a run with a settle phase profiles far more steps than --steps + --warmup; a wrong divisor scaled every per-step column)
+    steps = float(max([r[1] for r in rows if "cbce_count_kernel" in r[0]] or [1]))
 cmd = sys.argv[4] if len(sys.argv) > 4 else "python bench.py --steps 20 --warmup 5 --no-cpu-baseline"
-out = ["rocprofv3 --kernel-trace --stats  (command: %s; %d profiled steps incl. warm-up)" % (cmd, steps),
+out = ["rocprofv3 --kernel-trace --stats  (command: %s; %d profiled steps incl. settle / warm-up steps)" % (cmd, steps),
        "%-96s %7s %12s %10s %6s" % ("kernel", "calls", "us/step", "avg_us", "%")]
 # bench.py's one-off probes (the register-only MFMA loop behind roofline.pipe_sustained runs once AFTER the timed regions) are listed but kept
 # out of the per-step shares
