@@ -4,8 +4,8 @@ The reference decodes with ``cv2.imread`` inside ``DAVIS2016.__getitem__`` (data
 float32, subtracts the mean and augments with OpenCV on DataLoader workers (custom_transforms.py:21-52,87-121; train_online.py:92-97,
 train_parent.py:106-113).  Here the host only DECODES: ``DavisFrames`` lists the same files in the same order
 (davis_2016.py:36-63) and returns the raw uint8 BGR frame + uint8 label (decoded with Pillow -- OpenCV is not part of this
-image; both sit on libjpeg, the JPEG bit-exactness against cv2 is unpinned here), ``DevicePrefetcher`` moves them through
-pinned staging buffers to the GPU on a copy stream a few frames ahead of the consumer, and
+image; both sit on libjpeg, the JPEG bit-exactness against cv2 is unpinned here), ``DevicePrefetcher`` decodes them on a host thread into a ring of
+pinned staging buffers a few frames ahead and the consumer copies them to the GPU on its own stream, and
 ``osvos_pytorch_amd.augment.DeviceAugment`` does mean / flip / warp / CHW float32 in one kernel.
 """
 from __future__ import annotations
@@ -97,7 +97,7 @@ class DevicePrefetcher(object):
       2. no HIP call from the producer; the consumer issues the copies on a separate copy stream, 8 hardware queues ................ 154 / 310
       3. the same on 4 hardware queues (GPU_MAX_HW_QUEUES; with 5 or more the copy stream gets a queue of its own and every step
          stretches from 4.3 to 6.2 ms) .......................................................................................... 216 / 492
-      4. no copy stream at all (this form) ........................................................................................ 232 / 555"""
+      4. no copy stream at all (this form) ........................................................................................ 239 / 580"""
 
     def __init__(self, frames, indices, device, depth=3):
         self.frames, self.indices, self.device, self.depth = frames, list(indices), torch.device(device), max(1, int(depth))

@@ -40,7 +40,7 @@ def test_data_parallel_path_on_rccl_single_rank(tmp_path):
 
 
 def test_train_parent_device_augment_synthetic(tmp_path):
-    """--device-augment: uint8 frames -> pinned staging -> copy stream -> osvos_augment_frame, through the parent loop."""
+    """--device-augment: uint8 frames -> pinned staging ring -> H2D -> osvos_augment_frame, through the parent loop."""
     out = _run(["train_parent.py", "--synthetic", "4", "--epochs", "2", "--n-ave-grad", "2", "--height", "40", "--width", "56", "--device-augment"], tmp_path)
     assert "Loss 4:" in out and "optimizer steps taken: 4" in out
 

@@ -13,7 +13,7 @@ stream exactly (up to summation order).  N must divide nAveGrad (N in {1, 2, 5, 
 reference's 10); for N in {4, 8} pass --n-ave-grad 8 / 16 -- anything else is refused, not approximated.
 
 ``--device-augment`` replaces the reference's cv2 transform chain (train_parent.py:106-110) by Pillow
-decode -> pinned uint8 staging -> one HIP kernel (osvos_pytorch_amd.augment), prefetched on a copy stream.
+decode thread -> pinned uint8 ring -> H2D on the training stream -> one HIP kernel (osvos_pytorch_amd.augment), a few frames ahead.
 """
 from __future__ import division
 
@@ -80,7 +80,7 @@ def epoch_samples(args, trainset, plan, device, augment):
     """Yield {'image': [1,3,H,W], 'gt': [1,1,H,W]} for this rank's frames of one epoch, in plan order."""
     indices = [idx for idx, _ in plan]
     if augment is not None:
-        # decode on the host -> pinned uint8 -> GPU (copy stream, a few frames ahead) -> one HIP kernel: mean / flip / warp / CHW
+        # decode on a host thread -> pinned uint8 ring (a few frames ahead) -> H2D on this stream -> one HIP kernel: mean / flip / warp / CHW
         from osvos_pytorch_amd.davis_io import DevicePrefetcher
         import random
         for (_, img, lab), (_, g) in zip(DevicePrefetcher(trainset, indices, device, depth=args.prefetch), plan):
