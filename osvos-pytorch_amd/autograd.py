@@ -165,7 +165,11 @@ class OSVOSNetFunction(torch.autograd.Function):
         outs = [torch.empty((n, 1, h, w), device=xin.device, dtype=torch.float32) for _ in range(5)]
         check(l.osvos_net_forward(C.c_void_p(xin.data_ptr()), C.c_void_p(rt.wbuf.data_ptr()), C.c_void_p(ws.data_ptr()),
                                   ptr_array([o.data_ptr() for o in outs]), n, h, w, ctx.cdtype, _stream(), rt.auxf(xin.device)), "net_forward")
-        ctx.rt, ctx.ws, ctx.shape = rt, ws, (n, h, w)
+        # the activation workspace rides in autograd's saved-tensor slot: released right after a plain backward, kept under
+        # retain_graph=True (a second backward recomputes every gradient buffer from the untouched forward half: no buffer of the
+        # forward is written by the backward), and a second backward WITHOUT retain_graph raises autograd's own error, like the reference
+        ctx.save_for_backward(ws)
+        ctx.rt, ctx.shape = rt, (n, h, w)
         ctx.param_meta = [(tuple(p.shape), p.device) for p in ps]
         ctx.params = params          # for in-place gradient accumulation in backward
         ctx.pack_key = rt.key
@@ -173,10 +177,8 @@ class OSVOSNetFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *douts):
-        rt, ws = ctx.rt, ctx.ws
-        if ws is None:
-            raise RuntimeError("OSVOS backward called a second time on the same graph: the activation workspace was released after "
-                               "the first backward (retain_graph=True is not supported by the MI355X path; run forward again)")
+        rt = ctx.rt
+        (ws,) = ctx.saved_tensors      # (freed by a previous backward without retain_graph=True: autograd raises its usual error here)
         n, h, w = ctx.shape
         if rt.key != ctx.pack_key:
             raise RuntimeError("parameters changed between forward and backward of the same graph")
@@ -240,8 +242,6 @@ class OSVOSNetFunction(torch.autograd.Function):
                         if t is not None:
                             t.record_stream(st)
             rt.pending_join = dev
-        ctx.params = None
-        ctx.ws = None
         return (None, dx) + tuple(grads)
 
 

@@ -668,3 +668,37 @@ def test_deferred_backward_join_changes_nothing_but_the_schedule(tmp_path):
     for k in got["0"]:
         assert np.array_equal(got["0"][k], got["1"][k]), k
     assert len(got["0"]) == 52
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["fp32x3", "bf16"])
+def test_retain_graph_second_backward_and_autograds_own_error_without_it(precision):
+    """vgg_osvos.py:59-74 is plain autograd in the reference: `loss.backward(retain_graph=True)` followed by another backward on the same
+    graph works, a second backward WITHOUT it raises autograd's "backward through the graph a second time".  Here the activation workspace
+    rides in the Function's saved-tensor slot: kept under retain_graph, released after a plain backward.  The backward writes no buffer of
+    the forward, so the second pass must return the first one's gradients BIT FOR BIT (all five heads, every parameter, the input)."""
+    from oracle import synth
+    from osvos_pytorch_amd.layers.osvos_layers import class_balanced_cross_entropy_loss as cbce
+    wts, x, m = synth.calibrated_problem(1, 64, 96, seed=21)
+    net = build_net(wts, precision)
+    xin = torch.from_numpy(x).cuda().requires_grad_()
+    gt = torch.from_numpy(m).cuda()
+
+    def grads():
+        g = {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}
+        g["input"] = xin.grad.detach().clone()
+        net.zero_grad(set_to_none=True)
+        xin.grad = None
+        return g
+
+    outs = net.forward(xin)
+    loss = sum(cbce(o, gt, size_average=False) for o in outs)
+    loss.backward(retain_graph=True)
+    first = grads()
+    loss.backward()
+    second = grads()
+    assert set(first) == set(second) and len(first) > 40
+    for k in first:
+        assert torch.equal(first[k], second[k]), k
+    with pytest.raises(RuntimeError, match="second time|already been freed"):
+        loss.backward()
