@@ -77,12 +77,10 @@ int osvos_conv3x3_num_tiles(void);
  * three-way split operands -- v = hi + mid + lo exactly (three bf16 pieces), a*b ~ six bf16 products accumulated in fp32,
  * dropped terms <= 2^-24 |a b| each: fp32-grade results at up to 2.67x the fp32-MFMA rate.  Needs Cin % 16 == 0,
  * Cout % 4 == 0 and >= 32, y_cs % 4 == 0; other shapes (conv1_1, side_prep) stay on the exact kernel.
- *   tile 200 + k (k < osvos_conv3x3_f32x3_tiles(), +100 for the XCD-local map) forces an f32x3 tile config;
- *   osvos_set_fp32_conv_mode(1) makes tile = -1 choose f32x3 wherever it applies (0 = exact fp32 MFMA; the
- *   environment variable OSVOS_FP32_CONV=x3|exact sets the initial value); returns the previous mode. */
+ *   The arithmetic is chosen PER CALL: dtype OSVOS_F32_X3 with tile = -1 takes f32x3 wherever it applies, dtype OSVOS_F32 the exact
+ *   kernels; tile 200 + k (k < osvos_conv3x3_f32x3_tiles(), +100 for the XCD-local map) forces an f32x3 tile config.  (Rounds 2-3 also had
+ *   a process-wide osvos_set_fp32_conv_mode / OSVOS_FP32_CONV switch: removed in round 4 -- no mutable global state behind the ABI.) */
 int osvos_conv3x3_f32x3_tiles(void);
-int osvos_set_fp32_conv_mode(int mode);
-int osvos_get_fp32_conv_mode(void);
 /* f32x3 with PRE-SPLIT weights: the three bf16 piece planes of the filter are formed once (osvos_pack_conv3x3_x3; dgrad != 0 packs the
  * rotated / transposed filter of the data gradient) instead of by every workgroup while staging -- same pieces, bit-identical results,
  * less work between the two barriers of a K chunk.  osvos_net_* do this internally for dtype OSVOS_F32_X3 (OSVOS_X3_PRESPLIT=0: don't).

@@ -37,14 +37,12 @@ PROTOTYPES = {
     "osvos_conv3x3": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "osvos_conv3x3_num_tiles": (_i, []),
     "osvos_conv3x3_f32x3_tiles": (_i, []),
-    "osvos_set_fp32_conv_mode": (_i, [_i]),
     "osvos_wpack_x3_bytes_abi": (_sz, [_i, _i, _i]),
     "osvos_pack_conv3x3_x3": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "osvos_conv3x3_x3": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "osvos_conv3x3_x3_streamk_ws_bytes": (_sz, []),
     "osvos_conv3x3_x3_streamk_ticket_bytes": (_sz, []),
     "osvos_conv3x3_x3_streamk": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
-    "osvos_get_fp32_conv_mode": (_i, []),
     "osvos_conv3x3_splitk_ws_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "osvos_conv3x3_splitk": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "osvos_conv3x3_bf16io": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),

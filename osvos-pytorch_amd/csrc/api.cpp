@@ -112,7 +112,7 @@ int osvos_conv3x3_splitk(const void* x, const void* wpk, const float* bias, cons
   OSVOS_ARG_CHECK(part_ws != nullptr && ksplit >= 0 && ksplit <= 8, "conv3x3_splitk: bad ksplit / workspace");
   osvos_conv3x3_force_ksplit(ksplit);
   const int rc = osvos_conv3x3_f32_ws((const float*)x, (const float*)wpk, bias, (const float*)mask, (float*)y, N, H, W, Cin, Cout,
-                                      y_cs, relu, tile, part_ws, (hipStream_t)stream);
+                                      y_cs, relu, (dtype == OSVOS_F32_X3 && tile < 0) ? -2 : tile, part_ws, (hipStream_t)stream);
   osvos_conv3x3_force_ksplit(0);
   return rc;
 }
@@ -131,9 +131,9 @@ int osvos_conv3x3_wgrad(const void* x, const void* dy, void* ws, float* dw, floa
   if (dtype == OSVOS_F32_BF16MFMA && Cin == Cin_s && Cout % 64 == 0 && osvos_wgrad_bf16_applicable(Cin_s, Cout))
     return osvos_conv3x3_wgrad_bf16mfma((const float*)x, (const float*)dy, ws, dw, db, N, H, W, Cin, Cin_s, Cout, Cout_s,
                                         accumulate, (hipStream_t)stream);
-  // f32x3 (dtype OSVOS_F32_X3, or OSVOS_F32 under the process-wide f32x3 mode): the wide trunk layers on the bf16 matrix pipe with
-  // three-way split operands; conv1_1 and side_prep keep their exact skinny kernels
-  if ((dtype == OSVOS_F32_X3 || (dtype == OSVOS_F32 && osvos_fp32_conv_mode() == 1)) &&
+  // f32x3 (dtype OSVOS_F32_X3): the wide trunk layers on the bf16 matrix pipe with three-way split operands; conv1_1 and side_prep keep
+  // their exact skinny kernels
+  if (dtype == OSVOS_F32_X3 &&
       (osvos_wgrad_f32x3_applicable(Cin, Cin_s, Cout, Cout_s) || osvos_wgrad_f32x3_skinny_applicable(Cin, Cin_s, Cout, Cout_s)))
     return osvos_conv3x3_wgrad_f32x3((const float*)x, (const float*)dy, ws, dw, db, N, H, W, Cin, Cin_s, Cout, Cout_s, accumulate,
                                      (hipStream_t)stream);

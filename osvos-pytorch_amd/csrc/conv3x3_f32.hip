@@ -427,8 +427,9 @@ int osvos_conv3x3_f32_ws(const float* x, const float* wpk, const float* bias, co
   OSVOS_ARG_CHECK(y_cs >= Cout, "conv3x3: y channel stride %d < Cout %d", y_cs, Cout);
   OSVOS_ARG_CHECK((long)H * W * Cin < (1L << 29) && (long)H * W * y_cs < (1L << 29), "conv3x3: image too large for 31-bit byte offsets");
   // f32x3: the same fp32 problem on the bf16 matrix pipe with three-way split operands (conv3x3_f32x3.hip).  Tile ids
-  // 200.. force it (tests, tuning); otherwise the process-wide mode decides (osvos_set_fp32_conv_mode / OSVOS_FP32_CONV).
-  if ((tile >= 200 || (tile < 0 && osvos_fp32_conv_mode() == 1 && osvos_conv3x3_f32x3_applicable(Cin, Cout, y_cs))))
+  // 200.. force it (tests, tuning); tile -2 = "automatic, in the f32x3 arithmetic where it applies" (what the callers that were handed
+  // dtype OSVOS_F32_X3 pass; round 4: this replaces a process-wide mutable mode -- the arithmetic is a per-call argument of the ABI).
+  if ((tile >= 200 || (tile == -2 && osvos_conv3x3_f32x3_applicable(Cin, Cout, y_cs))))
     return osvos_conv3x3_f32x3(x, wpk, bias, mask, y, N, H, W, Cin, Cout, y_cs, relu, tile >= 200 ? tile - 200 : -1, g_force_ksplit, part_ws, stream);
   ConvArgs a;
   a.x = x; a.wpk = wpk; a.bias = bias; a.mask = mask; a.y = y;
@@ -486,15 +487,6 @@ int osvos_conv3x3_splitk_finalize_f32(const float* part, const float* bias, cons
   return 0;
 }
 
-// process-wide arithmetic of the fp32 convolutions: 0 = exact fp32 MFMA, 1 = f32x3 (three-way bf16 split, fp32-grade results)
-static int g_fp32_conv_mode = [] { const char* e = getenv("OSVOS_FP32_CONV"); return (e && (e[0] == 'x' || e[0] == '1')) ? 1 : 0; }();
-int osvos_fp32_conv_mode() { return g_fp32_conv_mode; }
-extern "C" int osvos_set_fp32_conv_mode(int mode) {
-  const int prev = g_fp32_conv_mode;
-  if (mode == 0 || mode == 1) g_fp32_conv_mode = mode;
-  return prev;
-}
-extern "C" int osvos_get_fp32_conv_mode(void) { return g_fp32_conv_mode; }
 
 #ifdef OSVOS_CONV_PROF   // C entry points of the scratch library tools/conv_phase_probe.py builds from this file alone
 __global__ void prof_pack_fwd_f32_kernel(const float* __restrict__ w, float* __restrict__ wpk, int Cout, int Cin, int CinP, int CoutP) {

@@ -12,7 +12,6 @@ int osvos_conv3x3_f32_ws(const float* x, const float* wpk, const float* bias, co
 int osvos_conv3x3_splitk_finalize_f32(const float* part, const float* bias, const float* mask, float* y, long npix, int Cout, int y_cs,
                                       int ksplit, int relu, hipStream_t stream);
 // f32x3 (conv3x3_f32x3.hip): fp32 tensors and fp32 packs, three-way bf16 split operands on the bf16 matrix pipe
-int osvos_fp32_conv_mode();          // 0 exact fp32 MFMA, 1 f32x3
 bool osvos_conv3x3_f32x3_applicable(int Cin, int Cout, int y_cs);
 int osvos_conv3x3_f32x3_num_tiles(void);
 size_t osvos_conv3x3_f32x3_streamk_ws_bytes(void);

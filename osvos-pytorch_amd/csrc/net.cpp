@@ -72,14 +72,6 @@ WbufLayout wbuf_layout(int dtype) {
   return L;
 }
 
-// bf16 operand copies next to the fp32 tensors of the bf16-MFMA mode.  OFF by default: measured at batch 12 the consumers gain
-// 12 % (half the operand bytes, no conversion) but writing a second copy in the producers' epilogues costs more (510 vs 523
-// frames/s) -- it pays only once the fp32 copies are dropped altogether.  OSVOS_BF16_SHADOW=1 turns it on.
-inline bool use_shadow(int dtype) {
-  static const bool on = [] { const char* e = getenv("OSVOS_BF16_SHADOW"); return e && e[0] == '1'; }();
-  return dtype == OSVOS_F32_BF16MFMA && on;
-}
-
 // bf16-ONLY trunk tensors: in the bf16-MFMA mode activations, pooled tensors and their gradients are stored as bf16 and nothing
 // fp32 is written for them (default; OSVOS_BF16_STORE=0 keeps fp32 tensors and rounds while staging).  Producers write half the
 // bytes, consumers read half the bytes; pooling and its backward run on bf16; bias / skinny weight gradients are formed from the
@@ -97,8 +89,9 @@ struct WsLayout {
   size_t side_part[4];       // the same for the side_prep convolutions, which run on the aux stream beside the trunk (own buffers)
   size_t dy[kNumTrunk], dpool[5], dside[4], dprep[4], wgrad[kNumConv], acc, dxin;
   size_t gbuf[4];            // generic head only: tap-indexed reductions G_i[16][k*k] + G1_i[k*k], doubles
-  // bf16 copies of the conv operands (dtype OSVOS_F32_BF16MFMA only): written by the producer's epilogue, read by the
-  // consuming convolution instead of the fp32 tensor (half the bytes, no conversion while staging)
+  // the bf16 trunk tensors of the bf16-store mode (dtype OSVOS_F32_BF16MFMA, OSVOS_BF16_STORE=1): the SAME offsets as the fp32 names above
+  // (nothing fp32 is written for them); 0 / unused otherwise.  (Rounds 1-3 could also keep bf16 COPIES next to fp32 tensors --
+  // OSVOS_BF16_SHADOW, measured a net loss at batch 12 -- removed in round 4.)
   size_t xin_b, act_b[kNumTrunk], pooled_b[5], dy_b[kNumTrunk], dpool_b[5], dside_b[4], dprep_b[4];
   // sign bits of the activations that later serve as ReLU masks (maskbits.h; (size_t)-1 = none): [N][h][w][cout / 32] words
   size_t bits[kNumTrunk];
@@ -131,21 +124,21 @@ WsLayout ws_layout(int N, int H, int W, int dtype) {
   auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
   ConvDesc d[kNumConv];
   conv_table(d);
-  const bool store = use_store(dtype), shadow = use_shadow(dtype) && !store;
+  const bool store = use_store(dtype);
   const size_t te = store ? 2 : es;          // element size of the trunk tensors
   L.xin = take(es * N * H * W * kInPad);
-  if (shadow || store) L.xin_b = take((size_t)2 * N * H * W * kInPad);
+  if (store) L.xin_b = take((size_t)2 * N * H * W * kInPad);
   for (int l = 0; l < kNumTrunk; ++l) {
     const int si = d[l].stage;
     const size_t e = (size_t)N * L.hs[si] * L.ws[si] * d[l].cout;
     L.act[l] = take(te * e);
-    L.act_b[l] = store ? L.act[l] : (shadow ? take(2 * e) : 0);
+    L.act_b[l] = store ? L.act[l] : 0;
     L.bits[l] = (use_mask_bits(dtype) && act_is_a_mask(d, l, dtype)) ? take(e / 8) : (size_t)-1;
   }
   for (int si = 1; si < 5; ++si) {
     const size_t e = (size_t)N * L.hs[si] * L.ws[si] * kStageC[si - 1];
     L.pooled[si] = take(te * e);
-    L.pooled_b[si] = store ? L.pooled[si] : (shadow ? take(2 * e) : 0);
+    L.pooled_b[si] = store ? L.pooled[si] : 0;
   }
   for (int i = 0; i < 4; ++i) {
     const size_t npix = (size_t)N * L.hs[i + 1] * L.ws[i + 1];
@@ -181,7 +174,7 @@ WsLayout ws_layout(int N, int H, int W, int dtype) {
   for (int l = 0; l < kNumTrunk; ++l) {
     const size_t e = (size_t)N * L.hs[d[l].stage] * L.ws[d[l].stage] * d[l].cout;
     L.dy[l] = take(te * e);
-    L.dy_b[l] = store ? L.dy[l] : (shadow ? take(2 * e) : 0);
+    L.dy_b[l] = store ? L.dy[l] : 0;
   }
   for (int si = 1; si < 5; ++si) {
     L.dpool[si] = take(te * N * L.hs[si] * L.ws[si] * kStageC[si - 1]);
@@ -403,8 +396,8 @@ int osvos_net_forward(const float* x_nchw, const void* wbuf, void* ws, float* co
   const WsLayout L = ws_layout(N, H, W, dtype);
   ConvDesc d[kNumConv];
   conv_table(d);
-  const bool store = use_store(dtype), shadow = use_shadow(dtype) && !store;
-  auto sh = [&](size_t off) -> void* { return (shadow || store) ? at(ws, off) : nullptr; };      // bf16 tensor (copy, or the only one)
+  const bool store = use_store(dtype);
+  auto sh = [&](size_t off) -> void* { return store ? at(ws, off) : nullptr; };      // bf16 tensor (copy, or the only one)
   auto f32 = [&](size_t off) -> void* { return store ? nullptr : at(ws, off); };                  // fp32 trunk tensor (absent in store mode)
   int rc = osvos_nchw_to_nhwc_f32(x_nchw, reinterpret_cast<float*>(at(ws, L.xin)), sh(L.xin_b), N, 3, H, W, kInPad, stream);
   if (rc) return rc;
@@ -536,8 +529,8 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
   const WsLayout L = ws_layout(N, H, W, dtype);
   ConvDesc d[kNumConv];
   conv_table(d);
-  const bool store = use_store(dtype), shadow = use_shadow(dtype) && !store;
-  auto sh = [&](size_t off) -> void* { return (shadow || store) ? at(ws, off) : nullptr; };
+  const bool store = use_store(dtype);
+  auto sh = [&](size_t off) -> void* { return store ? at(ws, off) : nullptr; };
   auto f32 = [&](size_t off) -> void* { return store ? nullptr : at(ws, off); };
   auto mk32 = [&](size_t off) -> const void* { return store ? nullptr : at(ws, off); };           // ReLU mask operand: fp32 ...
   auto mk16 = [&](size_t off) -> const void* { return store ? at(ws, off) : nullptr; };           // ... or bf16

@@ -61,13 +61,13 @@ def pack_dgrad(w_oihw, dtype=F32):
     return buf
 
 
-def conv3x3_splitk(x, wpk, bias, cout, ksplit, relu=False, mask=None, tile=-1):
-    """fp32 conv cut into `ksplit` K parts (0 = automatic) + finalize kernel."""
+def conv3x3_splitk(x, wpk, bias, cout, ksplit, relu=False, mask=None, tile=-1, dtype=F32):
+    """fp32 conv cut into `ksplit` K parts (0 = automatic) + finalize kernel; dtype F32_X3: in the f32x3 arithmetic where it applies."""
     _need_cuda(x, wpk, bias, mask)
     n, h, w, cin = x.shape
     y = torch.empty((n, h, w, cout), device=x.device, dtype=torch.float32)
     part = torch.empty(lib().osvos_conv3x3_splitk_ws_bytes(n, h, w, cout, F32), device=x.device, dtype=torch.uint8)
-    check(lib().osvos_conv3x3_splitk(_p(x), _p(wpk), _p(bias), _p(mask), _p(y), n, h, w, cin, cout, cout, int(relu), F32, tile,
+    check(lib().osvos_conv3x3_splitk(_p(x), _p(wpk), _p(bias), _p(mask), _p(y), n, h, w, cin, cout, cout, int(relu), dtype, tile,
                                      ksplit, _p(part), _stream()), "conv3x3_splitk")
     return y
 

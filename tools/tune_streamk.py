@@ -10,6 +10,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from osvos_pytorch_amd import ops, _lib  # noqa: E402
+from osvos_pytorch_amd._lib import F32_X3  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--height", type=int, default=480)
@@ -64,11 +65,7 @@ for name, h, w, cin, cout in layers:
         sk_ms = float("nan")
         if kin >= 256:
             wpk = ops.pack_fwd(wt) if direction == "fwd" else ops.pack_dgrad(wt)
-            prev = lib.osvos_set_fp32_conv_mode(1)
-            try:
-                sk_ms = timeit(lambda: ops.conv3x3_splitk(x, wpk, None, kout, 0, relu=True), args.reps)
-            finally:
-                lib.osvos_set_fp32_conv_mode(prev)
+            sk_ms = timeit(lambda: ops.conv3x3_splitk(x, wpk, None, kout, 0, relu=True, dtype=F32_X3), args.reps)
         row = []
         for g in grids:
             row.append(timeit(lambda: ops.conv3x3_x3_streamk(x, wpk3, None, kout, relu=True, grid=g), args.reps))

@@ -44,7 +44,7 @@ if __name__ == "__main__":
     res = {}
     for b in BLOCKS:
         for v in VARIANTS:
-            env = dict(os.environ, OSVOS_WGRAD_VARIANT=str(v), OSVOS_WGRAD_BLOCKS=str(b), OSVOS_FP32_CONV="exact")
+            env = dict(os.environ, OSVOS_WGRAD_VARIANT=str(v), OSVOS_WGRAD_BLOCKS=str(b))
             p = subprocess.run([sys.executable, os.path.abspath(__file__), "--child"], capture_output=True, text=True, env=env, timeout=900)
             res[(b, v)] = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     print("layer     GF     | " + " ".join("v%-2d/b%-4d" % (v, b) for b in BLOCKS for v in VARIANTS))
