@@ -200,7 +200,7 @@ def test_intermediate_activations_via_ws_query():
     net = build_net(wts)
     xg = torch.from_numpy(x).cuda().requires_grad_()
     outs = net.forward(xg)
-    ws = outs[0].grad_fn.ws
+    ws = outs[0].grad_fn.saved_tensors[0]
     p = {k: torch.from_numpy(v) for k, v in wts.items()}
     cur = torch.from_numpy(x)
     names = torch_ref.trunk_conv_names()
