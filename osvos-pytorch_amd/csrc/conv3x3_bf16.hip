@@ -32,6 +32,7 @@ struct ConvArgsB {
   const unsigned* mask_bits;   // ReLU mask as ONE BIT per element ([N][H][W][y_cs / 32] words, bit = channel % 32; maskbits.h): takes precedence over `mask`
   unsigned* y_bits;            // optional: the same for the result (written next to y / ybf by the forward of a layer whose output is a later mask)
   bf16_t* pooled;              // optional: maxpool2x2 (ceil mode) of the bf16 result, [N][ceil(H/2)][ceil(W/2)][y_cs] (last convolution of a stage; needs ReLU)
+  unsigned char* pool_code;    // optional, with pooled: one byte per pooled element for the pool's backward (pool.hip: first-max position + 4 "input > 0" bits)
   unsigned long long* prof;   // phase cycle counters (only read by builds with -DOSVOS_CONV_PROF; tools/conv_phase_probe.py)
 };
 
@@ -264,6 +265,8 @@ __global__ __launch_bounds__(C::NT, C::OCC) void conv3x3_bf16_kernel(ConvArgsB a
     const int PHo = (a.H + 1) / 2, PWo = (a.W + 1) / 2;
     const size_t poimg = (size_t)PHo * PWo * a.y_cs;
     const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(pool_fwd ? (void*)(a.pooled + n * poimg) : anyp, 0, pool_fwd ? (int)(poimg * 2) : 0, 0x00020000);
+    const bool pool_code = pool_fwd && a.pool_code != nullptr;
+    const __amdgpu_buffer_rsrc_t pcrs = __builtin_amdgcn_make_buffer_rsrc(pool_code ? (void*)(a.pool_code + n * poimg) : anyp, 0, pool_code ? (int)poimg : 0, 0x00020000);
     // one-bit masks (maskbits.h): words per pixel = y_cs / 32
     const int bw = a.y_cs >> 5;
     const size_t img_words = (size_t)a.H * a.W * bw;
@@ -351,20 +354,46 @@ __global__ __launch_bounds__(C::NT, C::OCC) void conv3x3_bf16_kernel(ConvArgsB a
           const unsigned ppix = writer ? (unsigned)(((oy >> 1) * PWo + (ox >> 1)) * a.y_cs) * 2u : OOB;
 #pragma unroll
           for (int pq = 0; pq < 2; ++pq) {
-            u16x8 m;
+            // this lane's column: r0 = its upper row, r1 = its lower row (RBW 16: for lanes li >= 16 the other way round -- they never write)
+            u32x4 r0, r1;
             if constexpr ((C::RBW == 32)) {
-              m = __builtin_elementwise_max(__builtin_bit_cast(u16x8, keep[2 * j][pq]), __builtin_bit_cast(u16x8, keep[2 * j + 1][pq]));
+              r0 = keep[2 * j][pq];
+              r1 = keep[2 * j + 1][pq];
             } else {
-              const u32x4 t = keep[j][pq];
-              const u32x4 u = {(unsigned)__shfl_xor((int)t[0], 16, 64), (unsigned)__shfl_xor((int)t[1], 16, 64), (unsigned)__shfl_xor((int)t[2], 16, 64),
-                               (unsigned)__shfl_xor((int)t[3], 16, 64)};
-              m = __builtin_elementwise_max(__builtin_bit_cast(u16x8, t), __builtin_bit_cast(u16x8, u));
+              r0 = keep[j][pq];
+              r1 = u32x4{(unsigned)__shfl_xor((int)r0[0], 16, 64), (unsigned)__shfl_xor((int)r0[1], 16, 64), (unsigned)__shfl_xor((int)r0[2], 16, 64),
+                         (unsigned)__shfl_xor((int)r0[3], 16, 64)};
             }
-            const u32x4 t = __builtin_bit_cast(u32x4, m);
-            const u32x4 u = {(unsigned)__shfl_xor((int)t[0], 1, 64), (unsigned)__shfl_xor((int)t[1], 1, 64), (unsigned)__shfl_xor((int)t[2], 1, 64),
-                             (unsigned)__shfl_xor((int)t[3], 1, 64)};
-            m = __builtin_elementwise_max(m, __builtin_bit_cast(u16x8, u));
+            u16x8 m = __builtin_elementwise_max(__builtin_bit_cast(u16x8, r0), __builtin_bit_cast(u16x8, r1));
             const int co = co0 + (wn * C::WN + ni) * 32 + 16 * pq + 8 * lh;
+            if (!pool_code) {
+              const u32x4 t = __builtin_bit_cast(u32x4, m);
+              const u32x4 u = {(unsigned)__shfl_xor((int)t[0], 1, 64), (unsigned)__shfl_xor((int)t[1], 1, 64), (unsigned)__shfl_xor((int)t[2], 1, 64),
+                               (unsigned)__shfl_xor((int)t[3], 1, 64)};
+              m = __builtin_elementwise_max(m, __builtin_bit_cast(u16x8, u));
+            } else {
+              // the neighbouring column's two rows arrive separately: the writer needs all four window values for the code byte
+              const u32x4 n0 = {(unsigned)__shfl_xor((int)r0[0], 1, 64), (unsigned)__shfl_xor((int)r0[1], 1, 64), (unsigned)__shfl_xor((int)r0[2], 1, 64),
+                                (unsigned)__shfl_xor((int)r0[3], 1, 64)};
+              const u32x4 n1 = {(unsigned)__shfl_xor((int)r1[0], 1, 64), (unsigned)__shfl_xor((int)r1[1], 1, 64), (unsigned)__shfl_xor((int)r1[2], 1, 64),
+                                (unsigned)__shfl_xor((int)r1[3], 1, 64)};
+              m = __builtin_elementwise_max(m, __builtin_elementwise_max(__builtin_bit_cast(u16x8, n0), __builtin_bit_cast(u16x8, n1)));
+              unsigned cw[2] = {0u, 0u};
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {      // scan order (0,0) (0,1) (1,0) (1,1), strict >: the first maximum (pool.hip); post-ReLU bf16 compare as u16
+                const int sh = 16 * (e & 1);
+                const unsigned av = (r0[e >> 1] >> sh) & 0xffffu, bv = (n0[e >> 1] >> sh) & 0xffffu;
+                const unsigned cv = (r1[e >> 1] >> sh) & 0xffffu, dv = (n1[e >> 1] >> sh) & 0xffffu;
+                unsigned bi = 0u, best = av;
+                if (bv > best) { best = bv; bi = 1u; }
+                if (cv > best) { best = cv; bi = 2u; }
+                if (dv > best) { bi = 3u; }
+                const unsigned byte = bi | (av ? 4u : 0u) | (bv ? 8u : 0u) | (cv ? 16u : 0u) | (dv ? 32u : 0u);
+                cw[e >> 2] |= byte << (8 * (e & 3));
+              }
+              typedef unsigned u32x2s __attribute__((ext_vector_type(2)));
+              __builtin_amdgcn_raw_buffer_store_b64(u32x2s{cw[0], cw[1]}, pcrs, (co < a.Cout && ppix != OOB) ? (ppix >> 1) + (unsigned)co : OOB, 0, 0);
+            }
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, m), prs, (co < a.Cout && ppix != OOB) ? ppix + (unsigned)co * 2u : OOB, 0, 0);
           }
         }
@@ -539,15 +568,17 @@ extern "C" void osvos_debug_set_conv_prof(void* p) { g_conv_prof = (unsigned lon
 // xb = 0: x fp32, xb = 1: x bf16; ybf (optional) receives a bf16 copy of y
 int osvos_conv3x3_bf16mfma_io(const void* x, int xb, const void* wpk, const float* bias, const void* mask, int mask_bf16, float* y, void* ybf,
                               int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int tile, hipStream_t stream) {
-  return osvos_conv3x3_bf16mfma_bits(x, xb, wpk, bias, mask, mask_bf16, nullptr, y, ybf, nullptr, nullptr, N, H, W, Cin, Cout, y_cs, relu, tile, stream);
+  return osvos_conv3x3_bf16mfma_bits(x, xb, wpk, bias, mask, mask_bf16, nullptr, y, ybf, nullptr, nullptr, N, H, W, Cin, Cout, y_cs, relu, tile, stream, nullptr);
 }
 
 // mask_bits: the ReLU mask as one bit per element (maskbits.h; takes precedence over `mask`); y_bits: sign bits of the result, written beside it
 // pooled_bf16 (optional; needs ybf, ReLU, a dense result with Cout % 8 == 0): maxpool2x2 (ceil mode) of the bf16 result, written by the same launch
 // ([N][ceil(H/2)][ceil(W/2)][Cout]; the 8 x 8-pixel tile cannot hold whole windows per wave: there the pooling kernel is launched behind the convolution)
+// pool_code (optional, with pooled_bf16): [N][ceil(H/2)][ceil(W/2)][Cout] bytes for osvos_maxpool2x2_bwd_bf16_code; written whichever kernel runs
 int osvos_conv3x3_bf16mfma_bits(const void* x, int xb, const void* wpk, const float* bias, const void* mask, int mask_bf16, const unsigned* mask_bits,
                                 float* y, void* ybf, unsigned* y_bits, void* pooled_bf16, int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int tile,
-                                hipStream_t stream) {
+                                hipStream_t stream, void* pool_code) {
+  OSVOS_ARG_CHECK(pool_code == nullptr || pooled_bf16 != nullptr, "conv3x3 bf16: pool code bytes without a pooled result");
   OSVOS_ARG_CHECK(pooled_bf16 == nullptr || (ybf != nullptr && relu && mask == nullptr && mask_bits == nullptr && Cout % 8 == 0 && y_cs == Cout),
                   "conv3x3 bf16: the fused forward pool needs a bf16 result, ReLU, no mask and a dense Cout %% 8 == 0 (Cout %d, stride %d)", Cout, y_cs);
   OSVOS_ARG_CHECK(x && wpk && (y || ybf), "conv3x3 bf16: null pointer");
@@ -564,6 +595,7 @@ int osvos_conv3x3_bf16mfma_bits(const void* x, int xb, const void* wpk, const fl
   a.x = x; a.wpk = reinterpret_cast<const uint4*>(wpk); a.bias = bias; a.mask = mask; a.mask_bf16 = mask_bf16 ? 1 : 0; a.y = y;
   a.ybf = reinterpret_cast<bf16_t*>(ybf);
   a.mask_bits = mask_bits; a.y_bits = y_bits; a.pooled = reinterpret_cast<bf16_t*>(pooled_bf16);
+  a.pool_code = reinterpret_cast<unsigned char*>(pool_code);
   a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.CinP = (Cin + 31) / 32 * 32; a.Cout = Cout; a.CoutP = osvos_cout_pad(Cout); a.y_cs = y_cs;
   a.relu = relu;
   a.prof = g_conv_prof;
@@ -585,12 +617,17 @@ int osvos_conv3x3_bf16mfma_bits(const void* x, int xb, const void* wpk, const fl
   tile %= 100;
   if (xb && tile >= 30 && tile <= 35) {      // LDS-DMA staged kernel
     OSVOS_ARG_CHECK(osvos_conv3x3_bf16_dma_applicable(Cin, Cout, y_cs), "conv3x3 bf16: tile %d (DMA staging) needs Cin %% 16 == 0, Cout, y_cs %% 8 == 0", tile);
+    if (pool_code != nullptr) {      // the DMA kernel's fused pool writes no code bytes: pooling (with them) as its own launch behind the convolution
+      const int rc = osvos_conv3x3_bf16_dma(x, wpk, bias, mask, mask_bf16, mask_bits, y, ybf, y_bits, nullptr, N, H, W, Cin, Cout, y_cs, relu, tile - 30, a.map, stream);
+      return rc ? rc : osvos_maxpool2x2_bf16_code(ybf, pooled_bf16, pool_code, N, H, W, Cout, stream);
+    }
     return osvos_conv3x3_bf16_dma(x, wpk, bias, mask, mask_bf16, mask_bits, y, ybf, y_bits, pooled_bf16, N, H, W, Cin, Cout, y_cs, relu, tile - 30, a.map, stream);
   }
   if (a.pooled != nullptr && !(xb && tile != 7 && tile >= 0 && tile < kNumTilesB)) {      // a tile whose waves do not hold whole windows: separate pooling launch
     a.pooled = nullptr;
-    const int rc = osvos_conv3x3_bf16mfma_bits(x, xb, wpk, bias, mask, mask_bf16, mask_bits, y, ybf, y_bits, nullptr, N, H, W, Cin, Cout, y_cs, relu, tile + 100 * a.map, stream);
-    return rc ? rc : osvos_maxpool2x2_bf16(ybf, pooled_bf16, N, H, W, Cout, stream);
+    const int rc = osvos_conv3x3_bf16mfma_bits(x, xb, wpk, bias, mask, mask_bf16, mask_bits, y, ybf, y_bits, nullptr, N, H, W, Cin, Cout, y_cs, relu, tile + 100 * a.map, stream,
+                                               nullptr);
+    return rc ? rc : osvos_maxpool2x2_bf16_code(ybf, pooled_bf16, pool_code, N, H, W, Cout, stream);
   }
   if (xb) {
     switch (tile) {
