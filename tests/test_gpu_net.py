@@ -677,8 +677,9 @@ def test_pool_code_bytes_change_nothing_but_the_bytes_read_bf16(tmp_path):
     """Round 5, bf16-store mode: the forward's pooling (fused epilogue of the stage's last convolution, or its own launch) writes one code
     byte per pooled element and maxpool_bwd reads it instead of the pool's input (OSVOS_POOL_CODE=1, default).  Logits, losses and EVERY
     gradient must equal the run that recomputes the argmax from the input (OSVOS_POOL_CODE=0) BIT FOR BIT, with the pools fused and not
-    (OSVOS_FUSE_POOL=0/1: the epilogue's bytes against the pooling kernel's), at odd sizes with clipped windows and at a size where the
-    deep stages run the LDS-DMA convolution (whose pooling then runs as its own launch)."""
+    (OSVOS_FUSE_POOL=0/1: the epilogue's bytes against the pooling kernel's), at odd sizes with clipped windows on both axes and at batch 12.
+    (The LDS-DMA convolution of the deep stages, whose pooling then runs as its own launch, only engages at the BASELINE size: the
+    854x480 batch-12 parity test of tests/test_gpu_baseline_configs.py runs through it.)"""
     import os, subprocess, sys, textwrap
     code = textwrap.dedent('''
         import sys, numpy as np, torch
