@@ -505,40 +505,58 @@ int pick_tile_b(int N, int H, int W, int CoutP, int Cin) {
 }
 
 // wpk[((tap*CG + cg)*CoutP + co)*8 + e] = bf16(W[co][8cg+e][tap])   (zero padded)
-__global__ void pack_fwd_bf16_kernel(const float* __restrict__ w, bf16_t* __restrict__ wpk, int Cout, int Cin, int CinP, int CoutP) {
-  const int CG = CinP / 8;
-  const long total = 9L * CG * CoutP * 8;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int e = (int)(i & 7);
-    long t = i >> 3;
-    const int co = (int)(t % CoutP);
-    t /= CoutP;
-    const int cg = (int)(t % CG);
-    const int tap = (int)(t / CG);
-    const int ci = cg * 8 + e;
-    wpk[i] = (co < Cout && ci < Cin) ? f32_to_bf16(w[((long)co * Cin + ci) * 9 + tap]) : (bf16_t)0;
-  }
-}
+// every layer's bf16 packs, forward and data-gradient form, in ONE launch (round 5 prep; the f32x3 twin is pack_x3_multi_kernel): osvos_net_pack
+// re-packs 17 filters x 2 forms after every optimizer step -- 34 launches of ~8 us each, one float per thread at a 36-byte stride.  A unit =
+// one (8-channel group cg of the reduction dimension, 32 output channels) block: its source values are whole contiguous runs of the OIHW
+// filter (forward: 72 floats per output channel; data gradient: 288 floats per reduction channel), turned through LDS, written as nine
+// 512-byte runs.  Reduction channels are padded to a multiple of 32 and output channels to a multiple of 32 with zeros, like the single packs.
+struct PackB16Table {
+  const float* w[OSVOS_PACK_MAX];
+  bf16_t* dst[OSVOS_PACK_MAX];
+  int Cout[OSVOS_PACK_MAX], Cin[OSVOS_PACK_MAX], dgrad[OSVOS_PACK_MAX];
+  long start[OSVOS_PACK_MAX + 1];      // in (cg, 32-channel) units
+  int n;
+};
 
-// data-gradient pack: roles swapped, filter rotated by 180 degrees
-__global__ void pack_dgrad_bf16_kernel(const float* __restrict__ w, bf16_t* __restrict__ wpk, int Cout, int Cin, int CoutK, int CinP) {
-  const int CG = CoutK / 8;
-  const long total = 9L * CG * CinP * 8;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int e = (int)(i & 7);
-    long t = i >> 3;
-    const int ci = (int)(t % CinP);
-    t /= CinP;
-    const int cog = (int)(t % CG);
-    const int tap = (int)(t / CG);
-    const int co = cog * 8 + e;
-    wpk[i] = (co < Cout && ci < Cin) ? f32_to_bf16(w[((long)co * Cin + ci) * 9 + (8 - tap)]) : (bf16_t)0;
+__global__ __launch_bounds__(256) void pack_bf16_multi_kernel(PackB16Table t) {
+  constexpr int ROW = 8 * 9 + 1;
+  __shared__ float tile[32 * ROW];
+  for (long blk = blockIdx.x; blk < t.start[t.n]; blk += gridDim.x) {
+    int k = 0;
+    while (blk >= t.start[k + 1]) ++k;
+    const int dgrad = t.dgrad[k], Cout = t.Cout[k], Cin = t.Cin[k];
+    const int K = dgrad ? Cout : Cin, M = dgrad ? Cin : Cout;       // reduction / output channels of the convolution this pack feeds
+    const int KP = (K + 31) / 32 * 32, MP = (M + 31) / 32 * 32, CG = KP / 8;
+    const int u = (int)(blk - t.start[k]);
+    const int cg = u % CG, m0 = (u / CG) * 32;
+    const float* __restrict__ w = t.w[k];
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 9; ++it) {
+      const int L = it * 256 + (int)threadIdx.x;
+      int ml, e, tap;
+      float v = 0.f;
+      if (dgrad) {                                           // row = reduction channel kk = 8 cg + e (a Cout index): [m0 .. m0 + 31][9] contiguous
+        e = L / 288;
+        const int j = L % 288;
+        ml = j / 9;
+        tap = 8 - j % 9;
+        if (m0 + ml < M && cg * 8 + e < K) v = w[((long)(cg * 8 + e) * Cin + m0) * 9 + j];
+      } else {                                               // row = output channel m0 + ml: [8 cg .. 8 cg + 7][9] contiguous (ragged at K = 3)
+        ml = L / 72;
+        const int j = L % 72;
+        e = j / 9;
+        tap = j % 9;
+        if (m0 + ml < M && cg * 8 + e < K) v = w[((long)(m0 + ml) * Cin + cg * 8) * 9 + j];
+      }
+      tile[ml * ROW + e * 9 + tap] = v;
+    }
+    __syncthreads();
+    const int ml = (int)threadIdx.x >> 3, e = (int)threadIdx.x & 7;
+    bf16_t* d = t.dst[k];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) d[(((long)tap * CG + cg) * MP + m0 + ml) * 8 + e] = f32_to_bf16(tile[ml * ROW + e * 9 + tap]);
   }
-}
-
-inline int grid_for(long total) {
-  long b = (total + 255) / 256;
-  return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
 }
 
 }  // namespace
@@ -547,16 +565,36 @@ int osvos_conv3x3_bf16mfma_num_tiles(void) { return kNumTilesB; }
 
 int osvos_pack_fwd_bf16(const float* w, void* wpk, int Cout, int Cin, hipStream_t stream) {
   OSVOS_ARG_CHECK(w && wpk && Cout > 0 && Cin > 0, "pack_fwd bf16: bad arguments");
-  const int CinP = (Cin + 31) / 32 * 32, CoutP = osvos_cout_pad(Cout);
-  hipLaunchKernelGGL(pack_fwd_bf16_kernel, dim3(grid_for(9L * CinP * CoutP)), dim3(256), 0, stream, w, (bf16_t*)wpk, Cout, Cin, CinP, CoutP);
-  OSVOS_LAUNCH_CHECK();
-  return 0;
+  const float* ws[1] = {w};
+  void* dsts[1] = {wpk};
+  const int co[1] = {Cout}, ci[1] = {Cin}, dg[1] = {0};
+  return osvos_pack_bf16_multi(ws, dsts, co, ci, dg, 1, stream);
 }
 
 int osvos_pack_dgrad_bf16(const float* w, void* wpk, int Cout, int Cin, hipStream_t stream) {
   OSVOS_ARG_CHECK(w && wpk && Cout > 0 && Cin > 0, "pack_dgrad bf16: bad arguments");
-  const int CoutK = (Cout + 31) / 32 * 32, CinP = osvos_cout_pad(Cin);
-  hipLaunchKernelGGL(pack_dgrad_bf16_kernel, dim3(grid_for(9L * CoutK * CinP)), dim3(256), 0, stream, w, (bf16_t*)wpk, Cout, Cin, CoutK, CinP);
+  const float* ws[1] = {w};
+  void* dsts[1] = {wpk};
+  const int co[1] = {Cout}, ci[1] = {Cin}, dg[1] = {1};
+  return osvos_pack_bf16_multi(ws, dsts, co, ci, dg, 1, stream);
+}
+
+// n bf16 packs (n <= OSVOS_PACK_MAX) in one launch: ws[k] OIHW fp32 [Couts[k]][Cins[k]][3][3] -> dsts[k] (osvos_pack_fwd_bf16 layout; dgrads[k] != 0:
+// osvos_pack_dgrad_bf16 layout)
+int osvos_pack_bf16_multi(const float* const* ws, void* const* dsts, const int* Couts, const int* Cins, const int* dgrads, int n, hipStream_t stream) {
+  OSVOS_ARG_CHECK(ws && dsts && Couts && Cins && dgrads && n >= 0 && n <= OSVOS_PACK_MAX, "pack_bf16_multi: bad table (n = %d)", n);
+  if (n == 0) return 0;
+  PackB16Table t;
+  t.n = n;
+  t.start[0] = 0;
+  for (int k = 0; k < n; ++k) {
+    const int K = dgrads[k] ? Couts[k] : Cins[k], M = dgrads[k] ? Cins[k] : Couts[k];
+    OSVOS_ARG_CHECK(ws[k] && dsts[k] && K > 0 && M > 0, "pack_bf16_multi: entry %d (K = %d, M = %d)", k, K, M);
+    t.w[k] = ws[k]; t.dst[k] = reinterpret_cast<bf16_t*>(dsts[k]); t.Cout[k] = Couts[k]; t.Cin[k] = Cins[k]; t.dgrad[k] = dgrads[k] ? 1 : 0;
+    t.start[k + 1] = t.start[k] + (long)(((K + 31) / 32 * 32) / 8) * (osvos_cout_pad(M) / 32);
+  }
+  const long blocks = t.start[n] < 8192 ? t.start[n] : 8192;
+  hipLaunchKernelGGL(pack_bf16_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, t);
   OSVOS_LAUNCH_CHECK();
   return 0;
 }

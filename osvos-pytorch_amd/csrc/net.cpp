@@ -358,8 +358,15 @@ int osvos_net_pack(const float* const* params, void* wbuf, int dtype_, int with_
   const bool x3ps = dtype == OSVOS_F32_X3 && use_presplit();
   const float* xw[OSVOS_PACK_MAX]; void* xd[OSVOS_PACK_MAX]; int xco[OSVOS_PACK_MAX], xci[OSVOS_PACK_MAX], xdg[OSVOS_PACK_MAX];
   int nx = 0;
+  const bool b16 = dtype == OSVOS_F32_BF16MFMA;      // all bf16 packs (17 filters x 2 forms) in ONE launch too (round 5 prep)
   for (int l = 0; l < kNumConv; ++l) {
     int rc;
+    if (b16) {
+      xw[nx] = params[d[l].w_param]; xd[nx] = at(wbuf, L.fwd[l]); xco[nx] = d[l].cout; xci[nx] = d[l].cin; xdg[nx] = 0; ++nx;
+      if (with_dgrad) { xw[nx] = params[d[l].w_param]; xd[nx] = at(wbuf, L.dgrad[l]); xco[nx] = d[l].cout; xci[nx] = d[l].cin; xdg[nx] = 1; ++nx; }
+      srcs[ns] = params[d[l].b_param]; dsts[ns] = L.bias[l]; counts[ns] = d[l].cout; ++ns;
+      continue;
+    }
     if (!(x3ps && L.fwd3[l] != (size_t)-1) && (rc = osvos_pack_conv3x3_fwd(params[d[l].w_param], at(wbuf, L.fwd[l]), d[l].cout, d[l].cin, dtype, stream))) return rc;
     if (with_dgrad && !(x3ps && L.dgrad3[l] != (size_t)-1 && l != 0) &&
         (rc = osvos_pack_conv3x3_dgrad(params[d[l].w_param], at(wbuf, L.dgrad[l]), d[l].cout, d[l].cin, dtype, stream))) return rc;
@@ -368,7 +375,7 @@ int osvos_net_pack(const float* const* params, void* wbuf, int dtype_, int with_
     srcs[ns] = params[d[l].b_param]; dsts[ns] = L.bias[l]; counts[ns] = d[l].cout; ++ns;
   }
   if (nx > 0) {
-    const int rc = osvos_pack_x3_multi(xw, xd, xco, xci, xdg, nx, stream);
+    const int rc = b16 ? osvos_pack_bf16_multi(xw, xd, xco, xci, xdg, nx, stream) : osvos_pack_x3_multi(xw, xd, xco, xci, xdg, nx, stream);
     if (rc) return rc;
   }
 

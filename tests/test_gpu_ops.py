@@ -1045,3 +1045,25 @@ def test_pool_code_bytes_and_the_backward_that_reads_them():
             a = ops.maxpool2x2_bwd_bf16act_code(code, dy, (h, w), side)
             b = ops.maxpool2x2_bwd_bf16act(xg, dy, side)
             assert torch.equal(a, b), (shape, side is None)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cout,cin", [(64, 3), (64, 64), (128, 64), (512, 512), (16, 256), (40, 24)])
+@pytest.mark.parametrize("dgrad", [False, True])
+def test_pack_bf16_layout_bit_exact(cout, cin, dgrad):
+    """The bf16 packs (round 5: whole contiguous runs of the OIHW filter turned through LDS, all of a network's packs in one launch) against
+    their definition, BIT FOR BIT: pack[tap][cg][m][e] = bf16_rne(W[m][8 cg + e][tap]) (forward) or bf16_rne(W[8 cg + e][m][8 - tap]) (data
+    gradient); reduction channels zero padded to a multiple of 32 (conv1_1: 3 -> 32), output channels to a multiple of 32."""
+    from osvos_pytorch_amd._lib import F32_BF16MFMA
+    ops = _ops()
+    g = torch.Generator().manual_seed(cout * 5 + cin + int(dgrad))
+    wt = torch.randn(cout, cin, 3, 3, generator=g)
+    buf = (ops.pack_dgrad if dgrad else ops.pack_fwd)(wt.cuda(), F32_BF16MFMA)
+    k, m = (cout, cin) if dgrad else (cin, cout)
+    kp, mp = (k + 31) // 32 * 32, (m + 31) // 32 * 32
+    pk = buf.view(torch.int16)[: 9 * (kp // 8) * mp * 8].view(9, kp // 8, mp, 8).cpu()
+    want = torch.zeros(9, kp, mp)
+    src = wt.flip(2, 3).permute(1, 0, 2, 3) if dgrad else wt                   # [m][k][3][3], tap -> 8 - tap for the data gradient
+    want[:, :k, :m] = src.reshape(m, k, 9).permute(2, 1, 0)
+    want = want.view(9, kp // 8, 8, mp).permute(0, 1, 3, 2).contiguous().bfloat16().view(torch.int16)
+    assert torch.equal(pk, want)
