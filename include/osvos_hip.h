@@ -134,6 +134,13 @@ int osvos_conv3x3_wgrad_bf16act(const void* x_bf16, const void* dy_bf16, void* w
                                 int Cout, int Cout_s, int accumulate, void* stream);
 int osvos_maxpool2x2_bwd_bf16act(const void* x_bf16, const void* dy_bf16, const void* dside_bf16, void* dx_bf16, int N, int H, int W, int C,
                                  void* stream);
+/* pool-code bytes (round 5): the forward pooling also writes ONE byte per pooled element ([N][ceil(H/2)][ceil(W/2)][C]: bits 1:0 = window
+ * position of the first maximum in scan order (0,0) (0,1) (1,0) (1,1), bits 5:2 = "input at position q > 0"), and the backward reads that byte
+ * instead of the pool's four inputs (vgg_osvos.py:140 ceil-mode max-pool + the ReLU backward of the producing convolution + the side-branch
+ * add, as osvos_maxpool2x2_bwd_bf16act): same results bit for bit, 1 byte instead of 8 read per pooled element. */
+int osvos_maxpool2x2_bf16act_code(const void* x_bf16, void* y_bf16, void* code, int N, int H, int W, int C, void* stream);
+int osvos_maxpool2x2_bwd_bf16act_code(const void* code, const void* dy_bf16, const void* dside_bf16, void* dx_bf16, int N, int H, int W, int C,
+                                      void* stream);
 int osvos_conv3x3_bf16io_tiles(int* tiles, int max);
 int osvos_nchw_to_nhwc_bf16copy(const float* src, void* dst, void* dst_bf16, int N, int C, int H, int W, int cpad, void* stream);
 int osvos_maxpool2x2_bf16copy(const float* x, float* y, void* y_bf16, int N, int H, int W, int C, void* stream);

@@ -99,6 +99,13 @@ int osvos_maxpool2x2_bwd_bf16act(const void* x_bf16, const void* dy_bf16, const 
                                  void* stream) {
   return osvos_maxpool2x2_bwd_bf16(x_bf16, dy_bf16, dside_bf16, dx_bf16, N, H, W, C, (hipStream_t)stream);
 }
+int osvos_maxpool2x2_bf16act_code(const void* x_bf16, void* y_bf16, void* code, int N, int H, int W, int C, void* stream) {
+  return osvos_maxpool2x2_bf16_code(x_bf16, y_bf16, code, N, H, W, C, (hipStream_t)stream);
+}
+int osvos_maxpool2x2_bwd_bf16act_code(const void* code, const void* dy_bf16, const void* dside_bf16, void* dx_bf16, int N, int H, int W, int C,
+                                      void* stream) {
+  return osvos_maxpool2x2_bwd_bf16_code(code, dy_bf16, dside_bf16, dx_bf16, N, H, W, C, (hipStream_t)stream);
+}
 int osvos_conv3x3_bf16io_tiles(int* tiles, int max) { return osvos_conv3x3_bf16mfma_xb_tiles(tiles, max); }
 
 size_t osvos_conv3x3_splitk_ws_bytes(int N, int H, int W, int Cout, int dtype) {

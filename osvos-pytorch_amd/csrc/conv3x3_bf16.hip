@@ -32,6 +32,7 @@ struct ConvArgsB {
   const unsigned* mask_bits;   // ReLU mask as ONE BIT per element ([N][H][W][y_cs / 32] words, bit = channel % 32; maskbits.h): takes precedence over `mask`
   unsigned* y_bits;            // optional: the same for the result (written next to y / ybf by the forward of a layer whose output is a later mask)
   bf16_t* pooled;              // optional: maxpool2x2 (ceil mode) of the bf16 result, [N][ceil(H/2)][ceil(W/2)][y_cs] (last convolution of a stage; needs ReLU)
+  unsigned char* pool_code;    // optional, with pooled: one byte per pooled element for the pool's backward (pool.hip: first-max position + 4 "input > 0" bits)
   unsigned long long* prof;   // phase cycle counters (only read by builds with -DOSVOS_CONV_PROF; tools/conv_phase_probe.py)
 };
 
@@ -264,6 +265,8 @@ __global__ __launch_bounds__(C::NT, C::OCC) void conv3x3_bf16_kernel(ConvArgsB a
     const int PHo = (a.H + 1) / 2, PWo = (a.W + 1) / 2;
     const size_t poimg = (size_t)PHo * PWo * a.y_cs;
     const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(pool_fwd ? (void*)(a.pooled + n * poimg) : anyp, 0, pool_fwd ? (int)(poimg * 2) : 0, 0x00020000);
+    const bool pool_code = pool_fwd && a.pool_code != nullptr;
+    const __amdgpu_buffer_rsrc_t pcrs = __builtin_amdgcn_make_buffer_rsrc(pool_code ? (void*)(a.pool_code + n * poimg) : anyp, 0, pool_code ? (int)poimg : 0, 0x00020000);
     // one-bit masks (maskbits.h): words per pixel = y_cs / 32
     const int bw = a.y_cs >> 5;
     const size_t img_words = (size_t)a.H * a.W * bw;
@@ -351,20 +354,46 @@ __global__ __launch_bounds__(C::NT, C::OCC) void conv3x3_bf16_kernel(ConvArgsB a
           const unsigned ppix = writer ? (unsigned)(((oy >> 1) * PWo + (ox >> 1)) * a.y_cs) * 2u : OOB;
 #pragma unroll
           for (int pq = 0; pq < 2; ++pq) {
-            u16x8 m;
+            // this lane's column: r0 = its upper row, r1 = its lower row (RBW 16: for lanes li >= 16 the other way round -- they never write)
+            u32x4 r0, r1;
             if constexpr ((C::RBW == 32)) {
-              m = __builtin_elementwise_max(__builtin_bit_cast(u16x8, keep[2 * j][pq]), __builtin_bit_cast(u16x8, keep[2 * j + 1][pq]));
+              r0 = keep[2 * j][pq];
+              r1 = keep[2 * j + 1][pq];
             } else {
-              const u32x4 t = keep[j][pq];
-              const u32x4 u = {(unsigned)__shfl_xor((int)t[0], 16, 64), (unsigned)__shfl_xor((int)t[1], 16, 64), (unsigned)__shfl_xor((int)t[2], 16, 64),
-                               (unsigned)__shfl_xor((int)t[3], 16, 64)};
-              m = __builtin_elementwise_max(__builtin_bit_cast(u16x8, t), __builtin_bit_cast(u16x8, u));
+              r0 = keep[j][pq];
+              r1 = u32x4{(unsigned)__shfl_xor((int)r0[0], 16, 64), (unsigned)__shfl_xor((int)r0[1], 16, 64), (unsigned)__shfl_xor((int)r0[2], 16, 64),
+                         (unsigned)__shfl_xor((int)r0[3], 16, 64)};
             }
-            const u32x4 t = __builtin_bit_cast(u32x4, m);
-            const u32x4 u = {(unsigned)__shfl_xor((int)t[0], 1, 64), (unsigned)__shfl_xor((int)t[1], 1, 64), (unsigned)__shfl_xor((int)t[2], 1, 64),
-                             (unsigned)__shfl_xor((int)t[3], 1, 64)};
-            m = __builtin_elementwise_max(m, __builtin_bit_cast(u16x8, u));
+            u16x8 m = __builtin_elementwise_max(__builtin_bit_cast(u16x8, r0), __builtin_bit_cast(u16x8, r1));
             const int co = co0 + (wn * C::WN + ni) * 32 + 16 * pq + 8 * lh;
+            if (!pool_code) {
+              const u32x4 t = __builtin_bit_cast(u32x4, m);
+              const u32x4 u = {(unsigned)__shfl_xor((int)t[0], 1, 64), (unsigned)__shfl_xor((int)t[1], 1, 64), (unsigned)__shfl_xor((int)t[2], 1, 64),
+                               (unsigned)__shfl_xor((int)t[3], 1, 64)};
+              m = __builtin_elementwise_max(m, __builtin_bit_cast(u16x8, u));
+            } else {
+              // the neighbouring column's two rows arrive separately: the writer needs all four window values for the code byte
+              const u32x4 n0 = {(unsigned)__shfl_xor((int)r0[0], 1, 64), (unsigned)__shfl_xor((int)r0[1], 1, 64), (unsigned)__shfl_xor((int)r0[2], 1, 64),
+                                (unsigned)__shfl_xor((int)r0[3], 1, 64)};
+              const u32x4 n1 = {(unsigned)__shfl_xor((int)r1[0], 1, 64), (unsigned)__shfl_xor((int)r1[1], 1, 64), (unsigned)__shfl_xor((int)r1[2], 1, 64),
+                                (unsigned)__shfl_xor((int)r1[3], 1, 64)};
+              m = __builtin_elementwise_max(m, __builtin_elementwise_max(__builtin_bit_cast(u16x8, n0), __builtin_bit_cast(u16x8, n1)));
+              unsigned cw[2] = {0u, 0u};
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {      // scan order (0,0) (0,1) (1,0) (1,1), strict >: the first maximum (pool.hip); post-ReLU bf16 compare as u16
+                const int sh = 16 * (e & 1);
+                const unsigned av = (r0[e >> 1] >> sh) & 0xffffu, bv = (n0[e >> 1] >> sh) & 0xffffu;
+                const unsigned cv = (r1[e >> 1] >> sh) & 0xffffu, dv = (n1[e >> 1] >> sh) & 0xffffu;
+                unsigned bi = 0u, best = av;
+                if (bv > best) { best = bv; bi = 1u; }
+                if (cv > best) { best = cv; bi = 2u; }
+                if (dv > best) { bi = 3u; }
+                const unsigned byte = bi | (av ? 4u : 0u) | (bv ? 8u : 0u) | (cv ? 16u : 0u) | (dv ? 32u : 0u);
+                cw[e >> 2] |= byte << (8 * (e & 3));
+              }
+              typedef unsigned u32x2s __attribute__((ext_vector_type(2)));
+              __builtin_amdgcn_raw_buffer_store_b64(u32x2s{cw[0], cw[1]}, pcrs, (co < a.Cout && ppix != OOB) ? (ppix >> 1) + (unsigned)co : OOB, 0, 0);
+            }
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, m), prs, (co < a.Cout && ppix != OOB) ? ppix + (unsigned)co * 2u : OOB, 0, 0);
           }
         }
@@ -476,40 +505,58 @@ int pick_tile_b(int N, int H, int W, int CoutP, int Cin) {
 }
 
 // wpk[((tap*CG + cg)*CoutP + co)*8 + e] = bf16(W[co][8cg+e][tap])   (zero padded)
-__global__ void pack_fwd_bf16_kernel(const float* __restrict__ w, bf16_t* __restrict__ wpk, int Cout, int Cin, int CinP, int CoutP) {
-  const int CG = CinP / 8;
-  const long total = 9L * CG * CoutP * 8;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int e = (int)(i & 7);
-    long t = i >> 3;
-    const int co = (int)(t % CoutP);
-    t /= CoutP;
-    const int cg = (int)(t % CG);
-    const int tap = (int)(t / CG);
-    const int ci = cg * 8 + e;
-    wpk[i] = (co < Cout && ci < Cin) ? f32_to_bf16(w[((long)co * Cin + ci) * 9 + tap]) : (bf16_t)0;
-  }
-}
+// every layer's bf16 packs, forward and data-gradient form, in ONE launch (round 5 prep; the f32x3 twin is pack_x3_multi_kernel): osvos_net_pack
+// re-packs 17 filters x 2 forms after every optimizer step -- 34 launches of ~8 us each, one float per thread at a 36-byte stride.  A unit =
+// one (8-channel group cg of the reduction dimension, 32 output channels) block: its source values are whole contiguous runs of the OIHW
+// filter (forward: 72 floats per output channel; data gradient: 288 floats per reduction channel), turned through LDS, written as nine
+// 512-byte runs.  Reduction channels are padded to a multiple of 32 and output channels to a multiple of 32 with zeros, like the single packs.
+struct PackB16Table {
+  const float* w[OSVOS_PACK_MAX];
+  bf16_t* dst[OSVOS_PACK_MAX];
+  int Cout[OSVOS_PACK_MAX], Cin[OSVOS_PACK_MAX], dgrad[OSVOS_PACK_MAX];
+  long start[OSVOS_PACK_MAX + 1];      // in (cg, 32-channel) units
+  int n;
+};
 
-// data-gradient pack: roles swapped, filter rotated by 180 degrees
-__global__ void pack_dgrad_bf16_kernel(const float* __restrict__ w, bf16_t* __restrict__ wpk, int Cout, int Cin, int CoutK, int CinP) {
-  const int CG = CoutK / 8;
-  const long total = 9L * CG * CinP * 8;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int e = (int)(i & 7);
-    long t = i >> 3;
-    const int ci = (int)(t % CinP);
-    t /= CinP;
-    const int cog = (int)(t % CG);
-    const int tap = (int)(t / CG);
-    const int co = cog * 8 + e;
-    wpk[i] = (co < Cout && ci < Cin) ? f32_to_bf16(w[((long)co * Cin + ci) * 9 + (8 - tap)]) : (bf16_t)0;
+__global__ __launch_bounds__(256) void pack_bf16_multi_kernel(PackB16Table t) {
+  constexpr int ROW = 8 * 9 + 1;
+  __shared__ float tile[32 * ROW];
+  for (long blk = blockIdx.x; blk < t.start[t.n]; blk += gridDim.x) {
+    int k = 0;
+    while (blk >= t.start[k + 1]) ++k;
+    const int dgrad = t.dgrad[k], Cout = t.Cout[k], Cin = t.Cin[k];
+    const int K = dgrad ? Cout : Cin, M = dgrad ? Cin : Cout;       // reduction / output channels of the convolution this pack feeds
+    const int KP = (K + 31) / 32 * 32, MP = (M + 31) / 32 * 32, CG = KP / 8;
+    const int u = (int)(blk - t.start[k]);
+    const int cg = u % CG, m0 = (u / CG) * 32;
+    const float* __restrict__ w = t.w[k];
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 9; ++it) {
+      const int L = it * 256 + (int)threadIdx.x;
+      int ml, e, tap;
+      float v = 0.f;
+      if (dgrad) {                                           // row = reduction channel kk = 8 cg + e (a Cout index): [m0 .. m0 + 31][9] contiguous
+        e = L / 288;
+        const int j = L % 288;
+        ml = j / 9;
+        tap = 8 - j % 9;
+        if (m0 + ml < M && cg * 8 + e < K) v = w[((long)(cg * 8 + e) * Cin + m0) * 9 + j];
+      } else {                                               // row = output channel m0 + ml: [8 cg .. 8 cg + 7][9] contiguous (ragged at K = 3)
+        ml = L / 72;
+        const int j = L % 72;
+        e = j / 9;
+        tap = j % 9;
+        if (m0 + ml < M && cg * 8 + e < K) v = w[((long)(m0 + ml) * Cin + cg * 8) * 9 + j];
+      }
+      tile[ml * ROW + e * 9 + tap] = v;
+    }
+    __syncthreads();
+    const int ml = (int)threadIdx.x >> 3, e = (int)threadIdx.x & 7;
+    bf16_t* d = t.dst[k];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) d[(((long)tap * CG + cg) * MP + m0 + ml) * 8 + e] = f32_to_bf16(tile[ml * ROW + e * 9 + tap]);
   }
-}
-
-inline int grid_for(long total) {
-  long b = (total + 255) / 256;
-  return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
 }
 
 }  // namespace
@@ -518,16 +565,36 @@ int osvos_conv3x3_bf16mfma_num_tiles(void) { return kNumTilesB; }
 
 int osvos_pack_fwd_bf16(const float* w, void* wpk, int Cout, int Cin, hipStream_t stream) {
   OSVOS_ARG_CHECK(w && wpk && Cout > 0 && Cin > 0, "pack_fwd bf16: bad arguments");
-  const int CinP = (Cin + 31) / 32 * 32, CoutP = osvos_cout_pad(Cout);
-  hipLaunchKernelGGL(pack_fwd_bf16_kernel, dim3(grid_for(9L * CinP * CoutP)), dim3(256), 0, stream, w, (bf16_t*)wpk, Cout, Cin, CinP, CoutP);
-  OSVOS_LAUNCH_CHECK();
-  return 0;
+  const float* ws[1] = {w};
+  void* dsts[1] = {wpk};
+  const int co[1] = {Cout}, ci[1] = {Cin}, dg[1] = {0};
+  return osvos_pack_bf16_multi(ws, dsts, co, ci, dg, 1, stream);
 }
 
 int osvos_pack_dgrad_bf16(const float* w, void* wpk, int Cout, int Cin, hipStream_t stream) {
   OSVOS_ARG_CHECK(w && wpk && Cout > 0 && Cin > 0, "pack_dgrad bf16: bad arguments");
-  const int CoutK = (Cout + 31) / 32 * 32, CinP = osvos_cout_pad(Cin);
-  hipLaunchKernelGGL(pack_dgrad_bf16_kernel, dim3(grid_for(9L * CoutK * CinP)), dim3(256), 0, stream, w, (bf16_t*)wpk, Cout, Cin, CoutK, CinP);
+  const float* ws[1] = {w};
+  void* dsts[1] = {wpk};
+  const int co[1] = {Cout}, ci[1] = {Cin}, dg[1] = {1};
+  return osvos_pack_bf16_multi(ws, dsts, co, ci, dg, 1, stream);
+}
+
+// n bf16 packs (n <= OSVOS_PACK_MAX) in one launch: ws[k] OIHW fp32 [Couts[k]][Cins[k]][3][3] -> dsts[k] (osvos_pack_fwd_bf16 layout; dgrads[k] != 0:
+// osvos_pack_dgrad_bf16 layout)
+int osvos_pack_bf16_multi(const float* const* ws, void* const* dsts, const int* Couts, const int* Cins, const int* dgrads, int n, hipStream_t stream) {
+  OSVOS_ARG_CHECK(ws && dsts && Couts && Cins && dgrads && n >= 0 && n <= OSVOS_PACK_MAX, "pack_bf16_multi: bad table (n = %d)", n);
+  if (n == 0) return 0;
+  PackB16Table t;
+  t.n = n;
+  t.start[0] = 0;
+  for (int k = 0; k < n; ++k) {
+    const int K = dgrads[k] ? Couts[k] : Cins[k], M = dgrads[k] ? Cins[k] : Couts[k];
+    OSVOS_ARG_CHECK(ws[k] && dsts[k] && K > 0 && M > 0, "pack_bf16_multi: entry %d (K = %d, M = %d)", k, K, M);
+    t.w[k] = ws[k]; t.dst[k] = reinterpret_cast<bf16_t*>(dsts[k]); t.Cout[k] = Couts[k]; t.Cin[k] = Cins[k]; t.dgrad[k] = dgrads[k] ? 1 : 0;
+    t.start[k + 1] = t.start[k] + (long)(((K + 31) / 32 * 32) / 8) * (osvos_cout_pad(M) / 32);
+  }
+  const long blocks = t.start[n] < 8192 ? t.start[n] : 8192;
+  hipLaunchKernelGGL(pack_bf16_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, t);
   OSVOS_LAUNCH_CHECK();
   return 0;
 }
@@ -539,15 +606,17 @@ extern "C" void osvos_debug_set_conv_prof(void* p) { g_conv_prof = (unsigned lon
 // xb = 0: x fp32, xb = 1: x bf16; ybf (optional) receives a bf16 copy of y
 int osvos_conv3x3_bf16mfma_io(const void* x, int xb, const void* wpk, const float* bias, const void* mask, int mask_bf16, float* y, void* ybf,
                               int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int tile, hipStream_t stream) {
-  return osvos_conv3x3_bf16mfma_bits(x, xb, wpk, bias, mask, mask_bf16, nullptr, y, ybf, nullptr, nullptr, N, H, W, Cin, Cout, y_cs, relu, tile, stream);
+  return osvos_conv3x3_bf16mfma_bits(x, xb, wpk, bias, mask, mask_bf16, nullptr, y, ybf, nullptr, nullptr, N, H, W, Cin, Cout, y_cs, relu, tile, stream, nullptr);
 }
 
 // mask_bits: the ReLU mask as one bit per element (maskbits.h; takes precedence over `mask`); y_bits: sign bits of the result, written beside it
 // pooled_bf16 (optional; needs ybf, ReLU, a dense result with Cout % 8 == 0): maxpool2x2 (ceil mode) of the bf16 result, written by the same launch
 // ([N][ceil(H/2)][ceil(W/2)][Cout]; the 8 x 8-pixel tile cannot hold whole windows per wave: there the pooling kernel is launched behind the convolution)
+// pool_code (optional, with pooled_bf16): [N][ceil(H/2)][ceil(W/2)][Cout] bytes for osvos_maxpool2x2_bwd_bf16_code; written whichever kernel runs
 int osvos_conv3x3_bf16mfma_bits(const void* x, int xb, const void* wpk, const float* bias, const void* mask, int mask_bf16, const unsigned* mask_bits,
                                 float* y, void* ybf, unsigned* y_bits, void* pooled_bf16, int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int tile,
-                                hipStream_t stream) {
+                                hipStream_t stream, void* pool_code) {
+  OSVOS_ARG_CHECK(pool_code == nullptr || pooled_bf16 != nullptr, "conv3x3 bf16: pool code bytes without a pooled result");
   OSVOS_ARG_CHECK(pooled_bf16 == nullptr || (ybf != nullptr && relu && mask == nullptr && mask_bits == nullptr && Cout % 8 == 0 && y_cs == Cout),
                   "conv3x3 bf16: the fused forward pool needs a bf16 result, ReLU, no mask and a dense Cout %% 8 == 0 (Cout %d, stride %d)", Cout, y_cs);
   OSVOS_ARG_CHECK(x && wpk && (y || ybf), "conv3x3 bf16: null pointer");
@@ -564,6 +633,7 @@ int osvos_conv3x3_bf16mfma_bits(const void* x, int xb, const void* wpk, const fl
   a.x = x; a.wpk = reinterpret_cast<const uint4*>(wpk); a.bias = bias; a.mask = mask; a.mask_bf16 = mask_bf16 ? 1 : 0; a.y = y;
   a.ybf = reinterpret_cast<bf16_t*>(ybf);
   a.mask_bits = mask_bits; a.y_bits = y_bits; a.pooled = reinterpret_cast<bf16_t*>(pooled_bf16);
+  a.pool_code = reinterpret_cast<unsigned char*>(pool_code);
   a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.CinP = (Cin + 31) / 32 * 32; a.Cout = Cout; a.CoutP = osvos_cout_pad(Cout); a.y_cs = y_cs;
   a.relu = relu;
   a.prof = g_conv_prof;
@@ -585,12 +655,17 @@ int osvos_conv3x3_bf16mfma_bits(const void* x, int xb, const void* wpk, const fl
   tile %= 100;
   if (xb && tile >= 30 && tile <= 35) {      // LDS-DMA staged kernel
     OSVOS_ARG_CHECK(osvos_conv3x3_bf16_dma_applicable(Cin, Cout, y_cs), "conv3x3 bf16: tile %d (DMA staging) needs Cin %% 16 == 0, Cout, y_cs %% 8 == 0", tile);
+    if (pool_code != nullptr) {      // the DMA kernel's fused pool writes no code bytes: pooling (with them) as its own launch behind the convolution
+      const int rc = osvos_conv3x3_bf16_dma(x, wpk, bias, mask, mask_bf16, mask_bits, y, ybf, y_bits, nullptr, N, H, W, Cin, Cout, y_cs, relu, tile - 30, a.map, stream);
+      return rc ? rc : osvos_maxpool2x2_bf16_code(ybf, pooled_bf16, pool_code, N, H, W, Cout, stream);
+    }
     return osvos_conv3x3_bf16_dma(x, wpk, bias, mask, mask_bf16, mask_bits, y, ybf, y_bits, pooled_bf16, N, H, W, Cin, Cout, y_cs, relu, tile - 30, a.map, stream);
   }
   if (a.pooled != nullptr && !(xb && tile != 7 && tile >= 0 && tile < kNumTilesB)) {      // a tile whose waves do not hold whole windows: separate pooling launch
     a.pooled = nullptr;
-    const int rc = osvos_conv3x3_bf16mfma_bits(x, xb, wpk, bias, mask, mask_bf16, mask_bits, y, ybf, y_bits, nullptr, N, H, W, Cin, Cout, y_cs, relu, tile + 100 * a.map, stream);
-    return rc ? rc : osvos_maxpool2x2_bf16(ybf, pooled_bf16, N, H, W, Cout, stream);
+    const int rc = osvos_conv3x3_bf16mfma_bits(x, xb, wpk, bias, mask, mask_bf16, mask_bits, y, ybf, y_bits, nullptr, N, H, W, Cin, Cout, y_cs, relu, tile + 100 * a.map, stream,
+                                               nullptr);
+    return rc ? rc : osvos_maxpool2x2_bf16_code(ybf, pooled_bf16, pool_code, N, H, W, Cout, stream);
   }
   if (xb) {
     switch (tile) {

@@ -26,6 +26,7 @@ int osvos_conv3x3_wgrad_f32x3(const float* x, const float* dy, void* ws, float* 
                               int N, int H, int W, int Cin, int Cin_s, int Cout, int Cout_s, int accumulate, hipStream_t stream);
 size_t osvos_wpack_x3_bytes(int M, int K);
 #define OSVOS_PACK_MAX 40
+int osvos_pack_bf16_multi(const float* const* ws, void* const* dsts, const int* Couts, const int* Cins, const int* dgrads, int n, hipStream_t stream);
 int osvos_pack_x3_multi(const float* const* ws, void* const* dsts, const int* Couts, const int* Cins, const int* dgrads, int n, hipStream_t stream);
 int osvos_pack_x3(const float* w, void* wpk3, int Cout, int Cin, int dgrad, hipStream_t stream);
 int osvos_conv3x3_f32x3_ps(const float* x, const float* wpk, const void* wpk3, const float* bias, const float* mask, float* y,
@@ -48,6 +49,8 @@ int osvos_maxpool2x2_f32(const float* x, float* y, void* ybf, int N, int H, int 
 int osvos_maxpool2x2_bwd_f32(const float* x, const float* dy, const float* dside, float* dx, void* dxbf,
                              int N, int H, int W, int C, hipStream_t stream);
 int osvos_maxpool2x2_bf16(const void* x, void* y, int N, int H, int W, int C, hipStream_t stream);
+int osvos_maxpool2x2_bf16_code(const void* x, void* y, void* code, int N, int H, int W, int C, hipStream_t stream);
+int osvos_maxpool2x2_bwd_bf16_code(const void* code, const void* dy, const void* dside, void* dx, int N, int H, int W, int C, hipStream_t stream);
 int osvos_maxpool2x2_bwd_bf16(const void* x, const void* dy, const void* dside, void* dx, int N, int H, int W, int C, hipStream_t stream);
 int osvos_head_lowres_f32(const float* prep, const float* wd, const float* bd, const float* wf,
                           float* score, float* fpart, int N, int h, int w, hipStream_t stream);
@@ -78,7 +81,7 @@ int osvos_conv3x3_bf16mfma_num_tiles(void);
 // xb = 1: x is bf16 NHWC; ybf (optional): bf16 copy of y
 int osvos_conv3x3_bf16mfma_bits(const void* x, int xb, const void* wpk, const float* bias, const void* mask, int mask_bf16, const unsigned* mask_bits,
                                 float* y, void* ybf, unsigned* y_bits, void* pooled_bf16, int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int tile,
-                                hipStream_t stream);
+                                hipStream_t stream, void* pool_code = nullptr);
 int osvos_conv3x3_bf16mfma_io(const void* x, int xb, const void* wpk, const float* bias, const void* mask, int mask_bf16, float* y, void* ybf,
                               int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int tile, hipStream_t stream);
 int osvos_conv3x3_bf16mfma_xb_tiles(int* tiles, int max);

@@ -95,6 +95,9 @@ struct WsLayout {
   size_t xin_b, act_b[kNumTrunk], pooled_b[5], dy_b[kNumTrunk], dpool_b[5], dside_b[4], dprep_b[4];
   // sign bits of the activations that later serve as ReLU masks (maskbits.h; (size_t)-1 = none): [N][h][w][cout / 32] words
   size_t bits[kNumTrunk];
+  // bf16-store mode: one code byte per pooled element, written by the forward's pooling (fused epilogue or kernel), read by maxpool_bwd
+  // instead of the pool's input (pool.hip; (size_t)-1 = none)
+  size_t pool_code[5];
   size_t fwd_total, total;
 };
 
@@ -113,10 +116,17 @@ inline bool act_is_a_mask(const ConvDesc* d, int l, int dtype) {
   return is;
 }
 
+// A/B switch of the round-5 pool-code bytes (OSVOS_POOL_CODE=0: maxpool_bwd recomputes the argmax from the pool's input, as in rounds 1-4)
+inline bool use_pool_code() {
+  static const bool on = [] { const char* e = getenv("OSVOS_POOL_CODE"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
 WsLayout ws_layout(int N, int H, int W, int dtype) {
   WsLayout L;
   memset(&L, 0, sizeof(L));
   for (int l = 0; l < kNumTrunk; ++l) L.bits[l] = (size_t)-1;
+  for (int si = 0; si < 5; ++si) L.pool_code[si] = (size_t)-1;
   const size_t es = osvos_elem(dtype);
   L.hs[0] = H; L.ws[0] = W;
   for (int i = 1; i < 5; ++i) { L.hs[i] = (L.hs[i - 1] + 1) / 2; L.ws[i] = (L.ws[i - 1] + 1) / 2; }
@@ -139,6 +149,7 @@ WsLayout ws_layout(int N, int H, int W, int dtype) {
     const size_t e = (size_t)N * L.hs[si] * L.ws[si] * kStageC[si - 1];
     L.pooled[si] = take(te * e);
     L.pooled_b[si] = store ? L.pooled[si] : 0;
+    L.pool_code[si] = (store && use_pool_code()) ? take(e) : (size_t)-1;
   }
   for (int i = 0; i < 4; ++i) {
     const size_t npix = (size_t)N * L.hs[i + 1] * L.ws[i + 1];
@@ -230,7 +241,8 @@ inline bool use_presplit() {
 // (epi: fused pooling epilogues, f32x3 only -- fuse_pool() says when the caller may ask for them)
 inline int conv_main(const void* x, const void* x_b, const void* wpk, const float* bias, const void* mask, const void* mask_b, void* y, void* y_b,
                      int N, int h, int w, int cin, int cout, int y_cs, int relu, int dtype, void* part, hipStream_t stream, const void* wpk3 = nullptr,
-                     const ConvEpi* epi = nullptr, const void* mask_bits = nullptr, void* y_bits = nullptr, void* pooled_b = nullptr, void* sk_ws = nullptr) {
+                     const ConvEpi* epi = nullptr, const void* mask_bits = nullptr, void* y_bits = nullptr, void* pooled_b = nullptr, void* sk_ws = nullptr,
+                     void* pool_code = nullptr) {
   if (dtype == OSVOS_F32_X3 && osvos_conv3x3_f32x3_applicable(cin, cout, y_cs)) {    // three-way bf16 split on the bf16 matrix pipe
     ConvEpi e2;
     if (epi != nullptr) e2 = *epi;
@@ -246,7 +258,7 @@ inline int conv_main(const void* x, const void* x_b, const void* wpk, const floa
     return osvos_conv3x3_f32_ws((const float*)x, (const float*)wpk, bias, (const float*)mask, (float*)y, N, h, w, cin, cout, y_cs,
                                 relu, -1, part, stream);
   return osvos_conv3x3_bf16mfma_bits(x_b ? x_b : x, x_b ? 1 : 0, wpk, bias, mask_b ? mask_b : mask, mask_b ? 1 : 0, (const unsigned*)mask_bits, (float*)y, y_b,
-                                     (unsigned*)y_bits, pooled_b, N, h, w, cin, cout, y_cs, relu, -1, stream);
+                                     (unsigned*)y_bits, pooled_b, N, h, w, cin, cout, y_cs, relu, -1, stream, pooled_b ? pool_code : nullptr);
 }
 
 // f32x3 and the bf16-store mode: the forward max-pool of a stage boundary runs as an epilogue of the stage's last convolution (epi.h).
@@ -346,8 +358,15 @@ int osvos_net_pack(const float* const* params, void* wbuf, int dtype_, int with_
   const bool x3ps = dtype == OSVOS_F32_X3 && use_presplit();
   const float* xw[OSVOS_PACK_MAX]; void* xd[OSVOS_PACK_MAX]; int xco[OSVOS_PACK_MAX], xci[OSVOS_PACK_MAX], xdg[OSVOS_PACK_MAX];
   int nx = 0;
+  const bool b16 = dtype == OSVOS_F32_BF16MFMA;      // all bf16 packs (17 filters x 2 forms) in ONE launch too (round 5 prep)
   for (int l = 0; l < kNumConv; ++l) {
     int rc;
+    if (b16) {
+      xw[nx] = params[d[l].w_param]; xd[nx] = at(wbuf, L.fwd[l]); xco[nx] = d[l].cout; xci[nx] = d[l].cin; xdg[nx] = 0; ++nx;
+      if (with_dgrad) { xw[nx] = params[d[l].w_param]; xd[nx] = at(wbuf, L.dgrad[l]); xco[nx] = d[l].cout; xci[nx] = d[l].cin; xdg[nx] = 1; ++nx; }
+      srcs[ns] = params[d[l].b_param]; dsts[ns] = L.bias[l]; counts[ns] = d[l].cout; ++ns;
+      continue;
+    }
     if (!(x3ps && L.fwd3[l] != (size_t)-1) && (rc = osvos_pack_conv3x3_fwd(params[d[l].w_param], at(wbuf, L.fwd[l]), d[l].cout, d[l].cin, dtype, stream))) return rc;
     if (with_dgrad && !(x3ps && L.dgrad3[l] != (size_t)-1 && l != 0) &&
         (rc = osvos_pack_conv3x3_dgrad(params[d[l].w_param], at(wbuf, L.dgrad[l]), d[l].cout, d[l].cin, dtype, stream))) return rc;
@@ -356,7 +375,7 @@ int osvos_net_pack(const float* const* params, void* wbuf, int dtype_, int with_
     srcs[ns] = params[d[l].b_param]; dsts[ns] = L.bias[l]; counts[ns] = d[l].cout; ++ns;
   }
   if (nx > 0) {
-    const int rc = osvos_pack_x3_multi(xw, xd, xco, xci, xdg, nx, stream);
+    const int rc = b16 ? osvos_pack_bf16_multi(xw, xd, xco, xci, xdg, nx, stream) : osvos_pack_x3_multi(xw, xd, xco, xci, xdg, nx, stream);
     if (rc) return rc;
   }
 
@@ -416,7 +435,8 @@ int osvos_net_forward(const float* x_nchw, const void* wbuf, void* ws, float* co
       cur_b = store ? at(ws, L.pooled_b[si]) : nullptr;
     } else if (si > 0) {
       if (store)
-        rc = osvos_maxpool2x2_bf16(cur_b, at(ws, L.pooled_b[si]), N, L.hs[si - 1], L.ws[si - 1], kStageC[si - 1], stream);
+        rc = osvos_maxpool2x2_bf16_code(cur_b, at(ws, L.pooled_b[si]), L.pool_code[si] != (size_t)-1 ? at(ws, L.pool_code[si]) : nullptr, N, L.hs[si - 1],
+                                        L.ws[si - 1], kStageC[si - 1], stream);
       else
         rc = osvos_maxpool2x2_f32(reinterpret_cast<const float*>(cur), reinterpret_cast<float*>(at(ws, L.pooled[si])), sh(L.pooled_b[si]), N,
                                   L.hs[si - 1], L.ws[si - 1], kStageC[si - 1], stream);
@@ -433,7 +453,8 @@ int osvos_net_forward(const float* x_nchw, const void* wbuf, void* ws, float* co
         rc = conv_main(cur, cur_b, at(wbuf, P.fwd[l]), reinterpret_cast<const float*>(at(wbuf, P.bias[l])), nullptr, nullptr,
                        f32(L.act[l]), sh(L.act_b[l]), N, h, w, d[l].cin_s, d[l].cout, d[l].cout, 1, dtype, at(ws, L.conv_part), stream,
                        P.fwd3[l] != (size_t)-1 ? at(wbuf, P.fwd3[l]) : nullptr, (pool_here && !store) ? &epi : nullptr, nullptr,
-                       L.bits[l] != (size_t)-1 ? at(ws, L.bits[l]) : nullptr, (pool_here && store) ? at(ws, L.pooled_b[si + 1]) : nullptr, sk_ws);
+                       L.bits[l] != (size_t)-1 ? at(ws, L.bits[l]) : nullptr, (pool_here && store) ? at(ws, L.pooled_b[si + 1]) : nullptr, sk_ws,
+                       (pool_here && store && L.pool_code[si + 1] != (size_t)-1) ? at(ws, L.pool_code[si + 1]) : nullptr);
       }
       if (rc) return rc;
       cur = at(ws, L.act[l]);
@@ -767,7 +788,10 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
       const int ps2 = si - 1;
       const void* dside = ps2 >= 1 ? at(ws, L.dside[ps2 - 1]) : nullptr;
       if (dbg_skip() & 2) continue;
-      if (store)
+      if (store && L.pool_code[si] != (size_t)-1)      // one code byte per pooled element instead of the pool's four inputs
+        rc = osvos_maxpool2x2_bwd_bf16_code(at(ws, L.pool_code[si]), at(ws, L.dpool_b[si]), dside, at(ws, L.dy_b[l - 1]), N, L.hs[ps2], L.ws[ps2],
+                                            kStageC[ps2], stream);
+      else if (store)
         rc = osvos_maxpool2x2_bwd_bf16(at(ws, L.act_b[l - 1]), at(ws, L.dpool_b[si]), dside, at(ws, L.dy_b[l - 1]), N, L.hs[ps2], L.ws[ps2],
                                        kStageC[ps2], stream);
       else

@@ -117,6 +117,28 @@ def maxpool2x2_bf16act(x):
     return y
 
 
+def maxpool2x2_bf16act_code(x):
+    """bf16 pooling that also returns the pool-code bytes [N,Ho,Wo,C] (uint8) for maxpool2x2_bwd_bf16act_code"""
+    _need_cuda(x)
+    assert x.dtype == torch.bfloat16
+    n, h, w, c = x.shape
+    y = torch.empty((n, (h + 1) // 2, (w + 1) // 2, c), device=x.device, dtype=torch.bfloat16)
+    code = torch.empty((n, (h + 1) // 2, (w + 1) // 2, c), device=x.device, dtype=torch.uint8)
+    check(lib().osvos_maxpool2x2_bf16act_code(_p(x), _p(y), _p(code), n, h, w, c, _stream()), "maxpool_bf16act_code")
+    return y, code
+
+
+def maxpool2x2_bwd_bf16act_code(code, dy, hw, dside=None):
+    """the pool's backward from the code bytes; hw = (H, W) of the pool's input"""
+    _need_cuda(code, dy, dside)
+    assert code.dtype == torch.uint8 and dy.dtype == torch.bfloat16 and (dside is None or dside.dtype == torch.bfloat16)
+    n, _, _, c = dy.shape
+    h, w = hw
+    dx = torch.empty((n, h, w, c), device=dy.device, dtype=torch.bfloat16)
+    check(lib().osvos_maxpool2x2_bwd_bf16act_code(_p(code), _p(dy), _p(dside), _p(dx), n, h, w, c, _stream()), "maxpool_bwd_bf16act_code")
+    return dx
+
+
 def maxpool2x2_bwd_bf16act(x, dy, dside=None):
     _need_cuda(x, dy, dside)
     assert x.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16 and (dside is None or dside.dtype == torch.bfloat16)

@@ -670,3 +670,49 @@ def test_retain_graph_second_backward_and_autograds_own_error_without_it(precisi
         assert torch.equal(first[k], second[k]), k
     with pytest.raises(RuntimeError, match="second time|already been freed"):
         loss.backward()
+
+
+@pytest.mark.gpu
+def test_pool_code_bytes_change_nothing_but_the_bytes_read_bf16(tmp_path):
+    """Round 5, bf16-store mode: the forward's pooling (fused epilogue of the stage's last convolution, or its own launch) writes one code
+    byte per pooled element and maxpool_bwd reads it instead of the pool's input (OSVOS_POOL_CODE=1, default).  Logits, losses and EVERY
+    gradient must equal the run that recomputes the argmax from the input (OSVOS_POOL_CODE=0) BIT FOR BIT, with the pools fused and not
+    (OSVOS_FUSE_POOL=0/1: the epilogue's bytes against the pooling kernel's), at odd sizes with clipped windows on both axes and at batch 12.
+    (The LDS-DMA convolution of the deep stages, whose pooling then runs as its own launch, only engages at the BASELINE size: the
+    854x480 batch-12 parity test of tests/test_gpu_baseline_configs.py runs through it.)"""
+    import os, subprocess, sys, textwrap
+    code = textwrap.dedent('''
+        import sys, numpy as np, torch
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        import test_gpu_net as T
+        from oracle import synth
+        from layers.osvos_layers import class_balanced_cross_entropy_loss as cbce
+        res = {}
+        for tag, (n, h, w) in {"a": (2, 37, 53), "b": (2, 120, 214), "c": (12, 61, 107)}.items():
+            wts, x, m = synth.calibrated_problem(n, h, w, seed=9)
+            net = T.build_net(wts, "bf16")
+            xg = torch.from_numpy(x).requires_grad_()
+            outs = net.forward(xg.cuda())
+            gt = torch.from_numpy(m).cuda()
+            losses = [cbce(o, gt, size_average=False) for o in outs]
+            (0.5 * sum(losses[:-1]) + losses[-1]).backward()
+            for i, o in enumerate(outs):
+                res["%%s:out%%d" %% (tag, i)] = o.detach().cpu().numpy()
+            for k, v in net.named_parameters():
+                if v.grad is not None:
+                    res["%%s:g:%%s" %% (tag, k)] = v.grad.cpu().numpy()
+            res[tag + ":dx"] = xg.grad.numpy()
+        np.savez(sys.argv[1], **res)
+    ''') % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    got = {}
+    for fuse, pc in (("1", "0"), ("1", "1"), ("0", "1"), ("0", "0")):
+        out = str(tmp_path / ("f%s%s.npz" % (fuse, pc)))
+        env = dict(os.environ, OSVOS_FUSE_POOL=fuse, OSVOS_POOL_CODE=pc)
+        subprocess.run([sys.executable, "-c", code, out], check=True, env=env, timeout=900)
+        got[fuse + pc] = dict(np.load(out))
+    base = got["10"]
+    assert len(base) > 120
+    for tag in ("11", "01", "00"):
+        assert got[tag].keys() == base.keys()
+        for k in base:
+            assert np.array_equal(got[tag][k], base[k]), (tag, k, float(np.abs(got[tag][k] - base[k]).max()))

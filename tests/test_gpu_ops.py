@@ -1010,3 +1010,60 @@ def test_input_gradient_of_the_first_convolution_on_the_matrix_pipe(shape):
     assert emax < 2e-5 and el2 < 1e-5, (shape, emax, el2)
     emax, el2 = rel_err(dx.cpu(), F.conv_transpose2d(dyb.double(), wt.double(), padding=1))
     assert emax < 1e-2 and el2 < 4e-3, (shape, "vs the unrounded filter", emax, el2)
+
+
+@pytest.mark.gpu
+def test_pool_code_bytes_and_the_backward_that_reads_them():
+    """Round 5: the bf16 pooling writes one code byte per pooled element (first-maximum position in scan order + four "input > 0" bits) and
+    maxpool_bwd_code_kernel reads it instead of the pool's input.  The bytes against their definition in numpy (ties, exact zeros, all-zero
+    windows, clipped windows at odd sizes), the pooled values unchanged, and the backward BIT-IDENTICAL to the kernel that recomputes the
+    argmax from the input -- with and without a side gradient."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(77)
+    for shape in [(2, 16, 9, 13), (1, 64, 8, 8), (1, 8, 1, 1), (1, 24, 7, 2), (2, 128, 30, 54)]:
+        n, c, h, w = shape
+        x = F.relu(torch.randn(shape, generator=g)).bfloat16()
+        x[:, : c // 4] = (x[:, : c // 4] * 2).round() / 2           # plenty of exact ties
+        x[:, c // 4: c // 2, ::2, ::2] = 0                              # zeros inside windows
+        x[:, -1] = 0                                                    # all-zero windows
+        xg = nhwc(x.float()).bfloat16()
+        y, code = ops.maxpool2x2_bf16act_code(xg)
+        assert torch.equal(y, ops.maxpool2x2_bf16act(xg))
+        ho, wo = (h + 1) // 2, (w + 1) // 2
+        xp = torch.full((n, 2 * ho, 2 * wo, c), -1.0)                   # (-1: outside the image -- never a maximum, never positive)
+        xp[:, :h, :w] = xg.float().cpu()
+        win = torch.stack([xp[:, 0::2, 0::2], xp[:, 0::2, 1::2], xp[:, 1::2, 0::2], xp[:, 1::2, 1::2]], dim=-1)      # [n, ho, wo, c, 4] in scan order
+        best = win.argmax(dim=-1)                                       # torch.argmax returns the FIRST maximum
+        assert bool((win.gather(-1, best[..., None])[..., 0] == win.max(dim=-1).values).all())
+        first = (win == win.max(dim=-1, keepdim=True).values).float().argmax(dim=-1)      # first index holding the maximum, explicitly
+        pos = (win > 0).long()
+        want = first + 4 * pos[..., 0] + 8 * pos[..., 1] + 16 * pos[..., 2] + 32 * pos[..., 3]
+        assert torch.equal(code.cpu().long(), want), shape
+        dy = nhwc(torch.randn(n, c, ho, wo, generator=g)).bfloat16()
+        ds = nhwc(torch.randn(shape, generator=g)).bfloat16()
+        for side in (ds, None):
+            a = ops.maxpool2x2_bwd_bf16act_code(code, dy, (h, w), side)
+            b = ops.maxpool2x2_bwd_bf16act(xg, dy, side)
+            assert torch.equal(a, b), (shape, side is None)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cout,cin", [(64, 3), (64, 64), (128, 64), (512, 512), (16, 256), (40, 24)])
+@pytest.mark.parametrize("dgrad", [False, True])
+def test_pack_bf16_layout_bit_exact(cout, cin, dgrad):
+    """The bf16 packs (round 5: whole contiguous runs of the OIHW filter turned through LDS, all of a network's packs in one launch) against
+    their definition, BIT FOR BIT: pack[tap][cg][m][e] = bf16_rne(W[m][8 cg + e][tap]) (forward) or bf16_rne(W[8 cg + e][m][8 - tap]) (data
+    gradient); reduction channels zero padded to a multiple of 32 (conv1_1: 3 -> 32), output channels to a multiple of 32."""
+    from osvos_pytorch_amd._lib import F32_BF16MFMA
+    ops = _ops()
+    g = torch.Generator().manual_seed(cout * 5 + cin + int(dgrad))
+    wt = torch.randn(cout, cin, 3, 3, generator=g)
+    buf = (ops.pack_dgrad if dgrad else ops.pack_fwd)(wt.cuda(), F32_BF16MFMA)
+    k, m = (cout, cin) if dgrad else (cin, cout)
+    kp, mp = (k + 31) // 32 * 32, (m + 31) // 32 * 32
+    pk = buf.view(torch.int16)[: 9 * (kp // 8) * mp * 8].view(9, kp // 8, mp, 8).cpu()
+    want = torch.zeros(9, kp, mp)
+    src = wt.flip(2, 3).permute(1, 0, 2, 3) if dgrad else wt                   # [m][k][3][3], tap -> 8 - tap for the data gradient
+    want[:, :k, :m] = src.reshape(m, k, 9).permute(2, 1, 0)
+    want = want.view(9, kp // 8, 8, mp).permute(0, 1, 3, 2).contiguous().bfloat16().view(torch.int16)
+    assert torch.equal(pk, want)
