@@ -199,6 +199,95 @@ def cpu_baseline(h, w, mode, n_ave, budget_s=20.0):
                       "(oneDNN), median after 1 warm-up" % (len(timed), mode, w, h, torch.__version__)}
 
 
+PARITY_BARS = {      # SURVEY.md 8(d) "Parity tolerances": GPU path vs the reference CPU fp32 path on the same inputs
+    "f32": {"max_dlogit_over_std": 1e-3, "loss_rel": 1e-5, "grad_rel_l2": 1e-3, "iou": 1.0 - 1e-3},
+    # bf16: logits / loss / gradients are SURVEY's bars; the survey gives no IoU bar for bf16 on a random-weight net ("reported with margin
+    # statistics": torch-CPU bf16 autocast itself reaches 0.9894 there, App. E) -- the gate uses the floor tests/test_gpu_baseline_configs.py asserts
+    "bf16": {"max_dlogit_over_std": 0.1, "loss_rel": 2e-3, "grad_rel_l2": 0.25, "iou": 0.985},
+}
+
+
+def parity_gate(wl):
+    """BASELINE.json's metric is "frames/sec ...; mask IoU vs ref" and BASELINE.md section 3 reports logit / loss / gradient / IoU parity with
+    every timing: ONE micro-batch of the net that is about to be timed -- the timed step's own calls (Workload._micro_batch), the bench's own
+    tensors and weights -- against the CPU oracle (oracle/torch_ref.py = the reference's forward vgg_osvos.py:59-74, loss
+    osvos_layers.py:19-48, and loss / nAveGrad backward train_online.py:124-141) on the host cores.  Runs before the settle / warm-up /
+    timed steps and is not part of any timed region; the oracle is the checker here, never the thing measured."""
+    from collections import OrderedDict
+    from oracle import torch_ref
+    t_start = time.perf_counter()
+    net, infer = wl.net, wl.mode == "infer"
+    sd = OrderedDict((k, v.detach().cpu().numpy().copy()) for k, v in net.state_dict().items())
+    x, gt = wl.x.detach().cpu(), wl.gt.detach().cpu()
+    if infer:
+        with torch.no_grad():
+            outs, losses, grads = net.forward(wl.x), [], {}
+    else:
+        wl.opt.zero_grad()
+        outs, losses = wl._micro_batch(False)
+        net.join_backward()
+        if wl.x.is_cuda:
+            torch.cuda.synchronize()
+        grads = {k: p.grad.detach().cpu().double() for k, p in net.named_parameters() if p.grad is not None}
+        losses = [float(l) for l in (losses.tolist() if torch.is_tensor(losses) else losses)]
+        wl.opt.zero_grad()
+        wl.running.zero_()
+    got = [o.detach().cpu().double() for o in outs]
+    del outs
+    nthreads = torch.get_num_threads()
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+    try:
+        p = torch_ref.as_leaf_params(sd, requires_grad=not infer)
+        if infer:
+            with torch.no_grad():
+                r_outs = torch_ref.forward(p, x)
+            r_losses, r_grads = [], {}
+        else:
+            r_outs = torch_ref.forward(p, x.clone().requires_grad_())
+            if wl.mode == "online":
+                r_l = [torch_ref.cbce_loss(r_outs[-1], gt, size_average=False)]
+                total = r_l[0]
+            else:
+                r_l = [torch_ref.cbce_loss(o, gt, size_average=False) for o in r_outs]
+                total = (1 - wl.epoch / 240) * sum(r_l[:-1]) + r_l[-1]          # train_parent.py:147
+            (total / wl.n_ave).backward()                                        # train_online.py:140-141
+            r_losses = [float(l.detach()) for l in r_l]
+            r_grads = {k: v.grad.double() for k, v in p.items() if v.grad is not None}
+    finally:
+        torch.set_num_threads(nthreads)
+    ref = [o.detach().double() for o in r_outs]
+    heads = range(5) if wl.mode != "online" else [4]
+    dl = {i: float((got[i] - ref[i]).abs().max() / ref[i].std()) for i in heads}
+    fused_g, fused_r = got[4] > 0, ref[4] > 0                                    # sigmoid(x) > 0.5  <=>  x > 0 (train_online.py:181-187)
+    union = int((fused_g | fused_r).sum())
+    iou = float((fused_g & fused_r).sum()) / union if union else 1.0
+    res = {"against": "oracle/torch_ref.py (the reference's forward / class-balanced loss / backward restated on torch CPU fp32, pinned to "
+                      "reference-made goldens in tests/) on THIS run's frames, labels and weights; one micro-batch of the timed step's own calls",
+           "dtype": DTYPE_NAME[wl.precision].split(";")[0][:40], "batch": int(wl.batch), "frame": "%dx%d" % (wl.w, wl.h),
+           "max_dlogit_over_std": float("%.3g" % max(dl.values())), "max_dlogit_over_std_fused": float("%.3g" % dl[4]),
+           "iou": round(iou, 6), "fused_positive_fraction": round(float(fused_r.float().mean()), 4),
+           "flipped_pixels": int((fused_g != fused_r).sum())}
+    bars = dict(PARITY_BARS["bf16" if wl.precision == "bf16" else "f32"])
+    ok = res["max_dlogit_over_std"] <= bars["max_dlogit_over_std"] and iou >= bars["iou"]
+    if not infer:
+        lrel = [abs(a - b) / abs(b) for a, b in zip(losses, r_losses)]
+        res["loss"] = [float("%.9g" % v) for v in losses]
+        res["loss_ref"] = [float("%.9g" % v) for v in r_losses]
+        res["loss_rel"] = float("%.3g" % max(lrel))
+        gerr = {k: float((grads[k] - r_grads[k]).norm() / r_grads[k].norm()) for k in grads if k in r_grads and float(r_grads[k].norm()) > 0}
+        named = ["stages.0.0.weight", "stages.2.1.weight", "fuse.weight"]
+        res["grad_rel_l2"] = {k: float("%.3g" % gerr[k]) for k in named if k in gerr}
+        worst = max(gerr, key=gerr.get)
+        res["grad_rel_l2_worst"] = {"tensor": worst, "value": float("%.3g" % gerr[worst]), "tensors_compared": len(gerr)}
+        ok = ok and res["loss_rel"] <= bars["loss_rel"] and gerr[worst] <= bars["grad_rel_l2"]
+    else:
+        bars.pop("loss_rel"), bars.pop("grad_rel_l2")
+    res["bars"] = bars
+    res["within_bars"] = bool(ok)
+    res["seconds"] = round(time.perf_counter() - t_start, 1)
+    return res
+
+
 class Workload(object):
     """One benchmark configuration: builds the net + synthetic batch, exposes step()."""
 
@@ -308,42 +397,8 @@ class Workload(object):
 
     def _train_step(self):
         # body of train_online.py:116-149 (train_parent.py:132-172 for --mode parent)
-        inputs = self.x.detach().requires_grad_()         # train_online.py:121: the input gradient is computed
-        outputs = self.net.forward(inputs)
         arm = self.reducer is not None and (self.ave + 1) % self.n_ave == 0      # last micro-batch of the step: chunked all-reduce behind the gradient-ready events
-        if self.fused_loss:
-            # TrainLoop._micro_batch_fused: loss, running_loss += loss and the gradient of loss / nAveGrad out of ONE call per head
-            inv = np.float32(1.0) / np.float32(self.n_ave)
-            heads = [outputs[-1]] if self.mode == "online" else list(outputs)
-            scales = [inv] if self.mode == "online" else [np.float32(inv * np.float32(1 - self.epoch / 240))] * 4 + [inv]
-            if len(heads) > 1 and os.environ.get('OSVOS_CBCE_MULTI', '1') != '0':      # the parent loop's five losses in one library call, as TrainLoop does
-                losses, grads = self.cbce_step_multi(heads, self.gt, size_average=False, grad_scales=[float(sc) for sc in scales],
-                                                     running=[None] * (len(heads) - 1) + [self.running])
-                loss = losses[-1]
-            else:
-                grads = []
-                for k, (o, sc) in enumerate(zip(heads, scales)):
-                    loss, g = self.cbce_step(o, self.gt, size_average=False, grad_scale=float(sc), running=self.running if k == len(heads) - 1 else None)
-                    grads.append(g)
-            if self.item_sync:
-                loss.item()                               # train_online.py:128: D2H sync every iteration
-            if arm:
-                self.reducer.arm()
-            torch.autograd.backward(heads, grads)
-        else:
-            if self.mode == "online":
-                loss = self.cbce(outputs[-1], self.gt, size_average=False)
-            else:
-                losses = [self.cbce(o, self.gt, size_average=False) for o in outputs]
-                loss = (1 - self.epoch / 240) * sum(losses[:-1]) + losses[-1]
-            if self.item_sync:
-                self.running.add_(loss.item())            # train_online.py:128: D2H sync every iteration
-            else:
-                self.running.add_(loss.detach())
-            loss /= self.n_ave
-            if arm:
-                self.reducer.arm()
-            loss.backward()
+        self._micro_batch(arm)
         self.ave += 1
         self.nsteps += 1
         if self.ave % self.n_ave == 0:
@@ -356,6 +411,48 @@ class Workload(object):
             else:
                 self.opt.zero_grad()
             self.ave = 0
+
+    def _micro_batch(self, arm=False):
+        """forward + loss(es) + backward of one micro-batch as the timed step runs it; returns (outputs, per-head losses) -- the parity gate reads them."""
+        inputs = self.x.detach().requires_grad_()         # train_online.py:121: the input gradient is computed
+        outputs = self.net.forward(inputs)
+        if self.fused_loss:
+            # TrainLoop._micro_batch_fused: loss, running_loss += loss and the gradient of loss / nAveGrad out of ONE call per head
+            inv = np.float32(1.0) / np.float32(self.n_ave)
+            heads = [outputs[-1]] if self.mode == "online" else list(outputs)
+            scales = [inv] if self.mode == "online" else [np.float32(inv * np.float32(1 - self.epoch / 240))] * 4 + [inv]
+            if len(heads) > 1 and os.environ.get('OSVOS_CBCE_MULTI', '1') != '0':      # the parent loop's five losses in one library call, as TrainLoop does
+                losses, grads = self.cbce_step_multi(heads, self.gt, size_average=False, grad_scales=[float(sc) for sc in scales],
+                                                     running=[None] * (len(heads) - 1) + [self.running])
+                loss = losses[-1]
+            else:
+                grads, losses = [], []
+                for k, (o, sc) in enumerate(zip(heads, scales)):
+                    loss, g = self.cbce_step(o, self.gt, size_average=False, grad_scale=float(sc), running=self.running if k == len(heads) - 1 else None)
+                    grads.append(g)
+                    losses.append(loss)
+            if self.item_sync:
+                loss.item()                               # train_online.py:128: D2H sync every iteration
+            if arm:
+                self.reducer.arm()
+            torch.autograd.backward(heads, grads)
+        else:
+            if self.mode == "online":
+                loss = self.cbce(outputs[-1], self.gt, size_average=False)
+                losses = [loss.detach().clone()]
+            else:
+                losses = [self.cbce(o, self.gt, size_average=False) for o in outputs]
+                loss = (1 - self.epoch / 240) * sum(losses[:-1]) + losses[-1]
+                losses = [l.detach().clone() for l in losses]
+            if self.item_sync:
+                self.running.add_(loss.item())            # train_online.py:128: D2H sync every iteration
+            else:
+                self.running.add_(loss.detach())
+            loss /= self.n_ave
+            if arm:
+                self.reducer.arm()
+            loss.backward()
+        return outputs, losses
 
     def _window_step(self):
         # TrainLoop.window_batch: one forward / loss / backward over the window's frames, then the optimizer step
@@ -717,6 +814,7 @@ def main():
                     "different frames as ONE batch with per-image class counts (TrainLoop.window_batch): the reference gradient up to summation "
                     "order.  A labelled secondary line; the headline stays the micro-batch loop")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the parity gate (one micro-batch of the net about to be timed vs the CPU oracle)")
     ap.add_argument("--no-prof", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip extra_configs (configs[2], configs[4]) and the item-sync figure")
     args = ap.parse_args()
@@ -759,6 +857,12 @@ def main():
         ranks_seen = int(t.item())              # = number of ranks RCCL actually reaches
     wl = Workload(args.mode, args.precision, args.height, args.width, args.batch, args.graph, args.n_ave_grad, args.item_sync,
                   device, rank, ctl, args.force_dist, graph_train=args.graph_train, comm=comm, window=args.window_fused)
+    parity = None
+    if rank == 0 and world == 1 and ctl is None and not args.no_parity and not args.window_fused and not args.graph_train:
+        try:
+            parity = parity_gate(wl)
+        except Exception as e:      # the timing must still be reported; a missing gate shows in the line
+            parity = {"error": repr(e)[:300]}
     res = measure(wl, args.steps, args.warmup, args.min_seconds, world, ctl, device, use_prof=not args.no_prof, settle_seconds=args.settle_seconds)
     settle = res["settle_steps"]
     frames_per_step = wl.batch
@@ -781,7 +885,7 @@ def main():
         import subprocess
         torch.cuda.synchronize()
         for (name, extra_args) in [
-                ("configs[1] on the EXACT fp32 MFMA kernels (v_mfma_f32_32x32x2_f32): same loop, precision 'fp32'", ["--precision", "fp32"]),
+                ("configs[1] on the EXACT fp32 MFMA kernels (v_mfma_f32_32x32x2_f32): same loop, precision 'fp32'", ["--precision", "fp32"]),       # (carries its own parity gate too)
                 ("configs[1] semantics, window-fused: the 5 micro-batches of an optimizer step (5 different frames) as ONE batch-5 pass with per-image "
                  "class counts -- the reference gradient up to summation order (tests/test_gpu_baseline_configs.py); what TrainLoop.window_batch / "
                  "train_online.py --window-fused run", ["--window-fused", "1"]),
@@ -789,7 +893,7 @@ def main():
                 ("configs[4]: 1920x1080 inference-only forward, batch=4, hipGraph-captured (f32x3)",
                  ["--mode", "infer", "--height", "1080", "--width", "1920", "--batch", "4", "--graph", "1"]),
                 ("configs[4] on the EXACT fp32 MFMA kernels",
-                 ["--mode", "infer", "--height", "1080", "--width", "1920", "--batch", "4", "--graph", "1", "--precision", "fp32"])]:
+                 ["--mode", "infer", "--height", "1080", "--width", "1920", "--batch", "4", "--graph", "1", "--precision", "fp32", "--no-parity"])]:
             cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(max(10, min(args.steps, 30))),
                    "--warmup", str(max(3, min(args.warmup, 5))), "--min-seconds", str(args.min_seconds), "--no-extra", "--no-cpu-baseline"] + extra_args
             try:
@@ -801,7 +905,7 @@ def main():
                 extras.append({"config": name, "command": "python bench.py " + " ".join(cmd[2:]), "workload": d["config"]["workload"],
                                "value": d["value"], "unit": d["unit"], "steps": d["steps"], "setup_settle_steps": d.get("setup_settle_steps"),
                                "ms_per_step": d["ms_per_step"], "dtype": d["dtype"],
-                               "sustained": d.get("sustained"), "roofline": d.get("roofline")})
+                               "sustained": d.get("sustained"), "parity": d.get("parity"), "roofline": d.get("roofline")})
             except Exception as e:  # the headline must still be reported
                 extras.append({"config": name, "error": repr(e)})
         # the headline command once more WITHOUT the settle phase, in its own process: what the ramp out of the idle power state costs a
@@ -843,9 +947,10 @@ def main():
                 workload += ("; WINDOW-FUSED: one step = the %d micro-batches of an optimizer step (%d different frames) as ONE forward / backward "
                              "with per-image class counts + the SGD step" % (n_ave * args.batch, n_ave * args.batch))
         line = {
-            "metric": ("frames/sec (fwd+bwd) OSVOS-VGG16 854x480 per GPU" if (args.height, args.width) == (480, 854) else
-                       "frames/sec (fwd+bwd) OSVOS-VGG16 %dx%d" % (args.width, args.height)) if args.mode != "infer" else
-                      "frames/sec (forward only) OSVOS-VGG16 %dx%d" % (args.width, args.height),
+            # BASELINE.json's metric string; its second half (mask IoU vs ref) is the `parity` object below
+            "metric": ("frames/sec (fwd+bwd) OSVOS-VGG16 854x480 per GPU; mask IoU vs ref" if (args.height, args.width) == (480, 854) else
+                       "frames/sec (fwd+bwd) OSVOS-VGG16 %dx%d; mask IoU vs ref" % (args.width, args.height)) if args.mode != "infer" else
+                      "frames/sec (forward only) OSVOS-VGG16 %dx%d; mask IoU vs ref" % (args.width, args.height),
             "value": round(res["value"], 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "setup_settle_steps": settle,      # untimed SETUP steps before the warm-up (device out of its idle power state; --settle-seconds)
             "value_without_settle": no_settle,
@@ -860,6 +965,7 @@ def main():
                        # class-balance counts (osvos_layers.py:28-34) run over each rank's own batch: every rank's batch is its own reference batch
                        # (weak scaling).  Sharding ONE batch over ranks needs parallel.global_class_counts / cbce_with_counts (tests/test_parallel_gloo.py)
                        "loss_class_counts": "per-rank batch" if world > 1 else "whole batch"},
+            "parity": parity,
             "roofline": res["roofline"], "cpu_baseline": base,
             "sustained": res.get("sustained"),
             "timed_region_detail": res.get("timing_detail"),

@@ -599,8 +599,15 @@ int osvos_pack_bf16_multi(const float* const* ws, void* const* dsts, const int* 
   return 0;
 }
 
+// phase-counter hook of tools/conv_phase_probe.py: exists only in probe builds (make EXTRA=-DOSVOS_CONV_PROF); the shipped library has no
+// process-global device pointer behind its re-entrant ABI
+#ifdef OSVOS_CONV_PROF
 static unsigned long long* g_conv_prof = nullptr;
 extern "C" void osvos_debug_set_conv_prof(void* p) { g_conv_prof = (unsigned long long*)p; }
+#define OSVOS_CONV_PROF_PTR g_conv_prof
+#else
+#define OSVOS_CONV_PROF_PTR nullptr
+#endif
 
 // x fp32 NHWC (stride Cin, multiple of 8), wpk from osvos_pack_{fwd,dgrad}_bf16 with the same Cin/Cout roles
 // xb = 0: x fp32, xb = 1: x bf16; ybf (optional) receives a bf16 copy of y
@@ -636,7 +643,7 @@ int osvos_conv3x3_bf16mfma_bits(const void* x, int xb, const void* wpk, const fl
   a.pool_code = reinterpret_cast<unsigned char*>(pool_code);
   a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.CinP = (Cin + 31) / 32 * 32; a.Cout = Cout; a.CoutP = osvos_cout_pad(Cout); a.y_cs = y_cs;
   a.relu = relu;
-  a.prof = g_conv_prof;
+  a.prof = OSVOS_CONV_PROF_PTR;
   if (tile < 0) {
     OSVOS_ENV_INT(env_tile, "OSVOS_CONV_TILE_BF16", -1);
     const bool env = env_tile >= 0;

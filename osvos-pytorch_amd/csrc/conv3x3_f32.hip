@@ -409,8 +409,15 @@ size_t osvos_conv3x3_splitk_ws_bytes_f32(int N, int H, int W, int Cout) {
 }
 
 // part_ws: NULL (never split) or a buffer of osvos_conv3x3_splitk_ws_bytes_f32() for the split-K partial sums
+// phase-counter hook of tools/conv_phase_probe.py: exists only in probe builds (make EXTRA=-DOSVOS_CONV_PROF); the shipped library has no
+// process-global device pointer behind its re-entrant ABI
+#ifdef OSVOS_CONV_PROF
 static unsigned long long* g_conv_prof_f32 = nullptr;
 extern "C" void osvos_debug_set_conv_prof_f32(void* p) { g_conv_prof_f32 = (unsigned long long*)p; }
+#define OSVOS_CONV_PROF_PTR g_conv_prof_f32
+#else
+#define OSVOS_CONV_PROF_PTR nullptr
+#endif
 static thread_local int g_force_ksplit = 0;      // tests / tuning: osvos_conv3x3_splitk(..., ksplit > 0, ...)
 void osvos_conv3x3_force_ksplit(int k) { g_force_ksplit = k; }
 
@@ -445,7 +452,7 @@ int osvos_conv3x3_f32_ws(const float* x, const float* wpk, const float* bias, co
   tile %= 100;
   OSVOS_ARG_CHECK(tile >= 0 && tile < kNumTiles, "conv3x3: unknown tile config %d", tile);
   a.ksplit = 1;
-  a.prof = g_conv_prof_f32;
+  a.prof = OSVOS_CONV_PROF_PTR;
   a.part = reinterpret_cast<float*>(part_ws);
   if (part_ws != nullptr) {
     // OSVOS_CONV_KSPLIT overrides the automatic choice, but only where the automatic choice could split as well (Cin >= 256):

@@ -9,6 +9,7 @@
 #include "prof.h"
 
 namespace {
+inline int streamk_mode();      // (defined with the other process-cached switches below)
 
 constexpr int kStageN[5] = {2, 2, 3, 3, 3};
 constexpr int kStageC[5] = {64, 128, 256, 512, 512};
@@ -165,7 +166,8 @@ WsLayout ws_layout(int N, int H, int W, int dtype) {
         if (b > mx) mx = b;
       }
     L.conv_part = take(mx);
-    L.sk_ws = dtype == OSVOS_F32_X3 ? take(osvos_conv3x3_f32x3_streamk_ws_bytes()) : (size_t)-1;
+    // stream-K is opt-in (OSVOS_X3_STREAMK, read once per process): its 64 MiB of tickets + partial tiles exist only in layouts that use them
+    L.sk_ws = (dtype == OSVOS_F32_X3 && streamk_mode() >= 1) ? take(osvos_conv3x3_f32x3_streamk_ws_bytes()) : (size_t)-1;
     // side_prep[i]: Cout = 16 on a small frame is a handful of workgroups walking K = 9 Cin serially (88 us for 0.24 GFLOP at
     // 30 x 54) -- and the last one sits exposed between conv5_3 and the head.  K splits turn it into a full-chip launch.
     for (int i = 0; i < 4; ++i)
