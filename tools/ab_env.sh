@@ -4,7 +4,7 @@ ARGS=$1; shift
 for rnd in 1 2; do
   for e in "$@"; do
     [ "$e" == "-" ] && e=""
-    v=$(env $e python bench.py --steps 40 --warmup 20 --no-extra --no-cpu-baseline --min-seconds 1 $ARGS 2>/dev/null | python -c "
+    v=$(env $e python bench.py --steps 40 --warmup 20 --no-extra --no-cpu-baseline --no-parity --min-seconds 1 $ARGS 2>/dev/null | python -c "
 import sys, json
 d = json.loads([l for l in sys.stdin if l.startswith('{')][-1])
 print('%.1f fps  %.3f ms/step  (sustained %.1f)' % (d['value'], d['ms_per_step'], d.get('sustained', {}).get('value', 0)))")
