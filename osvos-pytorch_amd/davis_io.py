@@ -78,8 +78,26 @@ class ArrayFrames(object):
         return self.frames[idx]
 
 
-_PINNED = {}      # (slot, shapes) -> pinned staging buffers, kept for the life of the process: pinning host memory costs milliseconds per buffer,
-                  # and train_parent.py builds one prefetcher per epoch (profiles/r04_scripts_e2e.txt: the feeder stall of round 4)
+_POOL = {}        # (image shape, label shape) -> free pinned (image, label) staging pairs, kept for the life of the process: pinning host memory costs
+                  # milliseconds per buffer and train_parent.py builds one prefetcher per epoch (profiles/r04_scripts_e2e.txt: the feeder stall of
+                  # round 4).  A pair belongs to exactly ONE prefetcher between _take and _give: two live prefetchers never share a buffer, and a
+                  # prefetcher gives its pairs back only after its producer has stopped and its in-flight copies have completed (close()).
+_POOL_LOCK = threading.Lock()
+
+
+def _take(img_shape, lab_shape):
+    key = (tuple(img_shape), tuple(lab_shape) if lab_shape is not None else None)
+    with _POOL_LOCK:
+        free = _POOL.setdefault(key, [])
+        if free:
+            return key, free.pop()
+    return key, (torch.empty(img_shape, dtype=torch.uint8).pin_memory(),
+                 torch.empty(lab_shape, dtype=torch.uint8).pin_memory() if lab_shape is not None else None)
+
+
+def _give(key, pair):
+    with _POOL_LOCK:
+        _POOL.setdefault(key, []).append(pair)
 
 
 class DevicePrefetcher(object):
@@ -107,55 +125,95 @@ class DevicePrefetcher(object):
         self.free = queue.Queue()                        # slots the consumer has finished copying out of
         for k in range(self.depth + 2):
             self.free.put(k)
-        self.slots = [None] * (self.depth + 2)           # pinned (img, lab) buffers, allocated at the first frame's size
+        self.slots = [None] * (self.depth + 2)           # (pool key, pinned (img, lab) pair) per slot, taken from the pool at the first frame's size
+        self._stop, self._closed, self._inflight = threading.Event(), False, []
         self.thread = threading.Thread(target=self._produce, daemon=True)
         self.thread.start()
 
     def _pinned(self, k, img, lab):
         cur = self.slots[k]
-        if cur is None or cur[0].shape != img.shape or (lab is not None and (cur[1] is None or cur[1].shape != lab.shape)):
-            key = (k, tuple(img.shape), tuple(lab.shape) if lab is not None else None)
-            cur = _PINNED.get(key)
-            if cur is None:
-                cur = _PINNED[key] = (torch.empty(img.shape, dtype=torch.uint8).pin_memory(),
-                                      torch.empty(lab.shape, dtype=torch.uint8).pin_memory() if lab is not None else None)
-            self.slots[k] = cur
-        return cur
+        want = (tuple(img.shape), tuple(lab.shape) if lab is not None else None)
+        if cur is None or cur[0] != want:
+            if cur is not None:
+                _give(*cur)                              # (only reached for slots whose copies have completed: the slot came off self.free)
+            cur = self.slots[k] = _take(img.shape, lab.shape if lab is not None else None)
+        return cur[1]
 
     def _produce(self):
         try:
             for idx in self.indices:
                 img, lab = self.frames[idx]
-                k = self.free.get()                      # a slot whose previous copy has completed
+                k = None
+                while k is None:                         # a slot whose previous copy has completed
+                    if self._stop.is_set():
+                        return
+                    try:
+                        k = self.free.get(timeout=0.05)
+                    except queue.Empty:
+                        pass
                 pi, pl = self._pinned(k, img, lab)
                 np.copyto(pi.numpy(), img)               # (numpy releases the GIL for the copy; also for the strided views synthetic frames are)
                 if lab is not None:
                     np.copyto(pl.numpy(), lab)
-                self.q.put((idx, k, lab is not None))
-            self.q.put(None)
+                if not self._put((idx, k, lab is not None)):
+                    return
+            self._put(None)
         except BaseException as e:          # surface decode errors in the consumer instead of hanging it
-            self.q.put(e)
+            self._put(e)
+
+    def _put(self, item):
+        while not self._stop.is_set():
+            try:
+                self.q.put(item, timeout=0.05)
+                return True
+            except queue.Full:
+                pass
+        return False
+
+    def close(self):
+        """Stop the producer, wait for the copies that still read staging buffers, hand the buffers back to the pool.  Runs when iteration
+        ends -- normally, by an exception, or because the consumer abandoned the iterator (generator close / garbage collection); idempotent."""
+        if self._closed:
+            return
+        self._closed = True
+        self._stop.set()
+        self.thread.join(timeout=5.0)
+        for _, e0 in self._inflight:
+            e0.synchronize()
+        self._inflight = []
+        if not self.thread.is_alive():                   # (a producer stuck in a decode keeps its buffers: never hand out memory a thread may still write)
+            for k, cur in enumerate(self.slots):
+                if cur is not None:
+                    _give(*cur)
+                    self.slots[k] = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def __iter__(self):
-        inflight = []                        # (slot, event) of copies not known to be complete yet
-        while True:
-            item = self.q.get()
-            if item is None:
-                for _, e0 in inflight:       # the pinned buffers outlive this object (pool): no copy may still be reading them
-                    e0.synchronize()
-                return
-            if isinstance(item, BaseException):
-                raise item
-            idx, k, has_lab = item
-            pi, pl = self.slots[k]
-            di = pi.to(self.device, non_blocking=True)
-            dl = pl.to(self.device, non_blocking=True) if has_lab else None
-            ev = torch.cuda.Event()
-            ev.record()
-            inflight.append((k, ev))
-            while inflight and (inflight[0][1].query() or len(inflight) > self.depth):
-                k0, e0 = inflight.pop(0)
-                if not e0.query():
-                    e0.synchronize()
-                self.free.put(k0)
-            yield idx, di, dl
+        inflight = self._inflight            # (slot, event) of copies not known to be complete yet
+        try:
+            while True:
+                item = self.q.get()
+                if item is None:
+                    return
+                if isinstance(item, BaseException):
+                    raise item
+                idx, k, has_lab = item
+                pi, pl = self.slots[k][1]
+                di = pi.to(self.device, non_blocking=True)        # (enqueued on the consumer's current stream of self.device)
+                dl = pl.to(self.device, non_blocking=True) if has_lab else None
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(self.device))      # ... and so is the event: self.device's stream, not the current device's
+                inflight.append((k, ev))
+                while inflight and (inflight[0][1].query() or len(inflight) > self.depth):
+                    k0, e0 = inflight.pop(0)
+                    if not e0.query():
+                        e0.synchronize()
+                    self.free.put(k0)
+                yield idx, di, dl
+        finally:
+            self.close()

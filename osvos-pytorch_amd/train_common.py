@@ -122,7 +122,11 @@ class TrainLoop(object):
         nAveGrad (``per_image`` mode of the loss kernel) -- so the accumulated gradient is the one ``local_ave`` ``micro_batch`` calls leave,
         up to fp32 summation order (train_online.py:116-149 / train_parent.py:132-172; the micro-batches of a window share the weights, nothing
         couples the images of a batch in this network).  conv5_x sees M = 5 x 1620 pixels instead of 1620, every launch of the step is issued
-        once instead of nAveGrad times.  Returns ``(sum of the window's plain fused losses, stepped)``."""
+        once instead of nAveGrad times.  Returns ``(sum of the window's plain fused losses, stepped)``.
+        ONE ``epoch`` applies to the whole window (its statistics bucket and, in parent mode, the side-head weight 1 - epoch / nEpochs):
+        a parent-mode window that straddles an epoch boundary differs from ``micro_batch`` in the side weight of the frames past the boundary --
+        callers that need the reference's per-frame epoch there run such a window through ``micro_batch`` (train_online.py has one epoch
+        counter per window by construction: nAveGrad consecutive iterations of one sequence)."""
         n = int(inputs.shape[0])
         if n != self.local_ave or self.ave != 0:
             raise RuntimeError("window_batch: needs exactly local_ave = %d frames at the start of a window (got %d, %d accumulated)" % (self.local_ave, n, self.ave))
@@ -144,7 +148,10 @@ class TrainLoop(object):
             self.reducer.arm()
         torch.autograd.backward(heads, grads)
         self.ave = self.local_ave - 1
-        return losses[-1], self._after_backward(will_step)
+        stepped = self._after_backward(will_step)
+        if not will_step:
+            self.ave = 0      # past max_steps the window's gradients are computed and dropped, like micro_batch's trailing windows: the next call starts a window
+        return losses[-1], stepped
 
     def _micro_batch_fused(self, outputs, gts, running, epoch):
         """The same micro-batch with the upstream gradients of ``loss /= nAveGrad; loss.backward()`` (train_online.py:140-141;

@@ -93,3 +93,51 @@ def test_device_augment_draws_like_the_reference_chain():
     assert out['image'].dtype == torch.float32 and tuple(out['gt'].shape) == (1, 26, 38)
     with pytest.raises(RuntimeError):
         DeviceAugment()(torch.from_numpy(img), torch.from_numpy(lab))
+
+
+@pytest.mark.gpu
+def test_prefetchers_own_their_staging_buffers_and_survive_an_abandoned_iteration():
+    """the pinned staging pool used to be keyed by slot index, so two live DevicePrefetchers wrote the SAME buffers, and an
+    iterator abandoned mid-way left its producer and in-flight copies on buffers the next prefetcher took.  Two prefetchers interleaved over
+    different frame lists, then one abandoned after two frames and a third started at once: every frame must arrive intact."""
+    import numpy as np
+    from osvos_pytorch_amd import davis_io
+    from osvos_pytorch_amd.davis_io import ArrayFrames, DevicePrefetcher
+    rng = np.random.default_rng(3)
+    h, w = 96, 128
+
+    def frames(n, tag):
+        out = []
+        for i in range(n):
+            img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+            img[0, 0, 0] = tag
+            out.append((img, rng.integers(0, 2, (h, w), dtype=np.uint8) * 255))
+        return out
+    fa, fb, fc = frames(12, 1), frames(12, 2), frames(9, 3)
+    ita, itb = iter(DevicePrefetcher(ArrayFrames(fa), range(12), "cuda", depth=3)), iter(DevicePrefetcher(ArrayFrames(fb), range(12), "cuda", depth=3))
+    got = []
+    for _ in range(12):
+        for src, it in ((fa, ita), (fb, itb)):
+            idx, img, lab = next(it)
+            got.append((src, idx, img, lab))
+    torch.cuda.synchronize()
+    for src, idx, img, lab in got:
+        assert np.array_equal(img.cpu().numpy(), src[idx][0]) and np.array_equal(lab.cpu().numpy(), src[idx][1]), idx
+    for it in (ita, itb):
+        with pytest.raises(StopIteration):
+            next(it)
+    # abandon after two frames (what zip() against a shorter plan does), start the next prefetcher immediately
+    pf = DevicePrefetcher(ArrayFrames(fa), range(12), "cuda", depth=3)
+    it = iter(pf)
+    first = [next(it), next(it)]
+    it.close()
+    assert pf._closed and not pf.thread.is_alive() and all(s is None for s in pf.slots)
+    out = list(DevicePrefetcher(ArrayFrames(fc), range(9), "cuda", depth=3))
+    torch.cuda.synchronize()
+    assert [i for i, _, _ in out] == list(range(9))
+    for idx, img, lab in out:
+        assert np.array_equal(img.cpu().numpy(), fc[idx][0]) and np.array_equal(lab.cpu().numpy(), fc[idx][1]), idx
+    for idx, img, lab in first:
+        assert np.array_equal(img.cpu().numpy(), fa[idx][0])
+    free = sum(len(v) for v in davis_io._POOL.values())
+    assert free >= 5          # the buffers went back to the pool instead of being re-pinned per prefetcher

@@ -156,11 +156,12 @@ def test_step_schedule_closes_every_epoch_once_and_in_collective_order():
     sequence every rank would issue (gradient all-reduce per complete window, statistics all-reduce per closed epoch) for W in {1,2,5,10}
     and for a run whose tail window is partial: all ranks must issue the SAME sequence."""
     from osvos_pytorch_amd.train_common import StepSchedule, check_world_divides, epoch_plan
-    for (n_items, n_ave, epochs, first) in [(2079, 10, 3, 0), (7, 4, 2, 0), (13, 10, 3, 1), (20, 10, 2, 0)]:
+    # (nAveGrad 8 / 16: the plans of a 4- and an 8-GPU node, whose world size does not divide the reference's 10 -- SURVEY 8e)
+    for (n_items, n_ave, epochs, first) in [(2079, 10, 3, 0), (7, 4, 2, 0), (13, 10, 3, 1), (20, 10, 2, 0), (2079, 8, 2, 0), (2079, 16, 2, 0), (37, 16, 3, 1)]:
         sched = StepSchedule(n_items, n_ave, first, epochs)
         assert sched.total_steps == ((epochs - first) * n_items) // n_ave
         seqs = []
-        for world in [w for w in (1, 2, 5, 10) if n_ave % w == 0]:
+        for world in [w for w in (1, 2, 4, 5, 8, 10, 16) if n_ave % w == 0]:
             local_ave = check_world_divides(n_ave, world)
             for rank in range(world):
                 seq, ave, steps, pending = [], 0, 0, []
@@ -264,3 +265,46 @@ def test_exact_resume_with_optimizer_state_continues_bit_for_bit(tmp_path, world
         assert d["steps"] == 3
         for k in a[0]["sd"]:
             torch.testing.assert_close(d["sd"][k], a[0]["sd"][k], rtol=2e-5, atol=1e-7, msg=k)
+
+
+def test_optimizer_bundle_with_a_window_that_takes_one_iteration_from_the_next_epoch(tmp_path):
+    """7 frames, nAveGrad 4, snapshot 1 -- the window {32..35} that closes epoch 4 holds exactly ONE iteration (35) of
+    epoch 5, and on two ranks only rank 1 runs it.  save_bundle used to size its statistics all-reduce from the rank's OWN counters: rank 0
+    skipped it and its next gradient all-reduce paired with rank 1's statistics exchange (gloo aborted with a collective mismatch).  Both
+    ranks must come back, agree bit for bit, and the bundle must carry that one iteration's statistics."""
+    sys.path.insert(0, REPO)
+    argv = ["--synthetic", "7", "--epochs", "6", "--n-ave-grad", "4", "--height", "24", "--width", "32", "--seed", "7", "--lr", "1e-6",
+            "--snapshot", "1", "--save-optimizer"]
+    out = str(tmp_path / "asym")
+    port = 34700 + (os.getpid() % 1500)
+    mp.spawn(_main_worker, args=(2, port, out, argv), nprocs=2, join=True)
+    r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
+    assert r0["steps"] == r1["steps"] == 10          # 42 iterations = 10 windows + 2 left over
+    for k in r0["sd"]:
+        assert torch.equal(r0["sd"][k], r1["sd"][k]), k
+    ck = torch.load(str(tmp_path / "parent_epoch-4.optim.pth"), weights_only=False)
+    assert ck["next_iteration"] == 36 and sorted(ck["partial_stats"]) == [5] and ck["partial_stats"][5][1] == 1
+    ck1 = torch.load(str(tmp_path / "parent_epoch-1.optim.pth"), weights_only=False)
+    assert ck1["next_iteration"] == 16 and ck1["partial_stats"][2][1] == 2
+
+
+def test_train_parent_main_four_ranks_with_n_ave_grad_8(tmp_path):
+    """The plan of a 4-GPU node (nAveGrad 8: W = 4 does not divide the reference's 10) through train_parent.main() on four gloo ranks, so
+    that the first multi-GPU run with W in {4, 8} is not also the first run of that plan code: 11 frames, 3 epochs = 33 iterations = 4
+    complete windows + 1 left over; equal weights on all ranks and the single-process trajectory up to summation order."""
+    sys.path.insert(0, REPO)
+    argv = ["--synthetic", "11", "--epochs", "3", "--n-ave-grad", "8", "--height", "24", "--width", "32", "--seed", "5", "--lr", "1e-6",
+            "--test-interval", "2"]
+    out = str(tmp_path / "four")
+    port = 36100 + (os.getpid() % 1500)
+    mp.spawn(_main_worker, args=(4, port, out, argv), nprocs=4, join=True)
+    rs = [torch.load(out + ".%d" % r) for r in range(4)]
+    mp.spawn(_main_worker, args=(1, port + 1, out + "_single", argv), nprocs=1, join=True)
+    single = torch.load(out + "_single.0")
+    assert [r["steps"] for r in rs] == [4] * 4 and single["steps"] == 4
+    for k in single["sd"]:
+        for r in rs[1:]:
+            assert torch.equal(rs[0]["sd"][k], r["sd"][k]), k
+        torch.testing.assert_close(rs[0]["sd"][k], single["sd"][k], rtol=2e-5, atol=1e-7, msg=k)
+    assert sorted(rs[0]["validation"]) == sorted(single["validation"]) == [1]
+    np.testing.assert_allclose(rs[0]["validation"][1][0], rs[3]["validation"][1][0], rtol=0, atol=0)

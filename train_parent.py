@@ -261,10 +261,17 @@ def main(argv=None, build_net=None, loss_fn=None):
         """network + optimizer + position, right after the optimizer step that closes epoch e (or after the last iteration of the run): every
         rank holds the same weights, no gradient is half accumulated (TrainLoop.ave == 0 unless the run ended in a partial window, whose
         gradients are dropped like the reference's), the ranks stand at the same point of their collective sequences."""
-        later = sorted(x for x in loop.counts if x > e)
+        # What the closing window already took from later epochs, summed over the ranks so that rank 0 can carry it.  WHICH epochs those are
+        # comes from the schedule, not from this rank's own counters: a window that takes fewer than `world` iterations from the next epoch
+        # gives some ranks none of them, and a rank that skipped the all-reduce here would pair its NEXT collective (a gradient all-reduce)
+        # with the other ranks' statistics exchange (ADVICE r04).  Every rank makes the same call with the same length; ranks without a
+        # share contribute zeros.
+        nxt = sched.next_iteration(loop.steps)
+        later = [x for x in range(e + 1, nEpochs) if x * len(trainset) < nxt]
         flat = []
-        for x in later:          # what the closing window already took from later epochs: summed over the ranks so that rank 0 can carry it
-            flat += [float(r.item()) for r in loop._running[x]] + [float(loop.counts[x])]
+        for x in later:
+            have = x in loop.counts
+            flat += ([float(r.item()) for r in loop._running[x]] if have else [0.0] * 5) + [float(loop.counts[x]) if have else 0.0]
         flat = reduce_sums(flat) if flat else flat
         if rank == 0:
             partial = {x: (flat[6 * i:6 * i + 5], int(round(flat[6 * i + 5]))) for i, x in enumerate(later)}
