@@ -246,7 +246,7 @@ def test_exact_resume_with_optimizer_state_continues_bit_for_bit(tmp_path, world
     keep = str(tmp_path / "bundle_epoch1.pth")
     shutil.copy(str(tmp_path / "parent_epoch-1.optim.pth"), keep)
     res = str(tmp_path / "resumed")
-    mp.spawn(_main_worker, args=(world, port + 1, res, base + ["--save-optimizer", "--resume-epoch", "2"]), nprocs=world, join=True)
+    mp.spawn(_main_worker, args=(world, port + 1, res, base + ["--resume-epoch", "2"]), nprocs=world, join=True)      # (the bundle is used because it exists)
     b = [torch.load(res + ".%d" % r) for r in range(world)]
     assert a[0]["steps"] == 7 and b[0]["steps"] == 7 - 4          # 28 iterations = 7 windows; 4 of them closed before the bundle
     for r in range(world):
@@ -254,7 +254,7 @@ def test_exact_resume_with_optimizer_state_continues_bit_for_bit(tmp_path, world
             assert torch.equal(a[r]["sd"][k], b[r]["sd"][k]), (world, r, k)
     # the reference's resume (no optimizer file read): a different trajectory
     ref = str(tmp_path / "refstyle")
-    mp.spawn(_main_worker, args=(world, port + 2, ref, base + ["--resume-epoch", "2"]), nprocs=world, join=True)
+    mp.spawn(_main_worker, args=(world, port + 2, ref, base + ["--resume-epoch", "2", "--no-resume-optimizer"]), nprocs=world, join=True)
     c = torch.load(ref + ".0")
     assert any(not torch.equal(a[0]["sd"][k], c["sd"][k]) for k in a[0]["sd"] if k.startswith("stages."))
     if world == 1:      # a single-process bundle continues on two ranks: same windows, same frames, the gradient sum in another order
@@ -308,3 +308,40 @@ def test_train_parent_main_four_ranks_with_n_ave_grad_8(tmp_path):
         torch.testing.assert_close(rs[0]["sd"][k], single["sd"][k], rtol=2e-5, atol=1e-7, msg=k)
     assert sorted(rs[0]["validation"]) == sorted(single["validation"]) == [1]
     np.testing.assert_allclose(rs[0]["validation"][1][0], rs[3]["validation"][1][0], rtol=0, atol=0)
+
+
+def _split_root_worker(rank, world, port, roots, argv, out):
+    sys.path.insert(0, REPO)
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_RANK": str(rank)})
+    os.environ["OSVOS_SAVE_ROOT"] = roots[rank]
+    torch.set_num_threads(2)
+    import train_parent
+    from oracle import torch_ref
+    try:
+        train_parent.main(argv, build_net=lambda: _cpu_net(seed=1), loss_fn=torch_ref.cbce_loss)
+        msg = "ran"
+    except SystemExit as e:
+        msg = "exit: %s" % (e,)
+    with open(out + ".%d" % rank, "w") as f:
+        f.write(msg)
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
+def test_resume_bundle_visible_to_one_rank_only_is_refused_on_every_rank(tmp_path):
+    """only rank 0 writes the optimizer bundle; without a shared filesystem rank 1 would fall back to the reference-style resume
+    (another start iteration, another collective sequence).  The ranks exchange "I see it" first and all of them stop with the same message."""
+    sys.path.insert(0, REPO)
+    base = ["--synthetic", "7", "--epochs", "3", "--n-ave-grad", "4", "--height", "24", "--width", "32", "--seed", "7", "--lr", "1e-6", "--snapshot", "1"]
+    roots = [str(tmp_path / "node0"), str(tmp_path / "node1")]
+    for r in roots:
+        os.makedirs(r)
+    port = 37300 + (os.getpid() % 1500)
+    mp.spawn(_main_worker, args=(1, port, os.path.join(roots[0], "w"), base + ["--save-optimizer"]), nprocs=1, join=True)
+    assert os.path.exists(os.path.join(roots[0], "parent_epoch-1.optim.pth"))
+    import shutil
+    shutil.copy(os.path.join(roots[0], "parent_epoch-1.pth"), os.path.join(roots[1], "parent_epoch-1.pth"))      # the network snapshot is on both nodes
+    out = str(tmp_path / "split")
+    mp.spawn(_split_root_worker, args=(2, port + 1, roots, base + ["--resume-epoch", "2"], out), nprocs=2, join=True)
+    msgs = [open(out + ".%d" % r).read() for r in range(2)]
+    assert all(m.startswith("exit: exact resume:") and "1 of 2 ranks" in m for m in msgs), msgs

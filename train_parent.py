@@ -123,7 +123,11 @@ def main(argv=None, build_net=None, loss_fn=None):
                          'global iteration stream, taken right after the optimizer step that closes the epoch (the one point at which all ranks '
                          'hold the same weights and no gradient is half accumulated); with --resume-epoch e+1 the run continues from it BIT FOR '
                          'BIT, on any number of ranks that divides nAveGrad.  The reference saves the network only and restarts momentum and '
-                         'the accumulation window on resume (train_parent.py:59-65,175-176): that remains the behaviour without this flag.')
+                         'the accumulation window on resume (train_parent.py:59-65,175-176): that remains what a run WRITES without this flag.  '
+                         'A bundle that exists for --resume-epoch is always used (see --no-resume-optimizer).')
+    ap.add_argument('--no-resume-optimizer', action='store_true',
+                    help="resume like the reference (network only: momentum and the open accumulation window restart) even when "
+                         "parent_epoch-<e>.optim.pth exists")
     args = ap.parse_args(argv)
 
     rank, world, device = init_distributed()
@@ -179,7 +183,22 @@ def main(argv=None, build_net=None, loss_fn=None):
 
     # exact resume: the bundle holds network + optimizer + the global iteration the run continues at
     start_iteration, bundle = None, None
-    if args.save_optimizer and resume_epoch > 0 and os.path.exists(optim_path(resume_epoch - 1)):
+    # The bundle is used whenever it exists (a resume that silently dropped the momentum because a flag was not repeated would be a trap;
+    # --no-resume-optimizer asks for the reference's network-only resume), and the ranks must AGREE: only rank 0 writes it, so without a shared
+    # filesystem some ranks would take the exact resume and others the reference's -- different start iterations, diverging collective
+    # sequences.  One small all-reduce of "I see it" settles it before anything depends on it.
+    have = resume_epoch > 0 and not args.no_resume_optimizer and os.path.exists(optim_path(resume_epoch - 1))
+    if reducer is not None:
+        seen = torch.tensor([1.0 if have else 0.0], device=device, dtype=torch.float64)
+        if reducer.comm is not None:
+            reducer.comm.all_reduce(seen)
+        else:
+            import torch.distributed as dist
+            dist.all_reduce(seen)
+        if 0 < int(round(seen.item())) < world:
+            raise SystemExit("exact resume: %s is visible to %d of %d ranks; put it where every rank reads it (rank 0 wrote it), or pass "
+                             "--no-resume-optimizer for the reference's network-only resume" % (optim_path(resume_epoch - 1), int(round(seen.item())), world))
+    if have:
         bundle = torch.load(optim_path(resume_epoch - 1), map_location='cpu', weights_only=False)
         if int(bundle['n_ave_grad']) != nAveGrad or int(bundle['n_items']) != len(trainset):
             raise SystemExit("exact resume: %s was written with nAveGrad %d over %d frames, this run has %d / %d"
