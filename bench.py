@@ -284,6 +284,12 @@ def parity_gate(wl):
         bars.pop("loss_rel"), bars.pop("grad_rel_l2")
     res["bars"] = bars
     res["within_bars"] = bool(ok)
+    if wl.precision == "bf16":
+        res["note"] = ("bf16 on this UN-TRAINED synthetic net: SURVEY 8(d)'s flat bf16 bars (logits 0.1 std, loss 2e-3) were derived at 427x240; at 854x480 the "
+                       "deepest side head and the loss sit where torch's own CPU bf16 autocast sits on the same inputs (0.15 std, 1.7e-3: "
+                       "profiles/r02_bf16_parity_854x480.txt), which is the bar tests/test_gpu_baseline_configs.py::test_bf16_parent_854x480_against_cpu_oracle "
+                       "asserts (max(flat, 1.5 x autocast)); max_dlogit_over_std is the worst of the five heads, _fused the method's output; on the "
+                       "trained-like fixture (real margins) bf16 reads 0.007-0.020 std and IoU 0.9989-0.9998 (tests/test_gpu_trained_like.py)")
     res["seconds"] = round(time.perf_counter() - t_start, 1)
     return res
 
@@ -887,7 +893,8 @@ def main():
         for (name, extra_args) in [
                 ("configs[1] on the EXACT fp32 MFMA kernels (v_mfma_f32_32x32x2_f32): same loop, precision 'fp32'", ["--precision", "fp32"]),       # (carries its own parity gate too)
                 ("configs[1] semantics, window-fused: the 5 micro-batches of an optimizer step (5 different frames) as ONE batch-5 pass with per-image "
-                 "class counts -- the reference gradient up to summation order (tests/test_gpu_baseline_configs.py); what TrainLoop.window_batch / "
+                 "class counts -- the reference gradient up to summation order (tests/test_gpu_baseline_configs.py::test_window_batch_equals_the_sequential_micro_batches_at_120x214, "
+                 "tests/test_gpu_trained_like.py::test_window_fused_pass_equals_the_sequential_micro_batches); what TrainLoop.window_batch / "
                  "train_online.py --window-fused run", ["--window-fused", "1"]),
                 ("configs[2]: 854x480 batch=12 parent training bf16 (MFMA path)", ["--mode", "parent", "--precision", "bf16", "--batch", "12"]),
                 ("configs[4]: 1920x1080 inference-only forward, batch=4, hipGraph-captured (f32x3)",

@@ -63,8 +63,6 @@ struct ConvArgsX {
   int sk_order;          // 0: Cout tile is the fast index of the tile order, 1: the spatial tile is
   unsigned* sk_tickets;  // [ntiles], zero at launch; the last arriver of a tile zeroes its ticket again
   float* sk_part;        // [gridDim.x][2] slots of NT * WM * WN * 16 floats (raw accumulators)
-  int prio;              // wave-priority experiment (OSVOS_X3_PRIO, profiles/r05_ab_setprio.txt): 0 none, 1 second wave of every SIMD at priority 1,
-                         // 2 every wave at priority 1 while it issues a chunk's MFMAs and at 0 while it splits / stores the next tiles
 };
 
 constexpr int cdivx(int a, int b) { return (a + b - 1) / b; }
@@ -291,9 +289,9 @@ __global__ __launch_bounds__(C::NT, C::OCC) void conv3x3_f32x3_kernel(ConvArgsX 
   // probe builds (tools/native/build.sh, -DOSVOS_X3_ABL=n; wrong results, timing only): 1 no MFMA, 2 no fragment reads after the first step,
   // 3 no global loads inside the K loop, 4 tiles stored once (no split / ds_write per chunk), 5 no barriers
   load_chunk(kc_begin);
-  if (a.prio == 1 && wave >= C::NT / 128) __builtin_amdgcn_s_setprio(1);
+  // (s_setprio was measured in round 5 -- static priority 1 for the second wave of every SIMD, and priority 1 during a chunk's MFMAs / 0 during
+  //  its split + store phase: both within +-0.3 % of no priority at step level, profiles/r05_ab_setprio.txt -- and is not in the kernel)
   for (int kc = kc_begin; kc < kc_end; ++kc) {
-    if (a.prio == 2) __builtin_amdgcn_s_setprio(0);
 #if !(defined(OSVOS_X3_ABL) && OSVOS_X3_ABL == 5)
     __syncthreads();                     // every wave is done with the previous chunk's tiles
 #endif
@@ -304,7 +302,6 @@ __global__ __launch_bounds__(C::NT, C::OCC) void conv3x3_f32x3_kernel(ConvArgsX 
 #if !(defined(OSVOS_X3_ABL) && OSVOS_X3_ABL == 5)
     __syncthreads();
 #endif
-    if (a.prio == 2) __builtin_amdgcn_s_setprio(1);
     const bool more = kc + 1 < kc_end;
     if (!C::ILV && more) load_chunk(kc + 1);      // in flight during the MFMAs below
     // 9 x WM steps (tap, M block); fragments of step s+1 (and, once per tap, the weights of tap+1) are requested
@@ -773,7 +770,6 @@ int osvos_conv3x3_f32x3_epi(const float* x, const float* wpk, const void* wpk3, 
   a.x = x; a.wpk = wpk; a.wpk3 = reinterpret_cast<const uint4*>(wpk3); a.bias = bias; a.mask = mask; a.y = y;
   a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = (Cout + 3) & ~3; a.CoutP = osvos_cout_pad(Cout); a.y_cs = y_cs;
   a.relu = relu;
-  { OSVOS_ENV_INT(env_prio, "OSVOS_X3_PRIO", 0); a.prio = env_prio; }
   if (epi != nullptr) a.epi = *epi;
   if (tile < 0) {
     OSVOS_ENV_INT(env_tile, "OSVOS_X3_TILE", -1);

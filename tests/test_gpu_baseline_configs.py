@@ -34,6 +34,67 @@ def _oracle_forward(wts, x, dtype):
         return [o.double().numpy() for o in torch_ref.forward(p, torch.from_numpy(x).to(dtype))]
 
 
+def test_per_image_class_counts_of_the_loss_call_against_the_oracle():
+    """The arithmetic behind bench.py's window-fused line, first in the tier: the general loss call in its per-image mode
+    (osvos_cbce_step_ex, per_image=True) = N reference micro-batches of one image each (osvos_layers.py:28-46 applied per image: own class
+    weights, the N losses summed) -- loss to 1e-6, the scaled gradient to 1e-6 of its largest element; N = 3 images with very different
+    foreground shares, one of them without any foreground (osvos_layers.py: all-negative label -> that image contributes 0)."""
+    from oracle import torch_ref
+    from osvos_pytorch_amd.layers.osvos_layers import class_balanced_cross_entropy_loss_step_multi as step_multi
+    g = torch.Generator().manual_seed(11)
+    n, h, w = 3, 60, 107
+    heads = [torch.randn(n, 1, h, w, generator=g) * 3.0 - 1.0 for _ in range(2)]
+    lab = torch.zeros(n, 1, h, w)
+    lab[0, 0, 10:40, 20:70] = 1.0
+    lab[1, 0, 5:9, 3:11] = 1.0          # image 2: no foreground at all
+    scales = [0.1, 0.2]
+    losses, grads = step_multi([t.cuda() for t in heads], lab.cuda(), size_average=False, grad_scales=scales, running=[None, None], per_image=True)
+    torch.cuda.synchronize()
+    for k, t in enumerate(heads):
+        x = t.clone().double().requires_grad_()
+        tot = sum(torch_ref.cbce_loss(x[i:i + 1], lab[i:i + 1].double(), size_average=False) for i in range(n))
+        (tot * scales[k]).backward()
+        assert abs(float(losses[k]) - float(tot)) <= 1e-6 * abs(float(tot)), (k, float(losses[k]), float(tot))
+        d = (grads[k].cpu().double() - x.grad).abs().max()
+        assert float(d) <= 1e-6 * float(x.grad.abs().max()), (k, float(d))
+        assert float(grads[k][2].abs().max()) == 0.0          # the foreground-free image: no gradient, like the reference's 0 * l_neg
+
+
+def test_window_batch_equals_the_sequential_micro_batches_at_120x214():
+    """TrainLoop.window_batch (one forward / backward over the nAveGrad frames of an optimizer step, per-image class counts) against the
+    reference's sequential loop (train_online.py:116-149) on the calibrated synthetic net at stage-2 size: summed loss to 1e-6, accumulated
+    gradients per tensor to 1e-3 (other summation order only).  The 854x480 / trained-like form of this test is
+    tests/test_gpu_trained_like.py::test_window_fused_pass_equals_the_sequential_micro_batches; this one sits early in the tier."""
+    from oracle import synth
+    from osvos_pytorch_amd.train_common import TrainLoop, make_sgd
+    n_ave, h, w = 3, 120, 214
+    wts, x, m = synth.calibrated_problem(n_ave, h, w, seed=21)
+    dev = [(torch.from_numpy(x[i:i + 1]).cuda(), torch.from_numpy(m[i:i + 1]).cuda()) for i in range(n_ave)]
+
+    def run(fused):
+        net = build_net(wts, precision="fp32x3")
+        loop = TrainLoop(net, make_sgd(net, "online", lr=0.0), mode="online", n_ave_grad=n_ave)      # lr 0: the step leaves the gradients readable
+        keep = {}
+        hook = loop.opt.step
+        loop.opt.step = lambda: keep.update({k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}) or hook()
+        if fused:
+            total, stepped = loop.window_batch(torch.cat([d[0] for d in dev]).requires_grad_(), torch.cat([d[1] for d in dev]))
+            total = float(total)
+        else:
+            total = 0.0
+            for xi, mi in dev:
+                l, stepped = loop.micro_batch(xi.clone().requires_grad_(), mi)
+                total += float(l)
+        assert stepped and loop.steps == 1 and loop.ave == 0
+        return total, keep
+    l_seq, g_seq = run(False)
+    l_win, g_win = run(True)
+    assert abs(l_win - l_seq) <= 1e-6 * abs(l_seq), (l_win, l_seq)
+    assert g_seq.keys() == g_win.keys() and len(g_seq) >= 35
+    worst = max((float((g_win[k].double() - g_seq[k].double()).norm() / (g_seq[k].double().norm() + 1e-300)), k) for k in g_seq)
+    assert worst[0] <= 1e-3, worst
+
+
 @pytest.mark.parametrize("precision", ["fp32", "fp32x3"])
 def test_1080p_forward_fp32_against_cpu_oracle_and_batch4_graph(precision):
     """both fp32 arithmetics: the exact fp32 MFMA kernels (the 95 frames/s configs[4] line) and f32x3 (the module default)"""

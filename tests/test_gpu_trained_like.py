@@ -129,17 +129,7 @@ def test_fp32_arithmetics_meet_the_flat_survey_bars_on_the_trained_like_net(trai
           % (precision, worst["logit"], worst["loss"], worst["iou"], worst["grad"][0], worst["grad"][1]))
 
 
-def test_bf16_on_the_trained_like_net_against_the_flat_survey_bars(trained):
-    """Where bf16 (bf16 MFMA operands + bf16 trunk tensors) lands when the margins are real (on the un-trained fixture the
-    flat SURVEY 8(d) bars were missed -- head 3 at 0.148 std, full-frame IoU 0.990 -- and the test encoded the miss).  Measured here
-    (profiles/r04_trained_like.txt) against the flat bars:
-      max |dlogit| <= 0.1 std: MET on every head (0.007-0.020);
-      mask IoU >= 1 - 1e-3 (north_star): AT the line -- 0.99888 .. 0.99984 over the four cases (1-19 flipped pixels); asserted at 1 - 2e-3;
-      gradients <= 0.25 relative L2: met by all parameter gradients as one vector (0.05-0.10) and by every trunk tensor (<= 0.25); NOT by
-        score_dsn.3 on a training frame (bias 1.35, weight 0.50: one number that is the residue of cancelling sums on a frame the net was
-        trained on) nor by the unused input gradient (0.26-0.36); asserted: one vector <= 0.25, trunk / side_prep / fuse tensors <= 0.3;
-      loss <= 2e-3 relative: NOT met (4e-5 .. 1.7e-2): the loss has fallen 23x and what is left sits on the few uncertain pixels, where a
-        0.01-std logit error is worth 1e-2 of it; asserted at 3e-2."""
+def _bf16_rows(trained):
     wts, frames, _ = trained
     rows = []
     for name, x, m in _cases(frames):
@@ -148,23 +138,48 @@ def test_bf16_on_the_trained_like_net_against_the_flat_survey_bars(trained):
         e_logit = [float(np.abs(outs[i] - t_outs[i]).max() / t_outs[i].std()) for i in range(5)]
         e_loss = [abs(losses[i] - t_losses[i]) / abs(t_losses[i]) for i in range(5)]
         j = _iou(outs[4], t_outs[4])
-        flips = int(((outs[4] > 0) != (t_outs[4] > 0)).sum())
+        fl = (outs[4] > 0) != (t_outs[4] > 0)
+        rms = float(np.sqrt(np.mean((outs[4] - t_outs[4]) ** 2)))
+        flips = (int(fl.sum()), int((fl & (np.abs(t_outs[4]) > 4.0 * rms)).sum()))      # (all, outside the |logit| <= 4 rms(dlogit) band)
         ge = sorted(((float((grads[k] - t).norm() / (t.norm() + 1e-300)), k) for k, t in t_grads.items()), reverse=True)
         print("   bf16 %s worst gradients:" % name, [(k, "%.2f" % e) for e, k in ge[:8]])
         num = sum(float((grads[k] - t).norm() ** 2) for k, t in t_grads.items() if k != "input")
         den = sum(float(t.norm() ** 2) for k, t in t_grads.items() if k != "input")
         print("   bf16 %s all parameter gradients as one vector: %.3f" % (name, (num / den) ** 0.5))
         rows.append((name, e_logit, e_loss, j, flips, ge, (num / den) ** 0.5))
-        print("trained-like bf16 %s: max |dlogit| / std per head %s | loss rel %s | fused IoU %.6f (%d flipped of %d) | gradients worst %.3f (%s) median %.3f"
-              % (name, ["%.3f" % e for e in e_logit], ["%.1e" % e for e in e_loss], j, flips, outs[4].size, ge[0][0], ge[0][1], ge[len(ge) // 2][0]))
-    for name, e_logit, e_loss, j, flips, ge, one_vec in rows:
-        assert max(e_logit) <= 0.1, (name, e_logit)
-        assert j >= 1 - 2e-3, (name, j, flips)
-        assert one_vec <= 0.25, (name, one_vec)
+        print("trained-like bf16 %s: max |dlogit| / std per head %s | loss rel %s | fused IoU %.6f (%d flipped of %d, %d outside the noise band) | gradients worst %.3f (%s) median %.3f"
+              % (name, ["%.3f" % e for e in e_logit], ["%.1e" % e for e in e_loss], j, flips[0], outs[4].size, flips[1], ge[0][0], ge[0][1], ge[len(ge) // 2][0]))
+    return rows
+
+
+def test_bf16_on_the_trained_like_net_measured_bars(trained):
+    """Where bf16 (bf16 MFMA operands + bf16 trunk tensors) lands when the margins are real, asserted at what was MEASURED plus a small margin, so
+    that a regression cannot hide inside a relaxed bar (profiles/r04_trained_like.txt, re-measured in round 5):
+      max |dlogit| <= 0.1 std (flat SURVEY bar): met on every head (0.007-0.020); asserted at 0.03;
+      mask IoU: 0.99888 .. 0.99984 over the four cases (3-19 flipped pixels, every one of them among the ~0.1 % of pixels with |logit| < 0.1 of
+        a std-7..12 map); asserted >= 0.9985 AND every flipped pixel inside the |logit| <= 4 rms(dlogit) band;
+      gradients: all parameter gradients as one vector 0.05-0.10, asserted <= 0.15; trunk / side_prep / fuse tensors <= 0.25 measured, asserted 0.3;
+      loss: 4e-5 .. 1.7e-2 relative (the loss has fallen 23x and what is left sits on the few uncertain pixels); asserted <= 2.5e-2.
+    The FLAT bars of SURVEY 8(d) / north_star that bf16 does not meet on this fixture are the next test (xfail), not a looser number here."""
+    for name, e_logit, e_loss, j, flips, ge, one_vec in _bf16_rows(trained):
+        assert max(e_logit) <= 0.03, (name, e_logit)
+        assert j >= 0.9985 and flips[1] == 0, (name, j, flips)
+        assert one_vec <= 0.15, (name, one_vec)
         for e, k in ge:
             if k.startswith(("stages.", "side_prep.", "fuse.")):
                 assert e <= 0.3, (name, k, e)
-        assert max(e_loss) <= 3e-2, (name, e_loss)
+        assert max(e_loss) <= 2.5e-2, (name, e_loss)
+
+
+@pytest.mark.xfail(strict=False, reason="bf16 on the trained-like fixture sits AT north_star's IoU line (0.99888 .. 0.99984 vs 1 - 1e-3: 6 flipped "
+                                        "pixels of 25680 on one case) and above SURVEY 8(d)'s 2e-3 loss bar (up to 1.7e-2): recorded as a known miss, "
+                                        "the measured bars are asserted by the test above")
+def test_bf16_on_the_trained_like_net_flat_survey_bars(trained):
+    """The flat bars: mask IoU >= 1 - 1e-3 (north_star), loss <= 2e-3, logits <= 0.1 std, gradients (one vector) <= 0.25."""
+    for name, e_logit, e_loss, j, flips, ge, one_vec in _bf16_rows(trained):
+        assert max(e_logit) <= 0.1 and one_vec <= 0.25, (name, e_logit, one_vec)
+        assert j >= 1 - 1e-3, (name, j, flips)
+        assert max(e_loss) <= 2e-3, (name, e_loss)
 
 
 @pytest.mark.parametrize("precision", ["fp32", "fp32x3"])
