@@ -3,10 +3,10 @@
 # and configs[2] (what profiles/r04_bench_default.json, r04_bench_*_kernel_stats.txt and r04_step_timeline*.txt are).  usage: gpu_evidence.sh <tag>
 R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R; export TMPDIR=/tmp; O=$R/gpurun_out/${1:-evidence}; mkdir -p $O
 t0=$(date +%s)
-timeout 300 python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "bench rc $? $(( $(date +%s) - t0 )) s" > $O/times.txt
+[ -z "$NOBENCH" ] && { timeout 600 python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "bench rc $? $(( $(date +%s) - t0 )) s" > $O/times.txt; }
 prof() { # tag, bench args...
   T=$1; shift
-  A="--no-extra --no-cpu-baseline --no-prof --min-seconds 0 --settle-seconds 1.0 --steps 20 --warmup 5 $*"
+  A="--no-extra --no-cpu-baseline --no-parity --no-prof --min-seconds 0 --settle-seconds 1.0 --steps 20 --warmup 5 $*"
   (cd /tmp && timeout 120 rocprofv3 --kernel-trace --stats -d $O/prof_$T -o bench -- python $R/bench.py $A > $O/rocprof_$T.log 2>&1)
   DB=$(find $O/prof_$T -name "*.db" | head -1)
   python tools/prof_summary.py $DB 0 $O/kernel_stats_$T.txt "python bench.py $A" > /dev/null 2>&1      # 0: count the profiled steps
