@@ -10,7 +10,7 @@ prof() { # tag, bench args...
   (cd /tmp && timeout 120 rocprofv3 --kernel-trace --stats -d $O/prof_$T -o bench -- python $R/bench.py $A > $O/rocprof_$T.log 2>&1)
   DB=$(find $O/prof_$T -name "*.db" | head -1)
   python tools/prof_summary.py $DB 0 $O/kernel_stats_$T.txt "python bench.py $A" > /dev/null 2>&1      # 0: count the profiled steps
-  python tools/step_timeline.py $DB 60 0 1 > $O/timeline_$T.txt 2>&1
+  python tools/step_timeline.py $DB 60 > $O/timeline_$T.txt 2>&1
   rm -rf $O/prof_$T
   echo "prof $T $(( $(date +%s) - t0 )) s" >> $O/times.txt
 }
