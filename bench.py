@@ -532,9 +532,15 @@ def load_traffic(wl):
         key = "configs1"
     elif (wl.mode, wl.precision, wl.h, wl.w, wl.batch, wl.window) == ("parent", "bf16", 480, 854, 12, False):
         key = "configs2"
+    elif (wl.mode, wl.precision, wl.h, wl.w, wl.batch, bool(wl.graph)) == ("infer", "fp32x3", 1080, 1920, 4, True):
+        key = "configs4"
+    elif (wl.mode, wl.precision, wl.h, wl.w, wl.batch, wl.window) == ("online", "fp32x3", 480, 854, 5, True):
+        key = "window_fused"
     if key is None:
         return None
-    name = "r04_pmc_traffic_%s.json" % key
+    name = next((n for n in ("r05_pmc_traffic_%s.json" % key, "r04_pmc_traffic_%s.json" % key) if os.path.exists(os.path.join(REPO, "profiles", n))), None)
+    if name is None:
+        return None
     path = os.path.join(REPO, "profiles", name)
     try:
         with open(path) as f:
@@ -729,7 +735,8 @@ def measure(wl, steps, warmup, min_seconds, world, ctl, device, use_prof=True, s
         act_gb = 0.904 * (wl.h * wl.w) / (480.0 * 854.0) * wl.batch * (0.5 if wl.precision == "bf16" else 1.0)   # min conv tensor traffic
         roof = {"bound": "mfma", "kernel": "hipGraph replay of osvos_net_forward (%s x17 + pool/head glue)" % kname[0],
                 "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                "traffic": None, "algorithmic_hbm_GBps": round(act_gb / (elapsed / steps), 1), "hbm_peak_GBps": 8000}
+                "traffic": load_traffic(wl),      # (PMC passes over the EAGER launches of the same forward: tools/gpu_pmc_step.sh ... --graph 0)
+                "algorithmic_hbm_GBps": round(act_gb / (elapsed / steps), 1), "hbm_peak_GBps": 8000}
         roof.update(x3_extra(ach / mult_f, mult_f))
     elif getattr(wl, "graph_train", False):
         # the micro-batch is ONE graph launch: no per-launch events inside; the family is the step's conv work over the step time

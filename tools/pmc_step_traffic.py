@@ -55,7 +55,13 @@ conv = {k: v for k, v in tot.items() if k.startswith(("conv3x3", "wgrad_f32x3", 
 cfg = line["config"]["workload"]
 batch = int(re.search(r"batch=(\d+)", cfg).group(1))
 bf16 = "bf16" in line["dtype"][:8]
-alg = (452.0 if bf16 else 904.0) * 3.0 * batch
+wh = re.match(r"(\d+)x(\d+)", cfg)
+scale = (int(wh.group(1)) * int(wh.group(2))) / (854.0 * 480.0) if wh else 1.0
+passes = 1.0 if "inference" in cfg else 3.0          # forward only / forward + data gradient + weight gradient
+if "WINDOW-FUSED" in cfg:                            # one step = the whole window: nAveGrad x batch frames
+    m = re.search(r"the (\d+) micro-batches", cfg)
+    batch = int(m.group(1)) if m else batch
+alg = (452.0 if bf16 else 904.0) * passes * batch * scale
 try:
     commit = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], cwd=os.path.dirname(os.path.abspath(__file__))).decode().strip()
 except Exception:
