@@ -186,7 +186,11 @@ __global__ __launch_bounds__(C::NT, C::OCC) void conv3x3_bf16_kernel(ConvArgsB a
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-  const int nchunks = a.CinP / (8 * C::KG);
+  // K chunks that hold real channels: the pack is zero padded to CinP = a multiple of 32, a 16-channel-chunk tile (KG = 2) on a layer with
+  // Cin <= 16 (conv1_1's 3 -> 8 input channels, the side branches' 16-channel data gradients) used to walk a second chunk of nothing but zeros --
+  // half of its staging and MFMA work (round 5; same bits: the dropped products are exact zeros; step level +0.0 .. +0.4 % at batch 12,
+  // profiles/r05_ab_small.txt: these launches are bound by their prologue / epilogue latency, not by the matrix pipe)
+  const int nchunks = (a.Cin + 8 * C::KG - 1) / (8 * C::KG);
 #ifdef OSVOS_CONV_PROF
   unsigned long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tq, tp = __builtin_amdgcn_s_memtime();
   const unsigned long long t_begin = tp;
