@@ -4,7 +4,7 @@
 //     blocks, or the two 16-lane halves of one), the horizontal neighbour is lane ^ 1
 // (The BACKWARD pool in the epilogue of the next data gradient was built and measured in round 3 -- backward 2.817 -> 2.861 ms at batch 1:
 //  the fused workgroup's tail is 12 dependent memory instructions per accumulator quad on a CU that holds nothing else -- and removed in
-//  round 4; DESIGN 3.8 keeps the numbers, git history the code.)
+//  round 4; docs/DESIGN_rounds_1-4.md 3.8 keeps the numbers, git history the code.)
 #pragma once
 #include "common.h"
 

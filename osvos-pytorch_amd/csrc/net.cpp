@@ -272,7 +272,7 @@ inline bool fuse_pool(int dtype) {
 }
 
 // f32x3 stream-K (conv3x3_f32x3.hip): OSVOS_X3_STREAMK = 0 (default) off, 1 the forward's main-stream convolutions, 2 also the data-gradient
-// chain.  Built and measured in round 4 (profiles/r04_tune_streamk.txt): op level the 64-cout tiles gain 4-7 % (conv1_2, conv4_x)
+// chain.  Built and measured in round 4 (profiles/r04_tune_streamk.txt, docs/DESIGN_rounds_1-4.md 3.9): op level the 64-cout tiles gain 4-7 % (conv1_2, conv4_x)
 // and the 128-cout tile loses 1-12 % (conv2_x, conv3_x); in the network, with the automatic choice restricted to the winners, the headline
 // loop reads 234.8-235.9 frames/s against 235.2-236.2 without it (three alternating runs on one box) and configs[4] 157.2-157.3 against
 // 157.3-157.5 -- the CUs a plain grid leaves without a tile are not idle in the step: the side-branch convolutions of the second stream run
