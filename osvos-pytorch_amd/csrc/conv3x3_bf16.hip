@@ -492,6 +492,10 @@ int pick_tile_b(int N, int H, int W, int CoutP, int Cin) {
   // one 16-channel K chunk (the side branches' data gradients, 16 -> C): all prologue and epilogue -- three small workgroups per CU cover each
   // other's phases (B9: 166 / 80 / 52 us against 215 / 90 / 57 for the automatic choice at batch 12, tools/tune_skinny_bf16.py)
   if (Cin <= 16) return 9;
+  // ... and the Cin = 64 layers (conv1_2, conv2_1; their data gradients): K = 576 is four such chunks, the launch is as much prologue / epilogue and
+  // HBM stream as matrix work -- the same small tile, three workgroups per CU, reads 2-5 % faster than the 32-channel-chunk tile at batch 12
+  // (tools/tune_conv.py) and the step +0.7-1.2 % (1136.3 / 1134.2 -> 1143.8 / 1147.5 frames/s, profiles/r05_ab_small.txt; Cin <= 128: +0.1-0.8 %)
+  if (Cin <= 64 && CoutP <= 128) return 9;
   const int order[] = {8, 1, 5, 7};
   for (int k = 0; k < 4; ++k) {
     const TileInfoB& t = kTilesB[order[k]];
@@ -657,8 +661,10 @@ int osvos_conv3x3_bf16mfma_bits(const void* x, int xb, const void* wpk, const fl
     // (conv4_x 0.355 -> 0.331 ms, conv5_x 0.117 -> 0.098 ms at batch 12)
     static const int dma_min_cin = getenv("OSVOS_DMA_MIN_CIN") ? atoi(getenv("OSVOS_DMA_MIN_CIN")) : kDmaMinCin;
     static const int dma_tile = getenv("OSVOS_DMA_TILE") ? atoi(getenv("OSVOS_DMA_TILE")) : kDmaTile;
-    if (!env && xb && Cin >= dma_min_cin && a.CoutP >= 128 && osvos_conv3x3_bf16_dma_applicable(Cin, Cout, y_cs) &&
-        (long)N * ceil_div(H, 16) * ceil_div(W, 32) * ceil_div(a.CoutP, 128) >= 256)
+    OSVOS_ENV_INT(dma_min_cout, "OSVOS_DMA_MIN_COUT", 128);      // TEMPORARY A/B switches
+    OSVOS_ENV_INT(dma_min_grid, "OSVOS_DMA_MIN_GRID", 256);
+    if (!env && xb && Cin >= dma_min_cin && a.CoutP >= dma_min_cout && osvos_conv3x3_bf16_dma_applicable(Cin, Cout, y_cs) &&
+        (long)N * ceil_div(H, 16) * ceil_div(W, 32) * ceil_div(a.CoutP, 128) >= dma_min_grid)
       tile = dma_tile;
     if (!env && (double)H * W * Cin * 4 > 9.0 * Cin * a.CoutP * 2) tile += 100;
   }
