@@ -661,10 +661,10 @@ int osvos_conv3x3_bf16mfma_bits(const void* x, int xb, const void* wpk, const fl
     // (conv4_x 0.355 -> 0.331 ms, conv5_x 0.117 -> 0.098 ms at batch 12)
     static const int dma_min_cin = getenv("OSVOS_DMA_MIN_CIN") ? atoi(getenv("OSVOS_DMA_MIN_CIN")) : kDmaMinCin;
     static const int dma_tile = getenv("OSVOS_DMA_TILE") ? atoi(getenv("OSVOS_DMA_TILE")) : kDmaTile;
-    OSVOS_ENV_INT(dma_min_cout, "OSVOS_DMA_MIN_COUT", 128);      // TEMPORARY A/B switches
-    OSVOS_ENV_INT(dma_min_grid, "OSVOS_DMA_MIN_GRID", 256);
-    if (!env && xb && Cin >= dma_min_cin && a.CoutP >= dma_min_cout && osvos_conv3x3_bf16_dma_applicable(Cin, Cout, y_cs) &&
-        (long)N * ceil_div(H, 16) * ceil_div(W, 32) * ceil_div(a.CoutP, 128) >= dma_min_grid)
+    // (grid threshold 256 -> 128 in round 5: at batch 12 conv5_x's 192 DMA workgroups still beat the register-staged tile, 0.100-0.104 vs 0.108 ms per
+    //  launch and +0.4-0.8 % on configs[2], profiles/r05_ab_small.txt; the persistent DMA tile 35 and "DMA only for Cout >= 512" measured -0.6 % / +0.2 %)
+    if (!env && xb && Cin >= dma_min_cin && a.CoutP >= 128 && osvos_conv3x3_bf16_dma_applicable(Cin, Cout, y_cs) &&
+        (long)N * ceil_div(H, 16) * ceil_div(W, 32) * ceil_div(a.CoutP, 128) >= 128)
       tile = dma_tile;
     if (!env && (double)H * W * Cin * 4 > 9.0 * Cin * a.CoutP * 2) tile += 100;
   }
