@@ -774,7 +774,11 @@ int osvos_conv3x3_f32x3_epi(const float* x, const float* wpk, const void* wpk3, 
   if (tile < 0) {
     OSVOS_ENV_INT(env_tile, "OSVOS_X3_TILE", -1);
     tile = env_tile >= 0 ? env_tile : pick_tile_x(N, H, W, a.CoutP);
-    if (env_tile < 0 && (double)H * W * Cin > 9.0 * Cin * a.CoutP) tile += 100;      // activations larger than the weights
+    // XCD-local map (cout tiles of one spatial tile on one XCD) only where the activations are MUCH larger than the weights: the rule of rounds 2-4
+    // (pixels > 9 CoutP, i.e. fp32 activation bytes > fp32 weight bytes) put conv4_x on it, where it measures 6-7 % slower per launch than the plain
+    // order (X14 on conv4_2: 0.166 vs 0.155 ms; the pre-split pack is 1.5x the fp32 weights and every XCD then streams all of it) -- with the factor 3
+    // the headline step gains 1.0-2.8 % on three boxes, configs[4] and the window-fused form are level (profiles/r05_ab_x3_map_rule.txt)
+    if (env_tile < 0 && (double)H * W * Cin > 27.0 * Cin * a.CoutP) tile += 100;
   }
   a.map = tile >= 100 ? 1 : 0;
   tile %= 100;
