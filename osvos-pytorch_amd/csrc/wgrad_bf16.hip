@@ -593,7 +593,10 @@ WbPlan make_plan(int N, int H, int W, int Cin_s, int Cout, int bco = BCO) {
   p.npx = ceil_div(W, PW);
   p.npy = ceil_div(H, PH);
   p.npatches = N * p.npx * p.npy;
-  int want = ceil_div(bco == BCO ? 512 : 256, p.nco_t * p.nci_t);
+  // workgroups aimed at: 512 for the four-wave form (two per CU), 192 for the eight-wave form (one per CU -- round 5: three quarters of the CUs
+  // instead of all of them, the data-gradient chain that runs beside it keeps a share: +0.6-1.0 % on configs[2] on two boxes; 128 / 224 / 256 level
+  // to -0.8 %, 384 -1.4 %, 512 -3 %; profiles/r05_ab_small.txt)
+  int want = ceil_div(bco == BCO ? 512 : 192, p.nco_t * p.nci_t);
   const int max_split = p.npatches / 2 > 0 ? p.npatches / 2 : 1;
   if (want > max_split) want = max_split;
   if (want > 256) want = 256;

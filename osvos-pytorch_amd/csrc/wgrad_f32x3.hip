@@ -345,7 +345,7 @@ W3Plan make_plan3(int N, int H, int W, int Cin_s, int Cout) {
   p.npx = ceil_div(W, PW);
   p.npy = ceil_div(H, p.ph);
   p.npatches = N * p.npx * p.npy;
-  int want = ceil_div(256, p.nco_t * p.nci_t);
+  int want = ceil_div(256, p.nco_t * p.nci_t);      // (round 5 re-check at step level: 192 -0.9 %, 320 -1.5 %, 384 -1.6 %, 512 -4.5 % against 256; profiles/r05_ab_small.txt)
   const int max_split = p.npatches / 2 > 0 ? p.npatches / 2 : 1;
   if (want > max_split) want = max_split;
   if (want > 256) want = 256;
