@@ -666,6 +666,7 @@ int osvos_conv3x3_bf16mfma_bits(const void* x, int xb, const void* wpk, const fl
     if (!env && xb && Cin >= dma_min_cin && a.CoutP >= 128 && osvos_conv3x3_bf16_dma_applicable(Cin, Cout, y_cs) &&
         (long)N * ceil_div(H, 16) * ceil_div(W, 32) * ceil_div(a.CoutP, 128) >= 128)
       tile = dma_tile;
+    // (round 5 re-check at step level, configs[2]: always / never / 3x / 10x this threshold all within +-0.3 % -- unlike the f32x3 rule)
     if (!env && (double)H * W * Cin * 4 > 9.0 * Cin * a.CoutP * 2) tile += 100;
   }
   a.map = tile >= 100 ? 1 : 0;
