@@ -25,6 +25,7 @@ pmc configs4 "configs[4] 1920x1080 b4 forward f32x3 (eager launches of the graph
 pmc window_fused "configs[1] window-fused (5 frames per step) f32x3" --window-fused 1
 mkdir -p $O/profiles; cp profiles/${TAG}_pmc_traffic_*.json $O/profiles/ 2>/dev/null
 timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "bench exit $? $(( $(date +%s) - t0 )) s" >> $O/summary.txt
+timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_cmd.json 2> $O/bench_driver_cmd.err; echo "bench (driver's command: --gpus 1 --steps 20 --warmup 5) exit $? $(( $(date +%s) - t0 )) s" >> $O/summary.txt
 NOBENCH=1 bash tools/gpu_evidence.sh ${TAG}_final > /dev/null 2>&1
 echo "total $(( $(date +%s) - t0 )) s" >> $O/summary.txt
 cat $O/summary.txt
