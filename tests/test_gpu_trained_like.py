@@ -156,10 +156,11 @@ def test_bf16_on_the_trained_like_net_measured_bars(trained):
     """Where bf16 (bf16 MFMA operands + bf16 trunk tensors) lands when the margins are real, asserted at what was MEASURED plus a small margin, so
     that a regression cannot hide inside a relaxed bar (profiles/r04_trained_like.txt, re-measured in round 5):
       max |dlogit| <= 0.1 std (flat SURVEY bar): met on every head (0.007-0.020); asserted at 0.03;
-      mask IoU: 0.99888 .. 0.99984 over the four cases (3-19 flipped pixels, every one of them among the ~0.1 % of pixels with |logit| < 0.1 of
-        a std-7..12 map); asserted >= 0.9985 AND every flipped pixel inside the |logit| <= 4 rms(dlogit) band;
+      mask IoU: 0.99869 .. 0.99981 over the four cases at the round-5 tree (1-15 flipped pixels, every one of them among the ~0.1 % of pixels with
+        |logit| < 0.1 of a std-7..12 map; round 4's tile rules gave 0.99888 .. 0.99984 -- a different fp32 summation order moves single pixels, and one
+        pixel is 1.9e-4 of IoU at 120x214); asserted >= 0.9985 AND every flipped pixel inside the |logit| <= 4 rms(dlogit) band;
       gradients: all parameter gradients as one vector 0.05-0.10, asserted <= 0.15; trunk / side_prep / fuse tensors <= 0.25 measured, asserted 0.3;
-      loss: 4e-5 .. 1.7e-2 relative (the loss has fallen 23x and what is left sits on the few uncertain pixels); asserted <= 2.5e-2.
+      loss: 5e-5 .. 1.3e-2 relative (the loss has fallen 23x and what is left sits on the few uncertain pixels); asserted <= 2.5e-2.
     The FLAT bars of SURVEY 8(d) / north_star that bf16 does not meet on this fixture are the next test (xfail), not a looser number here."""
     for name, e_logit, e_loss, j, flips, ge, one_vec in _bf16_rows(trained):
         assert max(e_logit) <= 0.03, (name, e_logit)
@@ -171,8 +172,8 @@ def test_bf16_on_the_trained_like_net_measured_bars(trained):
         assert max(e_loss) <= 2.5e-2, (name, e_loss)
 
 
-@pytest.mark.xfail(strict=False, reason="bf16 on the trained-like fixture sits AT north_star's IoU line (0.99888 .. 0.99984 vs 1 - 1e-3: 6 flipped "
-                                        "pixels of 25680 on one case) and above SURVEY 8(d)'s 2e-3 loss bar (up to 1.7e-2): recorded as a known miss, "
+@pytest.mark.xfail(strict=False, reason="bf16 on the trained-like fixture sits AT north_star's IoU line (0.99869 .. 0.99981 vs 1 - 1e-3: 7 flipped "
+                                        "pixels of 25680 on two cases) and above SURVEY 8(d)'s 2e-3 loss bar (up to 1.3e-2): recorded as a known miss, "
                                         "the measured bars are asserted by the test above")
 def test_bf16_on_the_trained_like_net_flat_survey_bars(trained):
     """The flat bars: mask IoU >= 1 - 1e-3 (north_star), loss <= 2e-3, logits <= 0.1 std, gradients (one vector) <= 0.25."""

@@ -21,15 +21,15 @@ SEQ_NAME=blackswan timeout 600 python train_online.py --synthetic --device-augme
 echo "== train_online.py --synthetic --device-augment --window-fused --epochs 3000"
 SEQ_NAME=blackswan timeout 600 python train_online.py --synthetic --device-augment --window-fused --epochs 3000 > $O/online_win.log 2>&1; fps online $O/online_win.log 3000
 echo "== bench.py (same loop, frame resident, no input pipeline)"
-timeout 300 python tools/bench_fields.py --no-extra --no-cpu-baseline --steps 20 --warmup 5 | cut -c1-110
-timeout 300 python tools/bench_fields.py --no-extra --no-cpu-baseline --steps 20 --warmup 5 --window-fused 1 | cut -c1-130
+timeout 300 python tools/bench_fields.py --no-extra --no-cpu-baseline --no-parity --steps 20 --warmup 5 | cut -c1-110
+timeout 300 python tools/bench_fields.py --no-extra --no-cpu-baseline --no-parity --steps 20 --warmup 5 --window-fused 1 | cut -c1-130
 echo "== train_parent.py --synthetic 512 --device-augment --precision bf16 --epochs 4 (854x480, batch 1 per micro-batch like the reference)"
 timeout 900 python train_parent.py --synthetic 512 --device-augment --precision bf16 --epochs 4 > $O/parent.log 2>&1; fps parent $O/parent.log 512
 echo "== train_parent.py --synthetic 512 --device-augment --epochs 3 (fp32x3)"
 timeout 900 python train_parent.py --synthetic 512 --device-augment --epochs 3 > $O/parent_x3.log 2>&1; fps parent $O/parent_x3.log 512
 echo "== bench.py --mode parent --precision bf16 --batch 1"
-timeout 300 python tools/bench_fields.py --no-extra --no-cpu-baseline --steps 20 --warmup 5 --mode parent --precision bf16 --batch 1 | cut -c1-150
-timeout 300 python tools/bench_fields.py --no-extra --no-cpu-baseline --steps 20 --warmup 5 --mode parent --batch 1 | cut -c1-130
+timeout 300 python tools/bench_fields.py --no-extra --no-cpu-baseline --no-parity --steps 20 --warmup 5 --mode parent --precision bf16 --batch 1 | cut -c1-150
+timeout 300 python tools/bench_fields.py --no-extra --no-cpu-baseline --no-parity --steps 20 --warmup 5 --mode parent --batch 1 | cut -c1-130
 echo "== kernel trace of train_online.py --device-augment (120 iterations): three steps"
 (cd /tmp && SEQ_NAME=blackswan timeout 600 rocprofv3 --kernel-trace -d $O/prof -o online -- python $R/train_online.py --synthetic --device-augment --epochs 120 > $O/rocprof.log 2>&1)
 DB=$(find $O/prof -name "*.db" | head -1)
