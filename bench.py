@@ -29,6 +29,7 @@ a captured hipGraph) -- and `with_loss_item_sync`, the headline loop with the re
 `loss.item()` every iteration (train_online.py:128) left in.  `--no-extra` skips them.
 """
 import argparse
+from collections import OrderedDict
 import ctypes as C
 import gc
 import json
@@ -195,6 +196,10 @@ def cpu_baseline(h, w, mode, n_ave, budget_s=20.0):
         pass
     return {"value": 1.0 / med, "unit": "frames/s", "cores": torch.get_num_threads(), "threads_used": torch.get_num_threads(),
             "host_nproc": ncpu, "cpu_model": model, "kind": "port",
+            # BASELINE.md 3 says os.cpu_count() threads; on the 256-thread GPU host that oversubscribes oneDNN (one box: 4x slower at 128 than at 16),
+            # so the count is the fastest of those timed on a REAL iteration
+            "threads_note": "fastest thread count by a timed iteration (s/iter: %s); all %d host threads oversubscribe oneDNN"
+                            % (", ".join("%d: %.2f" % (k, v) for k, v in sorted(per_iter.items())), ncpu),
             "sample": "%d fwd+bwd iterations of the restated train_%s.py loop at %dx%d, batch 1, fp32, torch %s CPU "
                       "(oneDNN), median after 1 warm-up" % (len(timed), mode, w, h, torch.__version__)}
 
@@ -775,6 +780,168 @@ def measure(wl, steps, warmup, min_seconds, world, ctl, device, use_prof=True, s
     return res
 
 
+LINE_LIMIT = 6000       # the driver keeps the last 8,000 characters of stdout: the line must fit there WHOLE, with room to spare
+DETAIL_PATH = os.path.join("gpurun_out", "bench_detail.json")
+
+
+def _num(v, digits=4):
+    """A finite float rounded to `digits` significant figures, or None (strict JSON has no NaN / Infinity)."""
+    if v is None or isinstance(v, bool):
+        return v
+    try:
+        v = float(v)
+    except (TypeError, ValueError):
+        return None
+    if not math.isfinite(v):
+        return None
+    return float("%.*g" % (digits, v))
+
+
+def _compact_parity(p):
+    if not p:
+        return None
+    if "error" in p:
+        return {"error": str(p["error"])[:120]}
+    out = {k: p[k] for k in ("max_dlogit_over_std", "loss_rel", "iou", "flipped_pixels", "within_bars") if k in p}
+    w = p.get("grad_rel_l2_worst")
+    if w:
+        out["grad_rel_l2_worst"] = w.get("value")
+    out["bars"] = p.get("bars")
+    out["vs"] = "CPU oracle (oracle/torch_ref.py), same frames/labels/weights"
+    return out
+
+
+def _compact_roofline(r):
+    if not r:
+        return None
+    out = {k: r[k] for k in ("bound", "achieved", "peak", "unit", "frac") if k in r}
+    out["kernel"] = (r.get("kernel") or "")[:110]
+    for k in ("launches", "avg_launch_ms", "algorithmic_gflop_per_launch", "step_conv_fraction_of_mfma_roofline", "executed_over_algorithmic",
+              "algorithmic_tflops", "algorithmic_hbm_GBps"):
+        if r.get(k) is not None:
+            out[k] = r[k]
+    ps = r.get("pipe_sustained") or {}
+    if ps.get("tflops_noise_operands"):
+        out["pipe_sustained"] = {"noise": ps["tflops_noise_operands"], "zeros": ps.get("tflops_zero_operands"), "frac_of_sustained": ps.get("frac_of_sustained")}
+    t = r.get("traffic")
+    if t:
+        cf = t.get("conv_family") or {}
+        out["traffic"] = {"conv_hbm_MB_per_step": cf.get("hbm_MB_per_step"), "conv_algorithmic_MB_per_step": cf.get("algorithmic_MB_per_step"),
+                          "ratio": cf.get("ratio"), "all_kernels_hbm_MB_per_step": t.get("all_kernels_hbm_MB_per_step"),
+                          "source": t.get("source"), "measured_at_commit": t.get("measured_at_commit"), "static": True}
+        if out.get("launches") and cf.get("hbm_MB_per_step"):
+            out["traffic"]["conv_hbm_MB_per_launch"] = _num(cf["hbm_MB_per_step"] / out["launches"])
+    else:
+        out["traffic"] = None
+    return out
+
+
+def compact_line(full, detail_path=None):
+    """The ONE line the driver reads: every contract field, the parity numbers, the roofline, the CPU baseline and one short row per extra
+    configuration -- numbers only.  Prose notes, per-kernel traffic tables and sub-process records live in the detail file (`detail`)."""
+    r = full.get("roofline") or {}
+    ps = (r.get("pipe_sustained") or {}).get("tflops_noise_operands")
+    cfg = full.get("config") or {}
+    line = OrderedDict()
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline"):
+        line[k] = full.get(k)
+    line["dtype"] = full.get("dtype_short") or (full.get("dtype") or "").split(";")[0][:48]
+    line["data"] = full.get("data")
+    line["config"] = {"workload": (cfg.get("workload") or "")[:200], "global_batch": cfg.get("global_batch"), "parallelism": cfg.get("parallelism"),
+                      "grad_allreduce": (cfg.get("grad_allreduce") or "")[:60], "rccl_ranks_seen": cfg.get("rccl_ranks_seen")}
+    # box speed next to the value: the bf16 matrix pipe's sustained rate on THIS chip (boxes differ by up to 9 %)
+    line["pipe_sustained_tflops"] = ps
+    line["sustained_value"] = (full.get("sustained") or {}).get("value")
+    line["setup_settle_steps"] = full.get("setup_settle_steps")
+    vws = full.get("value_without_settle") or {}
+    line["value_without_settle"] = vws.get("value")
+    line["value_with_loss_item_sync"] = (full.get("with_loss_item_sync") or {}).get("value")
+    line["parity"] = _compact_parity(full.get("parity"))
+    line["roofline"] = _compact_roofline(r)
+    b = full.get("cpu_baseline")
+    if b and "error" not in b:
+        line["cpu_baseline"] = {"value": _num(b.get("value")), "unit": b.get("unit"), "cores": b.get("cores"), "kind": b.get("kind"),
+                                "sample": (b.get("sample") or "")[:170], "host_nproc": b.get("host_nproc"), "cpu_model": (b.get("cpu_model") or "")[:40],
+                                "threads_note": (b.get("threads_note") or "")[:150]}
+        if b.get("value") and full.get("value"):
+            line["gpu_over_cpu"] = _num(full["value"] / b["value"], 4)
+    else:
+        line["cpu_baseline"] = b
+    ex = []
+    for e in full.get("extra_configs") or []:
+        name = e.get("config") or ""
+        cid = e.get("id") or (name.split(":")[0].split(" ")[0] + ("/fp32-exact" if "EXACT" in name else "/window-fused" if "window-fused" in name else ""))[:40]
+        if "error" in e:
+            ex.append({"config": cid, "error": str(e["error"])[:100]})
+            continue
+        er, ep = e.get("roofline") or {}, e.get("parity") or {}
+        row = {"config": cid, "args": (e.get("args") or "")[:110], "value": e.get("value"), "ms_per_step": e.get("ms_per_step"),
+               "dtype": (e.get("dtype") or "").split(";")[0].split(" ")[0], "frac": er.get("frac"), "step_frac": er.get("step_conv_fraction_of_mfma_roofline"),
+               "sustained_value": (e.get("sustained") or {}).get("value")}
+        if ep:
+            row.update({"within_bars": ep.get("within_bars"), "iou": ep.get("iou"), "max_dlogit_over_std": ep.get("max_dlogit_over_std"), "loss_rel": ep.get("loss_rel")})
+        tr = (er.get("traffic") or {}).get("conv_family") or {}
+        if tr:
+            row["traffic_ratio"] = tr.get("ratio")
+        if er.get("algorithmic_hbm_GBps") is not None:
+            row["algorithmic_hbm_GBps"] = er["algorithmic_hbm_GBps"]
+        ex.append(row)
+    line["extra_configs"] = ex or None
+    line["running_loss"] = _num(full.get("running_loss"), 7)
+    line["detail"] = detail_path
+    return line
+
+
+def _strict(o):
+    """NaN / +-Infinity -> None, recursively: the line must load under a strict JSON parser."""
+    if isinstance(o, float):
+        return o if math.isfinite(o) else None
+    if isinstance(o, dict):
+        return OrderedDict((str(k), _strict(v)) for k, v in o.items())
+    if isinstance(o, (list, tuple)):
+        return [_strict(v) for v in o]
+    return o
+
+
+def emit_line(full, print_full=False, out=None):
+    """Write the full record to gpurun_out/bench_detail.json (best effort) and print the compact line as the LAST line of stdout."""
+    out = out or sys.stdout
+    full = _strict(full)
+    if print_full:
+        out.write(json.dumps(full, allow_nan=False) + "\n")
+        out.flush()
+        return None
+    detail = None
+    try:
+        path = os.path.join(REPO, DETAIL_PATH)
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            json.dump(full, f, allow_nan=False, indent=1)
+            f.write("\n")
+        detail = DETAIL_PATH
+    except OSError:
+        pass
+    line = compact_line(full, detail)
+    text = json.dumps(line, allow_nan=False)
+    # belt and braces: shed optional fields until the line fits
+    for k in ("extra_configs", "cpu_baseline.sample", "roofline.kernel", "config.workload"):
+        if len(text) <= LINE_LIMIT:
+            break
+        if "." in k:
+            a, b_ = k.split(".")
+            if isinstance(line.get(a), dict) and line[a].get(b_):
+                line[a][b_] = line[a][b_][:40]
+        else:
+            line[k] = [{kk: e.get(kk) for kk in ("config", "value", "frac", "within_bars")} for e in (line[k] or [])] or None
+            while line[k] and len(json.dumps(line, allow_nan=False)) > LINE_LIMIT:      # (still too many rows: the detail file has them all)
+                line[k].pop()
+        text = json.dumps(line, allow_nan=False)
+    sys.stderr.flush()
+    out.write(text + "\n")
+    out.flush()
+    return line
+
+
 def launch_ranks(n):
     """Re-run this command line under torch.distributed.run with `n` ranks on this node; stdout / stderr / exit code pass through."""
     import socket
@@ -794,6 +961,7 @@ def launch_ranks(n):
     return subprocess.call(cmd, env=env)
 
 
+DTYPE_SHORT = {"fp32": "f32", "fp32x3": "f32 (3x bf16-split operands on MFMA, f32 accumulate)", "bf16": "bf16 (f32 accumulate)"}
 DTYPE_NAME = {"fp32": "f32",
               "fp32x3": "f32 tensors and parameters; wide 3x3 convolutions (fwd, dgrad) as three-way bf16 split on the bf16 MFMA pipe (6 bf16 products per f32 product, f32 accumulate: f32-grade results); everything else f32", "bf16": "bf16 MFMA operands and bf16 trunk tensors (fwd+dgrad+wgrad), f32 accumulate; head/loss/skinny wgrads/parameters f32"}
 
@@ -830,6 +998,8 @@ def main():
     ap.add_argument("--no-parity", action="store_true", help="skip the parity gate (one micro-batch of the net about to be timed vs the CPU oracle)")
     ap.add_argument("--no-prof", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip extra_configs (configs[2], configs[4]) and the item-sync figure")
+    ap.add_argument("--full-line", action="store_true", help="print the FULL record (what gpurun_out/bench_detail.json holds) instead of the compact "
+                    "line; used by this script for its own extra_configs sub-processes")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -876,6 +1046,9 @@ def main():
             parity = parity_gate(wl)
         except Exception as e:      # the timing must still be reported; a missing gate shows in the line
             parity = {"error": repr(e)[:300]}
+        if not parity.get("within_bars", False):      # the line carries it; say it where a person running the script looks, too
+            print("bench.py: PARITY GATE OUTSIDE ITS BARS (or not run): %s" % json.dumps({k: parity.get(k) for k in
+                  ("max_dlogit_over_std", "loss_rel", "iou", "bars", "error")}), file=sys.stderr, flush=True)
     res = measure(wl, args.steps, args.warmup, args.min_seconds, world, ctl, device, use_prof=not args.no_prof, settle_seconds=args.settle_seconds)
     settle = res["settle_steps"]
     frames_per_step = wl.batch
@@ -897,37 +1070,37 @@ def main():
         # headline one ran 25 % slow -- 98 instead of 130 frames/s for the exact-fp32 loop -- and that is not a property of the kernels.)
         import subprocess
         torch.cuda.synchronize()
-        for (name, extra_args) in [
-                ("configs[1] on the EXACT fp32 MFMA kernels (v_mfma_f32_32x32x2_f32): same loop, precision 'fp32'", ["--precision", "fp32"]),       # (carries its own parity gate too)
-                ("configs[1] semantics, window-fused: the 5 micro-batches of an optimizer step (5 different frames) as ONE batch-5 pass with per-image "
+        for (cid, name, extra_args) in [
+                ("configs[1]/fp32-exact", "configs[1] on the EXACT fp32 MFMA kernels (v_mfma_f32_32x32x2_f32): same loop, precision 'fp32'", ["--precision", "fp32"]),       # (carries its own parity gate too)
+                ("configs[1]/window-fused", "configs[1] semantics, window-fused: the 5 micro-batches of an optimizer step (5 different frames) as ONE batch-5 pass with per-image "
                  "class counts -- the reference gradient up to summation order (tests/test_gpu_baseline_configs.py::test_window_batch_equals_the_sequential_micro_batches_at_120x214, "
                  "tests/test_gpu_trained_like.py::test_window_fused_pass_equals_the_sequential_micro_batches); what TrainLoop.window_batch / "
                  "train_online.py --window-fused run", ["--window-fused", "1"]),
-                ("configs[2]: 854x480 batch=12 parent training bf16 (MFMA path)", ["--mode", "parent", "--precision", "bf16", "--batch", "12"]),
-                ("configs[4]: 1920x1080 inference-only forward, batch=4, hipGraph-captured (f32x3)",
+                ("configs[2]", "configs[2]: 854x480 batch=12 parent training bf16 (MFMA path)", ["--mode", "parent", "--precision", "bf16", "--batch", "12"]),
+                ("configs[4]", "configs[4]: 1920x1080 inference-only forward, batch=4, hipGraph-captured (f32x3)",
                  ["--mode", "infer", "--height", "1080", "--width", "1920", "--batch", "4", "--graph", "1"]),
-                ("configs[4] on the EXACT fp32 MFMA kernels",
+                ("configs[4]/fp32-exact", "configs[4] on the EXACT fp32 MFMA kernels",
                  ["--mode", "infer", "--height", "1080", "--width", "1920", "--batch", "4", "--graph", "1", "--precision", "fp32", "--no-parity"])]:
             cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(max(10, min(args.steps, 30))),
-                   "--warmup", str(max(3, min(args.warmup, 5))), "--min-seconds", str(args.min_seconds), "--no-extra", "--no-cpu-baseline"] + extra_args
+                   "--warmup", str(max(3, min(args.warmup, 5))), "--min-seconds", str(args.min_seconds), "--no-extra", "--no-cpu-baseline", "--full-line"] + extra_args
             try:
                 env = dict(os.environ)
                 for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
                     env.pop(k, None)
                 out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
                 d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
-                extras.append({"config": name, "command": "python bench.py " + " ".join(cmd[2:]), "workload": d["config"]["workload"],
+                extras.append({"id": cid, "config": name, "args": " ".join(extra_args), "command": "python bench.py " + " ".join(cmd[2:]), "workload": d["config"]["workload"],
                                "value": d["value"], "unit": d["unit"], "steps": d["steps"], "setup_settle_steps": d.get("setup_settle_steps"),
                                "ms_per_step": d["ms_per_step"], "dtype": d["dtype"],
                                "sustained": d.get("sustained"), "parity": d.get("parity"), "roofline": d.get("roofline")})
             except Exception as e:  # the headline must still be reported
-                extras.append({"config": name, "error": repr(e)})
+                extras.append({"id": cid, "config": name, "error": repr(e)})
         # the headline command once more WITHOUT the settle phase, in its own process: what the ramp out of the idle power state costs a
         # run that times its first steps (keep that cost visible)
         no_settle = None
         try:
             cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup), "--min-seconds", "0",
-                   "--settle-seconds", "0", "--no-extra", "--no-cpu-baseline", "--no-prof"]
+                   "--settle-seconds", "0", "--no-extra", "--no-cpu-baseline", "--no-prof", "--full-line"]
             env = dict(os.environ)
             for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
                 env.pop(k, None)
@@ -969,7 +1142,7 @@ def main():
             "setup_settle_steps": settle,      # untimed SETUP steps before the warm-up (device out of its idle power state; --settle-seconds)
             "value_without_settle": no_settle,
             "ms_per_step": round(res["ms_per_step"], 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": DTYPE_NAME[args.precision],
+            "vs_baseline": None, "dtype": DTYPE_NAME[args.precision], "dtype_short": DTYPE_SHORT[args.precision],
             "data": "synthetic",
             "config": {"workload": workload,
                        "global_batch": frames_per_step * world, "parallelism": "dp%d" % world, "rccl_ranks_seen": ranks_seen,
@@ -987,7 +1160,7 @@ def main():
             "extra_configs": extras,
             "running_loss": running_loss,
         }
-        print(json.dumps(line))
+        emit_line(line, args.full_line)
     if ctl is not None:
         ctl.close()
 

@@ -267,6 +267,28 @@ def test_exact_resume_with_optimizer_state_continues_bit_for_bit(tmp_path, world
             torch.testing.assert_close(d["sd"][k], a[0]["sd"][k], rtol=2e-5, atol=1e-7, msg=k)
 
 
+def test_a_stale_optimizer_bundle_does_not_outlive_a_new_snapshot(tmp_path):
+    """run 1 writes parent_epoch-1.pth + parent_epoch-1.optim.pth; run 2 in the same directory (another seed, NO
+    --save-optimizer) rewrites parent_epoch-1.pth.  The old bundle must be gone, so that `--resume-epoch 2` continues from run 2's snapshot the
+    way the reference does (train_parent.py:59-65 loads the .pth only) instead of silently taking run 1's weights, momentum and position."""
+    sys.path.insert(0, REPO)
+    base = ["--synthetic", "7", "--epochs", "2", "--n-ave-grad", "4", "--height", "24", "--width", "32", "--lr", "1e-6", "--snapshot", "1"]
+    port = 37300 + (os.getpid() % 1500)
+    mp.spawn(_main_worker, args=(1, port, str(tmp_path / "run1"), base + ["--seed", "7", "--save-optimizer"]), nprocs=1, join=True)
+    assert os.path.exists(str(tmp_path / "parent_epoch-1.optim.pth"))
+    mp.spawn(_main_worker, args=(1, port + 1, str(tmp_path / "run2"), base + ["--seed", "8"]), nprocs=1, join=True)
+    assert os.path.exists(str(tmp_path / "parent_epoch-1.pth")) and not os.path.exists(str(tmp_path / "parent_epoch-1.optim.pth"))
+    snap = torch.load(str(tmp_path / "parent_epoch-1.pth"))
+    run2 = torch.load(str(tmp_path / "run2.0"))
+    for k in snap:
+        assert torch.equal(snap[k], run2["sd"][k]), k
+    # a run WITH the flag keeps (rewrites) its own bundle
+    mp.spawn(_main_worker, args=(1, port + 2, str(tmp_path / "run3"), base + ["--seed", "9", "--save-optimizer"]), nprocs=1, join=True)
+    ck = torch.load(str(tmp_path / "parent_epoch-1.optim.pth"), weights_only=False)
+    run3 = torch.load(str(tmp_path / "run3.0"))
+    assert all(torch.equal(ck["net"][k], run3["sd"][k]) for k in ck["net"])
+
+
 def test_optimizer_bundle_with_a_window_that_takes_one_iteration_from_the_next_epoch(tmp_path):
     """7 frames, nAveGrad 4, snapshot 1 -- the window {32..35} that closes epoch 4 holds exactly ONE iteration (35) of
     epoch 5, and on two ranks only rank 1 runs it.  save_bundle used to size its statistics all-reduce from the rank's OWN counters: rank 0

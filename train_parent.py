@@ -180,6 +180,7 @@ def main(argv=None, build_net=None, loss_fn=None):
     # may be exchanged, and how many complete step windows the run has (no rank steps on the trailing partial one).
     def optim_path(e):
         return os.path.join(save_dir, modelName + '_epoch-' + str(e) + '.optim.pth')
+    bundles_written = set()      # epochs whose bundle THIS run wrote (rank 0)
 
     # exact resume: the bundle holds network + optimizer + the global iteration the run continues at
     start_iteration, bundle = None, None
@@ -297,6 +298,7 @@ def main(argv=None, build_net=None, loss_fn=None):
             torch.save({'net': {k: v.detach().cpu() for k, v in net.state_dict().items()}, 'optimizer': optimizer.state_dict(),
                         'next_iteration': sched.next_iteration(loop.steps), 'n_ave_grad': nAveGrad, 'n_items': len(trainset),
                         'partial_stats': partial, 'world': world}, optim_path(e))
+            bundles_written.add(e)
 
     print("Training Network")
     for epoch in range(first_epoch, nEpochs):
@@ -315,6 +317,12 @@ def main(argv=None, build_net=None, loss_fn=None):
                 close_epochs(sched.closed_by(loop.steps, pending))      # right after the SAME gradient collective on every rank
         if (epoch % snapshot) == snapshot - 1 and epoch != 0 and rank == 0:
             torch.save(net.state_dict(), os.path.join(save_dir, modelName + '_epoch-' + str(epoch) + '.pth'))      # (the reference's snapshot)
+            # A bundle of an EARLIER run for this epoch no longer belongs to the snapshot just written: a later --resume-epoch would take its
+            # weights, momentum and position over this run's .pth without a word.  With --save-optimizer this run's own bundle
+            # replaces it when the window that closes the epoch completes; until then, and without the flag, there is none.
+            if epoch not in bundles_written and os.path.exists(optim_path(epoch)):
+                os.remove(optim_path(epoch))
+                print("removed %s: written by an earlier run, it does not match the snapshot of this one" % optim_path(epoch))
     close_epochs(list(pending))        # epochs that end in the trailing partial window: every rank has left the loop, same order everywhere
     if rank == 0:
         print("optimizer steps taken: %d" % loop.steps)
