@@ -174,7 +174,9 @@ def test_bf16_on_the_trained_like_net_measured_bars(trained):
 
 @pytest.mark.xfail(strict=False, reason="bf16 on the trained-like fixture sits AT north_star's IoU line (0.99869 .. 0.99981 vs 1 - 1e-3: 7 flipped "
                                         "pixels of 25680 on two cases) and above SURVEY 8(d)'s 2e-3 loss bar (up to 1.3e-2): recorded as a known miss, "
-                                        "the measured bars are asserted by the test above")
+                                        "the measured bars are asserted by the test above.  profiles/r06_bf16_error_budget.txt: no per-stage "
+                                        "mixed-precision policy under +30 % step time brings the loss under 2e-3 on this fixture (only all-layer operand "
+                                        "splits do), so this stays a recorded miss of bf16 -- 'fp32x3' meets every flat bar")
 def test_bf16_on_the_trained_like_net_flat_survey_bars(trained):
     """The flat bars: mask IoU >= 1 - 1e-3 (north_star), loss <= 2e-3, logits <= 0.1 std, gradients (one vector) <= 0.25."""
     for name, e_logit, e_loss, j, flips, ge, one_vec in _bf16_rows(trained):
