@@ -141,6 +141,15 @@ int osvos_maxpool2x2_bwd_bf16act(const void* x_bf16, const void* dy_bf16, const 
 int osvos_maxpool2x2_bf16act_code(const void* x_bf16, void* y_bf16, void* code, int N, int H, int W, int C, void* stream);
 int osvos_maxpool2x2_bwd_bf16act_code(const void* code, const void* dy_bf16, const void* dside_bf16, void* dx_bf16, int N, int H, int W, int C,
                                       void* stream);
+/* The trunk convolution of the bf16-store mode WITH its fused epilogues, as osvos_net_forward / osvos_net_backward launch it (round 6: op-level
+ * access for the parity tests of every tile, vgg_osvos.py:136-145 conv -> ReLU [-> MaxPool2d(2, stride=2, ceil_mode=True)] and its autograd):
+ *   x_bf16, y_bf16: bf16 NHWC, dense (channel stride = channel count); wpk from osvos_pack_fwd / osvos_pack_dgrad with OSVOS_F32_BF16MFMA
+ *   mask_bits (optional): ReLU mask of a data gradient as ONE bit per element, [N][H][W][Cout/32] 32-bit words, bit b of word g = channel 32 g + b
+ *   y_bits (optional): the same for the result (what a later data gradient is masked with)
+ *   pooled_bf16 + pool_code (optional; need relu, no mask): the 2x2 ceil-mode max-pool of the result and its code bytes (see above)
+ *   tile: osvos_conv3x3_bf16io_tiles() ids (+100: XCD-local block order) or -1 = automatic; 36 / 37 need Cin == 64. */
+int osvos_conv3x3_bf16act_fused(const void* x_bf16, const void* wpk, const float* bias, const void* mask_bits, void* y_bf16, void* y_bits,
+                                void* pooled_bf16, void* pool_code, int N, int H, int W, int Cin, int Cout, int relu, int tile, void* stream);
 int osvos_conv3x3_bf16io_tiles(int* tiles, int max);
 int osvos_nchw_to_nhwc_bf16copy(const float* src, void* dst, void* dst_bf16, int N, int C, int H, int W, int cpad, void* stream);
 int osvos_maxpool2x2_bf16copy(const float* x, float* y, void* y_bf16, int N, int H, int W, int C, void* stream);

@@ -51,6 +51,7 @@ PROTOTYPES = {
     "osvos_maxpool2x2_bwd_bf16act": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "osvos_maxpool2x2_bf16act_code": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "osvos_maxpool2x2_bwd_bf16act_code": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "osvos_conv3x3_bf16act_fused": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "osvos_conv3x3_bf16io_tiles": (_i, [_vp, _i]),
     "osvos_nchw_to_nhwc_bf16copy": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "osvos_maxpool2x2_bf16copy": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),

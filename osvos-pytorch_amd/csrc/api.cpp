@@ -106,6 +106,12 @@ int osvos_maxpool2x2_bwd_bf16act_code(const void* code, const void* dy_bf16, con
                                       void* stream) {
   return osvos_maxpool2x2_bwd_bf16_code(code, dy_bf16, dside_bf16, dx_bf16, N, H, W, C, (hipStream_t)stream);
 }
+int osvos_conv3x3_bf16act_fused(const void* x_bf16, const void* wpk, const float* bias, const void* mask_bits, void* y_bf16, void* y_bits,
+                                void* pooled_bf16, void* pool_code, int N, int H, int W, int Cin, int Cout, int relu, int tile, void* stream) {
+  OSVOS_ARG_CHECK(y_bf16 != nullptr, "conv3x3_bf16act_fused: y_bf16 is required");
+  return osvos_conv3x3_bf16mfma_bits(x_bf16, 1, wpk, bias, nullptr, 0, reinterpret_cast<const unsigned*>(mask_bits), nullptr, y_bf16,
+                                     reinterpret_cast<unsigned*>(y_bits), pooled_bf16, N, H, W, Cin, Cout, Cout, relu, tile, (hipStream_t)stream, pool_code);
+}
 int osvos_conv3x3_bf16io_tiles(int* tiles, int max) { return osvos_conv3x3_bf16mfma_xb_tiles(tiles, max); }
 
 size_t osvos_conv3x3_splitk_ws_bytes(int N, int H, int W, int Cout, int dtype) {

@@ -666,18 +666,30 @@ int osvos_conv3x3_bf16mfma_bits(const void* x, int xb, const void* wpk, const fl
     if (!env && xb && Cin >= dma_min_cin && a.CoutP >= 128 && osvos_conv3x3_bf16_dma_applicable(Cin, Cout, y_cs) &&
         (long)N * ceil_div(H, 16) * ceil_div(W, 32) * ceil_div(a.CoutP, 128) >= 128)
       tile = dma_tile;
+    // Cin = 64, bf16 in / out, FORWARD launches with enough 512-pixel tiles to give every CU several: the persistent resident-filter kernel with the
+    // deferred + skewed packed epilogue (conv3x3_bf16_p64.hip; round 6): 6-10 % faster at op level at batch 12 (conv1_2 + pool 0.524 vs 0.582 ms,
+    // conv2_1 0.207 vs 0.226), step level within noise (profiles/r06_p64_diagnosis.txt).  NOT the data gradient (17 % faster alone, but one 160 KB / 256-VGPR
+    // workgroup per CU cannot share a CU with the weight-gradient stream the way tile 9's three small workgroups do).  OSVOS_P64_MIN_TILES: tiles per
+    // launch from which it is taken (0 = never); OSVOS_P64_DGRAD=1 takes it for masked launches too.
+    OSVOS_ENV_INT(p64_min, "OSVOS_P64_MIN_TILES", 1024);
+    OSVOS_ENV_INT(p64_dgrad, "OSVOS_P64_DGRAD", 0);
+    if (!env && xb && p64_min > 0 && (p64_dgrad || mask_bits == nullptr) && (long)N * ceil_div(H, 16) * ceil_div(W, 32) * ceil_div(Cout, 64) >= p64_min &&
+        osvos_conv3x3_bf16_p64_applicable(Cin, Cout, y_cs, y != nullptr, mask != nullptr, mask_bits != nullptr, y_bits != nullptr, pooled_bf16 != nullptr, relu))
+      tile = 38;
     // (round 5 re-check at step level, configs[2]: always / never / 3x / 10x this threshold all within +-0.3 % -- unlike the f32x3 rule)
     if (!env && (double)H * W * Cin * 4 > 9.0 * Cin * a.CoutP * 2) tile += 100;
   }
   a.map = tile >= 100 ? 1 : 0;
   tile %= 100;
-  if (xb && tile >= 30 && tile <= 35) {      // LDS-DMA staged kernel
+  if (xb && tile == 38) {      // Cin = 64: persistent, resident filter, deferred + skewed packed epilogue (conv3x3_bf16_p64.hip)
+    OSVOS_ARG_CHECK(osvos_conv3x3_bf16_p64_applicable(Cin, Cout, y_cs, y != nullptr, mask != nullptr, mask_bits != nullptr, y_bits != nullptr, pooled_bf16 != nullptr, relu),
+                    "conv3x3 bf16: tile 38 needs Cin = 64, bf16 in / out only, no full-tensor mask, sign bits only with ReLU (Cin %d, Cout %d)", Cin, Cout);
+    return osvos_conv3x3_bf16_p64(x, wpk, bias, mask_bits, ybf, y_bits, pooled_bf16, pool_code, N, H, W, Cout, y_cs, relu, a.map, stream);
+  }
+  if (xb && tile >= 30 && tile <= 37) {      // LDS-DMA staged kernel (its fused pool writes the code bytes too: round 6)
     OSVOS_ARG_CHECK(osvos_conv3x3_bf16_dma_applicable(Cin, Cout, y_cs), "conv3x3 bf16: tile %d (DMA staging) needs Cin %% 16 == 0, Cout, y_cs %% 8 == 0", tile);
-    if (pool_code != nullptr) {      // the DMA kernel's fused pool writes no code bytes: pooling (with them) as its own launch behind the convolution
-      const int rc = osvos_conv3x3_bf16_dma(x, wpk, bias, mask, mask_bf16, mask_bits, y, ybf, y_bits, nullptr, N, H, W, Cin, Cout, y_cs, relu, tile - 30, a.map, stream);
-      return rc ? rc : osvos_maxpool2x2_bf16_code(ybf, pooled_bf16, pool_code, N, H, W, Cout, stream);
-    }
-    return osvos_conv3x3_bf16_dma(x, wpk, bias, mask, mask_bf16, mask_bits, y, ybf, y_bits, pooled_bf16, N, H, W, Cin, Cout, y_cs, relu, tile - 30, a.map, stream);
+    OSVOS_ARG_CHECK(tile < 36 || Cin == 64, "conv3x3 bf16: tile %d (resident filter) is built for Cin = 64 (got %d)", tile, Cin);
+    return osvos_conv3x3_bf16_dma(x, wpk, bias, mask, mask_bf16, mask_bits, y, ybf, y_bits, pooled_bf16, N, H, W, Cin, Cout, y_cs, relu, tile - 30, a.map, stream, pool_code);
   }
   if (a.pooled != nullptr && !(xb && tile != 7 && tile >= 0 && tile < kNumTilesB)) {      // a tile whose waves do not hold whole windows: separate pooling launch
     a.pooled = nullptr;
@@ -720,7 +732,7 @@ int osvos_conv3x3_bf16mfma_bits(const void* x, int xb, const void* wpk, const fl
 }
 
 int osvos_conv3x3_bf16mfma_xb_tiles(int* tiles, int max) {      // tile ids built for bf16 activations
-  static const int t[] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 30, 31, 32, 33, 34, 35};
+  static const int t[] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 30, 31, 32, 33, 34, 35, 36, 37};      // (36, 37: Cin = 64 only)
   int n = 0;
   for (; n < (int)(sizeof(t) / sizeof(t[0])) && n < max; ++n) tiles[n] = t[n];
   return n;

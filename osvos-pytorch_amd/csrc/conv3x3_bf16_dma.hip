@@ -12,6 +12,13 @@
 // Workgroup: 4 waves, 256 pixels (8 rows x 32) x NB*32 couts; wave (wm, wn) owns 4 rows x NB/2 cout blocks.
 // LDS: 3 x 48 KB (NB = 4) -> one workgroup per CU, one wave per SIMD; latency is hidden by the DMA distance (two chunks)
 // and by software-pipelined fragment reads.  Needs Cin % 16 == 0 (every layer but conv1_1).
+//
+// RESIDENT-FILTER form (CINR = 64, round 6): the Cin = 64 layers (conv1_2, conv2_1 and conv1_2's data gradient) are HBM-side
+// (288 FLOP per byte at batch 12) and K = 576 is only four chunks, so a workgroup's life was mostly prologue + epilogue and every one of the
+// 19,215 small tiles re-streamed the whole 73.7 KB filter of its 64 couts from L2 (1.4 GB of L2 -> LDS traffic per launch, as much as the
+// tensor traffic itself).  Here the workgroups are PERSISTENT (one per CU, tiles b, b + G, ... all of ONE cout tile), the filter is loaded ONCE
+// into its own LDS region (9 x Cin/8 x 64 slots = 73.7 KB), only the 16-channel activation chunks rotate (3 buffers of 21.5 KB, DMA two chunks
+// ahead, crossing tile boundaries), and the next tile's first chunks are in flight while the epilogue stores drain.
 #include "common.h"
 #include "maskbits.h"
 
@@ -34,6 +41,7 @@ struct DmaArgs {
   const unsigned* mask_bits;   // one-bit-per-element ReLU mask (maskbits.h); takes precedence over `mask`
   unsigned* y_bits;            // optional: sign bits of the result
   bf16_t* pooled;              // optional: maxpool2x2 (ceil mode) of the bf16 result, [N][ceil(H/2)][ceil(W/2)][y_cs] (last convolution of a stage; needs ReLU)
+  unsigned char* pool_code;    // optional, with pooled: one byte per pooled element for the pool's backward (pool.hip: first-max position + 4 "input > 0" bits)
 };
 
 constexpr int TW = 32, HWD = TW + 2;
@@ -42,29 +50,36 @@ constexpr unsigned OOB = 0x80000000u;
 
 // WGM = 2: 4 waves, 8 rows x 32 px, three rotating LDS buffers, one wave per SIMD
 // WGM = 4: 8 waves, 16 rows x 32 px, two LDS buffers, two waves per SIMD (each covers the other's DMA issue and LDS waits)
-template <int NB, int WGM>
+// CINR = 0: the weights of a chunk travel with its activations (B_SLOTS per rotating buffer); CINR = Cin > 0: the whole filter is resident
+template <int NB, int WGM, int CINR = 0>
 struct DmaCfg {
+  static constexpr bool RES = CINR > 0;
   static constexpr int NW = 2 * WGM, NT = 64 * NW;         // wave grid WGM x 2
   static constexpr int TH = 4 * WGM, HHT = TH + 2, PLANE = HHT * HWD;
   static constexpr int A_SLOTS = (KG * PLANE + 63) / 64 * 64;
   static constexpr int A_INSTR = A_SLOTS / 64;
-  static constexpr int NBUF = WGM == 2 ? 3 : 2;
+  static constexpr int NBUF = (RES || WGM == 2) ? 3 : 2;
   static constexpr int BN = NB * 32;
   static constexpr int WN = NB / 2;                        // cout blocks per wave
   static constexpr int WM = 4;                             // rows per wave
-  static constexpr int B_SLOTS = 9 * KG * BN;              // multiple of 64
+  static constexpr int B_SLOTS = 9 * KG * BN;              // multiple of 64 (one chunk's weights)
   static constexpr int B_INSTR = B_SLOTS / 64;
-  static constexpr int BUF_SLOTS = A_SLOTS + B_SLOTS + 64; // + one spare instruction target (keeps every wave's DMA count equal)
-  static constexpr int NA = (A_INSTR + NW - 1) / NW, NBI = (B_INSTR + NW - 1) / NW;
+  static constexpr int BUF_B = RES ? 0 : B_SLOTS;          // weight slots inside a rotating buffer
+  static constexpr int BUF_SLOTS = A_SLOTS + BUF_B + 64;   // + one spare instruction target (keeps every wave's DMA count equal)
+  static constexpr int NA = (A_INSTR + NW - 1) / NW, NBI = RES ? 0 : (B_INSTR + NW - 1) / NW;
   static constexpr int NDMA = NA + NBI;                    // DMA instructions per wave per chunk
-  static constexpr size_t LDS_BYTES = (size_t)NBUF * BUF_SLOTS * 16;
+  static constexpr int RCG = CINR / 8;                     // resident filter: 8-channel groups of the reduction dimension
+  static constexpr int RB_BASE = NBUF * BUF_SLOTS, RB_SLOTS = 9 * RCG * BN, RB_INSTR = RB_SLOTS / 64;
+  static constexpr size_t LDS_BYTES = (size_t)(NBUF * BUF_SLOTS + RB_SLOTS) * 16;
+  static_assert(CINR % 16 == 0, "whole chunks");
   static_assert(B_SLOTS % 64 == 0, "weight tile must be whole DMA instructions");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 
-template <int NB, int WGM>
+template <int NB, int WGM, int CINR>
 __global__ __launch_bounds__(64 * 2 * WGM, WGM == 4 ? 2 : 1) void conv3x3_bf16_dma_kernel(DmaArgs a) {
-  using C = DmaCfg<NB, WGM>;
+  using C = DmaCfg<NB, WGM, CINR>;
+  constexpr bool RES = C::RES;
   constexpr int TH = C::TH, PLANE = C::PLANE, A_SLOTS = C::A_SLOTS, A_INSTR = C::A_INSTR, NBUF = C::NBUF, NW = C::NW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const uint4* lds = reinterpret_cast<const uint4*>(smem);
@@ -121,7 +136,7 @@ __global__ __launch_bounds__(64 * 2 * WGM, WGM == 4 ? 2 : 1) void conv3x3_bf16_d
 
   // per-lane source offsets of this wave's DMA instructions for the tile being ISSUED (chunk 0; the chunk advance rides in the
   // scalar offset).  The issue side runs DIST chunks ahead of the multiply side and crosses tile boundaries on its own.
-  unsigned a_off[C::NA], b_off[C::NBI];
+  unsigned a_off[C::NA], b_off[C::NBI > 0 ? C::NBI : 1];
   i32x4 xrs = make_rsrc(a.x, 0);
   auto set_issue_tile = [&](const Tile& T) {
     xrs = make_rsrc(a.x + (size_t)T.n * ximg_elems, (int)(ximg_elems * 2));
@@ -148,10 +163,10 @@ __global__ __launch_bounds__(64 * 2 * WGM, WGM == 4 ? 2 : 1) void conv3x3_bf16_d
     const unsigned base = lds0 + (unsigned)(buf * C::BUF_SLOTS * 16);
     if (d < C::NA) {
       const int j = wv + NW * d;
-      dma16(xrs, base + (unsigned)(j < A_INSTR ? j * 1024 : (A_SLOTS + C::B_SLOTS) * 16), a_off[d] | dead, kc * (8 * KG * 2));
-    } else {
+      dma16(xrs, base + (unsigned)(j < A_INSTR ? j * 1024 : (A_SLOTS + C::BUF_B) * 16), a_off[d] | dead, kc * (8 * KG * 2));
+    } else if constexpr (!RES) {
       const int i = d - C::NA, j = wv + NW * i;
-      dma16(wrs, base + (unsigned)(j < C::B_INSTR ? (A_SLOTS + 64 * j) * 16 : (A_SLOTS + C::B_SLOTS) * 16), b_off[i] | dead, kc * KG * a.CoutP * 16);
+      dma16(wrs, base + (unsigned)(j < C::B_INSTR ? (A_SLOTS + 64 * j) * 16 : (A_SLOTS + C::BUF_B) * 16), b_off[i] | dead, kc * KG * a.CoutP * 16);
     }
   };
   auto dma_chunk = [&](int kc, int buf, unsigned dead) {
@@ -161,6 +176,7 @@ __global__ __launch_bounds__(64 * 2 * WGM, WGM == 4 ? 2 : 1) void conv3x3_bf16_d
 
   const int a_idx = lh * PLANE + (wm * C::WM) * HWD + li;              // + mi * HWD + r * HWD + s
   const int b_idx = A_SLOTS + lh * C::BN + wn * C::WN * 32 + li;       // + tap * KG * BN + ni * 32
+  const int rb_idx = C::RB_BASE + lh * C::BN + wn * C::WN * 32 + li;   // resident filter: + (tap * RCG + kc * KG) * BN + ni * 32
 
   f32x16 acc[C::WM][C::WN];
   auto zero_acc = [&]() {
@@ -182,6 +198,17 @@ __global__ __launch_bounds__(64 * 2 * WGM, WGM == 4 ? 2 : 1) void conv3x3_bf16_d
   constexpr int WAITCNT = 0x0F70 | (VM & 15) | ((VM >> 4) << 14);
   // issue side: chunk stream position gi = (tile it_, chunk ikc)
   int it_ = blockIdx.x, ikc = 0, gi = 0;
+  if constexpr (RES) {
+    // the whole filter of THIS workgroup's cout tile (every tile it walks has the same one: the launcher keeps gridDim.x a multiple of 8 nct), once.
+    // Issued ahead of the first activation chunks: the first `s_waitcnt vmcnt` below covers it (VM counts complete in order).
+    const int co0 = decode(blockIdx.x).co0;
+    for (int j = wv; j < C::RB_INSTR; j += NW) {
+      const int e = 64 * j + lane;
+      const int tap = e / (C::RCG * C::BN), rem = e % (C::RCG * C::BN);
+      const int g = rem / C::BN, nn = rem % C::BN;
+      dma16(wrs, lds0 + (unsigned)((C::RB_BASE + 64 * j) * 16), co0 + nn < a.CoutP ? (unsigned)(((tap * CG + g) * a.CoutP + co0 + nn) * 16) : OOB, 0);
+    }
+  }
   set_issue_tile(decode(it_));
   auto issue_advance = [&]() {                               // after all DMA instructions of stream chunk gi have been issued
     ++gi;
@@ -214,7 +241,8 @@ __global__ __launch_bounds__(64 * 2 * WGM, WGM == 4 ? 2 : 1) void conv3x3_bf16_d
 #pragma unroll
       for (int mi = 0; mi < C::WM; ++mi) fa[set][mi] = As[a_idx + (mi + r) * HWD + s];
 #pragma unroll
-      for (int ni = 0; ni < C::WN; ++ni) fb[set][ni] = As[b_idx + tap * KG * C::BN + ni * 32];
+      for (int ni = 0; ni < C::WN; ++ni)
+        fb[set][ni] = RES ? lds[rb_idx + (tap * C::RCG + kc * KG) * C::BN + ni * 32] : As[b_idx + tap * KG * C::BN + ni * 32];
     };
     ldfrag(0, 0);
 #pragma unroll
@@ -265,6 +293,8 @@ __global__ __launch_bounds__(64 * 2 * WGM, WGM == 4 ? 2 : 1) void conv3x3_bf16_d
     const int PHo = (a.H + 1) / 2, PWo = (a.W + 1) / 2;
     const size_t poimg = (size_t)PHo * PWo * a.y_cs;
     const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(pool_fwd ? (void*)(a.pooled + n * poimg) : anyp, 0, pool_fwd ? (int)(poimg * 2) : 0, 0x00020000);
+    const bool pool_code = pool_fwd && a.pool_code != nullptr;
+    const __amdgpu_buffer_rsrc_t pcrs = __builtin_amdgcn_make_buffer_rsrc(pool_code ? (void*)(a.pool_code + n * poimg) : anyp, 0, pool_code ? (int)poimg : 0, 0x00020000);
     // one-bit masks (maskbits.h): words per pixel = y_cs / 32
     const int bw = a.y_cs >> 5;
     const size_t img_words = (size_t)a.H * a.W * bw;
@@ -335,31 +365,47 @@ __global__ __launch_bounds__(64 * 2 * WGM, WGM == 4 ? 2 : 1) void conv3x3_bf16_d
       if (pool_fwd) {
         // fused forward pool (this launch is the last convolution of a stage): max over the 2 x 2 window of the packed bf16 results.  Post-ReLU
         // values are >= 0, so positions outside the image count as 0 and 16-bit UNSIGNED integer max is the bf16 max.
-        // windows: RBW 32 -- M blocks 2j, 2j+1 of this wave are the two rows, lane ^ 1 the neighbouring column;
-        //          RBW 16 -- an M block holds both rows (lanes li and li ^ 16), lane ^ 1 the neighbouring column
         typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
-        constexpr int NP = true ? C::WM / 2 : C::WM;
+        constexpr int NP = C::WM / 2;
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
           const int oy = y0 + wm * C::WM + 2 * j, ox = x0 + li;      // top row of the window pair
-          const bool writer = (li & 1) == 0 && (true || li < 16) && oy < a.H && ox < a.W;
+          const bool writer = (li & 1) == 0 && oy < a.H && ox < a.W;
           const unsigned ppix = writer ? (unsigned)(((oy >> 1) * PWo + (ox >> 1)) * a.y_cs) * 2u : OOB;
 #pragma unroll
           for (int pq = 0; pq < 2; ++pq) {
-            u16x8 m;
-            if constexpr (true) {
-              m = __builtin_elementwise_max(__builtin_bit_cast(u16x8, keep[2 * j][pq]), __builtin_bit_cast(u16x8, keep[2 * j + 1][pq]));
-            } else {
-              const u32x4 t = keep[j][pq];
-              const u32x4 u = {(unsigned)__shfl_xor((int)t[0], 16, 64), (unsigned)__shfl_xor((int)t[1], 16, 64), (unsigned)__shfl_xor((int)t[2], 16, 64),
-                               (unsigned)__shfl_xor((int)t[3], 16, 64)};
-              m = __builtin_elementwise_max(__builtin_bit_cast(u16x8, t), __builtin_bit_cast(u16x8, u));
-            }
-            const u32x4 t = __builtin_bit_cast(u32x4, m);
-            const u32x4 u = {(unsigned)__shfl_xor((int)t[0], 1, 64), (unsigned)__shfl_xor((int)t[1], 1, 64), (unsigned)__shfl_xor((int)t[2], 1, 64),
-                             (unsigned)__shfl_xor((int)t[3], 1, 64)};
-            m = __builtin_elementwise_max(m, __builtin_bit_cast(u16x8, u));
+            // this lane's column: r0 = its upper row, r1 = its lower row (rows 2j, 2j+1 of this wave); lane ^ 1 the neighbouring column
+            const u32x4 r0 = keep[2 * j][pq], r1 = keep[2 * j + 1][pq];
+            u16x8 m = __builtin_elementwise_max(__builtin_bit_cast(u16x8, r0), __builtin_bit_cast(u16x8, r1));
             const int co = co0 + (wn * C::WN + ni) * 32 + 16 * pq + 8 * lh;
+            if (!pool_code) {
+              const u32x4 t = __builtin_bit_cast(u32x4, m);
+              const u32x4 u = {(unsigned)__shfl_xor((int)t[0], 1, 64), (unsigned)__shfl_xor((int)t[1], 1, 64), (unsigned)__shfl_xor((int)t[2], 1, 64),
+                               (unsigned)__shfl_xor((int)t[3], 1, 64)};
+              m = __builtin_elementwise_max(m, __builtin_bit_cast(u16x8, u));
+            } else {
+              // the neighbouring column's two rows arrive separately: the writer needs all four window values for the code byte (as conv3x3_bf16.hip)
+              const u32x4 n0 = {(unsigned)__shfl_xor((int)r0[0], 1, 64), (unsigned)__shfl_xor((int)r0[1], 1, 64), (unsigned)__shfl_xor((int)r0[2], 1, 64),
+                                (unsigned)__shfl_xor((int)r0[3], 1, 64)};
+              const u32x4 n1 = {(unsigned)__shfl_xor((int)r1[0], 1, 64), (unsigned)__shfl_xor((int)r1[1], 1, 64), (unsigned)__shfl_xor((int)r1[2], 1, 64),
+                                (unsigned)__shfl_xor((int)r1[3], 1, 64)};
+              m = __builtin_elementwise_max(m, __builtin_elementwise_max(__builtin_bit_cast(u16x8, n0), __builtin_bit_cast(u16x8, n1)));
+              unsigned cw[2] = {0u, 0u};
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {      // scan order (0,0) (0,1) (1,0) (1,1), strict >: the first maximum (pool.hip); post-ReLU bf16 compare as u16
+                const int sh = 16 * (e & 1);
+                const unsigned av = (r0[e >> 1] >> sh) & 0xffffu, bv2 = (n0[e >> 1] >> sh) & 0xffffu;
+                const unsigned cv = (r1[e >> 1] >> sh) & 0xffffu, dv = (n1[e >> 1] >> sh) & 0xffffu;
+                unsigned bi = 0u, best = av;
+                if (bv2 > best) { best = bv2; bi = 1u; }
+                if (cv > best) { best = cv; bi = 2u; }
+                if (dv > best) { bi = 3u; }
+                const unsigned byte = bi | (av ? 4u : 0u) | (bv2 ? 8u : 0u) | (cv ? 16u : 0u) | (dv ? 32u : 0u);
+                cw[e >> 2] |= byte << (8 * (e & 3));
+              }
+              typedef unsigned u32x2s __attribute__((ext_vector_type(2)));
+              __builtin_amdgcn_raw_buffer_store_b64(u32x2s{cw[0], cw[1]}, pcrs, (co < a.Cout && ppix != OOB) ? (ppix >> 1) + (unsigned)co : OOB, 0, 0);
+            }
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, m), prs, (co < a.Cout && ppix != OOB) ? ppix + (unsigned)co * 2u : OOB, 0, 0);
           }
         }
@@ -371,14 +417,15 @@ __global__ __launch_bounds__(64 * 2 * WGM, WGM == 4 ? 2 : 1) void conv3x3_bf16_d
   }
 }
 
-template <int NB, int WGM>
+template <int NB, int WGM, int CINR = 0>
 int launch(const DmaArgs& a0, int persist, hipStream_t stream) {
-  using C = DmaCfg<NB, WGM>;
+  using C = DmaCfg<NB, WGM, CINR>;
+  OSVOS_ARG_CHECK(CINR == 0 || a0.Cin == CINR, "conv3x3 bf16 dma: the resident-filter form is built for Cin = %d (got %d)", CINR, a0.Cin);
   constexpr int TH = C::TH;
   static bool attr_set_dev[OSVOS_MAX_DEVICES] = {};      // hipFuncSetAttribute is per device
   bool& attr_set = attr_set_dev[osvos_current_device()];
   if (!attr_set) {
-    OSVOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16_dma_kernel<NB, WGM>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    OSVOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16_dma_kernel<NB, WGM, CINR>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)C::LDS_BYTES));
     attr_set = true;
   }
@@ -400,8 +447,12 @@ int launch(const DmaArgs& a0, int persist, hipStream_t stream) {
     n_cu = n_cu / 8 * 8;
     if (n_cu < 8) n_cu = 8;
   }
-  const long grid = persist && blocks > n_cu ? n_cu : blocks;
-  hipLaunchKernelGGL((conv3x3_bf16_dma_kernel<NB, WGM>), dim3((unsigned)grid), dim3(C::NT), C::LDS_BYTES, stream, a);
+  // (resident filter: a workgroup keeps ONE cout tile -- map 0 needs G % nct == 0, map 1 (G / 8) % nct == 0: G a multiple of 8 nct serves both)
+  const int gmul = 8 * (CINR > 0 ? a.nct : 1);
+  const long gmax = (long)n_cu / gmul * gmul;
+  OSVOS_ARG_CHECK(gmax > 0, "conv3x3 bf16 dma: %d cout tiles do not fit a persistent grid of %d workgroups", a.nct, n_cu);
+  const long grid = persist && blocks > gmax ? gmax : blocks;
+  hipLaunchKernelGGL((conv3x3_bf16_dma_kernel<NB, WGM, CINR>), dim3((unsigned)grid), dim3(C::NT), C::LDS_BYTES, stream, a);
   OSVOS_LAUNCH_CHECK();
   return 0;
 }
@@ -413,8 +464,10 @@ bool osvos_conv3x3_bf16_dma_applicable(int Cin, int Cout, int y_cs) { return Cin
 // variant 0: 256 px x 128 couts (4 waves), 1: 256 px x 64 couts (4 waves), 2: 512 px x 128 couts (8 waves), 3: 512 px x 64 couts (8 waves),
 // 4 / 5: variants 0 / 2 as persistent workgroups (one per CU, tiles pipelined back to back);
 // map = 1: XCD-local spatial block order
+// 6 / 7: RESIDENT-FILTER persistent forms for Cin = 64 (512 px / 256 px x 64 couts): see the head of this file
 int osvos_conv3x3_bf16_dma(const void* x, const void* wpk, const float* bias, const void* mask, int mask_bf16, const unsigned* mask_bits, float* y, void* ybf,
-                           unsigned* y_bits, void* pooled_bf16, int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int variant, int map, hipStream_t stream) {
+                           unsigned* y_bits, void* pooled_bf16, int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int variant, int map, hipStream_t stream,
+                           void* pool_code) {
   OSVOS_ARG_CHECK(x && wpk && (y || ybf), "conv3x3 bf16 dma: null pointer");
   OSVOS_ARG_CHECK(N > 0 && H > 0 && W > 0 && osvos_conv3x3_bf16_dma_applicable(Cin, Cout, y_cs) && y_cs >= Cout,
                   "conv3x3 bf16 dma: needs Cin %% 16 == 0, Cout %% 8 == 0, y_cs %% 8 == 0 (got %d, %d, %d)", Cin, Cout, y_cs);
@@ -423,6 +476,7 @@ int osvos_conv3x3_bf16_dma(const void* x, const void* wpk, const float* bias, co
   a.x = reinterpret_cast<const bf16_t*>(x); a.wpk = reinterpret_cast<const uint4*>(wpk); a.bias = bias; a.mask = mask; a.mask_bf16 = mask_bf16 ? 1 : 0;
   a.y = y; a.ybf = reinterpret_cast<bf16_t*>(ybf);
   a.mask_bits = mask_bits; a.y_bits = y_bits; a.pooled = reinterpret_cast<bf16_t*>(pooled_bf16);
+  a.pool_code = reinterpret_cast<unsigned char*>(pool_code);
   a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.CinP = (Cin + 31) / 32 * 32; a.Cout = Cout; a.CoutP = osvos_cout_pad(Cout); a.y_cs = y_cs;
   a.relu = relu; a.map = map ? 1 : 0;
   switch (variant) {
@@ -432,6 +486,8 @@ int osvos_conv3x3_bf16_dma(const void* x, const void* wpk, const float* bias, co
     case 3: return launch<2, 4>(a, 0, stream);
     case 4: return launch<4, 2>(a, 1, stream);      // persistent forms of 0 and 2
     case 5: return launch<4, 4>(a, 1, stream);
+    case 6: return launch<2, 4, 64>(a, 1, stream);  // resident 64-channel filter, persistent
+    case 7: return launch<2, 2, 64>(a, 1, stream);
     default: osvos_set_error("conv3x3 bf16 dma: unknown variant %d", variant); return -1;
   }
 }

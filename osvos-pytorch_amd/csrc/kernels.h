@@ -85,10 +85,16 @@ int osvos_conv3x3_bf16mfma_bits(const void* x, int xb, const void* wpk, const fl
 int osvos_conv3x3_bf16mfma_io(const void* x, int xb, const void* wpk, const float* bias, const void* mask, int mask_bf16, float* y, void* ybf,
                               int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int tile, hipStream_t stream);
 int osvos_conv3x3_bf16mfma_xb_tiles(int* tiles, int max);
-// LDS-DMA staged variant (bf16 activations only): conv3x3_bf16_dma.hip; reached through tile ids 30..33 (256 px x 128 / 64 co with 4 waves, 512 px x 128 / 64 co with 8 waves)
+// LDS-DMA staged variant (bf16 activations only): conv3x3_bf16_dma.hip; reached through tile ids 30..37 (30-33: 256 px x 128 / 64 co with 4 waves, 512 px x 128 / 64 co with 8 waves; 34, 35: persistent forms; 36, 37: resident-filter persistent forms for Cin = 64)
 bool osvos_conv3x3_bf16_dma_applicable(int Cin, int Cout, int y_cs);
+// Cin = 64, bf16 in / out: persistent, resident filter, deferred + skewed packed epilogue (conv3x3_bf16_p64.hip; tile id 38)
+bool osvos_conv3x3_bf16_p64_applicable(int Cin, int Cout, int y_cs, bool has_y_f32, bool has_tensor_mask, bool has_mask_bits, bool has_y_bits, bool has_pool,
+                                       int relu);
+int osvos_conv3x3_bf16_p64(const void* x, const void* wpk, const float* bias, const unsigned* mask_bits, void* ybf, unsigned* y_bits, void* pooled_bf16,
+                           void* pool_code, int N, int H, int W, int Cout, int y_cs, int relu, int map, hipStream_t stream);
 int osvos_conv3x3_bf16_dma(const void* x, const void* wpk, const float* bias, const void* mask, int mask_bf16, const unsigned* mask_bits, float* y, void* ybf,
-                           unsigned* y_bits, void* pooled_bf16, int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int variant, int map, hipStream_t stream);
+                           unsigned* y_bits, void* pooled_bf16, int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int variant, int map, hipStream_t stream,
+                           void* pool_code = nullptr);
 
 // bf16-operand weight gradient (fp32 tensors): wgrad_bf16.hip
 bool osvos_wgrad_bf16_applicable(int Cin_s, int Cout);

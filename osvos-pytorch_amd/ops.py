@@ -96,6 +96,21 @@ def conv3x3_bf16io(x, wpk, bias, cout, relu=False, mask=None, y_cs=None, tile=-1
     return y, yb
 
 
+def conv3x3_bf16act_fused(x, wpk, bias, cout, relu=False, mask_bits=None, want_bits=False, want_pool=False, tile=-1):
+    """The bf16-store trunk convolution with its fused epilogues (osvos_conv3x3_bf16act_fused): x torch.bfloat16 [N,H,W,Cin];
+    returns (y bf16, y_bits int32 [N,H,W,cout/32] | None, pooled bf16 | None, pool_code uint8 | None)."""
+    _need_cuda(x, wpk, bias, mask_bits)
+    assert x.dtype == torch.bfloat16
+    n, h, w, cin = x.shape
+    y = torch.zeros((n, h, w, cout), device=x.device, dtype=torch.bfloat16)
+    bits = torch.zeros((n, h, w, cout // 32), device=x.device, dtype=torch.int32) if want_bits else None
+    pooled = torch.zeros((n, (h + 1) // 2, (w + 1) // 2, cout), device=x.device, dtype=torch.bfloat16) if want_pool else None
+    code = torch.zeros((n, (h + 1) // 2, (w + 1) // 2, cout), device=x.device, dtype=torch.uint8) if want_pool else None
+    check(lib().osvos_conv3x3_bf16act_fused(_p(x), _p(wpk), _p(bias), _p(mask_bits), _p(y), _p(bits), _p(pooled), _p(code), n, h, w, cin, cout,
+                                            int(relu), tile, _stream()), "conv3x3_bf16act_fused")
+    return y, bits, pooled, code
+
+
 def conv3x3_wgrad_bf16act(x, dy, cin, cout, want_bias=True):
     """x, dy torch.bfloat16 NHWC (wide layers) -> (dW fp32 [cout,cin,3,3], db fp32)"""
     _need_cuda(x, dy)

@@ -443,16 +443,20 @@ def test_conv3x3_bf16io_bf16_input_and_copy(shape):
     xg = nhwc(x)
     tiles = ops.conv3x3_bf16io_tiles()
     assert 1 in tiles and 8 in tiles
-    assert all(t in tiles for t in (30, 31, 32, 33, 34, 35))      # the LDS-DMA staged kernel
+    assert all(t in tiles for t in (30, 31, 32, 33, 34, 35, 36, 37))      # the LDS-DMA staged kernel (36, 37: resident filter, Cin = 64 only)
     for tile in tiles + [-1, 101, 108, 130, 132, 135]:
-        if tile % 100 in (30, 31, 32, 33, 34, 35) and (cin % 16 != 0 or cout % 8 != 0):
+        if tile % 100 in (36, 37) and cin != 64:
+            with pytest.raises(RuntimeError):
+                ops.conv3x3_bf16io(xg.bfloat16(), wpk, b.cuda(), cout, tile=tile)
+            continue
+        if tile % 100 in (30, 31, 32, 33, 34, 35, 36, 37) and (cin % 16 != 0 or cout % 8 != 0):
             with pytest.raises(RuntimeError):
                 ops.conv3x3_bf16io(xg.bfloat16(), wpk, b.cuda(), cout, tile=tile)
             continue
         y16, yb16 = ops.conv3x3_bf16io(xg.bfloat16(), wpk, b.cuda(), cout, relu=True, mask=nhwc(m), tile=tile)
         assert rel_err(nchw(y16), ref)[0] < 3e-5, (shape, tile)
         assert torch.equal(yb16, y16.bfloat16()), (shape, tile)
-        if tile % 100 in (30, 31, 32, 33, 34, 35):  # DMA staging exists for bf16 activations only
+        if tile % 100 in (30, 31, 32, 33, 34, 35, 36, 37):  # DMA staging exists for bf16 activations only
             with pytest.raises(RuntimeError):
                 ops.conv3x3_bf16io(xg, wpk, b.cuda(), cout, tile=tile)
             continue
@@ -461,6 +465,72 @@ def test_conv3x3_bf16io_bf16_input_and_copy(shape):
         assert torch.equal(yb32, y32.bfloat16()), (shape, tile)
     with pytest.raises(RuntimeError):
         ops.conv3x3_bf16io(xg.bfloat16(), wpk, b.cuda(), cout, tile=12)     # no such tile
+
+
+def _bits_of(t_nhwc):
+    """[N,H,W,C] -> int64 [N,H,W,C/32]: bit b of word g = (t[..., 32 g + b] > 0) (csrc/maskbits.h)"""
+    n, h, w, c = t_nhwc.shape
+    pos = (t_nhwc > 0).long().reshape(n, h, w, c // 32, 32)
+    return (pos << torch.arange(32)).sum(-1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 40, 70, 64, 64), (1, 33, 45, 64, 128), (3, 16, 32, 64, 64), (1, 7, 9, 64, 64), (13, 100, 140, 64, 64), (1, 36, 40, 128, 64),
+                                   (2, 17, 35, 32, 64)])
+def test_conv3x3_bf16act_fused_epilogues_every_tile(shape):
+    """The bf16-store trunk convolution as the network launches it, on EVERY tile built for bf16 activations -- among them the round-6
+    resident-filter persistent forms 36 / 37 (Cin = 64: conv1_2, conv2_1, conv1_2's data gradient) and the LDS-DMA tiles'
+    new pool-code epilogue: result vs float64 on bf16-representable operands (RNE of a value within fp32 summation noise of the truth), the
+    sign-bit words, the fused 2x2 ceil-mode pool and its code bytes EXACTLY what the separate pooling kernel makes of the same result, and
+    the data-gradient form (one-bit ReLU mask in, no ReLU).  Reference: vgg_osvos.py:136-145 (conv, ReLU, MaxPool2d ceil_mode) and autograd."""
+    ops = _ops()
+    from osvos_pytorch_amd._lib import F32_BF16MFMA
+    n, h, w, cin, cout = shape
+    g = torch.Generator().manual_seed(sum(shape) + 5)
+    x = torch.randn(n, cin, h, w, generator=g).bfloat16()
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)).bfloat16().float()
+    b = torch.randn(cout, generator=g) * 0.1
+    ref = F.relu(F.conv2d(x.double(), wt.double(), b.double(), padding=1))
+    wpk = ops.pack_fwd(wt.cuda(), F32_BF16MFMA)
+    xg = nhwc(x.float()).bfloat16()
+    m = torch.randn(n, cout, h, w, generator=g)
+    mbits = _bits_of(nhwc(m).cpu()).to(torch.int32).cuda()         # (values >= 2^31 wrap to the same 32 bits)
+    ref_masked = F.conv2d(x.double(), wt.double(), None, padding=1) * (m > 0)
+    tiles = [t for t in ops.conv3x3_bf16io_tiles() if (t < 36 or cin == 64) and (t < 30 or (cin % 16 == 0 and cout % 8 == 0))]
+    assert (36 in tiles) == (cin == 64)
+    # 38 / 138: the round-6 Cin = 64 kernel with the deferred + skewed packed epilogue (conv3x3_bf16_p64.hip): sign bits and the pool in separate calls
+    for tile in tiles + [-1] + ([136, 137, 38, 138] if cin == 64 else [130, 135]):
+        y, bits, _, _ = ops.conv3x3_bf16act_fused(xg, wpk, b.cuda(), cout, relu=True, want_bits=True, tile=tile)
+        yf = nchw(y.float())
+        err = (yf.double().cpu() - ref).abs()
+        assert float((err / (ref.abs() * 2.0 ** -8 + 1e-3)).max()) <= 1.0, (shape, tile, float(err.max()))      # within bf16 rounding of the truth
+        assert torch.equal(_bits_of(y.float().cpu()), bits.cpu().long() & 0xFFFFFFFF), (shape, tile)
+        y1, _, pooled, code = ops.conv3x3_bf16act_fused(xg, wpk, b.cuda(), cout, relu=True, want_pool=True, tile=tile)
+        assert torch.equal(y, y1), (shape, tile)
+        p_ref, c_ref = ops.maxpool2x2_bf16act_code(y)
+        assert torch.equal(pooled, p_ref), (shape, tile)
+        assert torch.equal(code, c_ref), (shape, tile)
+        # plain (an op-level caller without the extras): same result bits
+        y2, _, _, _ = ops.conv3x3_bf16act_fused(xg, wpk, b.cuda(), cout, relu=True, tile=tile)
+        assert torch.equal(y, y2), (shape, tile)
+        if tile % 100 != 38:      # sign bits AND the pool from one launch (the other tiles' epilogue takes any combination)
+            y3, bits3, pooled3, code3 = ops.conv3x3_bf16act_fused(xg, wpk, b.cuda(), cout, relu=True, want_bits=True, want_pool=True, tile=tile)
+            assert torch.equal(y, y3) and torch.equal(bits, bits3) and torch.equal(pooled, pooled3) and torch.equal(code, code3), (shape, tile)
+        # data-gradient form: one-bit mask, no ReLU, no bias
+        d, _, _, _ = ops.conv3x3_bf16act_fused(xg, wpk, None, cout, relu=False, mask_bits=mbits, tile=tile)
+        derr = (nchw(d.float()).double().cpu() - ref_masked).abs()
+        assert float((derr / (ref_masked.abs() * 2.0 ** -8 + 1e-3)).max()) <= 1.0, (shape, tile, float(derr.max()))
+        assert bool(((nchw(d.float()).cpu() != 0) <= (m > 0)).all()), (shape, tile)
+        if tile == 8:
+            d8, y8 = d, y
+    if cin == 64:      # the same arithmetic (fp32 bias add last, RNE, ReLU): the new kernel's bits equal the workhorse tile's up to fp32 summation order
+        d38, _, _, _ = ops.conv3x3_bf16act_fused(xg, wpk, None, cout, relu=False, mask_bits=mbits, tile=38)
+        y38, _, _, _ = ops.conv3x3_bf16act_fused(xg, wpk, b.cuda(), cout, relu=True, tile=38)
+        assert float((d38.float() - d8.float()).abs().max()) <= 2.0 ** -7 * float(d8.float().abs().max()), shape
+        assert float((y38 != y8).float().mean()) < 0.02, shape      # (a different k-order moves a value across a rounding boundary now and then)
+    if cin != 64:
+        with pytest.raises(RuntimeError):
+            ops.conv3x3_bf16act_fused(xg, wpk, b.cuda(), cout, relu=True, tile=36)
 
 
 @pytest.mark.gpu
