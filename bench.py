@@ -956,22 +956,38 @@ def emit_line(full, print_full=False, out=None):
     return line
 
 
+def rank_launch_command(n, argv=None):
+    """(command, environment) that stands `n` ranks of this script up on this node: torch.distributed.run on 127.0.0.1 with a free rendezvous
+    port, and a SECOND free port of its own for the C-ABI communicator's id store (OSVOS_COMM_PORT; parallel.comm_port would otherwise take
+    MASTER_PORT + 1, which back-to-back launches -- the driver's N = 1, 2, 4, 8 sweep -- or another job on the node may still hold)."""
+    import socket
+    socks, ports = [], []
+    for _ in range(2):      # both sockets stay open until both ports are known: two different ports
+        sk = socket.socket()
+        sk.bind(("127.0.0.1", 0))
+        socks.append(sk)
+        ports.append(sk.getsockname()[1])
+    for sk in socks:
+        sk.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    env["OSVOS_COMM_PORT"] = str(ports[1])
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(ports[0]), os.path.abspath(__file__)] + list(sys.argv[1:] if argv is None else argv)
+    return cmd, env
+
+
 def launch_ranks(n):
     """Re-run this command line under torch.distributed.run with `n` ranks on this node; stdout / stderr / exit code pass through."""
-    import socket
     import subprocess
     have = torch.cuda.device_count()
     if have < n:
         print("bench.py --gpus %d: this node shows %d GPU(s)" % (n, have), file=sys.stderr)
         return 2
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    env.setdefault("OMP_NUM_THREADS", "8")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    cmd, env = rank_launch_command(n)
     return subprocess.call(cmd, env=env)
 
 

@@ -37,6 +37,10 @@ extern "C" {
                                             caller's next forward needs ARE complete in stream order).  The caller owes one osvos_net_join before it reads
                                             a parameter gradient on `stream` (optimizer step, all-reduce) and must keep `ws` alive until then.  Lets the
                                             tail of the weight gradients run under the next micro-batch's forward (gradient-accumulation loops). */
+#define OSVOS_FLAG_INFERENCE 0x400       /* OR-ed into the dtype of osvos_net_forward: NO backward will follow (train_online.py:172-181, torch.no_grad): the
+                                            forward skips what only a backward reads -- the one-bit ReLU masks and the pool-code bytes -- so the
+                                            convolutions that write them keep their fused pooling epilogue and nothing is stored for nobody (round 6;
+                                            the workspace may be the inference-sized one, osvos_net_ws_bytes_infer).  Logits are bit-identical. */
 #define OSVOS_F32_X3 3        /* fp32 tensors, fp32 parameters and fp32 weight packs exactly as OSVOS_F32; the wide 3x3 convolutions
                                  (forward, data gradient) run on the bf16 matrix pipe with three-way split operands (six bf16
                                  products per fp32 product, fp32 accumulate): fp32-grade results, see osvos_conv3x3 below */

@@ -19,6 +19,7 @@ _lib = None
 
 F32, BF16, F32_BF16MFMA, F32_X3 = 0, 1, 2, 3
 DEFER_JOIN = 0x200         # OSVOS_FLAG_DEFER_JOIN: osvos_net_backward leaves the side streams un-joined (autograd.NetRuntime.join_backward)
+INFERENCE = 0x400           # OSVOS_FLAG_INFERENCE: osvos_net_forward writes nothing only a backward would read (sign bits, pool codes)
 GENERIC_DECONV = 0x100      # OSVOS_FLAG_GENERIC_DECONV: OR-ed into the dtype of the osvos_net_* calls
 NPARAMS = 52
 

@@ -8,7 +8,7 @@ import os
 
 import torch
 
-from ._lib import DEFER_JOIN, F32, F32_BF16MFMA, F32_X3, GENERIC_DECONV, NPARAMS, check, lib, ptr_array
+from ._lib import DEFER_JOIN, F32, F32_BF16MFMA, F32_X3, GENERIC_DECONV, INFERENCE, NPARAMS, check, lib, ptr_array
 
 # indices (state_dict order) of the frozen transposed-conv weights: lr 0 in both reference
 # scripts (train_online.py:84-85, train_parent.py:99-100); their gradients are never formed
@@ -110,10 +110,9 @@ class NetRuntime:
             self.deconv_key = None
         dkey = key[:4]
         if dkey != self.deconv_key:
+            # (round 6: the generic head runs on the bf16 trunk too -- the head is fp32 in every precision, its backward now also writes the bf16
+            #  copy of the side_prep output gradient the bf16-store mode's convolutions read)
             self.generic_head = not self._deconv_is_diagonal(params[:4])
-            if self.generic_head and self.dtype == F32_BF16MFMA:
-                raise NotImplementedError("non-diagonal upscale[i].weight (generic transposed-convolution head) is built for the fp32 / fp32x3 "
-                                          "precisions only; use set_precision('fp32x3') or restore the bilinear deconvolution weights")
             self.deconv_key = dkey
         check(l.osvos_net_pack(ptr_array([p.data_ptr() for p in params]), C.c_void_p(self.wbuf.data_ptr()),
                                self.cdtype(), 1, _stream()), "net_pack")
@@ -164,7 +163,8 @@ class OSVOSNetFunction(torch.autograd.Function):
         ws = torch.empty(nbytes, device=xin.device, dtype=torch.uint8)
         outs = [torch.empty((n, 1, h, w), device=xin.device, dtype=torch.float32) for _ in range(5)]
         check(l.osvos_net_forward(C.c_void_p(xin.data_ptr()), C.c_void_p(rt.wbuf.data_ptr()), C.c_void_p(ws.data_ptr()),
-                                  ptr_array([o.data_ptr() for o in outs]), n, h, w, ctx.cdtype, _stream(), rt.auxf(xin.device)), "net_forward")
+                                  ptr_array([o.data_ptr() for o in outs]), n, h, w, ctx.cdtype | (0 if need_bwd else INFERENCE), _stream(),
+                                  rt.auxf(xin.device)), "net_forward")
         # the activation workspace rides in autograd's saved-tensor slot: released right after a plain backward, kept under
         # retain_graph=True (a second backward recomputes every gradient buffer from the untouched forward half: no buffer of the
         # forward is written by the backward), and a second backward WITHOUT retain_graph raises autograd's own error, like the reference

@@ -495,7 +495,11 @@ int pick_tile_b(int N, int H, int W, int CoutP, int Cin) {
   // ... and the Cin = 64 layers (conv1_2, conv2_1; their data gradients): K = 576 is four such chunks, the launch is as much prologue / epilogue and
   // HBM stream as matrix work -- the same small tile, three workgroups per CU, reads 2-5 % faster than the 32-channel-chunk tile at batch 12
   // (tools/tune_conv.py) and the step +0.7-1.2 % (1136.3 / 1134.2 -> 1143.8 / 1147.5 frames/s, profiles/r05_ab_small.txt; Cin <= 128: +0.1-0.8 %)
-  if (Cin <= 64 && CoutP <= 128) return 9;
+  // (guarded in round 6, ADVICE r05: the rule was measured at 854x480 batch 12 only -- tiny frames and crops keep the size-aware choice below, where
+  //  a 107- or 54-pixel wide map loses up to 28 % of a 32 x 8 tile to padding)
+  if (Cin <= 64 && CoutP <= 128 && (long)N * ceil_div(H, kTilesB[9].th) * ceil_div(W, kTilesB[9].tw) * ceil_div(CoutP, kTilesB[9].bn) >= 400 &&
+      (long)ceil_div(H, 8) * 8 * ceil_div(W, 32) * 32 * 100 <= (long)H * W * 115)
+    return 9;
   const int order[] = {8, 1, 5, 7};
   for (int k = 0; k < 4; ++k) {
     const TileInfoB& t = kTilesB[order[k]];

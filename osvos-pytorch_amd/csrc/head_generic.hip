@@ -82,6 +82,7 @@ struct HbGArgs {
   const float* weff;
   const float* wd;
   f32x4* dprep;
+  uint2* dprep_b;   // optional bf16 copy of dprep (bf16-store mode: what the side_prep data / weight gradients read), [pix][16] bf16
   double* acc;   // per-workgroup partials [gridDim.x][34] in head.hip's layout: [0..15] (zero here: dwfuse comes from G), [16..31] dwd, [32] dbd
   int N, H, W, h, w, s;
 };
@@ -139,6 +140,12 @@ __global__ __launch_bounds__(256) void head_bwd_generic_kernel(HbGArgs a) {
           pwd[c] += p[e] * ds;
         }
         a.dprep[pix * 4 + q] = o;
+        if (a.dprep_b != nullptr) {
+          uint2 hb;
+          hb.x = (unsigned)f32_to_bf16(o[0]) | ((unsigned)f32_to_bf16(o[1]) << 16);
+          hb.y = (unsigned)f32_to_bf16(o[2]) | ((unsigned)f32_to_bf16(o[3]) << 16);
+          a.dprep_b[pix * 4 + q] = hb;
+        }
       }
       pbd += ds;
     }
@@ -252,13 +259,14 @@ int osvos_head_upsample_generic(const float* const* score, const float* const* p
 }
 
 int osvos_head_bwd_generic(const float* prep, const float* dside, const float* dfused, const float* f1, const float* weff, const float* wd,
-                           float* dprep, double* acc, int N, int H, int W, int h, int w, int scale_idx, hipStream_t stream) {
+                           float* dprep, void* dprep_bf16, double* acc, int N, int H, int W, int h, int w, int scale_idx, hipStream_t stream) {
   OSVOS_ARG_CHECK(prep && f1 && weff && wd && dprep && acc, "head_bwd_generic: null pointer");
   OSVOS_ARG_CHECK(scale_idx >= 0 && scale_idx < 4 && N > 0 && H > 0 && W > 0 && h > 0 && w > 0, "head_bwd_generic: bad shape");
   HbGArgs a;
   a.prep = reinterpret_cast<const f32x4*>(prep);
   a.dside = dside; a.dfused = dfused; a.f1 = f1; a.weff = weff; a.wd = wd;
   a.dprep = reinterpret_cast<f32x4*>(dprep);
+  a.dprep_b = reinterpret_cast<uint2*>(dprep_bf16);
   a.acc = acc;
   a.N = N; a.H = H; a.W = W; a.h = h; a.w = w; a.s = 2 << scale_idx;
   const int g = osvos_head_bwd_blocks(N, h, w, scale_idx);      // same partial-row count as the fast path (osvos_head_grads_finalize reads it)

@@ -67,7 +67,7 @@ int osvos_head_weff(const float* wup, const float* wf16, float* weff, int k, hip
 int osvos_head_upsample_generic(const float* const* score, const float* const* prep, const float* const* f1, const float* const* weff,
                                 const float* fuse_bias, float* const* outs, int N, int H, int W, const int* hs, const int* ws, hipStream_t stream);
 int osvos_head_bwd_generic(const float* prep, const float* dside, const float* dfused, const float* f1, const float* weff, const float* wd,
-                           float* dprep, double* acc, int N, int H, int W, int h, int w, int scale_idx, hipStream_t stream);
+                           float* dprep, void* dprep_bf16, double* acc, int N, int H, int W, int h, int w, int scale_idx, hipStream_t stream);
 int osvos_head_tapsum(const float* P, int channels, const float* d, double* G, int N, int H, int W, int h, int w, int scale_idx, hipStream_t stream);
 int osvos_head_generic_param_grads(const float* wup, const float* wf16, const double* G, float* dwf16, float* dwup, int k, int accumulate, hipStream_t stream);
 int osvos_head_dw1(const double* G1, float* dw, int k, int accumulate, hipStream_t stream);

@@ -406,6 +406,7 @@ int osvos_net_forward(const float* x_nchw, const void* wbuf, void* ws, float* co
   hipStream_t stream = (hipStream_t)stream_;
   const int dtype = dtype_ & 0xff;
   const bool generic = (dtype_ & OSVOS_FLAG_GENERIC_DECONV) != 0;
+  const bool infer = (dtype_ & OSVOS_FLAG_INFERENCE) != 0;      // no backward will read the sign bits / pool codes: do not write them
   hipStream_t aux_all = aux_stream_ ? (hipStream_t)aux_stream_ : stream;
   const bool two = aux_all != stream;
   EventPool& evp = event_pool();
@@ -437,7 +438,7 @@ int osvos_net_forward(const float* x_nchw, const void* wbuf, void* ws, float* co
       cur_b = store ? at(ws, L.pooled_b[si]) : nullptr;
     } else if (si > 0) {
       if (store)
-        rc = osvos_maxpool2x2_bf16_code(cur_b, at(ws, L.pooled_b[si]), L.pool_code[si] != (size_t)-1 ? at(ws, L.pool_code[si]) : nullptr, N, L.hs[si - 1],
+        rc = osvos_maxpool2x2_bf16_code(cur_b, at(ws, L.pooled_b[si]), (L.pool_code[si] != (size_t)-1 && !infer) ? at(ws, L.pool_code[si]) : nullptr, N, L.hs[si - 1],
                                         L.ws[si - 1], kStageC[si - 1], stream);
       else
         rc = osvos_maxpool2x2_f32(reinterpret_cast<const float*>(cur), reinterpret_cast<float*>(at(ws, L.pooled[si])), sh(L.pooled_b[si]), N,
@@ -455,8 +456,8 @@ int osvos_net_forward(const float* x_nchw, const void* wbuf, void* ws, float* co
         rc = conv_main(cur, cur_b, at(wbuf, P.fwd[l]), reinterpret_cast<const float*>(at(wbuf, P.bias[l])), nullptr, nullptr,
                        f32(L.act[l]), sh(L.act_b[l]), N, h, w, d[l].cin_s, d[l].cout, d[l].cout, 1, dtype, at(ws, L.conv_part), stream,
                        P.fwd3[l] != (size_t)-1 ? at(wbuf, P.fwd3[l]) : nullptr, (pool_here && !store) ? &epi : nullptr, nullptr,
-                       L.bits[l] != (size_t)-1 ? at(ws, L.bits[l]) : nullptr, (pool_here && store) ? at(ws, L.pooled_b[si + 1]) : nullptr, sk_ws,
-                       (pool_here && store && L.pool_code[si + 1] != (size_t)-1) ? at(ws, L.pool_code[si + 1]) : nullptr);
+                       (L.bits[l] != (size_t)-1 && !infer) ? at(ws, L.bits[l]) : nullptr, (pool_here && store) ? at(ws, L.pooled_b[si + 1]) : nullptr, sk_ws,
+                       (pool_here && store && L.pool_code[si + 1] != (size_t)-1 && !infer) ? at(ws, L.pool_code[si + 1]) : nullptr);
       }
       if (rc) return rc;
       cur = at(ws, L.act[l]);
@@ -645,7 +646,7 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
     if (generic)
       rc = osvos_head_bwd_generic(reinterpret_cast<const float*>(at(ws, L.prep[i])), douts[i], dfused, reinterpret_cast<const float*>(at(wbuf, P.f1[i])),
                                   reinterpret_cast<const float*>(at(wbuf, P.weff[i])), reinterpret_cast<const float*>(at(wbuf, P.wd[i])),
-                                  reinterpret_cast<float*>(at(ws, L.dprep[i])), acc + (size_t)i * OSVOS_HEAD_MAX_BLOCKS * 34,
+                                  reinterpret_cast<float*>(at(ws, L.dprep[i])), store ? at(ws, L.dprep_b[i]) : nullptr, acc + (size_t)i * OSVOS_HEAD_MAX_BLOCKS * 34,
                                   N, H, W, L.hs[si], L.ws[si], i, stream);
     else
       rc = osvos_head_bwd_f32(reinterpret_cast<const float*>(at(ws, L.prep[i])), douts[i], dfused, reinterpret_cast<const float*>(at(wbuf, P.f1[i])),

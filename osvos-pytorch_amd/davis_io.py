@@ -127,8 +127,16 @@ class DevicePrefetcher(object):
             self.free.put(k)
         self.slots = [None] * (self.depth + 2)           # (pool key, pinned (img, lab) pair) per slot, taken from the pool at the first frame's size
         self._stop, self._closed, self._inflight = threading.Event(), False, []
-        self.thread = threading.Thread(target=self._produce, daemon=True)
-        self.thread.start()
+        # the producer starts with the FIRST iteration, not here: a running thread holds a reference to its owner, so a prefetcher that
+        # was built but never iterated could not be collected -- its daemon thread polled the queue every 50 ms for ever and kept its pinned buffers
+        self.thread = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
 
     def _pinned(self, k, img, lab):
         cur = self.slots[k]
@@ -170,18 +178,19 @@ class DevicePrefetcher(object):
                 pass
         return False
 
-    def close(self):
+    def close(self, join_timeout=5.0):
         """Stop the producer, wait for the copies that still read staging buffers, hand the buffers back to the pool.  Runs when iteration
         ends -- normally, by an exception, or because the consumer abandoned the iterator (generator close / garbage collection); idempotent."""
         if self._closed:
             return
         self._closed = True
         self._stop.set()
-        self.thread.join(timeout=5.0)
+        if self.thread is not None:
+            self.thread.join(timeout=join_timeout)
         for _, e0 in self._inflight:
             e0.synchronize()
         self._inflight = []
-        if not self.thread.is_alive():                   # (a producer stuck in a decode keeps its buffers: never hand out memory a thread may still write)
+        if self.thread is None or not self.thread.is_alive():      # (a producer stuck in a decode keeps its buffers: never hand out memory a thread may still write)
             for k, cur in enumerate(self.slots):
                 if cur is not None:
                     _give(*cur)
@@ -189,11 +198,16 @@ class DevicePrefetcher(object):
 
     def __del__(self):
         try:
-            self.close()
+            self.close(join_timeout=0.2)     # (garbage collection / interpreter shutdown must not wait five seconds for a decode)
         except Exception:
             pass
 
     def __iter__(self):
+        if self._closed:
+            raise RuntimeError("DevicePrefetcher: already closed (one pass per prefetcher)")
+        if self.thread is None:
+            self.thread = threading.Thread(target=self._produce, daemon=True)
+            self.thread.start()
         inflight = self._inflight            # (slot, event) of copies not known to be complete yet
         try:
             while True:

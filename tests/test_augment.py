@@ -137,6 +137,20 @@ def test_prefetchers_own_their_staging_buffers_and_survive_an_abandoned_iteratio
     assert [i for i, _, _ in out] == list(range(9))
     for idx, img, lab in out:
         assert np.array_equal(img.cpu().numpy(), fc[idx][0]) and np.array_equal(lab.cpu().numpy(), fc[idx][1]), idx
+    # a prefetcher that is built but never iterated starts no thread and holds no pinned buffer -- and is collectable
+    import gc
+    import threading
+    import weakref
+    before = threading.active_count()
+    idle = DevicePrefetcher(ArrayFrames(fa), range(12), "cuda", depth=3)
+    assert idle.thread is None and threading.active_count() == before and all(s is None for s in idle.slots)
+    ref = weakref.ref(idle)
+    del idle
+    gc.collect()
+    assert ref() is None
+    with DevicePrefetcher(ArrayFrames(fc), range(9), "cuda", depth=2) as pf2:      # context-manager form
+        assert [i for i, _, _ in pf2] == list(range(9))
+    assert pf2._closed
     for idx, img, lab in first:
         assert np.array_equal(img.cpu().numpy(), fa[idx][0])
     free = sum(len(v) for v in davis_io._POOL.values())

@@ -290,9 +290,53 @@ def test_generic_transposed_conv_head_matches_the_reference_semantics(shape):
         fast.upscale[1].weight[0, 1, 2, 2] = 0.25
         fast.forward(torch.from_numpy(x).cuda())
         assert fast._runtime.generic_head
-    with pytest.raises(NotImplementedError):
-        fast.set_precision("bf16")
+    # round 6: the generic head also runs on the bf16 trunk (it refused until round 5)
+    fast.set_precision("bf16")
+    with torch.no_grad():
         fast.forward(torch.from_numpy(x).cuda())
+    assert fast._runtime.generic_head
+
+
+@pytest.mark.parametrize("shape", [(2, 37, 53), (1, 48, 64)])
+def test_generic_transposed_conv_head_on_the_bf16_trunk(shape):
+    """vgg_osvos.py:46,68 runs ANY [16,16,k,k] ConvTranspose2d weights; with precision 'bf16' (bf16 trunk tensors, fp32 head) the generic head must
+    deliver what the fast head delivers in that precision: logits within the bf16 bars of the float64 oracle, the deconv / fuse / score_dsn gradients
+    (formed in fp32 from fp32 side_prep outputs) close to float64, the trunk gradients within the bf16 gradient bar -- and the side_prep
+    convolutions must have read the bf16 copy of dprep the generic backward now writes (a missing copy = garbage trunk gradients)."""
+    from layers.osvos_layers import class_balanced_cross_entropy_loss as cbce
+    from oracle import synth, torch_ref
+    n, h, w = shape
+    wts, x, m = synth.calibrated_problem(n, h, w, seed=31)
+    rng = np.random.RandomState(5)
+    for i in range(4):
+        k = 4 << i
+        wts["upscale.%d.weight" % i] = (wts["upscale.%d.weight" % i] + rng.randn(16, 16, k, k).astype(np.float32) * (0.5 / k)).astype(np.float32)
+        wts["upscale_.%d.weight" % i] = (wts["upscale_.%d.weight" % i] * (1.0 + 0.3 * rng.randn(1, 1, k, k))).astype(np.float32)
+    p = torch_ref.as_leaf_params(wts, dtype=torch.float64)
+    xin = torch.from_numpy(x).double().requires_grad_()
+    outs_t = torch_ref.forward(p, xin)
+    losses_t = [torch_ref.cbce_loss(o, torch.from_numpy(m).double(), size_average=False) for o in outs_t]
+    (0.5 * sum(losses_t[:-1]) + losses_t[-1]).backward()
+    res = {}
+    for prec in ("bf16", "fp32"):
+        net = build_net(wts).set_precision(prec)
+        outs = net.forward(torch.from_numpy(x).cuda().requires_grad_())
+        assert net._runtime.generic_head
+        gt = torch.from_numpy(m).cuda()
+        losses = [cbce(o, gt, size_average=False) for o in outs]
+        (0.5 * sum(losses[:-1]) + losses[-1]).backward()
+        res[prec] = ([o.detach().cpu().double().numpy() for o in outs], {k: v.grad.cpu().double() for k, v in net.named_parameters() if v.grad is not None})
+    outs_b, grads_b = res["bf16"]
+    for i in range(5):
+        truth = outs_t[i].detach().numpy()
+        assert np.abs(outs_b[i] - truth).max() <= 0.1 * truth.std(), (shape, i, np.abs(outs_b[i] - truth).max(), truth.std())
+    assert set(grads_b) == set(res["fp32"][1])
+    errs = sorted(((float((grads_b[k] - p[k].grad).norm() / (p[k].grad.norm() + 1e-30)), k) for k in grads_b), reverse=True)
+    print("generic head on the bf16 trunk, gradients vs float64:", [(k, "%.1e" % e) for e, k in errs[:6]])
+    assert errs[0][0] <= 0.25, errs[0]
+    for e, k in errs:
+        if k.startswith(("upscale", "fuse", "score_dsn")):
+            assert e <= 0.05, (k, e)
 
 
 def test_batch_and_odd_sizes_no_grad_inference():
@@ -310,6 +354,23 @@ def test_batch_and_odd_sizes_no_grad_inference():
             ref = torch_ref.forward({k: torch.from_numpy(v) for k, v in wts.items()}, torch.from_numpy(x))[-1].numpy()
         assert np.abs(got - ref).max() <= max(LOGIT_TOL * ref.std(), 1e-5 * np.abs(ref).max(), 1e-6), (n, h, w)
         assert np.abs(sigmoid_np(got) - sigmoid_np(ref)).max() < 1e-4
+
+
+@pytest.mark.parametrize("precision", ["fp32x3", "bf16", "fp32"])
+def test_inference_forward_skips_backward_only_outputs_and_keeps_every_logit_bit(precision):
+    """OSVOS_FLAG_INFERENCE (round 6): under torch.no_grad() (train_online.py:172-181) the forward writes neither the one-bit ReLU
+    masks nor the pool-code bytes -- which only a backward reads -- and runs in the inference-sized workspace; the five logit maps must be
+    bit-identical to the ones of a forward that a backward could follow, at even and odd sizes."""
+    from oracle import synth
+    for (n, h, w) in [(2, 60, 107), (1, 33, 41)]:
+        wts, x, _ = synth.calibrated_problem(n, h, w, seed=12)
+        net = build_net(wts).set_precision(precision)
+        xs = torch.from_numpy(x).cuda()
+        with torch.no_grad():
+            a = [o.clone() for o in net.forward(xs)]
+        b = net.forward(xs.clone().requires_grad_())
+        for u, v in zip(a, b):
+            assert torch.equal(u, v.detach()), (precision, n, h, w)
 
 
 def test_forward_is_hipgraph_capturable():

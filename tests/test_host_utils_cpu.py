@@ -75,6 +75,39 @@ def test_bench_gpus_n_stands_up_its_own_ranks_or_says_why_not():
     assert out.returncode == 2 and "--gpus 2: this node shows" in out.stderr, (out.returncode, out.stderr[-400:])
 
 
+def test_bench_gpus_8_launch_command_and_ports():
+    """What `python bench.py --gpus 8` would start (no 8-GPU node is reachable from here): ONE torch.distributed.run command
+    for 8 ranks on 127.0.0.1 carrying the bench arguments, and an environment with HSA_ENABLE_IPC_MODE_LEGACY=0 and an OSVOS_COMM_PORT of the
+    job's own -- different from the rendezvous port and different between successive launches (the driver runs N = 1, 2, 4, 8 back to back)."""
+    import importlib.util
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_launch_test", os.path.join(repo, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    seen = set()
+    for n in (2, 4, 8):
+        cmd, env = b.rank_launch_command(n, ["--gpus", str(n), "--steps", "20", "--warmup", "5"])
+        assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and cmd[cmd.index("--nproc-per-node") + 1] == str(n)
+        assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", str(n), "--steps", "20", "--warmup", "5"]
+        assert os.path.basename(cmd[cmd.index("--master-port") + 2]) == "bench.py"
+        mport, cport = int(cmd[cmd.index("--master-port") + 1]), int(env["OSVOS_COMM_PORT"])
+        assert 1024 <= mport <= 65535 and 1024 <= cport <= 65535 and mport != cport
+        assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and "RANK" not in env and "WORLD_SIZE" not in env
+        seen.update((mport, cport))
+    assert len(seen) == 6
+    # ... and the communicator takes that port
+    from osvos_pytorch_amd import parallel
+    old = os.environ.get("OSVOS_COMM_PORT")
+    os.environ["OSVOS_COMM_PORT"] = env["OSVOS_COMM_PORT"]
+    try:
+        assert parallel.comm_port() == int(env["OSVOS_COMM_PORT"])
+    finally:
+        if old is None:
+            del os.environ["OSVOS_COMM_PORT"]
+        else:
+            os.environ["OSVOS_COMM_PORT"] = old
+
+
 def bytescale_scipy11(data):
     """scipy 1.1 misc.bytescale(data, cmin=None, cmax=None, high=255, low=0) as toimage() calls it for mode 'L' (float32 input): the
     restatement the result writer (osvos_mask_to_bytes) is tested against in tests/test_gpu_ops.py"""

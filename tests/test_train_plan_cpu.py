@@ -332,6 +332,28 @@ def test_train_parent_main_four_ranks_with_n_ave_grad_8(tmp_path):
     np.testing.assert_allclose(rs[0]["validation"][1][0], rs[3]["validation"][1][0], rtol=0, atol=0)
 
 
+@pytest.mark.parametrize("n_ave", [8, 16])
+def test_train_parent_main_eight_ranks(tmp_path, n_ave):
+    """The plan of an 8-GPU node through train_parent.main() on EIGHT gloo ranks (W <= 4 end to end until now): nAveGrad 8
+    (one micro-batch per rank and optimizer step) and 16 (two); 19 frames, 2 epochs = 38 iterations = 4 (2) complete windows + a partial one;
+    every rank ends on the same bits, and on the single-process trajectory up to the summation order of the gradient all-reduce
+    (reference: train_parent.py:46,163-172 -- nAveGrad micro-batches of batch 1 per optimizer step)."""
+    sys.path.insert(0, REPO)
+    argv = ["--synthetic", "19", "--epochs", "2", "--n-ave-grad", str(n_ave), "--height", "24", "--width", "32", "--seed", "3", "--lr", "1e-6"]
+    out = str(tmp_path / "eight")
+    port = 38100 + (os.getpid() % 1500) + n_ave
+    mp.spawn(_main_worker, args=(8, port, out, argv), nprocs=8, join=True)
+    rs = [torch.load(out + ".%d" % r) for r in range(8)]
+    mp.spawn(_main_worker, args=(1, port + 1, out + "_single", argv), nprocs=1, join=True)
+    single = torch.load(out + "_single.0")
+    want = 38 // n_ave
+    assert [r["steps"] for r in rs] == [want] * 8 and single["steps"] == want
+    for k in single["sd"]:
+        for r in rs[1:]:
+            assert torch.equal(rs[0]["sd"][k], r["sd"][k]), k
+        torch.testing.assert_close(rs[0]["sd"][k], single["sd"][k], rtol=2e-5, atol=1e-7, msg=k)
+
+
 def _split_root_worker(rank, world, port, roots, argv, out):
     sys.path.insert(0, REPO)
     os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_RANK": str(rank)})
