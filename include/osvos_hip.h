@@ -230,8 +230,11 @@ int osvos_cbce_step_multi(const float* const* outs, const float* label, float* c
  *   counts != NULL: device fp32[3] = {n_pos, n_total, n_images} of the GLOBAL batch these tensors are a shard of (the count exchange of a
  *     batch sharded over ranks; layers/osvos_layers.py:28-34,43-46 count over the whole input tensor): weights and divisors come
  *     from them, no count sweep runs.  Summed over the shards the losses / gradients are those of the whole batch.  Not with PER_IMAGE.
- *   scratch: osvos_cbce_scratch_bytes(n_heads, N, flags) bytes, zeroed by the call. */
+ *   scratch: osvos_cbce_scratch_bytes(n_heads, N, flags) bytes, zeroed by the call -- or, with flags & OSVOS_CBCE_SCRATCH_ZEROED, already zero by
+ *     the caller's promise (no memset is enqueued).  Every call LEAVES the scratch zero (its last workgroup forms the losses and clears what it
+ *     read), so a buffer that was zeroed once can be handed to call after call on one stream. */
 #define OSVOS_CBCE_PER_IMAGE 1
+#define OSVOS_CBCE_SCRATCH_ZEROED 2
 size_t osvos_cbce_scratch_bytes(int n_heads, int N, int flags);
 int osvos_cbce_step_ex(const float* const* outs, const float* label, float* const* losses, float* const* grads, void* scratch, long count,
                        int N, int mode, int flags, const float* counts, int n_heads, const float* grad_scales, float* const* running,

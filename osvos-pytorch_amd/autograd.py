@@ -302,6 +302,26 @@ class CBCECountsFunction(torch.autograd.Function):
 
 
 CBCE_PER_IMAGE = 1      # include/osvos_hip.h OSVOS_CBCE_PER_IMAGE
+CBCE_SCRATCH_ZEROED = 2  # include/osvos_hip.h OSVOS_CBCE_SCRATCH_ZEROED
+
+# The loss call's scratch (class counts, loss sums, arrival ticket): every call leaves it zero, so ONE zero-initialised buffer per (device, stream,
+# size) serves every call of a training loop and the call enqueues no memset (a 32-byte hipMemsetAsync is two fill kernels: 14 us between the
+# forward and the backward at batch 1).  Keyed by stream: calls on one stream are ordered, calls on different streams get different buffers.
+_CBCE_SCRATCH = {}
+
+
+def _cbce_scratch(dev, nbytes):
+    if os.environ.get("OSVOS_CBCE_PERSISTENT", "1") == "0":      # A/B switch: a fresh buffer and a memset per call, as rounds 1-5
+        return torch.empty(nbytes, device=dev, dtype=torch.uint8), 0
+    if torch.cuda.is_current_stream_capturing():      # a graph gets a buffer of its own, zeroed by a node of the graph (no sharing with eager calls)
+        return torch.zeros(nbytes, device=dev, dtype=torch.uint8), 0
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(dev).cuda_stream, nbytes)
+    buf = _CBCE_SCRATCH.get(key)
+    if buf is None:
+        if len(_CBCE_SCRATCH) > 64:
+            _CBCE_SCRATCH.clear()
+        buf = _CBCE_SCRATCH[key] = torch.zeros(nbytes, device=dev, dtype=torch.uint8)
+    return buf, CBCE_SCRATCH_ZEROED
 
 
 def _counts_tensor(counts, dev):
@@ -357,7 +377,8 @@ def cbce_step_multi(outputs, label, mode, grad_scales, runnings=None, per_image=
     cnt = _counts_tensor(counts, dev)
     losses = torch.empty(n, device=dev, dtype=torch.float32)
     grads = [torch.empty_like(o) for o in outs]
-    scratch = torch.empty(int(lib().osvos_cbce_scratch_bytes(n, n_img, flags)), device=dev, dtype=torch.uint8)
+    scratch, zeroed = _cbce_scratch(dev, int(lib().osvos_cbce_scratch_bytes(n, n_img, flags)))
+    flags |= zeroed
     vp = C.c_void_p
     a_out = (vp * n)(*[vp(o.data_ptr()) for o in outs])
     a_loss = (vp * n)(*[vp(losses.data_ptr() + 4 * k) for k in range(n)])

@@ -11,19 +11,23 @@
 
 namespace {
 
-// Scratch of one call, zeroed by it: npos[G] (unsigned long long), then lpos[H][G], lneg[H][G] (doubles) -- G = count groups (1, or the N
-// images in the per-image mode), H = heads.  8 G + 16 H G bytes (osvos_cbce_scratch_bytes); with G = 1 that fits the 32 bytes per head
-// the first form of the interface asked for.
+// Scratch of one call: npos[G] (unsigned long long), then lpos[H][G], lneg[H][G] (doubles), then the arrival ticket (8 bytes) -- G = count groups (1,
+// or the N images in the per-image mode), H = heads.  8 G + 16 H G + 8 bytes (osvos_cbce_scratch_bytes); with G = 1 that fits the 32 bytes per
+// head the first form of the interface asked for.  Zero on entry (zeroed by the call, or by the caller's promise: OSVOS_CBCE_SCRATCH_ZEROED) and
+// ALWAYS left zero on exit: the workgroup that arrives last forms the losses and clears what it read (round 6: the loss call is two launches --
+// count, sweep -- instead of memset (two fill kernels for a 32-byte region) + count + sweep + final: 114 -> ~90 us between forward and backward).
 struct ScratchView {
   unsigned long long* npos;
   double* lpos;
   double* lneg;
+  unsigned* ticket;
 };
 __device__ __host__ inline ScratchView scratch_view(void* p, int G, int H) {
   ScratchView v;
   v.npos = reinterpret_cast<unsigned long long*>(p);
   v.lpos = reinterpret_cast<double*>(v.npos + G);
   v.lneg = v.lpos + (size_t)H * G;
+  v.ticket = reinterpret_cast<unsigned*>(v.lneg + (size_t)H * G);
   return v;
 }
 
@@ -130,28 +134,43 @@ __global__ void cbce_main_kernel(CbceHeads hd, const float* __restrict__ label, 
   lpos = wave_sum(lpos);
   lneg = wave_sum(lneg);
   __shared__ double red[4][2];
+  __shared__ int last;
   if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = lpos; red[threadIdx.x >> 6][1] = lneg; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    atomicAdd(&sc.lpos[(size_t)head * G + grp], red[0][0] + red[1][0] + red[2][0] + red[3][0]);
+    atomicAdd(&sc.lpos[(size_t)head * G + grp], red[0][0] + red[1][0] + red[2][0] + red[3][0]);      // (device-scope RMWs at the L2)
     atomicAdd(&sc.lneg[(size_t)head * G + grp], red[0][1] + red[1][1] + red[2][1] + red[3][1]);
+    // arrival ticket: release the two sums, draw; the workgroup that draws the last number finishes the call (cdna_hip_programming.md 6 G16:
+    // agent-scope release before the ticket, agent-scope acquire in the last arriver, relaxed everything else)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    const unsigned total = gridDim.x * gridDim.y * gridDim.z;
+    last = __hip_atomic_fetch_add(sc.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == total - 1u ? 1 : 0;
   }
-}
-
-// one thread per head: loss = sum over the count groups of (w_pos * lpos + w_neg * lneg) / div  (one group unless per image: there the
-// sum of the images' losses = what the reference's loop adds to running_loss over the window)
-__global__ void cbce_final_kernel(CbceHeads hd, long per_group, CbceNorm nm, ScratchView sc, int G) {
-  const int head = threadIdx.x;
-  if (head >= hd.n) return;
-  float total = 0.f;
-  for (int grp = 0; grp < G; ++grp) {
-    float wpos, wneg, inv_div;
-    cbce_weights(nm, sc.npos, grp, per_group, wpos, wneg, inv_div);
-    const float l = (float)(((double)wpos * sc.lpos[(size_t)head * G + grp] + (double)wneg * sc.lneg[(size_t)head * G + grp]) * (double)inv_div);
-    total = grp == 0 ? l : total + l;      // (fp32 adds in image order: what `running_loss += loss.item()` does on the host in double is within 1 ulp of this)
+  __syncthreads();
+  if (!last) return;
+  if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  __syncthreads();
+  // one thread per head: loss = sum over the count groups of (w_pos * lpos + w_neg * lneg) / div  (one group unless per image: there the
+  // sum of the images' losses = what the reference's loop adds to running_loss over the window)
+  if ((int)threadIdx.x < hd.n) {
+    const int h2 = threadIdx.x;
+    float total = 0.f;
+    for (int g2 = 0; g2 < G; ++g2) {
+      float wp, wn, idv;
+      cbce_weights(nm, sc.npos, g2, per_group, wp, wn, idv);
+      const double lp = __hip_atomic_load(&sc.lpos[(size_t)h2 * G + g2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const double ln = __hip_atomic_load(&sc.lneg[(size_t)h2 * G + g2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const float l = (float)(((double)wp * lp + (double)wn * ln) * (double)idv);
+      total = g2 == 0 ? l : total + l;      // (fp32 adds in image order: what `running_loss += loss.item()` does on the host in double is within 1 ulp of this)
+    }
+    hd.loss[h2][0] = total;
+    if (hd.running[h2] != nullptr) hd.running[h2][0] += total;      // running_loss += loss (train_online.py:128) without a host round trip or an extra launch
   }
-  hd.loss[head][0] = total;
-  if (hd.running[head] != nullptr) hd.running[head][0] += total;      // running_loss += loss (train_online.py:128) without a host round trip or an extra launch
+  __syncthreads();
+  // leave the scratch zero for the next call (everything this call accumulated has been consumed)
+  for (int i = threadIdx.x; i < G; i += blockDim.x) sc.npos[i] = 0ull;
+  for (int i = threadIdx.x; i < 2 * hd.n * G; i += blockDim.x) sc.lpos[i] = 0.0;      // (lpos and lneg are contiguous)
+  if (threadIdx.x == 0) sc.ticket[0] = 0u;
 }
 
 __global__ void scale_kernel(const float* __restrict__ x, const float* __restrict__ scalar, float* __restrict__ y, long count) {
@@ -183,7 +202,7 @@ inline int grid_for(long total, int cap) {
 
 extern "C" size_t osvos_cbce_scratch_bytes(int n_heads, int N, int flags) {
   const size_t G = (flags & OSVOS_CBCE_PER_IMAGE) ? (size_t)(N > 0 ? N : 1) : 1, H = (size_t)(n_heads > 0 ? n_heads : 1);
-  return 8 * G + 16 * H * G;
+  return 8 * G + 16 * H * G + 8;
 }
 
 extern "C" int osvos_cbce_step_ex(const float* const* outs, const float* label, float* const* losses, float* const* grads, void* scratch, long count,
@@ -194,7 +213,8 @@ extern "C" int osvos_cbce_step_ex(const float* const* outs, const float* label, 
   OSVOS_ARG_CHECK(n_heads >= 1 && n_heads <= kMaxHeads, "cbce: %d heads (1..%d)", n_heads, kMaxHeads);
   OSVOS_ARG_CHECK(mode >= 0 && mode <= 2, "cbce: mode %d", mode);
   const bool per_image = (flags & OSVOS_CBCE_PER_IMAGE) != 0;
-  OSVOS_ARG_CHECK((flags & ~OSVOS_CBCE_PER_IMAGE) == 0 && !(per_image && counts != nullptr), "cbce: flags 0x%x (per-image counts and external counts exclude each other)", flags);
+  OSVOS_ARG_CHECK((flags & ~(OSVOS_CBCE_PER_IMAGE | OSVOS_CBCE_SCRATCH_ZEROED)) == 0 && !(per_image && counts != nullptr),
+                  "cbce: flags 0x%x (per-image counts and external counts exclude each other)", flags);
   OSVOS_ARG_CHECK(!per_image || (count % N == 0 && N <= 65535), "cbce: per-image mode needs count %% N == 0 (%ld, %d)", count, N);
   const int G = per_image ? N : 1;
   const long per_group = count / G;
@@ -218,14 +238,13 @@ extern "C" int osvos_cbce_step_ex(const float* const* outs, const float* label, 
   CbceNorm nm;
   nm.counts = counts; nm.mode = mode; nm.N = N; nm.per_image = per_image ? 1 : 0;
   const ScratchView sc = scratch_view(scratch, G, n_heads);
-  OSVOS_HIP_CHECK(hipMemsetAsync(scratch, 0, osvos_cbce_scratch_bytes(n_heads, N, flags), stream));
+  if (!(flags & OSVOS_CBCE_SCRATCH_ZEROED)) OSVOS_HIP_CHECK(hipMemsetAsync(scratch, 0, osvos_cbce_scratch_bytes(n_heads, N, flags), stream));
   // one double atomic pair per workgroup: few workgroups for a single frame (11 us), more for batches (94 -> ~25 us at batch 12)
   const long work = vec ? n4 : per_group;
   int g = grid_for(work, count > (1L << 21) ? 512 : 128);
   if (G > 1) { g = (g + G - 1) / G; if (g < 16) g = 16; }
   if (counts == nullptr) hipLaunchKernelGGL(cbce_count_kernel, dim3(g, G), dim3(256), 0, stream, label, per_group, n4, sc.npos);
   hipLaunchKernelGGL(cbce_main_kernel, dim3(g, G, n_heads), dim3(256), 0, stream, hd, label, per_group, n4, nm, sc, G);
-  hipLaunchKernelGGL(cbce_final_kernel, dim3(1), dim3(64), 0, stream, hd, per_group, nm, sc, G);
   OSVOS_LAUNCH_CHECK();
   return 0;
 }

@@ -663,7 +663,18 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
     rc = osvos_sum_partials(dfused, (long)N * H * W, fb_part, &fb_nblk, stream);
     if (rc) return rc;
   }
-  rc = osvos_head_grads_finalize(part, nblk, fb_part, fb_nblk, grads, accumulate, have_side ? 1 : 0, stream);
+  // The finalize kernel only feeds PARAMETER gradients (score_dsn, fuse): off the critical path -- on the reduce stream (or the weight-gradient
+  // stream) behind an event, so that the data-gradient chain starts one launch earlier (round 6; workspace partials only: nothing of the caller's
+  // is read off `stream`).  The generic head's extra reductions stay on `stream`.
+  OSVOS_ENV_INT(fin_side, "OSVOS_FINALIZE_SIDE", 1);      // A/B switch (0: on `stream`, as rounds 1-5)
+  hipStream_t fin = (!generic && two && fin_side) ? aux2 : stream;
+  if (fin != stream) {
+    hipEvent_t e = evp.next();
+    if (!e) return -1;
+    OSVOS_HIP_CHECK(hipEventRecord(e, stream));
+    OSVOS_HIP_CHECK(hipStreamWaitEvent(fin, e, 0));
+  }
+  rc = osvos_head_grads_finalize(part, nblk, fb_part, fb_nblk, grads, accumulate, have_side ? 1 : 0, fin);
   if (rc) return rc;
   if (generic) {
     // fuse.weight / upscale[i].weight gradients from the tap-indexed sums G_i (the partials above carried zeros for fuse.weight);
@@ -693,7 +704,7 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
       }
     }
   }
-  if ((rc = ready(0, stream))) return rc;      // score_dsn + fuse gradients
+  if ((rc = ready(0, fin))) return rc;      // score_dsn + fuse gradients
 
   // ---- data-gradient chain on `stream`, weight gradients trailing on `aux` ----------------------
   // ready[k]: event recorded on `stream` when the k-th upstream gradient tensor is complete

@@ -897,6 +897,65 @@ def test_cbce_step_multi_equals_the_single_head_calls():
             assert abs(float(r2[k]) - float(r1[k])) <= 2e-7 * abs(float(r1[k])), k
 
 
+def test_cbce_scratch_is_left_zero_and_the_zeroed_promise_changes_nothing():
+    """Round 6: the loss call is two launches -- the workgroup that arrives last at the sweep forms the losses (no final kernel) and clears the
+    scratch, and with OSVOS_CBCE_SCRATCH_ZEROED the call enqueues no memset (osvos_layers.py:19-48 arithmetic unchanged).  (1) after ANY call the
+    scratch reads zero; (2) forty back-to-back calls on ONE never-re-zeroed buffer with the promise == forty calls on freshly poisoned buffers
+    without it: gradients bit-identical, losses within the fp64 summation order; (3) the training-loop wrapper (persistent buffer per stream)
+    agrees with the C oracle over repeated calls, per-image and five-head forms included."""
+    import ctypes as C
+    from osvos_pytorch_amd import _lib
+    from osvos_pytorch_amd.autograd import CBCE_PER_IMAGE, CBCE_SCRATCH_ZEROED
+    from osvos_pytorch_amd.layers.osvos_layers import class_balanced_cross_entropy_loss_step_multi as multi
+    from oracle import c_oracle
+    l = _lib.lib()
+    vp = C.c_void_p
+    g = torch.Generator(device="cuda").manual_seed(5)
+
+    def call(outs, lab, scratch, flags, n_img):
+        n = len(outs)
+        losses = torch.full((n,), -7.0, device="cuda")
+        grads = [torch.empty_like(o) for o in outs]
+        a_out = (vp * n)(*[vp(o.data_ptr()) for o in outs])
+        a_loss = (vp * n)(*[vp(losses.data_ptr() + 4 * k) for k in range(n)])
+        a_grad = (vp * n)(*[vp(x.data_ptr()) for x in grads])
+        a_scale = (C.c_float * n)(*([0.2] * n))
+        _lib.check(l.osvos_cbce_step_ex(a_out, vp(lab.data_ptr()), a_loss, a_grad, vp(scratch.data_ptr()), lab.numel(), n_img, 2, flags, None, n, a_scale, None,
+                                        vp(torch.cuda.current_stream().cuda_stream)), "cbce")
+        return losses, grads
+    for (n_img, h, w, heads, per_image) in [(1, 48, 85, 1, False), (3, 40, 52, 5, False), (4, 24, 36, 1, True), (2, 33, 35, 5, True)]:
+        fl = CBCE_PER_IMAGE if per_image else 0
+        nb = int(l.osvos_cbce_scratch_bytes(heads, n_img, fl))
+        persistent = torch.zeros(nb, device="cuda", dtype=torch.uint8)
+        for it in range(40 if heads == 1 else 6):
+            outs = [torch.randn(n_img, 1, h, w, device="cuda", generator=g) * 3 - 1 for _ in range(heads)]
+            lab = (torch.rand(n_img, 1, h, w, device="cuda", generator=g) > 0.7).float()
+            la, ga = call(outs, lab, persistent, fl | CBCE_SCRATCH_ZEROED, n_img)
+            poisoned = torch.full((nb,), 0xA5, device="cuda", dtype=torch.uint8)
+            lb, gb = call(outs, lab, poisoned, fl, n_img)
+            torch.cuda.synchronize()
+            assert int(persistent.count_nonzero()) == 0 and int(poisoned.count_nonzero()) == 0, (n_img, heads, it)
+            for k in range(heads):
+                assert torch.equal(ga[k], gb[k]), (heads, k, it)
+                assert abs(float(la[k]) - float(lb[k])) <= 2e-7 * abs(float(lb[k])), (heads, k, it)
+            if not per_image:
+                ref, _ = c_oracle.cbce(outs[0].cpu().numpy().astype(np.float64).reshape(n_img, -1), lab.cpu().numpy().astype(np.float64).reshape(n_img, -1), 2)
+                assert abs(float(la[0]) - ref) <= 1e-5 * abs(ref), (n_img, it)
+    # the wrapper of the training loops: one persistent buffer per (device, stream, size); a side stream gets its own
+    outs = [torch.randn(2, 1, 30, 40, device="cuda", generator=g) for _ in range(5)]
+    lab = (torch.rand(2, 1, 30, 40, device="cuda", generator=g) > 0.6).float()
+    first = multi(outs, lab, size_average=False, grad_scales=[1.0] * 5)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        other = multi(outs, lab, size_average=False, grad_scales=[1.0] * 5)
+    torch.cuda.current_stream().wait_stream(side)
+    again = multi(outs, lab, size_average=False, grad_scales=[1.0] * 5)
+    torch.cuda.synchronize()
+    for a, b in ((first, other), (first, again)):
+        assert all(torch.equal(x, y) for x, y in zip(a[1], b[1])) and float((a[0] - b[0]).abs().max()) <= 2e-7 * float(a[0].abs().max())
+
+
 @pytest.mark.parametrize("shape", [(1, 24, 32, 128), (2, 17, 21, 256), (1, 30, 54, 512), (1, 7, 5, 128)])
 def test_skinny_side_prep_wgrad_on_the_bf16_pipe(shape):
     """side_prep's weight gradient (Cout = 16; vgg_osvos.py:41) -- the S16 form of wgrad_f32x3.hip, what the default fp32x3 network runs --
