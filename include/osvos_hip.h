@@ -41,6 +41,11 @@ extern "C" {
                                             forward skips what only a backward reads -- the one-bit ReLU masks and the pool-code bytes -- so the
                                             convolutions that write them keep their fused pooling epilogue and nothing is stored for nobody (round 6;
                                             the workspace may be the inference-sized one, osvos_net_ws_bytes_infer).  Logits are bit-identical. */
+#define OSVOS_FLAG_X3_TWO_PIECES 0x800   /* OR-ed into the dtype OSVOS_F32_X3 of osvos_net_forward / osvos_net_backward: precision 'fp32x2' -- the f32x3
+                                            kernels take TWO bf16 pieces per operand and form three products (ah*bh + ah*bm + am*bh) instead of three
+                                            pieces / six products: operands carry 16 significand bits (TF32, cuDNN's default for fp32 convolutions on
+                                            the reference's GPUs, carries 11), accumulation is fp32, half the matrix work.  Tensors, packs and workspaces
+                                            are those of OSVOS_F32_X3.  NOT fp32-grade: see profiles/r06_fp32x2.txt for where it lands. */
 #define OSVOS_F32_X3 3        /* fp32 tensors, fp32 parameters and fp32 weight packs exactly as OSVOS_F32; the wide 3x3 convolutions
                                  (forward, data gradient) run on the bf16 matrix pipe with three-way split operands (six bf16
                                  products per fp32 product, fp32 accumulate): fp32-grade results, see osvos_conv3x3 below */
@@ -155,6 +160,10 @@ int osvos_maxpool2x2_bwd_bf16act_code(const void* code, const void* dy_bf16, con
 int osvos_conv3x3_bf16act_fused(const void* x_bf16, const void* wpk, const float* bias, const void* mask_bits, void* y_bf16, void* y_bits,
                                 void* pooled_bf16, void* pool_code, int N, int H, int W, int Cin, int Cout, int relu, int tile, void* stream);
 int osvos_conv3x3_bf16io_tiles(int* tiles, int max);
+/* bf16 pieces per operand of the OSVOS_F32_X3 kernels called from THIS host thread through the op-level entry points (osvos_conv3x3,
+ * osvos_conv3x3_x3*, osvos_conv3x3_wgrad with that dtype): 3 (default: six products, fp32-grade) or 2 (three products; what
+ * OSVOS_FLAG_X3_TWO_PIECES selects for the osvos_net_* calls, which set and restore it themselves). */
+int osvos_set_x3_pieces(int pieces);
 int osvos_nchw_to_nhwc_bf16copy(const float* src, void* dst, void* dst_bf16, int N, int C, int H, int W, int cpad, void* stream);
 int osvos_maxpool2x2_bf16copy(const float* x, float* y, void* y_bf16, int N, int H, int W, int C, void* stream);
 int osvos_maxpool2x2_bwd_bf16copy(const float* x, const float* dy, const float* dside, float* dx, void* dx_bf16,

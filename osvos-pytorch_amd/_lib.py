@@ -19,6 +19,7 @@ _lib = None
 
 F32, BF16, F32_BF16MFMA, F32_X3 = 0, 1, 2, 3
 DEFER_JOIN = 0x200         # OSVOS_FLAG_DEFER_JOIN: osvos_net_backward leaves the side streams un-joined (autograd.NetRuntime.join_backward)
+X3_TWO_PIECES = 0x800       # OSVOS_FLAG_X3_TWO_PIECES: precision 'fp32x2' (two bf16 pieces per operand, three products)
 INFERENCE = 0x400           # OSVOS_FLAG_INFERENCE: osvos_net_forward writes nothing only a backward would read (sign bits, pool codes)
 GENERIC_DECONV = 0x100      # OSVOS_FLAG_GENERIC_DECONV: OR-ed into the dtype of the osvos_net_* calls
 NPARAMS = 52
@@ -54,6 +55,7 @@ PROTOTYPES = {
     "osvos_maxpool2x2_bwd_bf16act_code": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "osvos_conv3x3_bf16act_fused": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "osvos_conv3x3_bf16io_tiles": (_i, [_vp, _i]),
+    "osvos_set_x3_pieces": (_i, [_i]),
     "osvos_nchw_to_nhwc_bf16copy": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "osvos_maxpool2x2_bf16copy": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "osvos_maxpool2x2_bwd_bf16copy": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),

@@ -8,11 +8,14 @@ import os
 
 import torch
 
-from ._lib import DEFER_JOIN, F32, F32_BF16MFMA, F32_X3, GENERIC_DECONV, INFERENCE, NPARAMS, check, lib, ptr_array
+from ._lib import DEFER_JOIN, F32, F32_BF16MFMA, F32_X3, GENERIC_DECONV, INFERENCE, NPARAMS, X3_TWO_PIECES, check, lib, ptr_array
 
 # indices (state_dict order) of the frozen transposed-conv weights: lr 0 in both reference
 # scripts (train_online.py:84-85, train_parent.py:99-100); their gradients are never formed
 _FROZEN = set(range(8))
+# precision name -> (library dtype, two bf16 pieces per operand in the forward, ... in the backward); see OSVOS.set_precision
+PRECISIONS = {"fp32": (F32, False, False), "bf16": (F32_BF16MFMA, False, False), "fp32x3": (F32_X3, False, False), "fp32x2": (F32_X3, True, True),
+              "fp32x3b2": (F32_X3, False, True)}
 
 
 def _stream():
@@ -30,7 +33,8 @@ class NetRuntime:
         # 'fp32x3' (default: fp32 tensors and fp32-grade results, the wide 3x3 convolutions on the bf16 matrix pipe with three-way
         # split operands), 'fp32' (the same on the exact fp32 MFMA kernels) or 'bf16' (bf16 MFMA operands and bf16 trunk tensors,
         # fp32 accumulate; head and loss stay fp32).  OSVOS_PRECISION sets the initial value.
-        self.dtype = {"bf16": F32_BF16MFMA, "fp32": F32, "fp32x3": F32_X3}.get(os.environ.get("OSVOS_PRECISION", "fp32x3").lower(), F32_X3)
+        self.dtype, self.two_fwd, self.two_bwd = F32_X3, False, False
+        self.set_precision(os.environ.get("OSVOS_PRECISION", "fp32x3").lower() if os.environ.get("OSVOS_PRECISION", "fp32x3").lower() in PRECISIONS else "fp32x3")
         self.aux_stream = None        # second HIP stream: wgrad kernels overlap the dgrad kernels
         self.aux2_stream = None       # third: the slab reduces of the weight gradients
         self.auxf_stream = None       # forward side branches (own stream: a forward pipelined under the previous backward must not queue
@@ -95,7 +99,9 @@ class NetRuntime:
         return C.c_void_p(self.aux2_stream.cuda_stream)
 
     def set_precision(self, name):
-        dt = {"fp32": F32, "bf16": F32_BF16MFMA, "fp32x3": F32_X3}[name]
+        # round 6: the f32x3 kernels can take TWO bf16 pieces per operand (three products instead of six) -- same dtype, packs and workspaces, one flag
+        # on the network calls: 'fp32x2' in both passes, 'fp32x3b2' in the BACKWARD only (forward = 'fp32x3' bit for bit)
+        dt, self.two_fwd, self.two_bwd = PRECISIONS[name]
         if dt != self.dtype:
             self.dtype, self.wbuf, self.key = dt, None, None
 
@@ -121,6 +127,12 @@ class NetRuntime:
     def cdtype(self):
         """dtype argument of the osvos_net_* calls: precision, plus the generic-deconvolution flag when the upscale weights need it."""
         return self.dtype | (GENERIC_DECONV if self.generic_head else 0)
+
+    def cdtype_fwd(self):
+        return self.cdtype() | (X3_TWO_PIECES if self.two_fwd else 0)
+
+    def cdtype_bwd(self):
+        return self.cdtype() | (X3_TWO_PIECES if self.two_bwd else 0)
 
     @staticmethod
     def _deconv_is_diagonal(ups):
@@ -160,10 +172,11 @@ class OSVOSNetFunction(torch.autograd.Function):
         need_bwd = any(ctx.needs_input_grad)       # False under torch.no_grad(): forward-only workspace
         nbytes = l.osvos_net_ws_bytes(n, h, w, rt.dtype) if need_bwd else l.osvos_net_ws_bytes_infer(n, h, w, rt.dtype)
         ctx.cdtype = rt.cdtype()
+        ctx.cdtype_bwd = rt.cdtype_bwd()
         ws = torch.empty(nbytes, device=xin.device, dtype=torch.uint8)
         outs = [torch.empty((n, 1, h, w), device=xin.device, dtype=torch.float32) for _ in range(5)]
         check(l.osvos_net_forward(C.c_void_p(xin.data_ptr()), C.c_void_p(rt.wbuf.data_ptr()), C.c_void_p(ws.data_ptr()),
-                                  ptr_array([o.data_ptr() for o in outs]), n, h, w, ctx.cdtype | (0 if need_bwd else INFERENCE), _stream(),
+                                  ptr_array([o.data_ptr() for o in outs]), n, h, w, rt.cdtype_fwd() | (0 if need_bwd else INFERENCE), _stream(),
                                   rt.auxf(xin.device)), "net_forward")
         # the activation workspace rides in autograd's saved-tensor slot: released right after a plain backward, kept under
         # retain_graph=True (a second backward recomputes every gradient buffer from the untouched forward half: no buffer of the
@@ -231,7 +244,7 @@ class OSVOSNetFunction(torch.autograd.Function):
                                    ptr_array([None if g is None else g.data_ptr() for g in d]),
                                    ptr_array([None if g is None else g.data_ptr() for g in targets]),
                                    C.c_void_p(dx.data_ptr()) if dx is not None else None,
-                                   n, h, w, ctx.cdtype | (DEFER_JOIN if defer else 0), 1 if inplace else 0, _stream(), aux, aux2), "net_backward")
+                                   n, h, w, ctx.cdtype_bwd | (DEFER_JOIN if defer else 0), 1 if inplace else 0, _stream(), aux, aux2), "net_backward")
         if defer:
             # the side streams still read the workspace (activations, upstream gradients, slabs) and write the scratch halves: the caching
             # allocator must not hand that memory out again before they are done with it

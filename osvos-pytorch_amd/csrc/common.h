@@ -17,6 +17,7 @@ typedef short bf16x4 __attribute__((ext_vector_type(4)));
 void osvos_set_error(const char* fmt, ...);
 int osvos_wgrad_phase();            // 0 both, 1 partial slabs only, 2 slab reduce only (errors.cpp)
 void osvos_wgrad_set_phase(int p);
+int osvos_x3_pieces();             // bf16 pieces per operand of the f32x3 kernels on this thread: 3 (default) or 2 (errors.cpp)
 
 #define OSVOS_ARG_CHECK(cond, ...)                   \
   do {                                               \

@@ -120,11 +120,30 @@ __device__ inline void split8(const u32x4& lo, const u32x4& hi, uint4& p0, uint4
   split2(b[2], b[3], p0.w, p1.w, p2.w);
 }
 
+// the two leading pieces only (NP = 2): v ~ p0 + p1, the remainder (< 2^-16 |v|) dropped
+__device__ inline void split8_hm(const u32x4& lo, const u32x4& hi, uint4& p0, uint4& p1) {
+  const f32x4 a = __builtin_bit_cast(f32x4, lo), b = __builtin_bit_cast(f32x4, hi);
+  auto two = [](float x, float y, unsigned& q0, unsigned& q1) {
+    q0 = cvt2(x, y);
+    q1 = cvt2(x - __uint_as_float(q0 << 16), y - __uint_as_float(q0 & 0xffff0000u));
+  };
+  two(a[0], a[1], p0.x, p1.x);
+  two(a[2], a[3], p0.y, p1.y);
+  two(b[0], b[1], p0.z, p1.z);
+  two(b[2], b[3], p0.w, p1.w);
+}
+
 // PS = 1: the weights arrive PRE-SPLIT (three bf16 piece planes, made once per optimizer step by pack_x3_kernel): their staging is
 // a plain copy.  5 of the 7 items a thread stages per chunk are weights, re-split by every workgroup of every launch when PS = 0 --
 // 64 % of the VALU work between the two barriers of a chunk (profiles/r02_pmc_f32x3.txt).
-template <class C, int PS, int SK>
+// NP = 3: the three-way split, six products (fp32-grade).  NP = 2 ("f32x2", round 6): only the high and middle pieces are staged and the three
+// products ah*bh + ah*bm + am*bh are formed -- operands carry 16 significand bits (bf16 + bf16; TF32, what cuDNN runs fp32 convolutions in by
+// default on the reference's own GPUs, carries 11), accumulation stays fp32: half the matrix work, a relative error of ~2^-17 per product instead
+// of 2^-24.  Same LDS layout and the same pre-split packs (the low planes are simply not read).  Precision 'fp32x2' of the network; NOT the
+// default: it does not hold the flat fp32 parity bars on every head (profiles/r06_fp32x2.txt).
+template <class C, int PS, int SK, int NP = 3>
 __global__ __launch_bounds__(C::NT, C::OCC) void conv3x3_f32x3_kernel(ConvArgsX a) {
+  static_assert(NP == 2 || NP == 3, "two or three bf16 pieces per operand");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint4* As = reinterpret_cast<uint4*>(smem);
   uint4* Bs = As + C::A_U4;
@@ -190,7 +209,7 @@ __global__ __launch_bounds__(C::NT, C::OCC) void conv3x3_f32x3_kernel(ConvArgsX 
     a_dst[i] = slot ? g * C::PLANE + hy * C::PITCH + hx : -1;
     a_off[i] = (slot && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? (unsigned)(((gy * a.W + gx) * a.Cin + 8 * g) * 4) : OOB;
   }
-  constexpr int NBI = PS ? cdivx(3 * C::B_ITEMS, C::NT) : C::NBL;       // weight items per thread and chunk
+  constexpr int NBI = PS ? cdivx(NP * C::B_ITEMS, C::NT) : C::NBL;      // weight items per thread and chunk
   constexpr int TPI = C::NT / (2 * C::BN);                              // PS: (piece, tap) rows a thread advances per item
   static_assert(!PS || C::NT % (2 * C::BN) == 0, "pre-split staging: the thread block must cover whole (piece, tap) rows");
   unsigned b_off[PS ? 1 : C::NBL];
@@ -223,7 +242,7 @@ __global__ __launch_bounds__(C::NT, C::OCC) void conv3x3_f32x3_kernel(ConvArgsX 
     } else if (it < C::NA + NBI) {
       const int i = it - C::NA;
       if constexpr (PS != 0) {
-        const unsigned off = (b_row0 + i * TPI < 27) ? b_off[0] : OOB;       // (only a thread's last item can fall off the 27 rows)
+        const unsigned off = (b_row0 + i * TPI < 9 * NP) ? b_off[0] : OOB;   // (only a thread's last item can fall off the 9 NP (piece, tap) rows)
         rb[i][0] = __builtin_amdgcn_raw_buffer_load_b128(w3rs, off, kc * 2 * a.CoutP * 16 + i * b_step, 0);
       } else {
         rb[i][0] = __builtin_amdgcn_raw_buffer_load_b128(wrs, b_off[i], kc * 4 * a.CoutP * 16, 0);
@@ -240,29 +259,31 @@ __global__ __launch_bounds__(C::NT, C::OCC) void conv3x3_f32x3_kernel(ConvArgsX 
 #pragma unroll
     for (int i = 0; i < C::NA; ++i) {
       uint4 p0, p1, p2;
-      split8(ra[i][0], ra[i][1], p0, p1, p2);
+      if constexpr (NP == 3) split8(ra[i][0], ra[i][1], p0, p1, p2);
+      else split8_hm(ra[i][0], ra[i][1], p0, p1);
       if (C::A_ITEMS % C::NT == 0 || a_dst[i] >= 0) {
         As[a_dst[i]] = p0;
         As[a_dst[i] + 2 * C::PLANE] = p1;
-        As[a_dst[i] + 4 * C::PLANE] = p2;
+        if constexpr (NP == 3) As[a_dst[i] + 4 * C::PLANE] = p2;
       }
     }
     if constexpr (PS != 0) {
 #pragma unroll
       for (int i = 0; i < NBI; ++i) {
         const int e3 = tid + i * C::NT;                 // LDS image [piece][tap][group][BN] = the pack's order
-        if ((3 * C::B_ITEMS) % C::NT == 0 || e3 < 3 * C::B_ITEMS) Bs[e3] = __builtin_bit_cast(uint4, rb[i][0]);
+        if ((NP * C::B_ITEMS) % C::NT == 0 || e3 < NP * C::B_ITEMS) Bs[e3] = __builtin_bit_cast(uint4, rb[i][0]);
       }
     } else {
 #pragma unroll
       for (int i = 0; i < NBI; ++i) {
         uint4 p0, p1, p2;
-        split8(rb[i][0], rb[i][1], p0, p1, p2);
+        if constexpr (NP == 3) split8(rb[i][0], rb[i][1], p0, p1, p2);
+        else split8_hm(rb[i][0], rb[i][1], p0, p1);
         const int e = tid + i * C::NT;
         if (C::B_ITEMS % C::NT == 0 || e < C::B_ITEMS) {
           Bs[e] = p0;
           Bs[e + C::B_ITEMS] = p1;
-          Bs[e + 2 * C::B_ITEMS] = p2;
+          if constexpr (NP == 3) Bs[e + 2 * C::B_ITEMS] = p2;
         }
       }
     }
@@ -312,7 +333,7 @@ __global__ __launch_bounds__(C::NT, C::OCC) void conv3x3_f32x3_kernel(ConvArgsX 
       if (tap > 0) return;
 #endif
 #pragma unroll
-      for (int p = 0; p < 3; ++p)
+      for (int p = 0; p < NP; ++p)
 #pragma unroll
         for (int ni = 0; ni < C::WN; ++ni) fb[set][p][ni] = Bs[b_idx + (p * 9 + tap) * 2 * C::BN + ni * 32];
     };
@@ -322,7 +343,7 @@ __global__ __launch_bounds__(C::NT, C::OCC) void conv3x3_f32x3_kernel(ConvArgsX 
 #endif
       const int r = tap / 3, s = tap % 3;
 #pragma unroll
-      for (int p = 0; p < 3; ++p) fa[set][p] = As[a_idx[mi] + p * 2 * C::PLANE + r * C::PITCH + s];
+      for (int p = 0; p < NP; ++p) fa[set][p] = As[a_idx[mi] + p * 2 * C::PLANE + r * C::PITCH + s];
     };
     ldB(0, 0);
     ldA(0, 0, 0);
@@ -340,10 +361,11 @@ __global__ __launch_bounds__(C::NT, C::OCC) void conv3x3_f32x3_kernel(ConvArgsX 
         __builtin_amdgcn_sched_barrier(0);
         const int sa = step & 1, sb = tap & 1;
         // pieces: 0 = high, 1 = middle, 2 = low.  Small products first, the dominant hi x hi product last.
-        constexpr int PB[6] = {2, 0, 1, 1, 0, 0};
-        constexpr int PA[6] = {0, 2, 1, 0, 1, 0};
+        constexpr int NPROD = NP == 3 ? 6 : 3;
+        constexpr int PB[6] = {NP == 3 ? 2 : 1, NP == 3 ? 0 : 0, NP == 3 ? 1 : 0, 1, 0, 0};      // NP = 2: (bm, ah), (bh, am), (bh, ah)
+        constexpr int PA[6] = {NP == 3 ? 0 : 0, NP == 3 ? 2 : 1, NP == 3 ? 1 : 0, 0, 1, 0};
 #pragma unroll
-        for (int t = 0; t < 6; ++t)
+        for (int t = 0; t < NPROD; ++t)
 #pragma unroll
           for (int ni = 0; ni < C::WN; ++ni)
 #if defined(OSVOS_X3_ABL) && OSVOS_X3_ABL == 1
@@ -501,9 +523,9 @@ __global__ __launch_bounds__(C::NT, C::OCC) void conv3x3_f32x3_kernel(ConvArgsX 
     if (pool_fwd) {
       // windows: RBW 32 -- M blocks 2j, 2j+1 of this wave are the two rows, lane ^ 1 the neighbouring column;
       //          RBW 16 -- an M block holds both rows (lanes li and li ^ 16), lane ^ 1 the neighbouring column
-      constexpr int NP = C::RBW == 32 ? C::WM / 2 : C::WM;
+      constexpr int NPW = C::RBW == 32 ? C::WM / 2 : C::WM;
 #pragma unroll
-      for (int j = 0; j < NP; ++j) {
+      for (int j = 0; j < NPW; ++j) {
         const int mb = wm * C::WM + (C::RBW == 32 ? 2 * j : j);
         const int oy = y0 + (mb / C::TBX) * C::RBH, ox = x0 + (mb % C::TBX) * C::RBW + li % C::RBW;      // top row of the window pair
         const bool writer = (li & 1) == 0 && (C::RBW == 32 || li < 16) && oy < a.H && ox < a.W;
@@ -537,12 +559,12 @@ constexpr size_t kSkSlotBytes = 128 * 1024;               // the largest tile's 
 constexpr size_t kSkTicketBytes = (size_t)kSkMaxTiles * 4;
 
 // sk_grid > 0: the stream-K kernel with that many persistent workgroups (the caller has checked that the tile order has >= sk_grid units)
-template <class C, int PS, int SK>
+template <class C, int PS, int SK, int NP = 3>
 int launch_x2(const ConvArgsX& a0, int sk_grid, hipStream_t stream) {
   static bool attr_set_dev[OSVOS_MAX_DEVICES] = {};      // hipFuncSetAttribute is per device
   bool& attr_set = attr_set_dev[osvos_current_device()];
   if (!attr_set) {
-    OSVOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f32x3_kernel<C, PS, SK>),
+    OSVOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f32x3_kernel<C, PS, SK, NP>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
     attr_set = true;
   }
@@ -556,11 +578,11 @@ int launch_x2(const ConvArgsX& a0, int sk_grid, hipStream_t stream) {
     const long ntiles = (long)a.nct * a.nsp, units = ntiles * (a.Cin >> 4);
     OSVOS_ARG_CHECK(sk_grid > 0 && sk_grid <= kSkMaxGrid && ntiles <= kSkMaxTiles && units >= sk_grid && a.sk_tickets && a.sk_part && a.ksplit == 1,
                     "conv3x3 f32x3 stream-K: %ld tiles, %ld units on %d workgroups", ntiles, units, sk_grid);
-    hipLaunchKernelGGL((conv3x3_f32x3_kernel<C, PS, SK>), dim3((unsigned)sk_grid), dim3(C::NT), C::LDS_BYTES, stream, a);
+    hipLaunchKernelGGL((conv3x3_f32x3_kernel<C, PS, SK, NP>), dim3((unsigned)sk_grid), dim3(C::NT), C::LDS_BYTES, stream, a);
   } else {
     const long blocks = a.map == 0 ? (long)a.nct * a.nsp : (long)a.nct * ((a.nsp + 7) / 8) * 8;
     OSVOS_ARG_CHECK(blocks > 0 && blocks < (1L << 31), "conv3x3 f32x3: grid of %ld blocks", blocks);
-    hipLaunchKernelGGL((conv3x3_f32x3_kernel<C, PS, SK>), dim3((unsigned)blocks, (unsigned)a.ksplit), dim3(C::NT), C::LDS_BYTES, stream, a);
+    hipLaunchKernelGGL((conv3x3_f32x3_kernel<C, PS, SK, NP>), dim3((unsigned)blocks, (unsigned)a.ksplit), dim3(C::NT), C::LDS_BYTES, stream, a);
   }
   OSVOS_LAUNCH_CHECK();
   return 0;
@@ -569,6 +591,13 @@ int launch_x2(const ConvArgsX& a0, int sk_grid, hipStream_t stream) {
 // pre-split production tiles of the wide layers (SKT)
 template <class C, bool SKT = false>
 int launch_x(const ConvArgsX& a, int sk_grid, hipStream_t stream) {
+  if (osvos_x3_pieces() == 2) {      // two-piece mode (precision 'fp32x2'): the plain grid only, no stream-K form
+    if constexpr (C::ILV != 0 && C::NT == 512) {
+      if (a.wpk3 != nullptr) return launch_x2<C, 1, 0, 2>(a, 0, stream);
+    }
+    OSVOS_ARG_CHECK(a.wpk != nullptr, "conv3x3 f32x3: this tile config has no pre-split form and no fp32 pack was given");
+    return launch_x2<C, 0, 0, 2>(a, 0, stream);
+  }
   if constexpr (C::ILV != 0 && C::NT == 512) {
     if constexpr (SKT) {
       if (a.wpk3 != nullptr && sk_grid > 0) return launch_x2<C, 1, 1>(a, sk_grid, stream);

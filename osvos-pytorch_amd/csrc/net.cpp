@@ -294,6 +294,15 @@ inline int dbg_skip() {
 constexpr int dbg_skip() { return 0; }
 #endif
 
+// precision 'fp32x2' (OSVOS_FLAG_X3_TWO_PIECES): the f32x3 kernels of this call take two bf16 pieces per operand (three products) instead of three
+// (six); the per-thread switch (errors.cpp) is set for the duration of the call and restored on every return path
+extern "C" int osvos_set_x3_pieces(int pieces);
+struct PiecesScope {
+  int prev;
+  explicit PiecesScope(bool two) : prev(osvos_x3_pieces()) { osvos_set_x3_pieces(two ? 2 : 3); }
+  ~PiecesScope() { osvos_set_x3_pieces(prev); }
+};
+
 // gradient-ready events armed for the next backward of this host thread (osvos_net_arm_grad_events)
 struct GradEvents { hipEvent_t ev[OSVOS_NGRAD_GROUPS]; int n = 0; };
 GradEvents& grad_events() {
@@ -407,6 +416,7 @@ int osvos_net_forward(const float* x_nchw, const void* wbuf, void* ws, float* co
   const int dtype = dtype_ & 0xff;
   const bool generic = (dtype_ & OSVOS_FLAG_GENERIC_DECONV) != 0;
   const bool infer = (dtype_ & OSVOS_FLAG_INFERENCE) != 0;      // no backward will read the sign bits / pool codes: do not write them
+  PiecesScope pieces_scope((dtype_ & OSVOS_FLAG_X3_TWO_PIECES) != 0 && dtype == OSVOS_F32_X3);
   hipStream_t aux_all = aux_stream_ ? (hipStream_t)aux_stream_ : stream;
   const bool two = aux_all != stream;
   EventPool& evp = event_pool();
@@ -535,6 +545,7 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
   hipStream_t stream = (hipStream_t)stream_;
   const int dtype = dtype_ & 0xff;
   const bool generic = (dtype_ & OSVOS_FLAG_GENERIC_DECONV) != 0;
+  PiecesScope pieces_scope((dtype_ & OSVOS_FLAG_X3_TWO_PIECES) != 0 && dtype == OSVOS_F32_X3);
   hipStream_t aux = aux_stream_ ? (hipStream_t)aux_stream_ : stream;
   hipStream_t aux2 = aux2_stream_ ? (hipStream_t)aux2_stream_ : aux;
   const GradEvents gev = grad_events();      // armed for this call only

@@ -93,22 +93,24 @@ __device__ inline void split8w(const u32x4& lo, const u32x4& hi, u32x4& p0, u32x
 
 // scheduling groups of one stage, in program order: MFMA, then what may hide in its 32-cycle shadow -- its share of the NDS gathers and NVM
 // staging loads of the stage, a few VALU / SALU (the builtin wants literal sizes: compile-time recursion)
-template <int NDS, int NVM, int I = 0>
+// NM: MFMAs of the stage (18 with three pieces per operand, 9 with two)
+template <int NDS, int NVM, int NM = 18, int I = 0>
 __device__ __forceinline__ void stage_groups() {
-  if constexpr (I < 18) {
+  if constexpr (I < NM) {
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-    constexpr int nds = (NDS * (I + 1)) / 18 - (NDS * I) / 18, nvm = (NVM * (I + 1)) / 18 - (NVM * I) / 18;
+    constexpr int nds = (NDS * (I + 1)) / NM - (NDS * I) / NM, nvm = (NVM * (I + 1)) / NM - (NVM * I) / NM;
     if constexpr (nds > 0) __builtin_amdgcn_sched_group_barrier(0x100, nds, 0);
     if constexpr (nvm > 0) __builtin_amdgcn_sched_group_barrier(0x020, nvm, 0);
     __builtin_amdgcn_sched_group_barrier(0x006, 3, 0);
-    stage_groups<NDS, NVM, I + 1>();
+    stage_groups<NDS, NVM, NM, I + 1>();
   }
 }
 
 // ILV = 1 (four-wave forms): the next stage's 18-24 fragment gathers and the staging loads are INTERLEAVED with the stage's 18 MFMAs (one
 // gather per MFMA, sched_group_barrier) instead of being issued as a block in front of them: with one wave per SIMD nothing else covers
 // the ~150-250 cycles that block takes while the matrix pipe drains (576 cycles of MFMA per stage; the pipe was busy 51 % of the time).
-template <int PH, int WAVES, int S16 = 0, int ILV = 0>
+// NP = 2 (round 6, precision 'fp32x2'): two bf16 pieces per operand, three products (conv3x3_f32x3.hip) -- same tiles, the low planes unused
+template <int PH, int WAVES, int S16 = 0, int ILV = 0, int NP = 3>
 __global__ __launch_bounds__(64 * WAVES) void wgrad_f32x3_kernel(W3Args a) {
   using G = G3<PH, WAVES, S16>;
   constexpr int NT = G::NT, BCO = G::BCO, BCI = G::BCI;
@@ -183,7 +185,7 @@ __global__ __launch_bounds__(64 * WAVES) void wgrad_f32x3_kernel(W3Args a) {
         char* d = dYs + p * G::DYP + doct * 16;
         *reinterpret_cast<u32x4*>(d) = p0;
         *reinterpret_cast<u32x4*>(d + G::DY_B) = p1;
-        *reinterpret_cast<u32x4*>(d + 2 * G::DY_B) = p2;
+        if constexpr (NP == 3) *reinterpret_cast<u32x4*>(d + 2 * G::DY_B) = p2;
       }
     }
 #pragma unroll
@@ -195,7 +197,7 @@ __global__ __launch_bounds__(64 * WAVES) void wgrad_f32x3_kernel(W3Args a) {
         char* d = Xs + hp * G::XP + xoct * 16;
         *reinterpret_cast<u32x4*>(d) = p0;
         *reinterpret_cast<u32x4*>(d + G::X_B) = p1;
-        *reinterpret_cast<u32x4*>(d + 2 * G::X_B) = p2;
+        if constexpr (NP == 3) *reinterpret_cast<u32x4*>(d + 2 * G::X_B) = p2;
       }
     }
   };
@@ -231,12 +233,12 @@ __global__ __launch_bounds__(64 * WAVES) void wgrad_f32x3_kernel(W3Args a) {
     s16x8 af[NB][3], bfr[NB][3][3];      // [set][piece] / [set][piece][tap column]
     auto lda = [&](int ks) {
 #pragma unroll
-      for (int pc = 0; pc < 3; ++pc) af[ks & (NB - 1)][pc] = tr8(a_base + pc * G::DY_B + ks * PW * G::DYP, G::DYP);
+      for (int pc = 0; pc < NP; ++pc) af[ks & (NB - 1)][pc] = tr8(a_base + pc * G::DY_B + ks * PW * G::DYP, G::DYP);
     };
     auto ldb = [&](int st) {
       const int ks = st / 3, r = st % 3;
 #pragma unroll
-      for (int pc = 0; pc < 3; ++pc)
+      for (int pc = 0; pc < NP; ++pc)
 #pragma unroll
         for (int s = 0; s < 3; ++s) bfr[st & (NB - 1)][pc][s] = tr8(b_base + pc * G::X_B + ((ks + r) * G::HW_ + s) * G::XP, G::XP);
     };
@@ -259,10 +261,11 @@ __global__ __launch_bounds__(64 * WAVES) void wgrad_f32x3_kernel(W3Args a) {
       issue(nx, st);                    // next patch's fp32 pieces: one item (two 16-byte loads) per stage
       if constexpr (ILV == 0) __builtin_amdgcn_sched_barrier(0);
       // pieces: 0 = high, 1 = middle, 2 = low; small products first.  First operand = X (rows = cin), second = dY (columns = cout)
-      constexpr int PX[6] = {2, 0, 1, 1, 0, 0};
-      constexpr int PD[6] = {0, 2, 1, 0, 1, 0};
+      constexpr int NPROD = NP == 3 ? 6 : 3;
+      constexpr int PX[6] = {NP == 3 ? 2 : 1, 0, NP == 3 ? 1 : 0, 1, 0, 0};      // NP = 2: (xm, dh), (xh, dm), (xh, dh)
+      constexpr int PD[6] = {0, NP == 3 ? 2 : 1, NP == 3 ? 1 : 0, 0, 1, 0};
 #pragma unroll
-      for (int t = 0; t < 6; ++t)
+      for (int t = 0; t < NPROD; ++t)
 #pragma unroll
         for (int s = 0; s < 3; ++s)
           acc[r * 3 + s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, bfr[st & (NB - 1)][PX[t]][s]),
@@ -271,9 +274,10 @@ __global__ __launch_bounds__(64 * WAVES) void wgrad_f32x3_kernel(W3Args a) {
         // gathers of the NEXT stage (independent registers: the fragment sets are double buffered) and this stage's staging loads
         constexpr int V = 2;
         const bool last = st + 1 >= G::NST, wide = r == 2, vm = st < G::NIT;      // (compile-time after unrolling)
-        if (last) { if (vm) stage_groups<0, V>(); else stage_groups<0, 0>(); }
-        else if (wide) { if (vm) stage_groups<24, V>(); else stage_groups<24, 0>(); }
-        else { if (vm) stage_groups<18, V>(); else stage_groups<18, 0>(); }
+        constexpr int NM = 3 * NPROD, DN = 6 * NP, DW = 8 * NP;      // MFMAs of a stage; gathers of the next stage (narrow / with the dY fragment)
+        if (last) { if (vm) stage_groups<0, V, NM>(); else stage_groups<0, 0, NM>(); }
+        else if (wide) { if (vm) stage_groups<DW, V, NM>(); else stage_groups<DW, 0, NM>(); }
+        else { if (vm) stage_groups<DN, V, NM>(); else stage_groups<DN, 0, NM>(); }
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -356,17 +360,17 @@ W3Plan make_plan3(int N, int H, int W, int Cin_s, int Cout) {
   return p;
 }
 
-template <int PH, int WAVES, int S16 = 0, int ILV = 0>
+template <int PH, int WAVES, int S16 = 0, int ILV = 0, int NP = 3>
 int launch3(const W3Args& a, long blocks, hipStream_t stream) {
   static bool attr_set_dev[OSVOS_MAX_DEVICES] = {};
   bool& attr_set = attr_set_dev[osvos_current_device()];
   if (!attr_set) {
-    OSVOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_f32x3_kernel<PH, WAVES, S16, ILV>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    OSVOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_f32x3_kernel<PH, WAVES, S16, ILV, NP>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)G3<PH, WAVES, S16>::LDS));
     attr_set = true;
   }
   constexpr size_t lds = G3<PH, WAVES, S16>::LDS;
-  hipLaunchKernelGGL((wgrad_f32x3_kernel<PH, WAVES, S16, ILV>), dim3((unsigned)blocks), dim3(64 * WAVES), lds, stream, a);
+  hipLaunchKernelGGL((wgrad_f32x3_kernel<PH, WAVES, S16, ILV, NP>), dim3((unsigned)blocks), dim3(64 * WAVES), lds, stream, a);
   OSVOS_LAUNCH_CHECK();
   return 0;
 }
@@ -417,8 +421,11 @@ int wgrad3_run(const void* x, const void* dy, void* ws, float* dw, float* db,
   const int phase = osvos_wgrad_phase();
   if (phase != 2) {
     // gathers / staging loads interleaved with the MFMAs of the previous stage (round 3; the block-issue form measured level and is gone)
-    const int rc = skinny ? launch3<4, 4, 1, 1>(a, blocks, stream)
-                          : (p.ph == 6 ? launch3<6, 4, 0, 1>(a, blocks, stream) : launch3<4, 4, 0, 1>(a, blocks, stream));
+    const bool two = osvos_x3_pieces() == 2;      // precision 'fp32x2'
+    const int rc = two ? (skinny ? launch3<4, 4, 1, 1, 2>(a, blocks, stream)
+                                 : (p.ph == 6 ? launch3<6, 4, 0, 1, 2>(a, blocks, stream) : launch3<4, 4, 0, 1, 2>(a, blocks, stream)))
+                       : (skinny ? launch3<4, 4, 1, 1>(a, blocks, stream)
+                                 : (p.ph == 6 ? launch3<6, 4, 0, 1>(a, blocks, stream) : launch3<4, 4, 0, 1>(a, blocks, stream)));
     if (rc) return rc;
   }
   if (phase == 1) return 0;

@@ -76,7 +76,10 @@ class OSVOS(nn.Module):
     def set_precision(self, name):
         """'fp32x3' (default: fp32 tensors, fp32-grade results -- the wide 3x3 convolutions run on the bf16 matrix pipe with three-way split
         operands, six bf16 products per fp32 product), 'fp32' (the same arithmetic on the exact fp32 MFMA kernels, ~1.5x slower) or 'bf16'
-        (bf16 MFMA operands and bf16 trunk tensors, fp32 accumulate).  Not part of the reference's API."""
+        (bf16 MFMA operands and bf16 trunk tensors, fp32 accumulate).  'fp32x2' (round 6): the f32x3 kernels with TWO bf16 pieces per operand,
+        three products -- fp32 tensors, 16-bit-significand operands (finer than the TF32 cuDNN defaults to for fp32 convolutions), fp32
+        accumulate, ~half the matrix work; logits ~1e-4 std and losses ~1e-5 from fp32, NOT inside every flat fp32 bar.
+        Not part of the reference's API."""
         self._runtime.set_precision(name)
         return self
 

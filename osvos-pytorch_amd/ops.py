@@ -96,6 +96,12 @@ def conv3x3_bf16io(x, wpk, bias, cout, relu=False, mask=None, y_cs=None, tile=-1
     return y, yb
 
 
+def set_x3_pieces(pieces):
+    """bf16 pieces per operand of the OSVOS_F32_X3 kernels called from this thread through ops.*: 3 (default, six products) or 2 (three products:
+    what precision 'fp32x2' runs).  Callers restore 3 when they are done."""
+    check(lib().osvos_set_x3_pieces(int(pieces)), "set_x3_pieces")
+
+
 def conv3x3_bf16act_fused(x, wpk, bias, cout, relu=False, mask_bits=None, want_bits=False, want_pool=False, tile=-1):
     """The bf16-store trunk convolution with its fused epilogues (osvos_conv3x3_bf16act_fused): x torch.bfloat16 [N,H,W,Cin];
     returns (y bf16, y_bits int32 [N,H,W,cout/32] | None, pooled bf16 | None, pool_code uint8 | None)."""

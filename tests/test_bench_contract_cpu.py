@@ -124,7 +124,10 @@ def test_parity_gate_is_in_the_line(line):
     assert p["within_bars"] is True and p["bars"] == {"max_dlogit_over_std": 1e-3, "loss_rel": 1e-5, "grad_rel_l2": 1e-3, "iou": 1.0 - 1e-3}
     assert p["max_dlogit_over_std"] <= 1e-3 and p["loss_rel"] <= 1e-5 and p["iou"] >= 1 - 1e-3 and p["grad_rel_l2_worst"] <= 1e-3
     extras = {e["config"]: e for e in line["extra_configs"]}
-    assert set(extras) == {"configs[1]/fp32-exact", "configs[1]/window-fused", "configs[2]", "configs[4]", "configs[4]/fp32-exact"}
+    assert set(extras) >= {"configs[1]/fp32-exact", "configs[1]/window-fused", "configs[2]", "configs[4]", "configs[4]/fp32-exact"}      # (+ configs[1]/fp32x2 from round 6 on)
+    if "configs[1]/fp32x2" in extras:      # two bf16 pieces per operand: faster than the headline, flat f32 bars reported honestly, its own bars held
+        x2 = extras["configs[1]/fp32x2"]
+        assert x2["within_x2_bars"] is True and x2["iou"] >= 1 - 1e-3 and x2["max_dlogit_over_std"] <= 1e-3 and x2["value"] > line["value"]
     for e in extras.values():
         assert "error" not in e and e["value"] > 0 and e["ms_per_step"] > 0 and 0.2 < e["frac"] < 1.0
     c2, c4 = extras["configs[2]"], extras["configs[4]"]

@@ -467,6 +467,55 @@ def test_conv3x3_bf16io_bf16_input_and_copy(shape):
         ops.conv3x3_bf16io(xg.bfloat16(), wpk, b.cuda(), cout, tile=12)     # no such tile
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(1, 33, 70, 64, 128), (2, 24, 40, 128, 64), (1, 20, 24, 256, 256), (1, 16, 40, 16, 64)])
+def test_f32x3_kernels_with_two_pieces_per_operand(shape):
+    """Precision 'fp32x2' at op level (round 6): the f32x3 convolution (every production tile, forward + masked data gradient) and the f32x3 weight
+    gradient with TWO bf16 pieces per operand -- three products ah*bh + ah*bm + am*bh.  Against float64 (F.conv2d, vgg_osvos.py:41,142-143 and its
+    autograd): each operand is short of its fp32 value by < 2^-16 relative, so the result is within 2^-15 sum|a||b| of the truth (held at half of
+    that), a rel-L2 of a few 1e-6 -- several times the three-piece kernel's error (the switch really takes the other path) and 1000x below bf16's."""
+    from osvos_pytorch_amd._lib import F32_X3
+    ops = _ops()
+    n, h, w, cin, cout = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)
+    b = torch.randn(cout, generator=g)
+    m = torch.randn(n, cout, h, w, generator=g)
+    ref = F.relu(F.conv2d(x.double(), wt.double(), b.double(), padding=1))
+    mag = F.conv2d(x.abs().double(), wt.abs().double(), b.abs().double(), padding=1)          # sum |a||b| per output
+    dy = torch.randn(n, cout, h, w, generator=g)
+    wref = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), wref, padding=1).backward(dy.double())
+    pk, pk3, dpk3 = ops.pack_fwd(wt.cuda()), ops.pack_x3(wt.cuda()), ops.pack_x3(wt.cuda(), dgrad=True)
+    res = {}
+    try:
+        for pieces in (3, 2):
+            ops.set_x3_pieces(pieces)
+            errs = []
+            for tile in (10, 12, 14, 16, -1):      # pre-split packs (what the network runs) and the fp32 pack split in the kernel: the same bits
+                y3 = ops.conv3x3_x3(nhwc(x), pk3, b.cuda(), cout, relu=True, tile=tile)
+                if tile >= 0:
+                    assert torch.equal(y3, ops.conv3x3(nhwc(x), pk, b.cuda(), cout, relu=True, tile=200 + tile)), (shape, pieces, tile)
+                y = nchw(y3).cpu().double()
+                assert float(((y - ref).abs() / (mag * 2.0 ** -16 + 1e-30)).max()) <= 1.0, (shape, pieces, tile)
+                errs.append(float((y - ref).norm() / ref.norm()))
+            d = nchw(ops.conv3x3_x3(nhwc(dy), dpk3, None, cin, mask=None, tile=-1)).cpu().double() if cout % 16 == 0 else None
+            res[pieces] = (max(errs), ops.conv3x3_wgrad(nhwc(x), nhwc(dy), cin, cout, dtype=F32_X3)[0].cpu().double(), d)
+    finally:
+        ops.set_x3_pieces(3)
+    if res[2][2] is not None:      # data gradient (rotated pack): un-masked here, against conv_transpose2d
+        dfull = F.conv_transpose2d(dy.double(), wt.double(), padding=1)
+        d3, d2 = [float((res[k][2] - dfull).norm() / dfull.norm()) for k in (3, 2)]
+        assert d3 < 2e-6 and d2 < 2e-5, (shape, d3, d2)
+    e3, e2 = res[3][0], res[2][0]
+    w3 = float((res[3][1] - wref.grad).norm() / wref.grad.norm())
+    w2 = float((res[2][1] - wref.grad).norm() / wref.grad.norm())
+    print("f32x3 pieces 3 | 2: conv rel-L2 %.1e | %.1e, wgrad rel-L2 %.1e | %.1e" % (e3, e2, w3, w2))
+    assert e3 < 2e-6 and 4 * e3 < e2 < 2e-5, (shape, e3, e2)          # (measured 3.6e-7 .. 7.2e-7 and 4.4e-6)
+    assert w3 < 5e-6 and w2 < 5e-5 and (w2 > 2 * w3 or cin < 64), (shape, w3, w2)      # (Cin = 16 takes the exact fp32 skinny weight gradient in both modes)
+
+
 def _bits_of(t_nhwc):
     """[N,H,W,C] -> int64 [N,H,W,C/32]: bit b of word g = (t[..., 32 g + b] > 0) (csrc/maskbits.h)"""
     n, h, w, c = t_nhwc.shape

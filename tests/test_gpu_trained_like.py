@@ -92,7 +92,7 @@ def test_fixture_reaches_its_pinned_loss_curve(trained):
     assert g["oracle"]["max_rel_loss_diff"] < 5e-2
 
 
-@pytest.mark.parametrize("precision", ["fp32", "fp32x3"])
+@pytest.mark.parametrize("precision", ["fp32", "fp32x3", "fp32x3b2"])
 def test_fp32_arithmetics_meet_the_flat_survey_bars_on_the_trained_like_net(trained, precision):
     """SURVEY 8(d) bars with NO escape hatch (no check_grad_either, no 'or 2x the reference's own distance') on two training frames, a
     held-out frame and a held-out frame at four times the pixels, against the float64 oracle:
@@ -172,6 +172,30 @@ def test_bf16_on_the_trained_like_net_measured_bars(trained):
         assert max(e_loss) <= 2.5e-2, (name, e_loss)
 
 
+def test_fp32x2_on_the_trained_like_net(trained):
+    """Precision 'fp32x2' (round 6: the f32x3 kernels with TWO bf16 pieces per operand, three MFMA products per fp32 product; OSVOS_FLAG_X3_TWO_PIECES) on
+    the net with real margins, against the float64 oracle (vgg_osvos.py:59-74, osvos_layers.py:19-48 and their autograd): logits <= 1e-3 std -- the
+    flat fp32 bar -- on every head, mask IoU >= 1 - 1e-3, losses <= 1e-4 relative (the flat fp32 bar is 1e-5: NOT promised, the emulation of the mode
+    puts single heads at 1.7e-5), all parameter gradients as one vector <= 5e-3; and the mode really is another arithmetic than 'fp32x3'."""
+    wts, frames, _ = trained
+    rows = []
+    for name, x, m in _cases(frames):
+        t_outs, t_losses, t_grads = _oracle(wts, x, m, name)
+        outs, losses, grads = _gpu(wts, x, m, "fp32x2")
+        o3, _, _ = _gpu(wts, x, m, "fp32x3")
+        e_logit = max(float(np.abs(outs[i] - t_outs[i]).max() / t_outs[i].std()) for i in range(5))
+        e_loss = max(abs(losses[i] - t_losses[i]) / abs(t_losses[i]) for i in range(5))
+        j = _iou(outs[4], t_outs[4])
+        num = sum(float((grads[k] - t).norm() ** 2) for k, t in t_grads.items() if k != "input")
+        den = sum(float(t.norm() ** 2) for k, t in t_grads.items() if k != "input")
+        one_vec = (num / den) ** 0.5
+        rows.append((name, e_logit, e_loss, j, one_vec))
+        assert e_logit <= 1e-3 and j >= 1 - 1e-3 and e_loss <= 1e-4 and one_vec <= 5e-3, rows[-1]
+        assert any(not np.array_equal(outs[i], o3[i]) for i in range(5)), name
+    print("trained-like fp32x2 vs float64 (case, max |dlogit| / std, worst loss rel, fused IoU, gradients as one vector):",
+          [(n, "%.1e" % a, "%.1e" % b, "%.6f" % c, "%.1e" % d) for n, a, b, c, d in rows])
+
+
 @pytest.mark.xfail(strict=False, reason="bf16 on the trained-like fixture sits AT north_star's IoU line (0.99869 .. 0.99981 vs 1 - 1e-3: 7 flipped "
                                         "pixels of 25680 on two cases) and above SURVEY 8(d)'s 2e-3 loss bar (up to 1.3e-2): recorded as a known miss, "
                                         "the measured bars are asserted by the test above.  profiles/r06_bf16_error_budget.txt: no per-stage "
@@ -185,7 +209,7 @@ def test_bf16_on_the_trained_like_net_flat_survey_bars(trained):
         assert max(e_loss) <= 2e-3, (name, e_loss)
 
 
-@pytest.mark.parametrize("precision", ["fp32", "fp32x3"])
+@pytest.mark.parametrize("precision", ["fp32", "fp32x3", "fp32x3b2"])
 def test_window_fused_pass_equals_the_sequential_micro_batches(trained, precision):
     """TrainLoop.window_batch (the nAveGrad micro-batches of an optimizer step as ONE batch with per-image class counts; bench.py
     --window-fused) against the reference's sequential loop (train_online.py:116-149) on the trained-like net: five different frames, online
@@ -227,7 +251,7 @@ def test_window_fused_pass_equals_the_sequential_micro_batches(trained, precisio
     assert (num / den) ** 0.5 <= 5e-4 and worst[0] <= 1e-3, (worst, (num / den) ** 0.5)
 
 
-@pytest.mark.parametrize("precision", ["fp32", "fp32x3"])
+@pytest.mark.parametrize("precision", ["fp32", "fp32x3", "fp32x3b2"])
 def test_twenty_optimizer_steps_track_the_float64_trajectory(trained, precision):
     """The online loop for 20 optimizer steps (nAveGrad 2 = 40 micro-batches over four frames) at 60x107 from the trained-like weights,
     through the product's TrainLoop / FusedSGD, against the same loop on the float64 oracle: drift, momentum and weight re-pack bugs show up
