@@ -920,6 +920,12 @@ def compact_line(full, detail_path=None):
             row["algorithmic_hbm_GBps"] = er["algorithmic_hbm_GBps"]
         ex.append(row)
     line["extra_configs"] = ex or None
+    # the fastest row of this run that holds the FLAT f32 parity bars (the headline's own bars), next to the headline: the default precision stays
+    # the all-three-pieces one; 'fp32x3b2' has the same forward bit for bit and a two-piece backward
+    best = max((r for r in ex if r.get("within_bars") is True and r.get("dtype") == "f32" and (r.get("config") or "").startswith("configs[1]/fp32x")
+                and r.get("value")), key=lambda r: r["value"], default=None)
+    if best is not None:
+        line["fastest_within_flat_f32_bars"] = {"config": best["config"], "value": best["value"], "ms_per_step": best["ms_per_step"]}
     line["running_loss"] = _num(full.get("running_loss"), 7)
     line["detail"] = detail_path
     return line
@@ -1125,6 +1131,9 @@ def main():
         torch.cuda.synchronize()
         for (cid, name, extra_args) in [
                 ("configs[1]/fp32-exact", "configs[1] on the EXACT fp32 MFMA kernels (v_mfma_f32_32x32x2_f32): same loop, precision 'fp32'", ["--precision", "fp32"]),       # (carries its own parity gate too)
+                ("configs[1]/fp32x3b2", "configs[1] with the FORWARD exactly as the headline (fp32x3: logits, loss and masks bit-identical) and TWO bf16 pieces per operand "
+                 "in the backward (3 MFMA products per f32 product in the data and weight gradients): precision 'fp32x3b2', inside every flat f32 parity bar "
+                 "(tests/test_gpu_trained_like.py, test_gpu_net.py, test_gpu_baseline_configs.py run it next to fp32 / fp32x3)", ["--precision", "fp32x3b2"]),
                 ("configs[1]/fp32x2", "configs[1] with TWO bf16 pieces per operand (precision 'fp32x2': 3 MFMA products per f32 product, 16-bit significands -- finer "
                  "than the TF32 cuDNN runs the reference's fp32 convolutions in by default on its own GPUs; NOT f32-grade, see its parity row)", ["--precision", "fp32x2"]),
                 ("configs[1]/window-fused", "configs[1] semantics, window-fused: the 5 micro-batches of an optimizer step (5 different frames) as ONE batch-5 pass with per-image "
@@ -1134,6 +1143,9 @@ def main():
                 ("configs[2]", "configs[2]: 854x480 batch=12 parent training bf16 (MFMA path)", ["--mode", "parent", "--precision", "bf16", "--batch", "12"]),
                 ("configs[4]", "configs[4]: 1920x1080 inference-only forward, batch=4, hipGraph-captured (f32x3)",
                  ["--mode", "infer", "--height", "1080", "--width", "1920", "--batch", "4", "--graph", "1"]),
+                ("configs[4]/fp32x2", "configs[4] with TWO bf16 pieces per operand (precision 'fp32x2': 3 MFMA products per f32 product): the inference bars "
+                 "(logits 1e-3 std, mask IoU 1 - 1e-3) are the flat f32 ones",
+                 ["--mode", "infer", "--height", "1080", "--width", "1920", "--batch", "4", "--graph", "1", "--precision", "fp32x2"]),
                 ("configs[4]/fp32-exact", "configs[4] on the EXACT fp32 MFMA kernels",
                  ["--mode", "infer", "--height", "1080", "--width", "1920", "--batch", "4", "--graph", "1", "--precision", "fp32", "--no-parity"])]:
             cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(max(10, min(args.steps, 30))),

@@ -125,6 +125,9 @@ def test_parity_gate_is_in_the_line(line):
     assert p["max_dlogit_over_std"] <= 1e-3 and p["loss_rel"] <= 1e-5 and p["iou"] >= 1 - 1e-3 and p["grad_rel_l2_worst"] <= 1e-3
     extras = {e["config"]: e for e in line["extra_configs"]}
     assert set(extras) >= {"configs[1]/fp32-exact", "configs[1]/window-fused", "configs[2]", "configs[4]", "configs[4]/fp32-exact"}      # (+ configs[1]/fp32x2 from round 6 on)
+    if "configs[1]/fp32x3b2" in extras:    # forward = the headline's, backward on two pieces: faster AND inside the flat f32 bars
+        b2 = extras["configs[1]/fp32x3b2"]
+        assert b2["within_bars"] is True and b2["value"] > 1.1 * line["value"] and b2["max_dlogit_over_std"] == line["parity"]["max_dlogit_over_std"]
     if "configs[1]/fp32x2" in extras:      # two bf16 pieces per operand: faster than the headline, flat f32 bars reported honestly, its own bars held
         x2 = extras["configs[1]/fp32x2"]
         assert x2["within_x2_bars"] is True and x2["iou"] >= 1 - 1e-3 and x2["max_dlogit_over_std"] <= 1e-3 and x2["value"] > line["value"]
