@@ -208,10 +208,10 @@ WsLayout ws_layout(int N, int H, int W, int dtype) {
 
 // events for the fork/join of the two-stream backward: created once per host thread, reused round-robin
 struct EventPool {
-  hipEvent_t ev[64];
+  hipEvent_t ev[128];      // (round-robin: an event recorded early in a backward and waited for late must not come around in between -- ~45 per call)
   int n = 0, cur = 0;
   hipEvent_t next() {
-    if (n < 64) {
+    if (n < 128) {
       hipEvent_t e;
       if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
         osvos_set_error("net_backward: hipEventCreate failed");
@@ -221,7 +221,7 @@ struct EventPool {
       return e;
     }
     hipEvent_t e = ev[cur];
-    cur = (cur + 1) % 64;
+    cur = (cur + 1) % 128;
     return e;
   }
 };
@@ -744,6 +744,21 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
     }
   }
   if ((rc = ready(1, aux2))) return rc;        // the four side_prep layers (their slab reduces are the last writers, in order, on aux2)
+  // The side branches' data gradients (16 -> C channels: one K chunk, all prologue and epilogue, 13-51 us each at batch 1).  Only stage 4's is needed
+  // at once (it IS the upstream gradient of conv5_3); dside of stages 3, 2, 1 is consumed three, six and nine trunk layers later, by the pooling
+  // backward of the stage boundary.  OSVOS_SIDE_DGRAD_ASIDE=1 runs those three on the reduce stream beside the head of the chain instead of in
+  // front of it.  Measured in round 6 and NOT the default: the backward is bound by the chip's throughput over BOTH chains (the weight-gradient
+  // stream ends within 3 us of the data-gradient chain), not by the chain's length -- 238.2 vs 237.4 frames/s at batch 1 (noise), 1147 vs 1157 on
+  // configs[2] and 300 vs 306 with the two-piece backward (both slightly worse): same-box alternating rounds, tools/ab_env.sh.
+  OSVOS_ENV_INT(side_aside, "OSVOS_SIDE_DGRAD_ASIDE", 0);
+  hipStream_t sds = (two && side_aside) ? aux2 : stream;
+  hipEvent_t side_ev[3] = {nullptr, nullptr, nullptr};
+  if (sds != stream) {
+    hipEvent_t e = evp.next();
+    if (!e) return -1;
+    OSVOS_HIP_CHECK(hipEventRecord(e, stream));      // dprep[0..3] ready
+    OSVOS_HIP_CHECK(hipStreamWaitEvent(sds, e, 0));
+  }
   for (int i = 3; i >= 0; --i) {
     const int si = i + 1, sl = kNumTrunk + i, h = L.hs[si], w = L.ws[si];
     const int lx = last_of_stage(si);
@@ -752,11 +767,17 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
     void* dst = (i == 3) ? f32(L.dy[lx]) : f32(L.dside[i]);
     void* dst_b = (i == 3) ? sh(L.dy_b[lx]) : (store ? at(ws, L.dside_b[i]) : nullptr);
     if (dbg_skip() & 8) continue;
+    hipStream_t st = (i == 3) ? stream : sds;
     rc = conv_main(at(ws, L.dprep[i]), store ? at(ws, L.dprep_b[i]) : nullptr, at(wbuf, P.dgrad[sl]), nullptr, (i == 3) ? mk32(L.act[lx]) : nullptr,
-                   (i == 3) ? mk16(L.act_b[lx]) : nullptr, dst, dst_b, N, h, w, 16, d[sl].cin, d[sl].cin, 0, dtype, nullptr, stream,
+                   (i == 3) ? mk16(L.act_b[lx]) : nullptr, dst, dst_b, N, h, w, 16, d[sl].cin, d[sl].cin, 0, dtype, nullptr, st,
                    P.dgrad3[sl] != (size_t)-1 ? at(wbuf, P.dgrad3[sl]) : nullptr, nullptr,
                    (i == 3 && L.bits[lx] != (size_t)-1) ? at(ws, L.bits[lx]) : nullptr);
     if (rc) return rc;
+    if (st != stream) {
+      side_ev[i] = evp.next();
+      if (!side_ev[i]) return -1;
+      OSVOS_HIP_CHECK(hipEventRecord(side_ev[i], st));
+    }
   }
 
   // trunk, deepest layer first; dy[l] = dLoss/d(conv l output), ReLU mask already applied
@@ -813,6 +834,7 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
       const int ps2 = si - 1;
       const void* dside = ps2 >= 1 ? at(ws, L.dside[ps2 - 1]) : nullptr;
       if (dbg_skip() & 2) continue;
+      if (ps2 >= 1 && side_ev[ps2 - 1] != nullptr) OSVOS_HIP_CHECK(hipStreamWaitEvent(stream, side_ev[ps2 - 1], 0));      // dside written on the reduce stream
       if (store && L.pool_code[si] != (size_t)-1)      // one code byte per pooled element instead of the pool's four inputs
         rc = osvos_maxpool2x2_bwd_bf16_code(at(ws, L.pool_code[si]), at(ws, L.dpool_b[si]), dside, at(ws, L.dy_b[l - 1]), N, L.hs[ps2], L.ws[ps2],
                                             kStageC[ps2], stream);
