@@ -567,7 +567,8 @@ def load_traffic(wl):
         key = "window_fused"
     if key is None:
         return None
-    name = next((n for n in ("r05_pmc_traffic_%s.json" % key, "r04_pmc_traffic_%s.json" % key) if os.path.exists(os.path.join(REPO, "profiles", n))), None)
+    name = next((n for n in ("r06_pmc_traffic_%s.json" % key, "r05_pmc_traffic_%s.json" % key, "r04_pmc_traffic_%s.json" % key)
+                 if os.path.exists(os.path.join(REPO, "profiles", n))), None)
     if name is None:
         return None
     path = os.path.join(REPO, "profiles", name)
