@@ -734,9 +734,9 @@ def measure(wl, steps, warmup, min_seconds, world, ctl, device, use_prof=True, s
     # f32x3: fp32 results from the bf16 matrix pipe -- every algorithmic FLOP is executed as SIX bf16 MFMA FLOPs.  The roofline that
     # bounds those kernels is the bf16 dense peak; `achieved` counts the EXECUTED bf16 FLOPs (6 x algorithmic), the algorithmic rate
     # and its ratio to the fp32-MFMA peak (the roofline of the exact kernels, which this mode is free to exceed) are given next to it.
-    x3 = wl.precision in ("fp32x3", "fp32x2", "fp32x3b2")
-    nprod = 3.0 if wl.precision == "fp32x2" else 6.0      # bf16 MFMA products executed per algorithmic product (forward)
-    nprod_b = 3.0 if wl.precision in ("fp32x2", "fp32x3b2") else 6.0      # ... backward
+    x3 = wl.precision in ("fp32x3", "fp32x2", "fp32x3b2", "fp32h2", "fp32x3h2")
+    nprod = 3.0 if wl.precision in ("fp32x2", "fp32h2") else 6.0      # 16-bit MFMA products executed per algorithmic product (forward)
+    nprod_b = 3.0 if wl.precision in ("fp32x2", "fp32x3b2", "fp32h2", "fp32x3h2") else 6.0      # ... backward
     # executed / algorithmic FLOPs: 6 where a pass runs as f32x3, 1 where it stays on the exact fp32 kernel (conv1_1 forward, weight
     # gradient and input gradient) -- per family, from the layers' own FLOP shares
     mult_f = mult_b = mult_s = 1.0
@@ -750,6 +750,8 @@ def measure(wl, steps, warmup, min_seconds, world, ctl, device, use_prof=True, s
     kname = {"fp32": ("conv3x3_f32_kernel", "wgrad_f32_kernel"), "fp32x3": ("conv3x3 f32x3 kernels", "wgrad f32x3 kernels"),
              "fp32x2": ("conv3x3 f32x3 kernels (2 pieces)", "wgrad f32x3 kernels (2 pieces)"),
              "fp32x3b2": ("conv3x3 f32x3 kernels (fwd 3 pieces, dgrad 2)", "wgrad f32x3 kernels (2 pieces)"),
+             "fp32h2": ("conv3x3 f32x3 kernels (FP16 pairs)", "wgrad f32x3 kernels (FP16 pairs)"),
+             "fp32x3h2": ("conv3x3 f32x3 kernels (fwd 3 bf16 pieces, dgrad FP16 pairs)", "wgrad f32x3 kernels (FP16 pairs)"),
              "bf16": ("conv3x3_bf16_kernel", "wgrad_bf16_kernel")}[wl.precision]
     roof = None
     step_alg = passes * gf_fwd / 1e3 / (elapsed / steps)
@@ -913,6 +915,7 @@ def compact_line(full, detail_path=None):
                 row["within_autocast_bars"] = ep["within_autocast_bars"]
             if "within_x2_bars" in ep:            # fp32x2: flat f32 bars AND the mode's own
                 row["within_x2_bars"] = ep["within_x2_bars"]
+            if ep.get("within_bars") is False and ep.get("grad_rel_l2_worst"):      # outside the flat bars: say by how much on the gradients
                 row["grad_rel_l2_worst"] = (ep.get("grad_rel_l2_worst") or {}).get("value")
         tr = (er.get("traffic") or {}).get("conv_family") or {}
         if tr:
@@ -923,10 +926,14 @@ def compact_line(full, detail_path=None):
     line["extra_configs"] = ex or None
     # the fastest row of this run that holds the FLAT f32 parity bars (the headline's own bars), next to the headline: the default precision stays
     # the all-three-pieces one; 'fp32x3b2' has the same forward bit for bit and a two-piece backward
-    best = max((r for r in ex if r.get("within_bars") is True and r.get("dtype") == "f32" and (r.get("config") or "").startswith("configs[1]/fp32x")
+    best = max((r for r in ex if r.get("within_bars") is True and r.get("dtype") == "f32" and (r.get("config") or "").startswith(("configs[1]/fp32x", "configs[1]/fp32h"))
                 and r.get("value")), key=lambda r: r["value"], default=None)
     if best is not None:
         line["fastest_within_flat_f32_bars"] = {"config": best["config"], "value": best["value"], "ms_per_step": best["ms_per_step"]}
+    best4 = max((r for r in ex if r.get("within_bars") is True and r.get("dtype") == "f32" and (r.get("config") or "").startswith("configs[4]") and r.get("value")),
+                key=lambda r: r["value"], default=None)
+    if best4 is not None:
+        line["fastest_within_flat_f32_bars_configs4"] = {"config": best4["config"], "value": best4["value"], "ms_per_step": best4["ms_per_step"]}
     line["running_loss"] = _num(full.get("running_loss"), 7)
     line["detail"] = detail_path
     return line
@@ -1019,10 +1026,14 @@ def launch_ranks(n):
 
 DTYPE_SHORT = {"fp32": "f32", "fp32x3": "f32 (3x bf16-split operands on MFMA, f32 accumulate)", "bf16": "bf16 (f32 accumulate)",
                "fp32x2": "f32 tensors, 2x bf16-split operands (16-bit significands), f32 accumulate",
-               "fp32x3b2": "f32 (fwd: 3x bf16-split operands, bwd: 2x; f32 accumulate)"}
+               "fp32x3b2": "f32 (fwd: 3x bf16-split operands, bwd: 2x; f32 accumulate)",
+               "fp32h2": "f32 (2x FP16-split operands under block exponents on MFMA, f32 accumulate)",
+               "fp32x3h2": "f32 (fwd: 3x bf16-split operands, bwd: 2x FP16-split; f32 accumulate)"}
 DTYPE_NAME = {"fp32": "f32",
               "fp32x3": "f32 tensors and parameters; wide 3x3 convolutions (fwd, dgrad) as three-way bf16 split on the bf16 MFMA pipe (6 bf16 products per f32 product, f32 accumulate: f32-grade results); everything else f32", "bf16": "bf16 MFMA operands and bf16 trunk tensors (fwd+dgrad+wgrad), f32 accumulate; head/loss/skinny wgrads/parameters f32",
               "fp32x3b2": "f32 tensors and parameters; FORWARD exactly as fp32x3 (three-way bf16 split, 6 products: f32-grade logits / loss / masks); data and weight gradients with TWO-way split operands (3 products, 16 significand bits), f32 accumulate; everything else f32",
+              "fp32h2": "f32 tensors and parameters; wide 3x3 convolutions (fwd, dgrad, wgrad) as TWO-way FP16 split under block exponents on the f16 MFMA pipe (3 f16 products per f32 product; operands carry 22-23 significand bits, f32 accumulate: error against float64 = the exact f32 kernels'); everything else f32",
+              "fp32x3h2": "f32 tensors and parameters; FORWARD exactly as fp32x3 (bit-identical logits / loss / masks); data and weight gradients as TWO-way FP16 split under block exponents (3 products, 22-23 significand bits), f32 accumulate; everything else f32",
               "fp32x2": "f32 tensors and parameters; wide 3x3 convolutions as TWO-way bf16 split on the bf16 MFMA pipe (3 bf16 products per f32 product: operands carry 16 significand bits, f32 accumulate; finer than TF32, NOT f32-grade); everything else f32"}
 
 
@@ -1034,7 +1045,7 @@ def main():
     ap.add_argument("--mode", default="online", choices=["online", "parent", "infer"],
                     help="online/parent: restated training loops (fwd+loss+bwd+SGD); infer: forward only under no_grad "
                          "(BASELINE.json configs[4]: use --height 1080 --width 1920 --batch 4 --graph 1)")
-    ap.add_argument("--precision", default=os.environ.get("OSVOS_PRECISION", "fp32x3"), choices=["fp32", "fp32x3", "fp32x2", "fp32x3b2", "bf16"],
+    ap.add_argument("--precision", default=os.environ.get("OSVOS_PRECISION", "fp32x3"), choices=["fp32", "fp32x3", "fp32x2", "fp32x3b2", "fp32h2", "fp32x3h2", "bf16"],
                     help="fp32x3 (default, the module's default): fp32 tensors, fp32-grade results, the wide 3x3 convolutions (fwd, dgrad, wgrad) on the "
                          "bf16 matrix pipe with three-way split operands; fp32: the same on the exact fp32 MFMA kernels; bf16: bf16 MFMA operands "
                          "and bf16 trunk tensors (configs[2])")
@@ -1135,8 +1146,12 @@ def main():
                 ("configs[1]/fp32x3b2", "configs[1] with the FORWARD exactly as the headline (fp32x3: logits, loss and masks bit-identical) and TWO bf16 pieces per operand "
                  "in the backward (3 MFMA products per f32 product in the data and weight gradients): precision 'fp32x3b2', inside every flat f32 parity bar "
                  "(tests/test_gpu_trained_like.py, test_gpu_net.py, test_gpu_baseline_configs.py run it next to fp32 / fp32x3)", ["--precision", "fp32x3b2"]),
-                ("configs[1]/fp32x2", "configs[1] with TWO bf16 pieces per operand (precision 'fp32x2': 3 MFMA products per f32 product, 16-bit significands -- finer "
-                 "than the TF32 cuDNN runs the reference's fp32 convolutions in by default on its own GPUs; NOT f32-grade, see its parity row)", ["--precision", "fp32x2"]),
+                ("configs[1]/fp32x3h2", "configs[1] with the FORWARD exactly as the headline and the backward on TWO FP16 pieces per operand under block exponents "
+                 "(csrc/h2split.h: 22-23 significand bits, 3 MFMA products; op-level error against float64 at or below the exact fp32 kernels', every per-tensor "
+                 "gradient error equal to fp32x3's: profiles/r06_fp32h2.txt): precision 'fp32x3h2'", ["--precision", "fp32x3h2"]),
+                ("configs[1]/fp32h2", "configs[1] with FP16 pairs in BOTH passes (precision 'fp32h2'): activations closer to float64 than fp32x3's and no more ReLU flips, "
+                 "logits / loss / IoU inside the flat bars; the one-vector gradient bar against the fp32 CPU reference is a lottery of single ReLU flips in the "
+                 "30x54-pixel layers (1e-3 each) that this forward loses on this problem (profiles/r06_fp32h2.txt)", ["--precision", "fp32h2"]),
                 ("configs[1]/window-fused", "configs[1] semantics, window-fused: the 5 micro-batches of an optimizer step (5 different frames) as ONE batch-5 pass with per-image "
                  "class counts -- the reference gradient up to summation order (tests/test_gpu_baseline_configs.py::test_window_batch_equals_the_sequential_micro_batches_at_120x214, "
                  "tests/test_gpu_trained_like.py::test_window_fused_pass_equals_the_sequential_micro_batches); what TrainLoop.window_batch / "
@@ -1144,9 +1159,9 @@ def main():
                 ("configs[2]", "configs[2]: 854x480 batch=12 parent training bf16 (MFMA path)", ["--mode", "parent", "--precision", "bf16", "--batch", "12"]),
                 ("configs[4]", "configs[4]: 1920x1080 inference-only forward, batch=4, hipGraph-captured (f32x3)",
                  ["--mode", "infer", "--height", "1080", "--width", "1920", "--batch", "4", "--graph", "1"]),
-                ("configs[4]/fp32x2", "configs[4] with TWO bf16 pieces per operand (precision 'fp32x2': 3 MFMA products per f32 product): the inference bars "
-                 "(logits 1e-3 std, mask IoU 1 - 1e-3) are the flat f32 ones",
-                 ["--mode", "infer", "--height", "1080", "--width", "1920", "--batch", "4", "--graph", "1", "--precision", "fp32x2"]),
+                ("configs[4]/fp32h2", "configs[4] with TWO FP16 pieces per operand under block exponents (precision 'fp32h2': 3 MFMA products per f32 product, "
+                 "logits closer to the oracle than fp32x3's): the inference bars (logits 1e-3 std, mask IoU 1 - 1e-3) are the flat f32 ones",
+                 ["--mode", "infer", "--height", "1080", "--width", "1920", "--batch", "4", "--graph", "1", "--precision", "fp32h2"]),
                 ("configs[4]/fp32-exact", "configs[4] on the EXACT fp32 MFMA kernels",
                  ["--mode", "infer", "--height", "1080", "--width", "1920", "--batch", "4", "--graph", "1", "--precision", "fp32", "--no-parity"])]:
             cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(max(10, min(args.steps, 30))),

@@ -46,6 +46,15 @@ extern "C" {
                                             pieces / six products: operands carry 16 significand bits (TF32, cuDNN's default for fp32 convolutions on
                                             the reference's GPUs, carries 11), accumulation is fp32, half the matrix work.  Tensors, packs and workspaces
                                             are those of OSVOS_F32_X3.  NOT fp32-grade: see profiles/r06_fp32x2.txt for where it lands. */
+#define OSVOS_FLAG_X3_HALF_PIECES 0x1000 /* OR-ed into the dtype OSVOS_F32_X3: precision 'fp32h2' -- the f32x3 kernels take TWO FP16 pieces per operand under
+                                            block exponents (csrc/h2split.h): 22-23 significand bits per operand, three products on
+                                            v_mfma_f32_32x32x16_f16, fp32 accumulation; measured against float64 the error is the exact fp32 kernels'
+                                            (tests/test_gpu_ops.py::test_f32x3_kernels_with_fp16_pairs).  osvos_net_forward / osvos_net_backward: the
+                                            call's kernels run in that form.  osvos_net_pack: the FORWARD packs are written in the FP16-pair format
+                                            (same buffers; a pack and the calls that read it must agree -- a forward with the flag needs forward packs
+                                            with it, a backward with the flag needs data-gradient packs with OSVOS_FLAG_X3_HALF_PIECES_BWD). */
+#define OSVOS_FLAG_X3_HALF_PIECES_BWD 0x2000 /* osvos_net_pack only: the DATA-GRADIENT packs are written in the FP16-pair format (for backward calls that
+                                            carry OSVOS_FLAG_X3_HALF_PIECES) */
 #define OSVOS_F32_X3 3        /* fp32 tensors, fp32 parameters and fp32 weight packs exactly as OSVOS_F32; the wide 3x3 convolutions
                                  (forward, data gradient) run on the bf16 matrix pipe with three-way split operands (six bf16
                                  products per fp32 product, fp32 accumulate): fp32-grade results, see osvos_conv3x3 below */
@@ -160,9 +169,11 @@ int osvos_maxpool2x2_bwd_bf16act_code(const void* code, const void* dy_bf16, con
 int osvos_conv3x3_bf16act_fused(const void* x_bf16, const void* wpk, const float* bias, const void* mask_bits, void* y_bf16, void* y_bits,
                                 void* pooled_bf16, void* pool_code, int N, int H, int W, int Cin, int Cout, int relu, int tile, void* stream);
 int osvos_conv3x3_bf16io_tiles(int* tiles, int max);
-/* bf16 pieces per operand of the OSVOS_F32_X3 kernels called from THIS host thread through the op-level entry points (osvos_conv3x3,
- * osvos_conv3x3_x3*, osvos_conv3x3_wgrad with that dtype): 3 (default: six products, fp32-grade) or 2 (three products; what
- * OSVOS_FLAG_X3_TWO_PIECES selects for the osvos_net_* calls, which set and restore it themselves). */
+/* pieces per operand of the OSVOS_F32_X3 kernels called from THIS host thread through the op-level entry points (osvos_conv3x3,
+ * osvos_conv3x3_x3*, osvos_conv3x3_wgrad, osvos_pack_conv3x3_x3 with that dtype): 3 (default: three bf16 pieces, six products, fp32-grade),
+ * 2 (two bf16 pieces, three products; what OSVOS_FLAG_X3_TWO_PIECES selects for the osvos_net_* calls, which set and restore it themselves)
+ * or 22 (two FP16 pieces under block exponents, three products; OSVOS_FLAG_X3_HALF_PIECES -- a pack made under 22 is in the FP16-pair
+ * format and must be read under 22). */
 int osvos_set_x3_pieces(int pieces);
 int osvos_nchw_to_nhwc_bf16copy(const float* src, void* dst, void* dst_bf16, int N, int C, int H, int W, int cpad, void* stream);
 int osvos_maxpool2x2_bf16copy(const float* x, float* y, void* y_bf16, int N, int H, int W, int C, void* stream);

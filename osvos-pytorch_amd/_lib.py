@@ -20,6 +20,8 @@ _lib = None
 F32, BF16, F32_BF16MFMA, F32_X3 = 0, 1, 2, 3
 DEFER_JOIN = 0x200         # OSVOS_FLAG_DEFER_JOIN: osvos_net_backward leaves the side streams un-joined (autograd.NetRuntime.join_backward)
 X3_TWO_PIECES = 0x800       # OSVOS_FLAG_X3_TWO_PIECES: precision 'fp32x2' (two bf16 pieces per operand, three products)
+X3_HALF_PIECES = 0x1000     # OSVOS_FLAG_X3_HALF_PIECES: precision 'fp32h2' (two FP16 pieces under block exponents, three products); on net_pack: forward packs
+X3_HALF_PIECES_BWD = 0x2000 # OSVOS_FLAG_X3_HALF_PIECES_BWD: net_pack only -- data-gradient packs in the FP16-pair format
 INFERENCE = 0x400           # OSVOS_FLAG_INFERENCE: osvos_net_forward writes nothing only a backward would read (sign bits, pool codes)
 GENERIC_DECONV = 0x100      # OSVOS_FLAG_GENERIC_DECONV: OR-ed into the dtype of the osvos_net_* calls
 NPARAMS = 52

@@ -8,14 +8,16 @@ import os
 
 import torch
 
-from ._lib import DEFER_JOIN, F32, F32_BF16MFMA, F32_X3, GENERIC_DECONV, INFERENCE, NPARAMS, X3_TWO_PIECES, check, lib, ptr_array
+from ._lib import DEFER_JOIN, F32, F32_BF16MFMA, F32_X3, GENERIC_DECONV, INFERENCE, NPARAMS, X3_HALF_PIECES, X3_HALF_PIECES_BWD, X3_TWO_PIECES, check, lib, ptr_array
 
 # indices (state_dict order) of the frozen transposed-conv weights: lr 0 in both reference
 # scripts (train_online.py:84-85, train_parent.py:99-100); their gradients are never formed
 _FROZEN = set(range(8))
-# precision name -> (library dtype, two bf16 pieces per operand in the forward, ... in the backward); see OSVOS.set_precision
-PRECISIONS = {"fp32": (F32, False, False), "bf16": (F32_BF16MFMA, False, False), "fp32x3": (F32_X3, False, False), "fp32x2": (F32_X3, True, True),
-              "fp32x3b2": (F32_X3, False, True)}
+# precision name -> (library dtype, pieces per operand of the f32x3 kernels in the forward, ... in the backward); see OSVOS.set_precision.
+# Pieces: 3 = three bf16 (six products, the default), 2 = two bf16 (three products), 22 = two FP16 under block exponents (three products; csrc/h2split.h)
+PRECISIONS = {"fp32": (F32, 3, 3), "bf16": (F32_BF16MFMA, 3, 3), "fp32x3": (F32_X3, 3, 3), "fp32x2": (F32_X3, 2, 2), "fp32x3b2": (F32_X3, 3, 2),
+              "fp32h2": (F32_X3, 22, 22), "fp32x3h2": (F32_X3, 3, 22)}
+_PIECE_FLAG = {3: 0, 2: X3_TWO_PIECES, 22: X3_HALF_PIECES}
 
 
 def _stream():
@@ -33,7 +35,7 @@ class NetRuntime:
         # 'fp32x3' (default: fp32 tensors and fp32-grade results, the wide 3x3 convolutions on the bf16 matrix pipe with three-way
         # split operands), 'fp32' (the same on the exact fp32 MFMA kernels) or 'bf16' (bf16 MFMA operands and bf16 trunk tensors,
         # fp32 accumulate; head and loss stay fp32).  OSVOS_PRECISION sets the initial value.
-        self.dtype, self.two_fwd, self.two_bwd = F32_X3, False, False
+        self.dtype, self.pieces_fwd, self.pieces_bwd = F32_X3, 3, 3
         self.set_precision(os.environ.get("OSVOS_PRECISION", "fp32x3").lower() if os.environ.get("OSVOS_PRECISION", "fp32x3").lower() in PRECISIONS else "fp32x3")
         self.aux_stream = None        # second HIP stream: wgrad kernels overlap the dgrad kernels
         self.aux2_stream = None       # third: the slab reduces of the weight gradients
@@ -101,7 +103,12 @@ class NetRuntime:
     def set_precision(self, name):
         # round 6: the f32x3 kernels can take TWO bf16 pieces per operand (three products instead of six) -- same dtype, packs and workspaces, one flag
         # on the network calls: 'fp32x2' in both passes, 'fp32x3b2' in the BACKWARD only (forward = 'fp32x3' bit for bit)
-        dt, self.two_fwd, self.two_bwd = PRECISIONS[name]
+        # 'fp32h2': TWO FP16 pieces under block exponents in both passes (fp32-grade at three products: the packs change format, hence the re-pack);
+        # 'fp32x3h2': the forward of 'fp32x3' bit for bit, the backward on FP16 pairs
+        dt, pf, pb = PRECISIONS[name]
+        if (pf == 22) != (self.pieces_fwd == 22) or (pb == 22) != (self.pieces_bwd == 22):
+            self.key = None
+        self.pieces_fwd, self.pieces_bwd = pf, pb
         if dt != self.dtype:
             self.dtype, self.wbuf, self.key = dt, None, None
 
@@ -121,7 +128,8 @@ class NetRuntime:
             self.generic_head = not self._deconv_is_diagonal(params[:4])
             self.deconv_key = dkey
         check(l.osvos_net_pack(ptr_array([p.data_ptr() for p in params]), C.c_void_p(self.wbuf.data_ptr()),
-                               self.cdtype(), 1, _stream()), "net_pack")
+                               self.cdtype() | (X3_HALF_PIECES if self.pieces_fwd == 22 else 0) | (X3_HALF_PIECES_BWD if self.pieces_bwd == 22 else 0),
+                               1, _stream()), "net_pack")
         self.key = key
 
     def cdtype(self):
@@ -129,10 +137,10 @@ class NetRuntime:
         return self.dtype | (GENERIC_DECONV if self.generic_head else 0)
 
     def cdtype_fwd(self):
-        return self.cdtype() | (X3_TWO_PIECES if self.two_fwd else 0)
+        return self.cdtype() | _PIECE_FLAG[self.pieces_fwd]
 
     def cdtype_bwd(self):
-        return self.cdtype() | (X3_TWO_PIECES if self.two_bwd else 0)
+        return self.cdtype() | _PIECE_FLAG[self.pieces_bwd]
 
     @staticmethod
     def _deconv_is_diagonal(ups):

@@ -39,6 +39,7 @@
 #include "kernels.h"
 #include "epi.h"
 #include "maskbits.h"
+#include "h2split.h"
 
 namespace {
 
@@ -91,6 +92,9 @@ struct CfgX {
   static constexpr int MB = TBX * TBY;
   static constexpr int WM = MB / WGM, WN = NB / WGN;
   static constexpr size_t LDS_BYTES = (size_t)(BUF_U4 + 2) * 16;      // (+ one slot of slack, + the stream-K ticket word)
+  // two pieces per operand (NP = 2): two thirds of the planes (+ four slots for the h2 exchange words) -- the 64-cout tiles then fit a CU TWICE
+  static constexpr int A_U4_2 = 4 * PLANE, B_U4_2 = 2 * B_ITEMS;
+  static constexpr size_t LDS_BYTES_2 = (size_t)(A_U4_2 + B_U4_2 + 2 + 4) * 16;
   static constexpr int SK_SLOT_F4 = NT * WM * WN * 4;       // float4 per stream-K partial slot
   static_assert(WGM * WGN == 4 || WGM * WGN == 8, "4 or 8 waves per workgroup");
   static_assert(MB % WGM == 0 && NB % WGN == 0, "wave grid must divide the tile");
@@ -141,12 +145,19 @@ __device__ inline void split8_hm(const u32x4& lo, const u32x4& hi, uint4& p0, ui
 // default on the reference's own GPUs, carries 11), accumulation stays fp32: half the matrix work, a relative error of ~2^-17 per product instead
 // of 2^-24.  Same LDS layout and the same pre-split packs (the low planes are simply not read).  Precision 'fp32x2' of the network; NOT the
 // default: it does not hold the flat fp32 parity bars on every head (profiles/r06_fp32x2.txt).
-template <class C, int PS, int SK, int NP = 3>
+// HP = 1 ("h2", precision 'fp32h2'; h2split.h): the two pieces are FP16 with a block exponent -- 22-23 significand bits per operand instead of 16,
+// the same three products on v_mfma_f32_32x32x16_f16.  The weights arrive pre-split AND pre-scaled by the pack (their exponent rides in the
+// pack's unused third plane); the activations' exponent is the workgroup's own: before a chunk is split, the waves exchange the largest
+// magnitude of the chunk's raw values through LDS (no extra barrier: written before the barrier that opens the staging phase, read after it);
+// the running exponent only ever decreases, and when it does the accumulators are multiplied by the (exact) power of two that separates the
+// old scale from the new one.  The epilogue un-scales once.
+template <class C, int PS, int SK, int NP = 3, int HP = 0>
 __global__ __launch_bounds__(C::NT, C::OCC) void conv3x3_f32x3_kernel(ConvArgsX a) {
   static_assert(NP == 2 || NP == 3, "two or three bf16 pieces per operand");
+  static_assert(HP == 0 || (NP == 2 && PS == 1 && SK == 0), "h2: two pieces, pre-split pack, plain grid");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint4* As = reinterpret_cast<uint4*>(smem);
-  uint4* Bs = As + C::A_U4;
+  uint4* Bs = As + (NP == 3 ? C::A_U4 : C::A_U4_2);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int wm = wave / C::WGN, wn = wave % C::WGN;
@@ -255,11 +266,16 @@ __global__ __launch_bounds__(C::NT, C::OCC) void conv3x3_f32x3_kernel(ConvArgsX 
     for (int it = 0; it < C::NA + NBI; ++it) load_item(it, kc);
   };
   static_assert(!C::ILV || C::NA + NBI <= 9 * C::WM, "interleaved staging: one item per step must cover the chunk");
+  int h2_ea = kH2NoScale;                 // h2: the tile's running block exponent ...
+  float h2_sc = 1.f;                      // ... and 2^h2_ea
+  unsigned* const h2_mx = reinterpret_cast<unsigned*>(As + C::A_U4_2 + C::B_U4_2 + 2);      // [parity 2][wave 8] words behind the two-piece tiles
+  static_assert(HP == 0 || C::NT <= 512, "h2: exchange slots");
   auto store_chunk = [&]() {
 #pragma unroll
     for (int i = 0; i < C::NA; ++i) {
       uint4 p0, p1, p2;
-      if constexpr (NP == 3) split8(ra[i][0], ra[i][1], p0, p1, p2);
+      if constexpr (HP != 0) h2_split8(ra[i][0], ra[i][1], h2_sc, p0, p1);
+      else if constexpr (NP == 3) split8(ra[i][0], ra[i][1], p0, p1, p2);
       else split8_hm(ra[i][0], ra[i][1], p0, p1);
       if (C::A_ITEMS % C::NT == 0 || a_dst[i] >= 0) {
         As[a_dst[i]] = p0;
@@ -313,9 +329,35 @@ __global__ __launch_bounds__(C::NT, C::OCC) void conv3x3_f32x3_kernel(ConvArgsX 
   // (s_setprio was measured in round 5 -- static priority 1 for the second wave of every SIMD, and priority 1 during a chunk's MFMAs / 0 during
   //  its split + store phase: both within +-0.3 % of no priority at step level, profiles/r05_ab_setprio.txt -- and is not in the kernel)
   for (int kc = kc_begin; kc < kc_end; ++kc) {
+    if constexpr (HP != 0) {             // this wave's largest |raw value| of the chunk about to be staged
+      unsigned m = 0;
+#pragma unroll
+      for (int i = 0; i < C::NA; ++i) m = h2_amax8(ra[i][0], ra[i][1], m);
+      m = h2_wave_max(m);
+      if (lane == 0) h2_mx[(kc & 1) * 8 + wave] = m;
+    }
 #if !(defined(OSVOS_X3_ABL) && OSVOS_X3_ABL == 5)
     __syncthreads();                     // every wave is done with the previous chunk's tiles
 #endif
+    if constexpr (HP != 0) {
+      const uint4 m0 = reinterpret_cast<const uint4*>(h2_mx)[(kc & 1) * 2], m1 = reinterpret_cast<const uint4*>(h2_mx)[(kc & 1) * 2 + 1];
+      unsigned m = max(max(max(m0.x, m0.y), max(m0.z, m0.w)), max(max(m1.x, m1.y), max(m1.z, m1.w)));
+      if (C::NT < 512) m = max(max(m0.x, m0.y), max(m0.z, m0.w));
+      const int e_new = h2_exp(__builtin_amdgcn_readfirstlane(m));
+      if (e_new < h2_ea) {               // (uniform) a larger value than any so far: re-express the accumulators at the new scale
+        if (h2_ea != kH2NoScale) {
+          const int dl = e_new - h2_ea;
+#pragma unroll
+          for (int mi = 0; mi < C::WM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < C::WN; ++ni)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) acc[mi][ni][r] = __builtin_ldexpf(acc[mi][ni][r], dl);
+        }
+        h2_ea = e_new;
+        h2_sc = h2_pow2(e_new);
+      }
+    }
 #if defined(OSVOS_X3_ABL) && OSVOS_X3_ABL == 4
     if (kc == kc_begin)
 #endif
@@ -371,14 +413,28 @@ __global__ __launch_bounds__(C::NT, C::OCC) void conv3x3_f32x3_kernel(ConvArgsX 
 #if defined(OSVOS_X3_ABL) && OSVOS_X3_ABL == 1
             acc[mi][ni][t] += __uint_as_float(fb[sb][PB[t]][ni].x ^ fb[sb][PB[t]][ni].w ^ fa[sa][PA[t]].x ^ fa[sa][PA[t]].w);
 #else
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fb[sb][PB[t]][ni]),
-                                                                  __builtin_bit_cast(bf16x8_t, fa[sa][PA[t]]), acc[mi][ni], 0, 0, 0);
+            if constexpr (HP != 0)
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, fb[sb][PB[t]][ni]),
+                                                                   __builtin_bit_cast(f16x8_t, fa[sa][PA[t]]), acc[mi][ni], 0, 0, 0);
+            else
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fb[sb][PB[t]][ni]),
+                                                                    __builtin_bit_cast(bf16x8_t, fa[sa][PA[t]]), acc[mi][ni], 0, 0, 0);
 #endif
         __builtin_amdgcn_sched_barrier(0);
       }
     }
   }
 
+  if constexpr (HP != 0) {      // un-scale: the pack's exponent (word 0 of its third plane) + the tile's
+    const unsigned wbits = reinterpret_cast<const unsigned*>(a.wpk3 + (size_t)2 * 9 * (a.Cin >> 3) * a.CoutP)[0];
+    const int dl = -(h2_ea + h2_exp(wbits));
+#pragma unroll
+    for (int mi = 0; mi < C::WM; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < C::WN; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mi][ni][r] = __builtin_ldexpf(acc[mi][ni][r], dl);
+  }
   if constexpr (SK != 0) {
     u += (unsigned)(kc_end - kc_begin);
     if (!(kc_begin == 0 && kc_end == nch_all)) {      // this tile's K range is shared with other workgroups
@@ -559,13 +615,14 @@ constexpr size_t kSkSlotBytes = 128 * 1024;               // the largest tile's 
 constexpr size_t kSkTicketBytes = (size_t)kSkMaxTiles * 4;
 
 // sk_grid > 0: the stream-K kernel with that many persistent workgroups (the caller has checked that the tile order has >= sk_grid units)
-template <class C, int PS, int SK, int NP = 3>
+template <class C, int PS, int SK, int NP = 3, int HP = 0>
 int launch_x2(const ConvArgsX& a0, int sk_grid, hipStream_t stream) {
   static bool attr_set_dev[OSVOS_MAX_DEVICES] = {};      // hipFuncSetAttribute is per device
   bool& attr_set = attr_set_dev[osvos_current_device()];
+  constexpr size_t lds_bytes = NP == 3 ? C::LDS_BYTES : C::LDS_BYTES_2;
   if (!attr_set) {
-    OSVOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f32x3_kernel<C, PS, SK, NP>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
+    OSVOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f32x3_kernel<C, PS, SK, NP, HP>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     attr_set = true;
   }
   ConvArgsX a = a0;
@@ -578,11 +635,11 @@ int launch_x2(const ConvArgsX& a0, int sk_grid, hipStream_t stream) {
     const long ntiles = (long)a.nct * a.nsp, units = ntiles * (a.Cin >> 4);
     OSVOS_ARG_CHECK(sk_grid > 0 && sk_grid <= kSkMaxGrid && ntiles <= kSkMaxTiles && units >= sk_grid && a.sk_tickets && a.sk_part && a.ksplit == 1,
                     "conv3x3 f32x3 stream-K: %ld tiles, %ld units on %d workgroups", ntiles, units, sk_grid);
-    hipLaunchKernelGGL((conv3x3_f32x3_kernel<C, PS, SK, NP>), dim3((unsigned)sk_grid), dim3(C::NT), C::LDS_BYTES, stream, a);
+    hipLaunchKernelGGL((conv3x3_f32x3_kernel<C, PS, SK, NP, HP>), dim3((unsigned)sk_grid), dim3(C::NT), lds_bytes, stream, a);
   } else {
     const long blocks = a.map == 0 ? (long)a.nct * a.nsp : (long)a.nct * ((a.nsp + 7) / 8) * 8;
     OSVOS_ARG_CHECK(blocks > 0 && blocks < (1L << 31), "conv3x3 f32x3: grid of %ld blocks", blocks);
-    hipLaunchKernelGGL((conv3x3_f32x3_kernel<C, PS, SK, NP>), dim3((unsigned)blocks, (unsigned)a.ksplit), dim3(C::NT), C::LDS_BYTES, stream, a);
+    hipLaunchKernelGGL((conv3x3_f32x3_kernel<C, PS, SK, NP, HP>), dim3((unsigned)blocks, (unsigned)a.ksplit), dim3(C::NT), lds_bytes, stream, a);
   }
   OSVOS_LAUNCH_CHECK();
   return 0;
@@ -591,6 +648,13 @@ int launch_x2(const ConvArgsX& a0, int sk_grid, hipStream_t stream) {
 // pre-split production tiles of the wide layers (SKT)
 template <class C, bool SKT = false>
 int launch_x(const ConvArgsX& a, int sk_grid, hipStream_t stream) {
+  if (osvos_x3_pieces() == 22) {     // two fp16 pieces with block exponents (precision 'fp32h2'): the pre-split production tiles only
+    if constexpr (C::ILV != 0 && C::NT == 512) {
+      if (a.wpk3 != nullptr) return launch_x2<C, 1, 0, 2, 1>(a, 0, stream);
+    }
+    osvos_set_error("conv3x3 f32x3: the fp16-pair form is built for the pre-split eight-wave tiles (10, 12, 14, 15, 16, 17) with a pre-split pack");
+    return -1;
+  }
   if (osvos_x3_pieces() == 2) {      // two-piece mode (precision 'fp32x2'): the plain grid only, no stream-K form
     if constexpr (C::ILV != 0 && C::NT == 512) {
       if (a.wpk3 != nullptr) return launch_x2<C, 1, 0, 2>(a, 0, stream);
@@ -671,9 +735,33 @@ struct PackX3Table {
   const float* w[OSVOS_PACK_MAX];
   unsigned short* dst[OSVOS_PACK_MAX];
   int Cout[OSVOS_PACK_MAX], Cin[OSVOS_PACK_MAX], dgrad[OSVOS_PACK_MAX];
+  unsigned char half[OSVOS_PACK_MAX];  // 1: two FP16 pieces scaled by the filter's block exponent (h2split.h); the filter's largest magnitude sits in word 0 of plane 2
   long start[OSVOS_PACK_MAX + 1];      // in (cg, 32-channel) units
   int n;
 };
+
+__device__ inline long pack_plane_elems(const PackX3Table& t, int k) {
+  const int K = t.dgrad[k] ? t.Cout[k] : t.Cin[k], M = t.dgrad[k] ? t.Cin[k] : t.Cout[k];
+  return 9L * (K / 8) * ((M + 31) / 32 * 32) * 8;
+}
+// h2 packs, pass 1 and 2: the largest |w| of every filter (bits of a non-negative float: unsigned order = float order)
+__global__ void wamax_zero_kernel(PackX3Table t) {
+  const int k = (int)threadIdx.x;
+  if (k < t.n && t.half[k]) *reinterpret_cast<unsigned*>(t.dst[k] + 2 * pack_plane_elems(t, k)) = 0u;
+}
+__global__ __launch_bounds__(256) void wamax_kernel(PackX3Table t) {
+  const int k = (int)blockIdx.y;
+  if (!t.half[k]) return;
+  const long len = 9L * t.Cout[k] * t.Cin[k];
+  const float* __restrict__ w = t.w[k];
+  unsigned m = 0;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < len; i += (long)gridDim.x * 256) {
+    const unsigned b = __float_as_uint(w[i]) & 0x7fffffffu;
+    m = m > b ? m : b;
+  }
+  m = h2_wave_max(m);
+  if ((threadIdx.x & 63) == 0 && m != 0u) atomicMax(reinterpret_cast<unsigned*>(t.dst[k] + 2 * pack_plane_elems(t, k)), m);
+}
 
 __global__ __launch_bounds__(256) void pack_x3_multi_kernel(PackX3Table t) {
   constexpr int ROW = 8 * 9 + 1;                      // one output channel's 8 x 9 values, padded
@@ -687,6 +775,8 @@ __global__ __launch_bounds__(256) void pack_x3_multi_kernel(PackX3Table t) {
     const int u = (int)(blk - t.start[k]);
     const int cg = u % CG, m0 = (u / CG) * 32;
     const float* __restrict__ w = t.w[k];
+    const bool half = t.half[k] != 0;
+    const float hsc = half ? h2_pow2(h2_exp(*reinterpret_cast<const unsigned*>(t.dst[k] + 2 * plane))) : 1.f;
     __syncthreads();                                         // the previous unit's reads of `tile`
 #pragma unroll
     for (int it = 0; it < 9; ++it) {
@@ -714,8 +804,14 @@ __global__ __launch_bounds__(256) void pack_x3_multi_kernel(PackX3Table t) {
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       unsigned p0, p1, p2;
-      split2(tile[ml * ROW + e * 9 + tap], 0.f, p0, p1, p2);
       const long i = (((long)tap * CG + cg) * MP + m0 + ml) * 8 + e;
+      if (half) {
+        h2_split2(tile[ml * ROW + e * 9 + tap], 0.f, hsc, p0, p1);
+        d[i] = (unsigned short)(p0 & 0xffffu);
+        d[plane + i] = (unsigned short)(p1 & 0xffffu);
+        continue;
+      }
+      split2(tile[ml * ROW + e * 9 + tap], 0.f, p0, p1, p2);
       d[i] = (unsigned short)(p0 & 0xffffu);
       d[plane + i] = (unsigned short)(p1 & 0xffffu);
       d[2 * plane + i] = (unsigned short)(p2 & 0xffffu);
@@ -727,16 +823,29 @@ __global__ __launch_bounds__(256) void pack_x3_multi_kernel(PackX3Table t) {
 
 // n packs (n <= OSVOS_PACK_MAX) in one launch: ws[k] OIHW fp32 [Couts[k]][Cins[k]][3][3] -> dsts[k] (osvos_pack_x3 layout; dgrads[k] != 0: data-gradient form)
 int osvos_pack_x3_multi(const float* const* ws, void* const* dsts, const int* Couts, const int* Cins, const int* dgrads, int n, hipStream_t stream) {
+  return osvos_pack_x3_multi_fmt(ws, dsts, Couts, Cins, dgrads, nullptr, n, stream);
+}
+// halfs[k] != 0: entry k in the two-piece FP16 format (h2split.h; three launches instead of one: zero + largest magnitude + pack); NULL: every
+// entry in the format of this thread's osvos_x3_pieces() (22 = FP16 pairs, else three bf16 planes)
+int osvos_pack_x3_multi_fmt(const float* const* ws, void* const* dsts, const int* Couts, const int* Cins, const int* dgrads, const int* halfs, int n,
+                            hipStream_t stream) {
   OSVOS_ARG_CHECK(ws && dsts && Couts && Cins && dgrads && n >= 0 && n <= OSVOS_PACK_MAX, "pack_x3_multi: bad table (n = %d)", n);
   if (n == 0) return 0;
   PackX3Table t;
   t.n = n;
   t.start[0] = 0;
+  bool any_half = false;
   for (int k = 0; k < n; ++k) {
+    t.half[k] = (halfs != nullptr ? halfs[k] != 0 : osvos_x3_pieces() == 22) ? 1 : 0;
+    any_half = any_half || t.half[k];
     const int K = dgrads[k] ? Couts[k] : Cins[k], M = dgrads[k] ? Cins[k] : Couts[k];
     OSVOS_ARG_CHECK(ws[k] && dsts[k] && K % 16 == 0 && M > 0, "pack_x3_multi: entry %d (K = %d, M = %d)", k, K, M);
     t.w[k] = ws[k]; t.dst[k] = reinterpret_cast<unsigned short*>(dsts[k]); t.Cout[k] = Couts[k]; t.Cin[k] = Cins[k]; t.dgrad[k] = dgrads[k] ? 1 : 0;
     t.start[k + 1] = t.start[k] + (long)(K / 8) * (osvos_cout_pad(M) / 32);
+  }
+  if (any_half) {
+    hipLaunchKernelGGL(wamax_zero_kernel, dim3(1), dim3(64), 0, stream, t);
+    hipLaunchKernelGGL(wamax_kernel, dim3(64, (unsigned)n), dim3(256), 0, stream, t);
   }
   const long blocks = t.start[n] < 8192 ? t.start[n] : 8192;
   hipLaunchKernelGGL(pack_x3_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, t);
@@ -803,6 +912,11 @@ int osvos_conv3x3_f32x3_epi(const float* x, const float* wpk, const void* wpk3, 
   if (tile < 0) {
     OSVOS_ENV_INT(env_tile, "OSVOS_X3_TILE", -1);
     tile = env_tile >= 0 ? env_tile : pick_tile_x(N, H, W, a.CoutP);
+    // tuning knobs for the two-piece forms (half the matrix work per staged byte): another tile where the rule says 10 / 12 (launches without the
+    // fused pool only: that epilogue exists for tiles 10, 12, 14)
+    OSVOS_ENV_INT(wide2, "OSVOS_X2_TILE_FOR_10", 10);
+    OSVOS_ENV_INT(mid2, "OSVOS_X2_TILE_FOR_12", 12);
+    if (env_tile < 0 && osvos_x3_pieces() != 3 && !pool_fwd) tile = tile == 10 ? wide2 : (tile == 12 ? mid2 : tile);
     // XCD-local map (cout tiles of one spatial tile on one XCD) only where the activations are MUCH larger than the weights: the rule of rounds 2-4
     // (pixels > 9 CoutP, i.e. fp32 activation bytes > fp32 weight bytes) put conv4_x on it, where it measures 6-7 % slower per launch than the plain
     // order (X14 on conv4_2: 0.166 vs 0.155 ms; the pre-split pack is 1.5x the fp32 weights and every XCD then streams all of it) -- with the factor 3

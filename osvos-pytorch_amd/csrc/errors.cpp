@@ -21,12 +21,12 @@ static thread_local int g_wgrad_phase = 0;
 int osvos_wgrad_phase() { return g_wgrad_phase; }
 void osvos_wgrad_set_phase(int p) { g_wgrad_phase = p; }
 
-// bf16 pieces per operand of the f32x3 kernels on this host thread: 3 (default: six products, fp32-grade) or 2 (three products: precision
-// 'fp32x2').  Set by osvos_net_forward / osvos_net_backward from OSVOS_FLAG_X3_TWO_PIECES for the duration of the call, or by osvos_set_x3_pieces.
+// pieces per operand of the f32x3 kernels on this host thread: 3 (default: three bf16 pieces, six products, fp32-grade), 2 (two bf16 pieces, three
+// products: precision 'fp32x2') or 22 (two FP16 pieces with block exponents, three products: precision 'fp32h2', h2split.h).  Set by osvos_net_forward / osvos_net_backward from OSVOS_FLAG_X3_TWO_PIECES for the duration of the call, or by osvos_set_x3_pieces.
 static thread_local int g_x3_pieces = 3;
 int osvos_x3_pieces() { return g_x3_pieces; }
 extern "C" int osvos_set_x3_pieces(int pieces) {
-  OSVOS_ARG_CHECK(pieces == 2 || pieces == 3, "set_x3_pieces: %d (2 or 3)", pieces);
+  OSVOS_ARG_CHECK(pieces == 2 || pieces == 3 || pieces == 22, "set_x3_pieces: %d (2, 3 or 22)", pieces);
   g_x3_pieces = pieces;
   return 0;
 }

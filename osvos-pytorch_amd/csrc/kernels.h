@@ -28,6 +28,8 @@ size_t osvos_wpack_x3_bytes(int M, int K);
 #define OSVOS_PACK_MAX 40
 int osvos_pack_bf16_multi(const float* const* ws, void* const* dsts, const int* Couts, const int* Cins, const int* dgrads, int n, hipStream_t stream);
 int osvos_pack_x3_multi(const float* const* ws, void* const* dsts, const int* Couts, const int* Cins, const int* dgrads, int n, hipStream_t stream);
+int osvos_pack_x3_multi_fmt(const float* const* ws, void* const* dsts, const int* Couts, const int* Cins, const int* dgrads, const int* halfs, int n,
+                            hipStream_t stream);
 int osvos_pack_x3(const float* w, void* wpk3, int Cout, int Cin, int dgrad, hipStream_t stream);
 int osvos_conv3x3_f32x3_ps(const float* x, const float* wpk, const void* wpk3, const float* bias, const float* mask, float* y,
                            int N, int H, int W, int Cin, int Cout, int y_cs, int relu, int tile, int ksplit, void* part_ws, hipStream_t stream);

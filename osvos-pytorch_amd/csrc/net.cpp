@@ -297,9 +297,14 @@ constexpr int dbg_skip() { return 0; }
 // precision 'fp32x2' (OSVOS_FLAG_X3_TWO_PIECES): the f32x3 kernels of this call take two bf16 pieces per operand (three products) instead of three
 // (six); the per-thread switch (errors.cpp) is set for the duration of the call and restored on every return path
 extern "C" int osvos_set_x3_pieces(int pieces);
+// precision 'fp32h2' (OSVOS_FLAG_X3_HALF_PIECES): two FP16 pieces under block exponents (h2split.h) -- the packs the call reads must have been
+// written in that format (osvos_net_pack with the matching flag)
 struct PiecesScope {
   int prev;
-  explicit PiecesScope(bool two) : prev(osvos_x3_pieces()) { osvos_set_x3_pieces(two ? 2 : 3); }
+  explicit PiecesScope(int dtype_) : prev(osvos_x3_pieces()) {
+    const bool x3 = (dtype_ & 0xff) == OSVOS_F32_X3;
+    osvos_set_x3_pieces(x3 && (dtype_ & OSVOS_FLAG_X3_HALF_PIECES) ? 22 : (x3 && (dtype_ & OSVOS_FLAG_X3_TWO_PIECES) ? 2 : 3));
+  }
   ~PiecesScope() { osvos_set_x3_pieces(prev); }
 };
 
@@ -367,8 +372,11 @@ int osvos_net_pack(const float* const* params, void* wbuf, int dtype_, int with_
   // f32x3 with pre-split weights: the fp32 packs are read only where no pre-split pack exists (conv1_1 forward: the exact kernel) and by
   // the input-gradient kernel (layer 0's data-gradient pack); all pre-split packs are formed by ONE launch
   const bool x3ps = dtype == OSVOS_F32_X3 && use_presplit();
-  const float* xw[OSVOS_PACK_MAX]; void* xd[OSVOS_PACK_MAX]; int xco[OSVOS_PACK_MAX], xci[OSVOS_PACK_MAX], xdg[OSVOS_PACK_MAX];
+  const float* xw[OSVOS_PACK_MAX]; void* xd[OSVOS_PACK_MAX]; int xco[OSVOS_PACK_MAX], xci[OSVOS_PACK_MAX], xdg[OSVOS_PACK_MAX], xhalf[OSVOS_PACK_MAX];
   int nx = 0;
+  // precision 'fp32h2': forward and / or data-gradient packs in the FP16-pair format (h2split.h) -- same buffers, other contents
+  const int half_fwd = (dtype_ & OSVOS_FLAG_X3_HALF_PIECES) ? 1 : 0, half_bwd = (dtype_ & OSVOS_FLAG_X3_HALF_PIECES_BWD) ? 1 : 0;
+  OSVOS_ARG_CHECK(!(half_fwd || half_bwd) || x3ps, "net_pack: the FP16-pair packs exist for dtype OSVOS_F32_X3 with pre-split weights only");
   const bool b16 = dtype == OSVOS_F32_BF16MFMA;      // all bf16 packs (17 filters x 2 forms) in ONE launch too (round 5 prep)
   for (int l = 0; l < kNumConv; ++l) {
     int rc;
@@ -381,12 +389,12 @@ int osvos_net_pack(const float* const* params, void* wbuf, int dtype_, int with_
     if (!(x3ps && L.fwd3[l] != (size_t)-1) && (rc = osvos_pack_conv3x3_fwd(params[d[l].w_param], at(wbuf, L.fwd[l]), d[l].cout, d[l].cin, dtype, stream))) return rc;
     if (with_dgrad && !(x3ps && L.dgrad3[l] != (size_t)-1 && l != 0) &&
         (rc = osvos_pack_conv3x3_dgrad(params[d[l].w_param], at(wbuf, L.dgrad[l]), d[l].cout, d[l].cin, dtype, stream))) return rc;
-    if (L.fwd3[l] != (size_t)-1) { xw[nx] = params[d[l].w_param]; xd[nx] = at(wbuf, L.fwd3[l]); xco[nx] = d[l].cout; xci[nx] = d[l].cin; xdg[nx] = 0; ++nx; }
-    if (with_dgrad && L.dgrad3[l] != (size_t)-1) { xw[nx] = params[d[l].w_param]; xd[nx] = at(wbuf, L.dgrad3[l]); xco[nx] = d[l].cout; xci[nx] = d[l].cin; xdg[nx] = 1; ++nx; }
+    if (L.fwd3[l] != (size_t)-1) { xw[nx] = params[d[l].w_param]; xd[nx] = at(wbuf, L.fwd3[l]); xco[nx] = d[l].cout; xci[nx] = d[l].cin; xdg[nx] = 0; xhalf[nx] = half_fwd; ++nx; }
+    if (with_dgrad && L.dgrad3[l] != (size_t)-1) { xw[nx] = params[d[l].w_param]; xd[nx] = at(wbuf, L.dgrad3[l]); xco[nx] = d[l].cout; xci[nx] = d[l].cin; xdg[nx] = 1; xhalf[nx] = half_bwd; ++nx; }
     srcs[ns] = params[d[l].b_param]; dsts[ns] = L.bias[l]; counts[ns] = d[l].cout; ++ns;
   }
   if (nx > 0) {
-    const int rc = b16 ? osvos_pack_bf16_multi(xw, xd, xco, xci, xdg, nx, stream) : osvos_pack_x3_multi(xw, xd, xco, xci, xdg, nx, stream);
+    const int rc = b16 ? osvos_pack_bf16_multi(xw, xd, xco, xci, xdg, nx, stream) : osvos_pack_x3_multi_fmt(xw, xd, xco, xci, xdg, xhalf, nx, stream);
     if (rc) return rc;
   }
 
@@ -416,7 +424,7 @@ int osvos_net_forward(const float* x_nchw, const void* wbuf, void* ws, float* co
   const int dtype = dtype_ & 0xff;
   const bool generic = (dtype_ & OSVOS_FLAG_GENERIC_DECONV) != 0;
   const bool infer = (dtype_ & OSVOS_FLAG_INFERENCE) != 0;      // no backward will read the sign bits / pool codes: do not write them
-  PiecesScope pieces_scope((dtype_ & OSVOS_FLAG_X3_TWO_PIECES) != 0 && dtype == OSVOS_F32_X3);
+  PiecesScope pieces_scope(dtype_);
   hipStream_t aux_all = aux_stream_ ? (hipStream_t)aux_stream_ : stream;
   const bool two = aux_all != stream;
   EventPool& evp = event_pool();
@@ -545,7 +553,7 @@ int osvos_net_backward(const void* wbuf, void* ws, const float* const* douts, fl
   hipStream_t stream = (hipStream_t)stream_;
   const int dtype = dtype_ & 0xff;
   const bool generic = (dtype_ & OSVOS_FLAG_GENERIC_DECONV) != 0;
-  PiecesScope pieces_scope((dtype_ & OSVOS_FLAG_X3_TWO_PIECES) != 0 && dtype == OSVOS_F32_X3);
+  PiecesScope pieces_scope(dtype_);
   hipStream_t aux = aux_stream_ ? (hipStream_t)aux_stream_ : stream;
   hipStream_t aux2 = aux2_stream_ ? (hipStream_t)aux2_stream_ : aux;
   const GradEvents gev = grad_events();      // armed for this call only

@@ -17,6 +17,7 @@
 //   * deterministic: fixed patch -> split assignment, fp32 slabs [split][tap][co][ci] + the shared slab reduce (wgrad_f32.hip)
 #include "common.h"
 #include "kernels.h"
+#include "h2split.h"
 
 namespace {
 
@@ -110,8 +111,13 @@ __device__ __forceinline__ void stage_groups() {
 // gather per MFMA, sched_group_barrier) instead of being issued as a block in front of them: with one wave per SIMD nothing else covers
 // the ~150-250 cycles that block takes while the matrix pipe drains (576 cycles of MFMA per stage; the pipe was busy 51 % of the time).
 // NP = 2 (round 6, precision 'fp32x2'): two bf16 pieces per operand, three products (conv3x3_f32x3.hip) -- same tiles, the low planes unused
-template <int PH, int WAVES, int S16 = 0, int ILV = 0, int NP = 3>
+// HP = 1 ("h2", precision 'fp32h2'; h2split.h): the two pieces are FP16 with a block exponent per operand.  Both operands are activations
+// here, so both exponents are the workgroup's own running ones: the waves exchange the largest magnitudes of the patch about to be staged
+// (dY and X separately) through two words of LDS before the barrier that opens the staging phase; when an exponent drops the nine accumulators
+// are multiplied by the power of two that separates the scales; the slab epilogue un-scales.  (The bias gradient stays the exact fp32 column sum.)
+template <int PH, int WAVES, int S16 = 0, int ILV = 0, int NP = 3, int HP = 0>
 __global__ __launch_bounds__(64 * WAVES) void wgrad_f32x3_kernel(W3Args a) {
+  static_assert(HP == 0 || NP == 2, "h2: two pieces");
   using G = G3<PH, WAVES, S16>;
   constexpr int NT = G::NT, BCO = G::BCO, BCI = G::BCI;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -170,6 +176,10 @@ __global__ __launch_bounds__(64 * WAVES) void wgrad_f32x3_kernel(W3Args a) {
       rx[j][1] = __builtin_amdgcn_raw_buffer_load_b128(q.xrs, off + 16u, 0, 0);
     }
   };
+  int h2_ed = kH2NoScale, h2_ex = kH2NoScale;      // h2: running block exponents of dY and X ...
+  float h2_sd = 1.f, h2_sx = 1.f;                  // ... and their powers of two
+  unsigned* const h2_mx = reinterpret_cast<unsigned*>(smem + G::LDS - 128);      // [parity 2][operand 2][wave <= 8] words at the end of X's unused third plane
+  static_assert(HP == 0 || (G::X_B >= 128 && WAVES <= 8), "h2: exchange slots");
   auto store_patch = [&]() {
 #pragma unroll
     for (int i = 0; i < G::NDY; ++i) {
@@ -179,7 +189,8 @@ __global__ __launch_bounds__(64 * WAVES) void wgrad_f32x3_kernel(W3Args a) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) { bsum[c] += lo[c]; bsum[4 + c] += hi[c]; }
       }
-      split8w(rdy[i][0], rdy[i][1], p0, p1, p2);
+      if constexpr (HP != 0) h2_split8(rdy[i][0], rdy[i][1], h2_sd, p0, p1);
+      else split8w(rdy[i][0], rdy[i][1], p0, p1, p2);
       const int p = dpg + G::DPG * i;
       if (G::DY_ITEMS % NT == 0 || p < G::PPIX) {
         char* d = dYs + p * G::DYP + doct * 16;
@@ -191,7 +202,8 @@ __global__ __launch_bounds__(64 * WAVES) void wgrad_f32x3_kernel(W3Args a) {
 #pragma unroll
     for (int j = 0; j < G::NX; ++j) {
       u32x4 p0, p1, p2;
-      split8w(rx[j][0], rx[j][1], p0, p1, p2);
+      if constexpr (HP != 0) h2_split8(rx[j][0], rx[j][1], h2_sx, p0, p1);
+      else split8w(rx[j][0], rx[j][1], p0, p1, p2);
       const int hp = xpg + G::XPG * j;
       if (G::X_ITEMS % NT == 0 || hp < G::XPIX) {
         char* d = Xs + hp * G::XP + xoct * 16;
@@ -225,7 +237,36 @@ __global__ __launch_bounds__(64 * WAVES) void wgrad_f32x3_kernel(W3Args a) {
     for (int it = 0; it < G::NIT; ++it) issue(q, it);
   }
   for (int p = p_begin; p < p_end; ++p) {
+    if constexpr (HP != 0) {           // this wave's largest |raw value| of the patch about to be staged, per operand
+      unsigned md = 0, mxx = 0;
+#pragma unroll
+      for (int i = 0; i < G::NDY; ++i) md = h2_amax8(rdy[i][0], rdy[i][1], md);
+#pragma unroll
+      for (int j = 0; j < G::NX; ++j) mxx = h2_amax8(rx[j][0], rx[j][1], mxx);
+      md = h2_wave_max(md);
+      mxx = h2_wave_max(mxx);
+      if (lane == 0) { h2_mx[(p & 1) * 16 + wave] = md; h2_mx[(p & 1) * 16 + 8 + wave] = mxx; }
+    }
     __syncthreads();                   // every wave is done with the previous patch's tiles
+    if constexpr (HP != 0) {
+      const uint4* q = reinterpret_cast<const uint4*>(h2_mx) + (p & 1) * 4;
+      const uint4 d0 = q[0], d1 = q[1], x0 = q[2], x1 = q[3];
+      unsigned md = max(max(d0.x, d0.y), max(d0.z, d0.w)), mxx = max(max(x0.x, x0.y), max(x0.z, x0.w));
+      if (WAVES == 8) { md = max(md, max(max(d1.x, d1.y), max(d1.z, d1.w))); mxx = max(mxx, max(max(x1.x, x1.y), max(x1.z, x1.w))); }
+      const int ed = h2_exp(__builtin_amdgcn_readfirstlane(md)), ex = h2_exp(__builtin_amdgcn_readfirstlane(mxx));
+      const int nd = ed < h2_ed ? ed : h2_ed, nx_ = ex < h2_ex ? ex : h2_ex;
+      if (nd != h2_ed || nx_ != h2_ex) {          // (uniform) a larger value than any so far: re-express the accumulators at the new scales
+        const int dl = (h2_ed == kH2NoScale ? 0 : nd - h2_ed) + (h2_ex == kH2NoScale ? 0 : nx_ - h2_ex);
+        if (dl != 0) {
+#pragma unroll
+          for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = __builtin_ldexpf(acc[t][r], dl);
+        }
+        h2_ed = nd; h2_ex = nx_;
+        h2_sd = h2_pow2(nd); h2_sx = h2_pow2(nx_);
+      }
+    }
     store_patch();
     __syncthreads();
     const Patch nx = locate(p + 1, p + 1 < p_end);
@@ -268,8 +309,12 @@ __global__ __launch_bounds__(64 * WAVES) void wgrad_f32x3_kernel(W3Args a) {
       for (int t = 0; t < NPROD; ++t)
 #pragma unroll
         for (int s = 0; s < 3; ++s)
-          acc[r * 3 + s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, bfr[st & (NB - 1)][PX[t]][s]),
-                                                                  __builtin_bit_cast(bf16x8_t, af[ks & (NB - 1)][PD[t]]), acc[r * 3 + s], 0, 0, 0);
+          if constexpr (HP != 0)
+            acc[r * 3 + s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, bfr[st & (NB - 1)][PX[t]][s]),
+                                                                   __builtin_bit_cast(f16x8_t, af[ks & (NB - 1)][PD[t]]), acc[r * 3 + s], 0, 0, 0);
+          else
+            acc[r * 3 + s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, bfr[st & (NB - 1)][PX[t]][s]),
+                                                                    __builtin_bit_cast(bf16x8_t, af[ks & (NB - 1)][PD[t]]), acc[r * 3 + s], 0, 0, 0);
       if constexpr (ILV != 0) {
         // gathers of the NEXT stage (independent registers: the fragment sets are double buffered) and this stage's staging loads
         constexpr int V = 2;
@@ -283,6 +328,13 @@ __global__ __launch_bounds__(64 * WAVES) void wgrad_f32x3_kernel(W3Args a) {
     }
   }
   __syncthreads();
+  if constexpr (HP != 0) {
+    const int dl = (h2_ed == kH2NoScale || h2_ex == kH2NoScale) ? 0 : -(h2_ed + h2_ex);      // (no patch at all: the accumulators are zero)
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = __builtin_ldexpf(acc[t][r], dl);
+  }
 
   {   // slab epilogue: D = [cin rows][cout columns]; lane (li, lh) holds cout li and cins 8 q + 4 lh + (0..3) = one 16-byte store
     const int li = lane & 31;
@@ -360,17 +412,17 @@ W3Plan make_plan3(int N, int H, int W, int Cin_s, int Cout) {
   return p;
 }
 
-template <int PH, int WAVES, int S16 = 0, int ILV = 0, int NP = 3>
+template <int PH, int WAVES, int S16 = 0, int ILV = 0, int NP = 3, int HP = 0>
 int launch3(const W3Args& a, long blocks, hipStream_t stream) {
   static bool attr_set_dev[OSVOS_MAX_DEVICES] = {};
   bool& attr_set = attr_set_dev[osvos_current_device()];
   if (!attr_set) {
-    OSVOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_f32x3_kernel<PH, WAVES, S16, ILV, NP>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    OSVOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_f32x3_kernel<PH, WAVES, S16, ILV, NP, HP>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)G3<PH, WAVES, S16>::LDS));
     attr_set = true;
   }
   constexpr size_t lds = G3<PH, WAVES, S16>::LDS;
-  hipLaunchKernelGGL((wgrad_f32x3_kernel<PH, WAVES, S16, ILV, NP>), dim3((unsigned)blocks), dim3(64 * WAVES), lds, stream, a);
+  hipLaunchKernelGGL((wgrad_f32x3_kernel<PH, WAVES, S16, ILV, NP, HP>), dim3((unsigned)blocks), dim3(64 * WAVES), lds, stream, a);
   OSVOS_LAUNCH_CHECK();
   return 0;
 }
@@ -422,7 +474,10 @@ int wgrad3_run(const void* x, const void* dy, void* ws, float* dw, float* db,
   if (phase != 2) {
     // gathers / staging loads interleaved with the MFMAs of the previous stage (round 3; the block-issue form measured level and is gone)
     const bool two = osvos_x3_pieces() == 2;      // precision 'fp32x2'
-    const int rc = two ? (skinny ? launch3<4, 4, 1, 1, 2>(a, blocks, stream)
+    const bool h2 = osvos_x3_pieces() == 22;      // precision 'fp32h2'
+    const int rc = h2  ? (skinny ? launch3<4, 4, 1, 1, 2, 1>(a, blocks, stream)
+                                 : (p.ph == 6 ? launch3<6, 4, 0, 1, 2, 1>(a, blocks, stream) : launch3<4, 4, 0, 1, 2, 1>(a, blocks, stream)))
+                 : two ? (skinny ? launch3<4, 4, 1, 1, 2>(a, blocks, stream)
                                  : (p.ph == 6 ? launch3<6, 4, 0, 1, 2>(a, blocks, stream) : launch3<4, 4, 0, 1, 2>(a, blocks, stream)))
                        : (skinny ? launch3<4, 4, 1, 1>(a, blocks, stream)
                                  : (p.ph == 6 ? launch3<6, 4, 0, 1>(a, blocks, stream) : launch3<4, 4, 0, 1>(a, blocks, stream)));

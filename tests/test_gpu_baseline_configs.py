@@ -95,7 +95,7 @@ def test_window_batch_equals_the_sequential_micro_batches_at_120x214():
     assert worst[0] <= 1e-3, worst
 
 
-@pytest.mark.parametrize("precision", ["fp32", "fp32x3", "fp32x3b2"])
+@pytest.mark.parametrize("precision", ["fp32", "fp32x3", "fp32x3b2", "fp32h2", "fp32x3h2"])
 def test_1080p_forward_fp32_against_cpu_oracle_and_batch4_graph(precision):
     """both fp32 arithmetics: the exact fp32 MFMA kernels (the 95 frames/s configs[4] line) and f32x3 (the module default)"""
     from oracle import synth
@@ -289,7 +289,7 @@ def _float64_trajectory(n_ave, h, w, lr):
     return _TRAJ[key]
 
 
-@pytest.mark.parametrize("precision", ["fp32", "fp32x3", "fp32x3b2"])
+@pytest.mark.parametrize("precision", ["fp32", "fp32x3", "fp32x3b2", "fp32h2", "fp32x3h2"])
 def test_online_trajectory_854x480_two_optimizer_steps_against_float64(precision):
     """SURVEY section 4 (iii) at the BASELINE size: 2 x nAveGrad micro-batches of the online fine-tune loop (train_online.py:112-149 --
     fused-head loss, loss /= 5, backward, SGD step with the 8 parameter groups every 5th) through the scripts' own TrainLoop (fused loss

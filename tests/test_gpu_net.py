@@ -21,7 +21,7 @@ IOU_TOL = 1e-3
 # the two fp32 arithmetics of the convolutions: exact fp32 MFMA and f32x3 (three-way bf16 split on the bf16 matrix pipe);
 # both are held to the same fp32 bars.  The module's default is fp32x3, so every un-parametrised test of the GPU tier runs under it;
 # OSVOS_TEST_PRECISION=fp32 runs them on the exact kernels instead.
-FP32_MODES = ["fp32", "fp32x3", "fp32x3b2"]
+FP32_MODES = ["fp32", "fp32x3", "fp32x3b2", "fp32h2", "fp32x3h2"]
 
 
 def build_net(wts, precision=None):

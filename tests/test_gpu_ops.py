@@ -516,6 +516,81 @@ def test_f32x3_kernels_with_two_pieces_per_operand(shape):
     assert w3 < 5e-6 and w2 < 5e-5 and (w2 > 2 * w3 or cin < 64), (shape, w3, w2)      # (Cin = 16 takes the exact fp32 skinny weight gradient in both modes)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("spread", ["unit", "tiny", "huge", "lognormal", "sparse"])
+@pytest.mark.parametrize("shape", [(1, 33, 70, 64, 128), (2, 24, 40, 128, 64), (1, 20, 24, 256, 256), (1, 18, 40, 512, 512), (1, 40, 64, 128, 16)])
+def test_f32x3_kernels_with_fp16_pairs(shape, spread):
+    """Precision 'fp32h2' at op level (round 6; csrc/h2split.h): the f32x3 convolution (every production tile; forward with bias + ReLU, and the
+    data-gradient pack) and the f32x3 weight gradient with TWO FP16 pieces per operand under block exponents -- three products on
+    v_mfma_f32_32x32x16_f16.  Against float64 (F.conv2d, vgg_osvos.py:41,142-143, and its autograd), NEXT TO the exact fp32 MFMA kernel on the same
+    inputs: every output within 2^-19 sum|a||b| of the truth, and the rel-L2 error no larger than the exact fp32 kernel's or 3.5e-7 (three fp32 roundings
+    of the result; 5e-7 for the K = 4608 data gradient; measured: dense operands 1.3-1.9e-7 against the exact kernel's 2.0-3.0e-7 -- sixteen products enter one rounding instead of two --, 95 %
+    zeros 1.6-2.9e-7 against 1.0-1.9e-7).  Operand magnitudes are swept over what the block exponents must absorb: ~1e-9 (gradients), ~1e+6, log-normal
+    magnitudes across pixels (5 decades inside one tile: values below 2^-17 of their tile's maximum keep an ABSOLUTE error of 2^-40 of that maximum,
+    which is where the per-output bound is 2^-19 and not 2^-21), and 95 % exact zeros (post-ReLU maps)."""
+    from osvos_pytorch_amd._lib import F32_X3
+    ops = _ops()
+    n, h, w, cin, cout = shape
+    g = torch.Generator().manual_seed(sum(shape) + len(spread))
+    x = torch.randn(n, cin, h, w, generator=g)
+    dy = torch.randn(n, cout, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)
+    if spread == "tiny":
+        x, dy, wt = x * 3e-9, dy * 7e-10, wt * 1e-3
+    elif spread == "huge":
+        x, dy, wt = x * 2.5e6, dy * 4e5, wt * 30.0
+    elif spread == "lognormal":
+        x = x * torch.exp(2.5 * torch.randn(n, 1, h, w, generator=g))
+        dy = dy * torch.exp(2.5 * torch.randn(n, 1, h, w, generator=g)) * 1e-6
+        wt = wt * torch.exp(1.5 * torch.randn(cout, cin, 1, 1, generator=g))
+    elif spread == "sparse":
+        x = x * (torch.rand(n, cin, h, w, generator=g) > 0.95)
+        dy = dy * (torch.rand(n, cout, h, w, generator=g) > 0.95)
+    b = torch.randn(cout, generator=g) * float(x.abs().mean() * wt.abs().mean() * cin)
+    ref = F.relu(F.conv2d(x.double(), wt.double(), b.double(), padding=1))
+    mag = F.conv2d(x.abs().double(), wt.abs().double(), b.abs().double(), padding=1)
+    wref = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), wref, padding=1).backward(dy.double())
+    wmag = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.abs().double(), wmag, padding=1).backward(dy.abs().double())
+    dfull = F.conv_transpose2d(dy.double(), wt.double(), padding=1)
+    dmag = F.conv_transpose2d(dy.abs().double(), wt.abs().double(), padding=1)
+    rel = lambda a, r: float((a.cpu().double() - r).norm() / r.norm())
+    xg, dyg, bg = nhwc(x), nhwc(dy), b.cuda()
+    # the exact fp32 MFMA kernels on the same inputs
+    pk, dpk = ops.pack_fwd(wt.cuda()), ops.pack_dgrad(wt.cuda())
+    e_exact = rel(nchw(ops.conv3x3(xg, pk, bg, cout, relu=True)), ref)
+    d_exact = rel(nchw(ops.conv3x3(dyg, dpk, None, cin)), dfull) if cout % 16 == 0 and cin % 4 == 0 else None
+    w_exact = rel(ops.conv3x3_wgrad(xg, dyg, cin, cout)[0], wref.grad)
+    try:
+        ops.set_x3_pieces(22)
+        pk3, dpk3 = ops.pack_x3(wt.cuda()), (ops.pack_x3(wt.cuda(), dgrad=True) if cout % 16 == 0 else None)
+        errs = []
+        for tile in ((15, -1) if cout <= 32 else (10, 12, 14, 16, 17, -1)):
+            y = nchw(ops.conv3x3_x3(xg, pk3, bg, cout, relu=True, tile=tile)).cpu().double()
+            assert torch.isfinite(y).all(), (shape, spread, tile)
+            assert float(((y - ref).abs() / (mag * 2.0 ** -19 + 1e-300)).max()) <= 1.0, (shape, spread, tile)
+            errs.append(float((y - ref).norm() / ref.norm()))
+        e_h2 = max(errs)
+        if dpk3 is not None:
+            d = nchw(ops.conv3x3_x3(dyg, dpk3, None, cin, tile=-1)).cpu().double()
+            assert float(((d - dfull).abs() / (dmag * 2.0 ** -19 + 1e-300)).max()) <= 1.0, (shape, spread)
+            d_h2 = rel(d, dfull)
+        gw = ops.conv3x3_wgrad(xg, dyg, cin, cout, dtype=F32_X3)[0].cpu().double()
+        assert float(((gw - wref.grad).abs() / (wmag.grad * 2.0 ** -19 + 1e-300)).max()) <= 1.0, (shape, spread)
+        w_h2 = rel(gw, wref.grad)
+        with pytest.raises(RuntimeError):                     # no fp16-pair form of the four-wave tiles
+            ops.conv3x3_x3(xg, pk3, bg, cout, relu=True, tile=3)
+    finally:
+        ops.set_x3_pieces(3)
+    print("h2 vs exact fp32 (rel-L2 against float64) %s %s: conv %.2e | %.2e, dgrad %s, wgrad %.2e | %.2e" %
+          (shape, spread, e_h2, e_exact, "%.2e | %.2e" % (d_h2, d_exact) if dpk3 is not None and d_exact is not None else "-", w_h2, w_exact))
+    assert e_h2 <= max(e_exact, 3.5e-7), (shape, spread, e_h2, e_exact)
+    if dpk3 is not None and d_exact is not None:
+        assert d_h2 <= max(d_exact, 5e-7), (shape, spread, d_h2, d_exact)
+    assert w_h2 <= max(w_exact, 3e-7), (shape, spread, w_h2, w_exact)
+
+
 def _bits_of(t_nhwc):
     """[N,H,W,C] -> int64 [N,H,W,C/32]: bit b of word g = (t[..., 32 g + b] > 0) (csrc/maskbits.h)"""
     n, h, w, c = t_nhwc.shape

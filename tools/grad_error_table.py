@@ -25,7 +25,7 @@ losses = [torch_ref.cbce_loss(o, torch.from_numpy(m).double(), size_average=Fals
 truth = {k: v.grad.clone() for k, v in p.items() if v.grad is not None and not k.startswith("upscale")}
 truth["input"] = xi.grad.clone()
 table = {}
-precs = ["fp32", "fp32x3", "fp32x3b2", "fp32x2"]
+precs = ["fp32", "fp32x3", "fp32x3b2", "fp32x2", "fp32h2", "fp32x3h2"]
 for prec in precs:
     net = tf.build(wts, prec)
     xg = torch.from_numpy(x).requires_grad_()
@@ -36,13 +36,16 @@ for prec in precs:
     g = {k: v.grad.cpu().double() for k, v in net.named_parameters() if v.grad is not None}
     g["input"] = xg.grad.double()
     table[prec] = {k: float((g[k] - t).norm() / (t.norm() + 1e-300)) for k, t in truth.items()}
-print("%-22s %10s %10s %10s %10s | b2 / x3" % ("tensor", *precs))
-ratios = []
+print("%-22s %10s %10s %10s %10s %10s %10s | b2 / x3  h2 / x3" % ("tensor", *precs))
+ratios, ratios_h = [], []
 for k in truth:
     r = table["fp32x3b2"][k] / max(table["fp32x3"][k], 1e-30)
+    rh = table["fp32h2"][k] / max(table["fp32x3"][k], 1e-30)
     ratios.append(r)
-    print("%-22s %10.2e %10.2e %10.2e %10.2e | %6.2f" % (k, table["fp32"][k], table["fp32x3"][k], table["fp32x3b2"][k], table["fp32x2"][k], r))
+    ratios_h.append(rh)
+    print("%-22s %s | %6.2f  %6.2f" % (k, " ".join("%10.2e" % table[q][k] for q in precs), r, rh))
 for prec in precs:
     v = np.array(list(table[prec].values()))
     print("%-9s median %.2e  max %.2e  (%s)" % (prec, np.median(v), v.max(), max(table[prec], key=table[prec].get)))
 print("fp32x3b2 / fp32x3 per-tensor error ratio: median %.2f, max %.2f, tensors above 2x: %d of %d" % (np.median(ratios), max(ratios), sum(r > 2 for r in ratios), len(ratios)))
+print("fp32h2 / fp32x3 per-tensor error ratio: median %.2f, max %.2f, tensors above 2x: %d of %d" % (np.median(ratios_h), max(ratios_h), sum(r > 2 for r in ratios_h), len(ratios_h)))

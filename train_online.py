@@ -126,7 +126,7 @@ def main():
                     help='input pipeline on the GPU: Pillow decode -> pinned uint8 -> osvos_augment_frame (flip, scale+rotate, mean, CHW); '
                          'the first frame is decoded ONCE and re-augmented on the device every iteration')
     ap.add_argument('--prefetch', type=int, default=3, help='--device-augment: test frames decoded / copied ahead of the forward')
-    ap.add_argument('--precision', default=os.environ.get('OSVOS_PRECISION', 'fp32x3'), choices=['fp32', 'fp32x3', 'fp32x3b2', 'fp32x2', 'bf16'])
+    ap.add_argument('--precision', default=os.environ.get('OSVOS_PRECISION', 'fp32x3'), choices=['fp32', 'fp32x3', 'fp32x3b2', 'fp32x3h2', 'fp32h2', 'fp32x2', 'bf16'])
     ap.add_argument('--window-fused', action='store_true',
                     help='run the nAveGrad micro-batches of every optimizer step as ONE batch with per-image class counts (TrainLoop.window_batch): '
                          'the same gradient up to fp32 summation order, one set of kernel launches per optimizer step instead of nAveGrad')

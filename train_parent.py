@@ -114,7 +114,7 @@ def main(argv=None, build_net=None, loss_fn=None):
     ap.add_argument('--device-augment', action='store_true',
                     help='input pipeline on the GPU: Pillow decode -> pinned uint8 -> osvos_augment_frame (flip, scale+rotate, mean, CHW)')
     ap.add_argument('--prefetch', type=int, default=3, help='--device-augment: frames decoded / copied ahead of the training step')
-    ap.add_argument('--precision', default=os.environ.get('OSVOS_PRECISION', 'fp32x3'), choices=['fp32', 'fp32x3', 'fp32x3b2', 'fp32x2', 'bf16'])
+    ap.add_argument('--precision', default=os.environ.get('OSVOS_PRECISION', 'fp32x3'), choices=['fp32', 'fp32x3', 'fp32x3b2', 'fp32x3h2', 'fp32h2', 'fp32x2', 'bf16'])
     ap.add_argument('--lr', type=float, default=1e-8, help='base learning rate of the SGD groups (train_parent.py:83)')
     ap.add_argument('--snapshot', type=int, default=40, help='store a model every this many epochs (train_parent.py:38)')
     ap.add_argument('--test-interval', type=int, default=5, help='run the validation pass every this many epochs (train_parent.py:39)')
