@@ -131,6 +131,16 @@ def test_parity_gate_is_in_the_line(line):
     if "configs[1]/fp32x2" in extras:      # two bf16 pieces per operand: faster than the headline, flat f32 bars reported honestly, its own bars held
         x2 = extras["configs[1]/fp32x2"]
         assert x2["within_x2_bars"] is True and x2["iou"] >= 1 - 1e-3 and x2["max_dlogit_over_std"] <= 1e-3 and x2["value"] > line["value"]
+    if "configs[1]/fp32x3h2" in extras:    # forward = the headline's, backward on FP16 pairs under block exponents (22-23-bit operands, three products)
+        h = extras["configs[1]/fp32x3h2"]
+        assert h["within_bars"] is True and h["value"] > 1.1 * line["value"] and h["max_dlogit_over_std"] == line["parity"]["max_dlogit_over_std"]
+    if "configs[1]/fp32h2" in extras:      # FP16 pairs in both passes: logits / loss / IoU at the flat bars; the gradient bar is the ReLU-flip lottery (profiles/r06_fp32h2.txt)
+        h = extras["configs[1]/fp32h2"]
+        assert h["max_dlogit_over_std"] <= 1e-3 and h["loss_rel"] <= 1e-5 and h["iou"] >= 1 - 1e-3 and h["value"] > 1.2 * line["value"]
+        assert h["within_bars"] is True or h["grad_rel_l2_worst"] <= 3e-3
+    if "configs[4]/fp32h2" in extras:      # inference: inside the flat bars, faster than the three-piece forward
+        h = extras["configs[4]/fp32h2"]
+        assert h["within_bars"] is True and h["value"] > 1.3 * extras["configs[4]"]["value"]
     for e in extras.values():
         assert "error" not in e and e["value"] > 0 and e["ms_per_step"] > 0 and 0.2 < e["frac"] < 1.0
     c2, c4 = extras["configs[2]"], extras["configs[4]"]

@@ -17,5 +17,8 @@ cp $O/timeline_configs1.txt $P/${TAG}_step_timeline.txt
 cp $O/timeline_configs2.txt $P/${TAG}_step_timeline_bf16_b12.txt
 [ -s $O/kernel_stats_configs1_fp32x3b2.txt ] && cp $O/kernel_stats_configs1_fp32x3b2.txt $P/${TAG}_bench_fp32x3b2_kernel_stats.txt
 [ -s $O/timeline_configs1_fp32x3b2.txt ] && cp $O/timeline_configs1_fp32x3b2.txt $P/${TAG}_step_timeline_fp32x3b2.txt
+[ -s $O/kernel_stats_configs1_fp32h2.txt ] && cp $O/kernel_stats_configs1_fp32h2.txt $P/${TAG}_bench_fp32h2_kernel_stats.txt
+[ -s $O/mfma_f16_probe.txt ] && cp $O/mfma_f16_probe.txt $P/${TAG}_mfma_f16_probe.txt
+[ -s $O/net_flips.txt ] && cp $O/net_flips.txt $P/${TAG}_net_flips.txt
 cp $O/profiles/${TAG}_pmc_traffic_*.json $P/ 2>/dev/null
 ls -la $P/${TAG}_*

@@ -17,4 +17,5 @@ prof() { # tag, bench args...
 prof configs1
 prof configs2 --mode parent --precision bf16 --batch 12
 prof configs1_fp32x3b2 --precision fp32x3b2
+prof configs1_fp32h2 --precision fp32h2
 cat $O/times.txt

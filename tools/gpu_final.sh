@@ -9,7 +9,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R; export TMPDIR=/tmp; O=$R/gpurun_out/${TAG}_
 t0=$(date +%s)
 echo "tree: ${OSVOS_COMMIT:-unknown}" > $O/summary.txt
 python -c "import torch; print(torch.__version__, torch.cuda.get_device_name(0))" >> $O/summary.txt 2>&1
-timeout 1500 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider --durations=15 > $O/pytest_gpu.log 2>&1; echo "pytest exit $?" >> $O/summary.txt
+timeout 2100 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider --durations=15 > $O/pytest_gpu.log 2>&1; echo "pytest exit $?" >> $O/summary.txt
 tail -3 $O/pytest_gpu.log >> $O/summary.txt
 timeout 300 python __graft_entry__.py smoke > $O/smoke.log 2>&1; echo "smoke exit $?" >> $O/summary.txt; tail -1 $O/smoke.log >> $O/summary.txt
 echo "tier+smoke $(( $(date +%s) - t0 )) s" >> $O/summary.txt
@@ -34,6 +34,9 @@ NOBENCH=1 bash tools/gpu_evidence.sh ${TAG}_final > /dev/null 2>&1
 bash tools/gpu_run.sh ${TAG}_final "layers:bf16 12 --all" "layers:x3 1 --all" > $O/layers.log 2>&1
 timeout 120 python tools/tune_p64.py --tiles 9,109,36,136,38,138 > $O/tune_p64.txt 2>&1
 timeout 300 python tools/grad_error_table.py 2>&1 | grep -v "amdgpu.ids\|Constructing\|Initializing" > $O/grad_error_table.txt
+# FP16-pair precisions: the f16 pipe next to the bf16 one, per-layer ReLU flips of every fp32-family precision against float64
+timeout 120 tools/native/bin/mfma_f16_probe > $O/mfma_f16_probe.txt 2>&1
+{ timeout 300 python tools/net_flip_probe.py 240 427; timeout 300 python tools/net_flip_probe.py 480 854; } 2>&1 | grep -v "amdgpu.ids\|Constructing\|Initializing" > $O/net_flips.txt
 echo "extras $(( $(date +%s) - t0 )) s" >> $O/summary.txt
 echo "total $(( $(date +%s) - t0 )) s" >> $O/summary.txt
 cat $O/summary.txt

@@ -16,3 +16,5 @@ COUT=bin/conv_probe; [ "$XABL" != "0" ] && COUT=bin/conv_probe_x3abl$XABL
   $C/conv3x3_f32.hip $C/conv3x3_f32x3.hip $C/conv3x3_bf16.hip $C/conv3x3_bf16_dma.hip $C/pack.hip -x hip $C/errors.cpp conv_probe.cpp -o $COUT
 /opt/rocm/bin/hipcc -O2 -std=c++17 --offload-arch=gfx950 tr_probe.cpp -o bin/tr_probe
 /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 mfma_probe.cpp -o bin/mfma_probe
+# round-6 micro-benchmarks (single-file HIP programs)
+for p in mfma_valu_overlap valu_rate mfma_vs_other mfma_f16_probe; do /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 $p.hip -o bin/$p; done
