@@ -649,14 +649,14 @@ int launch_x2(const ConvArgsX& a0, int sk_grid, hipStream_t stream) {
 template <class C, bool SKT = false>
 int launch_x(const ConvArgsX& a, int sk_grid, hipStream_t stream) {
   if (osvos_x3_pieces() == 22) {     // two fp16 pieces with block exponents (precision 'fp32h2'): the pre-split production tiles only
-    if constexpr (C::ILV != 0 && C::NT == 512) {
+    if constexpr (C::ILV != 0 && (C::NT == 512 || C::NT == 256)) {
       if (a.wpk3 != nullptr) return launch_x2<C, 1, 0, 2, 1>(a, 0, stream);
     }
     osvos_set_error("conv3x3 f32x3: the fp16-pair form is built for the pre-split eight-wave tiles (10, 12, 14, 15, 16, 17) with a pre-split pack");
     return -1;
   }
   if (osvos_x3_pieces() == 2) {      // two-piece mode (precision 'fp32x2'): the plain grid only, no stream-K form
-    if constexpr (C::ILV != 0 && C::NT == 512) {
+    if constexpr (C::ILV != 0 && (C::NT == 512 || C::NT == 256)) {
       if (a.wpk3 != nullptr) return launch_x2<C, 1, 0, 2>(a, 0, stream);
     }
     OSVOS_ARG_CHECK(a.wpk != nullptr, "conv3x3 f32x3: this tile config has no pre-split form and no fp32 pack was given");

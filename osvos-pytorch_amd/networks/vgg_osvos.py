@@ -79,6 +79,9 @@ class OSVOS(nn.Module):
         (bf16 MFMA operands and bf16 trunk tensors, fp32 accumulate).  'fp32x2' (round 6): the f32x3 kernels with TWO bf16 pieces per operand,
         three products -- fp32 tensors, 16-bit-significand operands (finer than the TF32 cuDNN defaults to for fp32 convolutions), fp32
         accumulate, ~half the matrix work; logits ~1e-4 std and losses ~1e-5 from fp32, NOT inside every flat fp32 bar.
+        'fp32x3b2' / 'fp32x3h2': the forward of 'fp32x3' bit for bit, the BACKWARD convolutions on two bf16 pieces / on two FP16 pieces under block
+        exponents (22-23-bit operands) -- three products, every parity number of 'fp32x3' unchanged, 1.2-1.3x its step rate.  'fp32h2': FP16 pairs in
+        both passes (activations closer to float64 than 'fp32x3''s; see DESIGN.md 3.1a for what that does and does not buy in training).
         Not part of the reference's API."""
         self._runtime.set_precision(name)
         return self

@@ -566,7 +566,7 @@ def test_f32x3_kernels_with_fp16_pairs(shape, spread):
         ops.set_x3_pieces(22)
         pk3, dpk3 = ops.pack_x3(wt.cuda()), (ops.pack_x3(wt.cuda(), dgrad=True) if cout % 16 == 0 else None)
         errs = []
-        for tile in ((15, -1) if cout <= 32 else (10, 12, 14, 16, 17, -1)):
+        for tile in ((15, -1) if cout <= 32 else (10, 11, 12, 13, 14, 16, 17, -1)):
             y = nchw(ops.conv3x3_x3(xg, pk3, bg, cout, relu=True, tile=tile)).cpu().double()
             assert torch.isfinite(y).all(), (shape, spread, tile)
             assert float(((y - ref).abs() / (mag * 2.0 ** -19 + 1e-300)).max()) <= 1.0, (shape, spread, tile)
