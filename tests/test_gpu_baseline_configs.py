@@ -95,9 +95,10 @@ def test_window_batch_equals_the_sequential_micro_batches_at_120x214():
     assert worst[0] <= 1e-3, worst
 
 
-@pytest.mark.parametrize("precision", ["fp32", "fp32x3", "fp32x3b2", "fp32h2", "fp32x3h2"])
+@pytest.mark.parametrize("precision", ["fp32", "fp32x3", "fp32h2"])
 def test_1080p_forward_fp32_against_cpu_oracle_and_batch4_graph(precision):
-    """both fp32 arithmetics: the exact fp32 MFMA kernels (the 95 frames/s configs[4] line) and f32x3 (the module default)"""
+    """the three fp32-grade FORWARD arithmetics: the exact fp32 MFMA kernels (the 96 frames/s configs[4] line), f32x3 (the module default; 'fp32x3b2' /
+    'fp32x3h2' share its forward bit for bit) and the FP16 pairs of 'fp32h2' (the 249 frames/s line)"""
     from oracle import synth
     n, h, w = 4, 1080, 1920
     x = synth.make_frame(n, h, w, seed=41)
