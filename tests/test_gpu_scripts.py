@@ -26,6 +26,23 @@ def test_train_online_synthetic(tmp_path):
     assert os.path.exists(os.path.join(str(tmp_path), "Results", "blackswan", "00000.png"))
 
 
+def test_train_online_test_phase_on_fp16_pairs_writes_the_same_masks(tmp_path):
+    """--test-precision fp32h2 (round 6): training in the default arithmetic, the TEST forwards (reference train_online.py:172-189) on two FP16 pieces
+    per operand under block exponents -- a re-pack between the phases, same result files; the masks equal the default run's except for pixels whose
+    logit sits within rounding of the threshold (allowed: 1 in 1000)."""
+    import numpy as np
+    from PIL import Image
+    a, b = tmp_path / "a", tmp_path / "b"
+    a.mkdir(); b.mkdir()
+    args = ["train_online.py", "--synthetic", "--epochs", "10", "--height", "48", "--width", "64"]
+    _run(args, a, {"SEQ_NAME": "blackswan"})
+    out = _run(args + ["--test-precision", "fp32h2"], b, {"SEQ_NAME": "blackswan"})
+    assert "Online training time" in out
+    pa = np.asarray(Image.open(os.path.join(str(a), "Results", "blackswan", "00000.png"))).astype(np.int32)
+    pb = np.asarray(Image.open(os.path.join(str(b), "Results", "blackswan", "00000.png"))).astype(np.int32)
+    assert pa.shape == pb.shape and (np.abs(pa - pb) > 1).mean() <= 1e-3, float((np.abs(pa - pb) > 1).mean())
+
+
 def test_train_parent_synthetic(tmp_path):
     out = _run(["train_parent.py", "--synthetic", "4", "--epochs", "5", "--n-ave-grad", "2", "--height", "40", "--width", "56"], tmp_path)
     assert "Loss 4:" in out and "***Testing (epoch 4, 2 frames) *** Loss 4" in out

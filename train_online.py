@@ -127,6 +127,10 @@ def main():
                          'the first frame is decoded ONCE and re-augmented on the device every iteration')
     ap.add_argument('--prefetch', type=int, default=3, help='--device-augment: test frames decoded / copied ahead of the forward')
     ap.add_argument('--precision', default=os.environ.get('OSVOS_PRECISION', 'fp32x3'), choices=['fp32', 'fp32x3', 'fp32x3b2', 'fp32x3h2', 'fp32h2', 'fp32x2', 'bf16'])
+    ap.add_argument('--test-precision', default=os.environ.get('OSVOS_TEST_PRECISION', ''), choices=['', 'fp32', 'fp32x3', 'fp32h2', 'bf16'],
+                    help="precision of the TEST forwards (train_online.py:172-189 of the reference; default: the training precision).  'fp32h2' -- the f32x3 "
+                         "convolutions on two FP16 pieces under block exponents -- runs a forward 1.5x as fast as 'fp32x3' with logits closer to float64 "
+                         "(DESIGN.md 3.1a); the masks are the same up to pixels within 1e-5 std of the threshold")
     ap.add_argument('--window-fused', action='store_true',
                     help='run the nAveGrad micro-batches of every optimizer step as ONE batch with per-image class counts (TrainLoop.window_batch): '
                          'the same gradient up to fp32 summation order, one set of kernel launches per optimizer step instead of nAveGrad')
@@ -191,6 +195,8 @@ def main():
         os.makedirs(save_dir_res, exist_ok=True)
         print('Testing Network')
         js = []
+        if args.test_precision:
+            net.set_precision(args.test_precision)      # (re-packs the weights once: the FP16-pair packs are another format)
         with torch.no_grad():
             for sample in testloader:
                 img, fname = sample['image'], sample['fname']
