@@ -16,6 +16,9 @@ pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "trained_like.json")
 
 
+_ORACLE_CACHE = {}      # float64 oracle results shared by the parametrisations of a test (host time, not GPU time)
+
+
 @pytest.fixture(scope="module")
 def trained():
     wts, frames, curve = tf.train_like()
@@ -267,17 +270,20 @@ def test_twenty_optimizer_steps_track_the_float64_trajectory(trained, precision)
     wts, _, _ = trained
     n_ave, steps, lr = 2, 20, 5e-8
     frames = [synth.trainable_frame(1, 60, 107, seed=tf.RECIPE["frame_seed"] + 200 + k) for k in range(4)]
-    p = torch_ref.as_leaf_params(wts, dtype=torch.float64)
-    opt = torch.optim.SGD(torch_ref.sgd_groups(p, lr=lr, mode="online"), lr=lr, momentum=0.9)
-    ref_losses = []
-    for it in range(steps * n_ave):
-        x, m = frames[it % 4]
-        loss, _ = torch_ref.train_loss(p, torch.from_numpy(x).double(), torch.from_numpy(m).double(), mode="online")
-        ref_losses.append(float(loss))
-        (loss / n_ave).backward()
-        if it % n_ave == n_ave - 1:
-            opt.step()
-            opt.zero_grad()
+    if "traj20" not in _ORACLE_CACHE:      # the float64 trajectory is the same for every precision: computed once per session (15-25 s of host time)
+        p = torch_ref.as_leaf_params(wts, dtype=torch.float64)
+        opt = torch.optim.SGD(torch_ref.sgd_groups(p, lr=lr, mode="online"), lr=lr, momentum=0.9)
+        ref_losses = []
+        for it in range(steps * n_ave):
+            x, m = frames[it % 4]
+            loss, _ = torch_ref.train_loss(p, torch.from_numpy(x).double(), torch.from_numpy(m).double(), mode="online")
+            ref_losses.append(float(loss))
+            (loss / n_ave).backward()
+            if it % n_ave == n_ave - 1:
+                opt.step()
+                opt.zero_grad()
+        _ORACLE_CACHE["traj20"] = (ref_losses, {k: v.detach().clone() for k, v in p.items()})
+    ref_losses, p = _ORACLE_CACHE["traj20"]
     net = tf.build(wts, precision)
     loop = TrainLoop(net, make_sgd(net, "online", lr=lr), mode="online", n_ave_grad=n_ave)
     losses = []
